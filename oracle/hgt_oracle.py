@@ -1,0 +1,279 @@
+"""CPU oracle for one HGTConv layer -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may
+import this file; pyhgt_amd/ never does (the product path fails loudly when
+the HIP library is missing instead of falling back to anything in here).
+
+It restates, in plain torch-on-CPU, the algorithm of the reference layer
+    /root/reference/pyHGT/conv.py:11-139   (HGTConv)
+    /root/reference/pyHGT/conv.py:283-299  (RelTemporalEncoding)
+plus the three PyTorch-Geometric 1.3.2 symbols the reference delegates to
+(MessagePassing.propagate, utils.softmax, nn.inits.glorot -- not vendored in
+/root/reference; restated from their published semantics, see
+oracle/pyg_shim/).
+
+Pinning: the reference ships NO tests and NO golden vectors for this path
+(SURVEY.md section 8c), so the oracle is pinned against outputs of the
+reference itself: oracle/gen_golden.py imports the reference's conv.py
+verbatim (through oracle/pyg_shim) in the build container, runs it on seeded
+inputs and commits inputs+outputs under tests/golden/*.npz;
+tests/test_oracle.py checks both entry points below against those fixtures.
+
+Two entry points over the same math:
+  * forward_closed_form -- node-level restatement (projections once per node,
+    relation transforms per edge); runs in fp64 or fp32, fast enough for
+    10^5..10^6 edges.  This is the parity checker.
+  * forward_meta_relation_port -- same cost structure as the reference
+    (per-meta-relation edge groups, projections recomputed per EDGE, E x d
+    intermediates); this is what bench.py times as `cpu_baseline` ("port"),
+    because the real reference cannot travel to the GPU box.
+
+Parameter names/shapes are the reference module's state_dict
+(conv.py:28-51): {k,q,v,a}_linears.{t}.{weight,bias}, norms.{t}.{weight,bias},
+relation_pri [R,H], relation_att/relation_msg [R,H,dk,dk], skip [T],
+emb.emb.weight [240,in], emb.lin.{weight,bias}.
+"""
+import math
+
+import torch
+
+RTE_MAX_LEN = 240  # conv.py:287
+
+
+# --------------------------------------------------------------------------
+# parameter construction (independent re-statement of conv.py:28-54,289-297)
+# --------------------------------------------------------------------------
+def sinusoid_table(n_hid, max_len=RTE_MAX_LEN, dtype=torch.float32):
+    """emb[p,2c]=sin(p*w_c)/sqrt(n), emb[p,2c+1]=cos(p*w_c)/sqrt(n) (conv.py:289-294)."""
+    pos = torch.arange(0.0, max_len).unsqueeze(1)
+    freq = torch.exp(torch.arange(0, n_hid, 2) * -(math.log(10000.0) / n_hid))
+    tab = torch.empty(max_len, n_hid)
+    tab[:, 0::2] = torch.sin(pos * freq) / math.sqrt(n_hid)
+    tab[:, 1::2] = torch.cos(pos * freq) / math.sqrt(n_hid)
+    return tab.to(dtype)
+
+
+def make_state_dict(in_dim, out_dim, num_types, num_relations, n_heads,
+                    use_norm=True, use_RTE=True, seed=0, randomize_gates=True):
+    """Random parameters in the reference's state_dict layout.
+
+    Distributions mirror the reference init (Linear: U(+-1/sqrt(fan_in));
+    relation_att/msg: glorot U(+-sqrt(6/(2*dk)))), but relation_pri and skip are
+    randomised (the reference defaults, all ones, would leave those code
+    paths untested -- SURVEY.md appendix D.7).
+    """
+    g = torch.Generator().manual_seed(seed)
+    dk = out_dim // n_heads
+
+    def uni(shape, bound):
+        return (torch.rand(shape, generator=g) * 2 - 1) * bound
+
+    sd = {}
+    for t in range(num_types):
+        for name, fin in (("k", in_dim), ("q", in_dim), ("v", in_dim), ("a", out_dim)):
+            b = 1.0 / math.sqrt(fin)
+            sd["%s_linears.%d.weight" % (name, t)] = uni((out_dim, fin), b)
+            sd["%s_linears.%d.bias" % (name, t)] = uni((out_dim,), b)
+        if use_norm:
+            sd["norms.%d.weight" % t] = 1.0 + 0.1 * uni((out_dim,), 1.0)
+            sd["norms.%d.bias" % t] = 0.1 * uni((out_dim,), 1.0)
+    ga = math.sqrt(6.0 / (2 * dk))
+    sd["relation_att"] = uni((num_relations, n_heads, dk, dk), ga)
+    sd["relation_msg"] = uni((num_relations, n_heads, dk, dk), ga)
+    if randomize_gates:
+        sd["relation_pri"] = 0.5 + torch.rand((num_relations, n_heads), generator=g)
+        sd["skip"] = torch.randn((num_types,), generator=g)
+    else:
+        sd["relation_pri"] = torch.ones(num_relations, n_heads)
+        sd["skip"] = torch.ones(num_types)
+    if use_RTE:
+        sd["emb.emb.weight"] = sinusoid_table(in_dim)
+        b = 1.0 / math.sqrt(in_dim)
+        sd["emb.lin.weight"] = uni((in_dim, in_dim), b)
+        sd["emb.lin.bias"] = uni((in_dim,), b)
+    return sd
+
+
+def _stack(sd, fmt, n, dtype):
+    return torch.stack([sd[fmt % t] for t in range(n)]).to(dtype)
+
+
+def _gelu_erf(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def _layer_norm(y, w, b, eps=1e-5):
+    mu = y.mean(dim=-1, keepdim=True)
+    var = ((y - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (y - mu) / torch.sqrt(var + eps) * w + b
+
+
+def _segment_softmax(s, dst, n_nodes):
+    """Per (target, head) softmax over incoming edges; PyG 1.3.2 utils.softmax
+    (conv.py:108): exp(s-max)/(sum exp(s-max) + 1e-16)."""
+    m = torch.full((n_nodes, s.shape[1]), float("-inf"), dtype=s.dtype)
+    m.scatter_reduce_(0, dst.view(-1, 1).expand_as(s), s, reduce="amax", include_self=True)
+    p = torch.exp(s - m[dst])
+    z = torch.zeros((n_nodes, s.shape[1]), dtype=s.dtype).index_add_(0, dst, p)
+    return p / (z[dst] + 1e-16)
+
+
+def _update(sd, agg, x, node_type, num_types, use_norm, dtype):
+    """conv.py:114-134 (eval mode: dropout is the identity)."""
+    N, d = agg.shape
+    Wa = _stack(sd, "a_linears.%d.weight", num_types, dtype)
+    ba = _stack(sd, "a_linears.%d.bias", num_types, dtype)
+    g = _gelu_erf(agg)                                              # conv.py:119
+    out = torch.zeros(N, d, dtype=dtype)                            # conv.py:120
+    alpha = torch.sigmoid(sd["skip"].to(dtype))                     # conv.py:129
+    for t in range(num_types):
+        rows = (node_type == t).nonzero(as_tuple=True)[0]
+        if rows.numel() == 0:
+            continue
+        o = g[rows] @ Wa[t].T + ba[t]                               # conv.py:125
+        y = o * alpha[t] + x[rows] * (1.0 - alpha[t])               # conv.py:131/133
+        if use_norm:
+            y = _layer_norm(y, sd["norms.%d.weight" % t].to(dtype), sd["norms.%d.bias" % t].to(dtype))
+        out[rows] = y
+    return out
+
+
+# --------------------------------------------------------------------------
+# entry point 1: node-level closed form (the parity checker)
+# --------------------------------------------------------------------------
+def forward_closed_form(sd, num_types, num_relations, n_heads, x, node_type, edge_index,
+                        edge_type, edge_time=None, use_norm=True, use_RTE=True,
+                        dtype=torch.float64, return_att=False, return_agg=False):
+    """One HGTConv forward (eval mode).  Math follows conv.py:60-134:
+
+      q_e = W_q[tau(i)] x_i + b          (conv.py:73-77,96)
+      k_e = W_k[tau(j)] (x_j + RTE(dt_e)) + b   (conv.py:91-92,97)
+      k'_e,h = k_e,h . A[phi(e),h]       (conv.py:98)
+      s_e,h = <q_e,h, k'_e,h> * pri[phi(e),h] / sqrt(dk)   (conv.py:99)
+      att = softmax over incoming edges of i  (conv.py:108)
+      msg_e,h = (v_e,h . M[phi(e),h]) * att_e,h           (conv.py:104,109)
+      agg_i = sum_e msg_e ; out = update(agg)             (conv.py:13,114-134)
+
+    Linear maps are applied once per NODE (x -> Q,K,V) plus an additive
+    per-(type, dt) table for the temporal term; that is algebraically the
+    per-edge form of the reference because nn.Linear is affine.
+    Edges whose node/relation ids fall outside [0,T)/[0,R) keep logit 0 and
+    message 0 but stay in the softmax, like the reference's zero-initialised
+    res_att/res_msg (conv.py:68-69).
+    """
+    T, R, H = num_types, num_relations, n_heads
+    x = x.to(dtype)
+    N, d_in = x.shape
+    d = sd["relation_att"].shape[1] * sd["relation_att"].shape[2]
+    dk = d // H
+    src, dst = edge_index[0].long(), edge_index[1].long()
+    E = src.numel()
+    etype = edge_type.long()
+    ntype = node_type.long()
+
+    Wq = _stack(sd, "q_linears.%d.weight", T, dtype); bq = _stack(sd, "q_linears.%d.bias", T, dtype)
+    Wk = _stack(sd, "k_linears.%d.weight", T, dtype); bk = _stack(sd, "k_linears.%d.bias", T, dtype)
+    Wv = _stack(sd, "v_linears.%d.weight", T, dtype); bv = _stack(sd, "v_linears.%d.bias", T, dtype)
+
+    Q = torch.zeros(N, d, dtype=dtype); K = torch.zeros(N, d, dtype=dtype); V = torch.zeros(N, d, dtype=dtype)
+    for t in range(T):
+        rows = (ntype == t).nonzero(as_tuple=True)[0]
+        if rows.numel() == 0:
+            continue
+        xt = x[rows]
+        Q[rows] = xt @ Wq[t].T + bq[t]
+        K[rows] = xt @ Wk[t].T + bk[t]
+        V[rows] = xt @ Wv[t].T + bv[t]
+
+    tj = ntype[src]
+    ti = ntype[dst]
+    valid = (tj >= 0) & (tj < T) & (ti >= 0) & (ti < T) & (etype >= 0) & (etype < R)
+    k_e = K[src]
+    v_e = V[src]
+    if use_RTE:
+        if edge_time is None:
+            raise ValueError("use_RTE=True needs edge_time")
+        rte = sd["emb.emb.weight"].to(dtype) @ sd["emb.lin.weight"].to(dtype).T + sd["emb.lin.bias"].to(dtype)
+        rte_k = torch.einsum("pd,tod->tpo", rte, Wk)   # [T, 240, d] = rte @ Wk[t].T
+        rte_v = torch.einsum("pd,tod->tpo", rte, Wv)
+        tjc = tj.clamp(0, T - 1)
+        et = edge_time.long()
+        k_e = k_e + rte_k[tjc, et]
+        v_e = v_e + rte_v[tjc, et]
+    q_e = Q[dst]
+
+    rc = etype.clamp(0, R - 1)
+    A = sd["relation_att"].to(dtype)[rc]               # [E,H,dk,dk]
+    M = sd["relation_msg"].to(dtype)[rc]
+    pri = sd["relation_pri"].to(dtype)[rc]             # [E,H]
+    kp = torch.einsum("ehk,ehkc->ehc", k_e.view(E, H, dk), A)
+    s = (q_e.view(E, H, dk) * kp).sum(-1) * pri / math.sqrt(dk)
+    vp = torch.einsum("ehk,ehkc->ehc", v_e.view(E, H, dk), M)
+    vm = valid.to(dtype).view(E, 1)
+    s = s * vm
+    vp = vp * vm.view(E, 1, 1)
+
+    if E > 0:
+        att = _segment_softmax(s, dst, N)
+    else:
+        att = s
+    msg = (vp * att.unsqueeze(-1)).reshape(E, d)
+    agg = torch.zeros(N, d, dtype=dtype).index_add_(0, dst, msg)
+    out = _update(sd, agg, x, ntype, T, use_norm, dtype)
+    res = [out]
+    if return_att:
+        res.append(att)
+    if return_agg:
+        res.append(agg)
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+# --------------------------------------------------------------------------
+# entry point 2: reference-cost port (what bench.py times on the host cores)
+# --------------------------------------------------------------------------
+def forward_meta_relation_port(sd, num_types, num_relations, n_heads, x, node_type, edge_index,
+                               edge_type, edge_time=None, use_norm=True, use_RTE=True,
+                               return_att=False):
+    """fp32 port with the reference's cost structure (conv.py:56-134 + PyG
+    propagate): materialise x_i/x_j per edge, walk the T x T x R meta-relation
+    cube, and for every non-empty meta relation run the three Linear layers
+    and the two per-head d_k x d_k transforms on the EDGE rows, writing into
+    E x H / E x d scratch; then segment softmax, scatter-add and update."""
+    T, R, H = num_types, num_relations, n_heads
+    dtype = torch.float32
+    x = x.to(dtype)
+    N = x.shape[0]
+    d = sd["relation_att"].shape[1] * sd["relation_att"].shape[2]
+    dk = d // H
+    src, dst = edge_index[0].long(), edge_index[1].long()
+    E = src.numel()
+    x_i = x.index_select(0, dst)                        # propagate(): *_i gathers
+    x_j = x.index_select(0, src)                        # propagate(): *_j gathers
+    t_i = node_type.long().index_select(0, dst)
+    t_j = node_type.long().index_select(0, src)
+    logits = torch.zeros(E, H, dtype=dtype)             # conv.py:68
+    msg = torch.zeros(E, H, dk, dtype=dtype)            # conv.py:69
+    inv = 1.0 / math.sqrt(dk)
+    for st in range(T):                                 # conv.py:71
+        from_st = t_j == st
+        for tt in range(T):                             # conv.py:75
+            st_tt = from_st & (t_i == tt)
+            for r in range(R):                          # conv.py:78
+                sel = st_tt & (edge_type == r)
+                if not bool(sel.any()):                 # conv.py:83
+                    continue
+                xs = x_j[sel]
+                if use_RTE:                             # conv.py:91-92
+                    tvec = sd["emb.emb.weight"][edge_time[sel].long()]
+                    xs = xs + torch.addmm(sd["emb.lin.bias"], tvec, sd["emb.lin.weight"].T)
+                qm = torch.addmm(sd["q_linears.%d.bias" % tt], x_i[sel], sd["q_linears.%d.weight" % tt].T)
+                km = torch.addmm(sd["k_linears.%d.bias" % st], xs, sd["k_linears.%d.weight" % st].T)
+                vm = torch.addmm(sd["v_linears.%d.bias" % st], xs, sd["v_linears.%d.weight" % st].T)
+                km = torch.bmm(km.view(-1, H, dk).transpose(0, 1), sd["relation_att"][r]).transpose(0, 1)
+                logits[sel] = (qm.view(-1, H, dk) * km).sum(-1) * sd["relation_pri"][r] * inv
+                msg[sel] = torch.bmm(vm.view(-1, H, dk).transpose(0, 1), sd["relation_msg"][r]).transpose(0, 1)
+    att = _segment_softmax(logits, dst, N) if E > 0 else logits
+    res = (msg * att.unsqueeze(-1)).reshape(E, d)
+    agg = torch.zeros(N, d, dtype=dtype).index_add_(0, dst, res)
+    out = _update(sd, agg, x, node_type.long(), T, use_norm, dtype)
+    return (out, att) if return_att else out
