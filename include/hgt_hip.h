@@ -1,0 +1,217 @@
+/*
+ * hgt_hip.h -- C ABI of libhgt_hip.so: MI355X (gfx950) kernels for the forward pass of the
+ * Heterogeneous Graph Transformer convolution (acbull/pyHGT, pyHGT/conv.py::HGTConv).
+ *
+ * Boundary conventions:
+ *   - extern "C", plain pointers and sizes, no torch / C++ types in any signature;
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in _host;
+ *   - every call enqueues work on the given hipStream_t (passed as void*) and returns; nothing
+ *     here synchronises the stream, allocates or frees device memory (the caller owns every
+ *     buffer, sized with the *_sizes() helpers);
+ *   - return value 0 = HGT_OK, negative = error (hgt_strerror()); nothing throws or exits;
+ *   - re-entrant and thread-safe as long as concurrent calls use distinct workspaces.
+ *
+ * Each entry point cites the reference code (file:line under /root/reference) it replaces.
+ * The Python binding that calls these through ctypes is pyhgt_amd/_lib.py; the binding a
+ * maintainer of the reference would add is shown in INTEGRATION.md.
+ */
+#ifndef HGT_HIP_H_
+#define HGT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HGT_ABI_VERSION 1
+
+/* error codes */
+#define HGT_OK 0
+#define HGT_ERR_INVALID_ARG (-1)   /* null pointer, negative size, d % n_heads != 0, ... */
+#define HGT_ERR_UNSUPPORTED (-2)   /* shape outside what the kernels are instantiated for */
+#define HGT_ERR_WORKSPACE (-3)     /* caller-provided buffer too small */
+#define HGT_ERR_TOO_LARGE (-4)     /* N or E beyond 32-bit plan indices */
+#define HGT_ERR_LAUNCH (-5)        /* HIP runtime reported a launch error */
+
+/* length of the relative-temporal-encoding table, conv.py:287 (max_len = 240) */
+#define HGT_RTE_LEN 240
+
+const char* hgt_strerror(int code);
+int hgt_abi_version(void);
+
+/* ----------------------------------------------------------------------------------------------
+ * Internal "head-padded" feature layout.  Q/K/V/agg rows hold n_heads blocks of dk_pad floats
+ * (dk_pad >= d_k = d_out / n_heads, extra columns are zero) so that one 64-lane wavefront covers
+ * a row with `vec` contiguous floats per lane and every head maps to dk_pad / vec adjacent lanes.
+ * Replaces the .view(-1, n_heads, d_k) of conv.py:96-97,103.
+ * Requires: d_out % n_heads == 0 and 64 % n_heads == 0 (n_heads a power of two <= 64).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hgt_layout {
+    int32_t d_k;     /* d_out / n_heads                         */
+    int32_t dk_pad;  /* padded head width                       */
+    int32_t d_pad;   /* n_heads * dk_pad = 64 * vec             */
+    int32_t vec;     /* floats per lane (1,2,4,8,16)            */
+} hgt_layout;
+int hgt_layout_for(int32_t d_out, int32_t n_heads, hgt_layout* out_host);
+
+/* ----------------------------------------------------------------------------------------------
+ * Graph plan: everything that depends only on (edge_index, edge_type, edge_time, node_type).
+ * Built once per sampled subgraph and shared by all layers (the reference reuses the same graph
+ * tensors for every layer, model.py:78-79).  Replaces, for the whole layer, PyG's per-call
+ * index_select gathers (MessagePassing.propagate, called at conv.py:57), the T*T*R boolean mask
+ * cube and its host syncs (conv.py:71-84) and the per-type masks of update() (conv.py:121-123):
+ *   - edges stably sorted by (dst / 64, relation, dst % 64), ids compacted int64 -> int32,
+ *     source-type*240 + edge_time folded into one uint16 per edge;
+ *   - a segment table over (dst tile, relation, dst) and a list of wavefront work items
+ *     (<= 256 consecutive edges of one (dst tile, relation));
+ *   - nodes stably sorted by type (row lists for the typed linears) + per-type offsets.
+ * Edges whose relation id or endpoint node types fall outside [0,R) / [0,T) go to an extra
+ * "unclaimed" relation bucket: logit 0, message 0, still part of the softmax -- the behaviour of
+ * the reference's zero-initialised res_att / res_msg (conv.py:68-69).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hgt_plan_sizes {
+    uint64_t plan_bytes;   /* persistent plan buffer                         */
+    uint64_t tmp_bytes;    /* scratch needed only during hgt_plan_build      */
+    int64_t  max_items;    /* upper bound on wavefront work items            */
+    int64_t  n_bins;       /* (dst tiles) * (R+1) * 64                       */
+} hgt_plan_sizes;
+
+int hgt_plan_sizes_for(int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                       hgt_plan_sizes* out_host);
+
+/* Row lists exported by a built plan (device pointers INTO the plan buffer), for hgt_typed_linear:
+ *   rows_all / off_all : all n_nodes nodes stably sorted by type, int32[n_nodes] / int32[T+2]
+ *   rows_q   / off_q   : the target nodes [0, n_q_rows) sorted by type (identical to the above
+ *                        when n_q_rows == n_nodes); group T holds nodes with an out-of-range type. */
+typedef struct hgt_plan_rows {
+    const int32_t* rows_all; const int32_t* off_all;
+    const int32_t* rows_q;   const int32_t* off_q;
+} hgt_plan_rows;
+int hgt_plan_row_lists(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types,
+                       int32_t n_relations, hgt_plan_rows* out_host);
+
+/* edge_index: int64, element (row, e) at edge_index[row * stride_row + e * stride_col]; row 0 =
+ * source j, row 1 = target i (conv.py:60-63, data.py:245,254 -- the reference hands over the
+ * (1,2)-strided transpose of an [E,2] tensor).  edge_time may be NULL (use_RTE = False).
+ * n_q_rows: nodes [0, n_q_rows) are targets that get Q / aggregation / update; nodes beyond are
+ * source-only halo rows (multi-GPU destination partitioning); pass n_nodes on a single GPU.
+ * Every edge target must be < n_q_rows. */
+int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col,
+                   const int64_t* edge_type, const int64_t* edge_time, const int64_t* node_type,
+                   int64_t n_nodes, int64_t n_q_rows, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                   void* plan, uint64_t plan_bytes, void* tmp, uint64_t tmp_bytes, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Typed (grouped) linear layer on MFMA: for every node type t and every row n of that type
+ *     y[n, :] = prologue(x[n, :]) @ W[t]^T + b[t]
+ * Replaces the per-meta-relation, per-EDGE nn.Linear calls of conv.py:96-97,103 (Q, K, V) and
+ * the per-type a_linear of conv.py:125, plus RelTemporalEncoding.lin (conv.py:297-299) when
+ * building the temporal tables.  Row lists come from the plan (or any caller-made row list).
+ *   x         [*, ldx] fp32 rows, gathered through rows[] (node ids)
+ *   rows      int32[n_rows] row ids grouped by type; group g = rows[group_off[g] .. group_off[g+1])
+ *   group_off int32[n_groups+1] (device)
+ *   W         fp32 [n_groups][n_out][k] with stride w_group_stride floats between groups
+ *   bias      fp32 [n_groups][n_out] with stride b_group_stride, or NULL
+ *   out0..2   the n_out columns are split into blocks of block_cols columns, block c is written
+ *             to out{c}[row * block_cols + col]; row = rows[p] (out_by_position = 0) or p (= 1)
+ *   prologue  0 = none, 1 = exact (erf) GELU applied to x on load (conv.py:119)
+ *   precision 0 = fp32 MFMA (exact fp32 FMA chain), 1 = 3-term split-bf16 MFMA
+ * ---------------------------------------------------------------------------------------------- */
+int hgt_typed_linear(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off,
+                     int32_t n_groups, int64_t n_rows, int32_t k, int32_t n_out,
+                     const float* W, int64_t w_group_stride, const float* bias, int64_t b_group_stride,
+                     float* out0, float* out1, float* out2, int32_t block_cols,
+                     int32_t out_by_position, int32_t prologue, int32_t precision, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Relation parameter packing (per forward, R*H*dk*dk elements):
+ *   att_t[r][h][c][k] = relation_att[r][h][k][c] * relation_pri[r][h] / sqrt(d_k)   (zero padded)
+ *   msg_p[r][h][k][c] = relation_msg[r][h][k][c]                                     (zero padded)
+ * both [R][H][dk_pad][dk_pad].  Folds conv.py:99's "* relation_pri / sqrt_dk" into the matrix and
+ * transposes relation_att so that  q . (k A) = (A q) . k  can be evaluated on the target side.
+ * ---------------------------------------------------------------------------------------------- */
+int hgt_relation_pack(const float* relation_att, const float* relation_msg, const float* relation_pri,
+                      int32_t n_relations, int32_t n_heads, int32_t d_k, int32_t dk_pad,
+                      float* att_t, float* msg_p, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Edge phase (replaces conv.py:98-99,104,108-111 and PyG's scatter-add, conv.py:13 aggr='add').
+ * All feature rows are in the head-padded layout, row stride d_pad.
+ *   hgt_edge_logits    s[p][h] = (A'[rel] q[dst])_h . (K[src] + rte_k[src_type, dt])_h  for every
+ *                      sorted edge position p (conv.py:98-99); unclaimed edges get 0
+ *   hgt_edge_softmax   in place: s -> exp(s - max_i) / (sum_i exp(s - max_i) + 1e-16) over all
+ *                      in-edges of each target, per head (PyG softmax, conv.py:108)
+ *   hgt_edge_aggregate agg[i] += (sum_{e in (i,rel)} att_e (V[src] + rte_v[...])) M[rel]
+ *                      (conv.py:104,109-111 + scatter-add); agg must be zero on entry
+ *   hgt_att_export     att_out[original edge id][h] = att[p][h]   (self.att, conv.py:108)
+ * rte_k / rte_v: [n_types*240][d_pad] tables or NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int hgt_edge_logits(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                    int32_t n_heads, int32_t dk_pad, const float* Q, const float* K, const float* rte_k,
+                    const float* att_t, float* logits, void* stream);
+int hgt_edge_softmax(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                     int32_t n_heads, float* logits_att, void* stream);
+int hgt_edge_aggregate(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                       int32_t n_heads, int32_t dk_pad, const float* att, const float* V, const float* rte_v,
+                       const float* msg_p, float* agg, void* stream);
+int hgt_att_export(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                   int32_t n_heads, const float* att_sorted, float* att_out, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Node update epilogue (conv.py:129-133): per node n of type t (rows with a type outside [0,T)
+ * are written as zeros, like the reference's zero-initialised `res`, conv.py:120):
+ *     y = trans[n] * sigmoid(skip[t]) + x[n] * (1 - sigmoid(skip[t]));
+ *     out[n] = use_norm ? LayerNorm(y; ln_w[t], ln_b[t], eps 1e-5) : y
+ * ---------------------------------------------------------------------------------------------- */
+int hgt_node_update(const float* trans, const float* x, int64_t ldx, const int64_t* node_type,
+                    const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm,
+                    int64_t n_nodes, int32_t d, int32_t n_types, float* out, void* stream);
+
+/* row gather used to pack halo rows for the multi-GPU exchange: out[i] = x[idx[i]] */
+int hgt_gather_rows(const float* x, int64_t ldx, const int32_t* idx, int64_t n, int32_t d, float* out, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * One whole HGTConv.forward (conv.py:56-134, eval mode) as a single enqueue of the kernels above.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hgt_conv_args {
+    /* problem */
+    int64_t n_nodes, n_edges;
+    int32_t in_dim, out_dim, n_types, n_relations, n_heads;
+    int32_t use_norm, use_rte, precision, want_att;
+    int64_t n_q_rows;            /* nodes [0, n_q_rows) get Q/aggregate/update; others only K,V (halo) */
+    /* inputs */
+    const float* x;              /* [n_nodes][in_dim]                          */
+    const int64_t* node_type;    /* [n_nodes]                                  */
+    const void* plan;            /* hgt_plan_build output                      */
+    /* parameters (packed by the caller, see pyhgt_amd/conv.py::_pack_parameters) */
+    const float* w_qkv;          /* [T][3*d_pad][in_dim] head-padded rows      */
+    const float* b_qkv;          /* [T][3*d_pad]                               */
+    const float* w_a;            /* [T][out_dim][d_pad] head-padded columns    */
+    const float* b_a;            /* [T][out_dim]                               */
+    const float* relation_att;   /* [R][H][d_k][d_k]                           */
+    const float* relation_msg;   /* [R][H][d_k][d_k]                           */
+    const float* relation_pri;   /* [R][H]                                     */
+    const float* skip;           /* [T]                                        */
+    const float* ln_w;           /* [T][out_dim] or NULL                       */
+    const float* ln_b;           /* [T][out_dim] or NULL                       */
+    const float* rte_emb;        /* [240][in_dim]   (use_rte)                  */
+    const float* rte_w;          /* [in_dim][in_dim]                           */
+    const float* rte_b;          /* [in_dim]                                   */
+    /* workspace + outputs */
+    void* workspace;             /* hgt_conv_workspace_bytes()                 */
+    uint64_t workspace_bytes;
+    float* out;                  /* [n_nodes][out_dim]                         */
+    float* att_out;              /* [n_edges][n_heads] or NULL                 */
+} hgt_conv_args;
+
+int hgt_conv_workspace_bytes(int64_t n_nodes, int64_t n_edges, int32_t in_dim, int32_t out_dim,
+                             int32_t n_types, int32_t n_relations, int32_t n_heads, int32_t use_rte,
+                             uint64_t* out_host);
+int hgt_conv_forward(const hgt_conv_args* args_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGT_HIP_H_ */

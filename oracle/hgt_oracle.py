@@ -202,16 +202,19 @@ def forward_closed_form(sd, num_types, num_relations, n_heads, x, node_type, edg
         v_e = v_e + rte_v[tjc, et]
     q_e = Q[dst]
 
-    rc = etype.clamp(0, R - 1)
-    A = sd["relation_att"].to(dtype)[rc]               # [E,H,dk,dk]
-    M = sd["relation_msg"].to(dtype)[rc]
-    pri = sd["relation_pri"].to(dtype)[rc]             # [E,H]
-    kp = torch.einsum("ehk,ehkc->ehc", k_e.view(E, H, dk), A)
-    s = (q_e.view(E, H, dk) * kp).sum(-1) * pri / math.sqrt(dk)
-    vp = torch.einsum("ehk,ehkc->ehc", v_e.view(E, H, dk), M)
-    vm = valid.to(dtype).view(E, 1)
-    s = s * vm
-    vp = vp * vm.view(E, 1, 1)
+    # relation transforms, one relation at a time (keeps memory at O(E*d))
+    A_all = sd["relation_att"].to(dtype)
+    M_all = sd["relation_msg"].to(dtype)
+    pri_all = sd["relation_pri"].to(dtype)
+    s = torch.zeros(E, H, dtype=dtype)                 # unclaimed edges keep logit 0 (conv.py:68)
+    vp = torch.zeros(E, H, dk, dtype=dtype)            # ... and message 0 (conv.py:69)
+    for r in range(R):
+        sel = ((etype == r) & valid).nonzero(as_tuple=True)[0]
+        if sel.numel() == 0:
+            continue
+        kp = torch.einsum("ehk,hkc->ehc", k_e[sel].view(-1, H, dk), A_all[r])
+        s[sel] = (q_e[sel].view(-1, H, dk) * kp).sum(-1) * pri_all[r] / math.sqrt(dk)
+        vp[sel] = torch.einsum("ehk,hkc->ehc", v_e[sel].view(-1, H, dk), M_all[r])
 
     if E > 0:
         att = _segment_softmax(s, dst, N)

@@ -1,0 +1,99 @@
+"""ctypes binding of libhgt_hip.so (the C ABI declared in include/hgt_hip.h).
+
+The library is built in-tree (pyhgt_amd/lib/libhgt_hip.so, see __graft_entry__.build() or
+`make -C pyhgt_amd/csrc`).  There is NO fallback: if the shared object is missing or a call
+returns an error code, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhgt_hip.so")
+
+HGT_RTE_LEN = 240
+
+
+class HgtLayout(C.Structure):
+    _fields_ = [("d_k", C.c_int32), ("dk_pad", C.c_int32), ("d_pad", C.c_int32), ("vec", C.c_int32)]
+
+
+class HgtPlanSizes(C.Structure):
+    _fields_ = [("plan_bytes", C.c_uint64), ("tmp_bytes", C.c_uint64), ("max_items", C.c_int64), ("n_bins", C.c_int64)]
+
+
+class HgtPlanRows(C.Structure):
+    _fields_ = [("rows_all", C.c_void_p), ("off_all", C.c_void_p), ("rows_q", C.c_void_p), ("off_q", C.c_void_p)]
+
+
+class HgtConvArgs(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int64), ("n_edges", C.c_int64),
+        ("in_dim", C.c_int32), ("out_dim", C.c_int32), ("n_types", C.c_int32), ("n_relations", C.c_int32),
+        ("n_heads", C.c_int32),
+        ("use_norm", C.c_int32), ("use_rte", C.c_int32), ("precision", C.c_int32), ("want_att", C.c_int32),
+        ("n_q_rows", C.c_int64),
+        ("x", C.c_void_p), ("node_type", C.c_void_p), ("plan", C.c_void_p),
+        ("w_qkv", C.c_void_p), ("b_qkv", C.c_void_p), ("w_a", C.c_void_p), ("b_a", C.c_void_p),
+        ("relation_att", C.c_void_p), ("relation_msg", C.c_void_p), ("relation_pri", C.c_void_p),
+        ("skip", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p),
+        ("rte_emb", C.c_void_p), ("rte_w", C.c_void_p), ("rte_b", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64),
+        ("out", C.c_void_p), ("att_out", C.c_void_p),
+    ]
+
+
+_i32, _i64, _u64, _vp = C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/hgt_hip.h declares
+SIGNATURES = {
+    "hgt_strerror": (C.c_char_p, [C.c_int]),
+    "hgt_abi_version": (C.c_int, []),
+    "hgt_layout_for": (C.c_int, [_i32, _i32, C.POINTER(HgtLayout)]),
+    "hgt_plan_sizes_for": (C.c_int, [_i64, _i64, _i32, _i32, C.POINTER(HgtPlanSizes)]),
+    "hgt_plan_row_lists": (C.c_int, [_vp, _i64, _i64, _i32, _i32, C.POINTER(HgtPlanRows)]),
+    "hgt_plan_build": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _u64, _vp, _u64, _vp]),
+    "hgt_typed_linear": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
+                                   _i32, _i32, _i32, _i32, _vp]),
+    "hgt_relation_pack": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "hgt_edge_logits": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hgt_edge_softmax": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "hgt_edge_aggregate": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hgt_att_export": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "hgt_node_update": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
+    "hgt_gather_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
+    "hgt_conv_workspace_bytes": (C.c_int, [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_u64)]),
+    "hgt_conv_forward": (C.c_int, [C.POINTER(HgtConvArgs), _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libhgt_hip.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                "pyhgt_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C pyhgt_amd/csrc`; there is no CPU/PyTorch fallback for HGTConv" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        if lib.hgt_abi_version() != 1:
+            raise RuntimeError("pyhgt_amd: ABI version mismatch in %s" % LIB_PATH)
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().hgt_strerror(code).decode()
+        raise RuntimeError("pyhgt_amd: %s failed: %s (code %d)" % (what, msg, code))
+
+
+def layout_for(d_out, n_heads):
+    lay = HgtLayout()
+    check(load().hgt_layout_for(d_out, n_heads, C.byref(lay)), "hgt_layout_for(d=%d, heads=%d)" % (d_out, n_heads))
+    return lay

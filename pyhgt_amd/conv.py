@@ -1,0 +1,321 @@
+"""Host-side mirror of the reference's conv module for the HGT hot path.
+
+`HGTConv` keeps the reference layer's constructor, parameter/state_dict names and forward
+signature (/root/reference/pyHGT/conv.py:11-58), so it drops into the reference's
+`GeneralConv` / `model.GNN` unchanged (`install_into(pyHGT.conv)`), but forward() enqueues the
+hand-written HIP kernels of libhgt_hip.so (include/hgt_hip.h) instead of PyG message passing.
+
+PyTorch is used for parameter storage, device memory and the current stream only.  There is no
+CPU / eager fallback: a non-GPU input or a missing library raises.
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+__all__ = ["HGTConv", "GeneralConv", "RelTemporalEncoding", "GraphPlan", "install_into"]
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Workspace:
+    """One growing device scratch buffer per device, shared by all layers (layers run back to
+    back on one stream; the C ABI never allocates)."""
+    _bufs = {}
+
+    @classmethod
+    def get(cls, device, nbytes):
+        buf = cls._bufs.get(device)
+        if buf is None or buf.numel() < nbytes:
+            buf = None
+            cls._bufs.pop(device, None)
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            cls._bufs[device] = buf
+        return buf
+
+    @classmethod
+    def clear(cls):
+        cls._bufs.clear()
+
+
+class GraphPlan:
+    """Device-resident plan of one typed (sub)graph: dst-tile/relation sorted int32 edges, segment
+    table, wavefront work items, typed row lists.  Built once per graph by hgt_plan_build and
+    reused by every layer (the reference re-derives all of this per layer per call through PyG
+    gathers and the T*T*R mask loop, conv.py:57,71-84)."""
+
+    _cache = OrderedDict()
+    CACHE_SIZE = 4
+
+    def __init__(self, node_type, edge_index, edge_type, edge_time, num_types, num_relations, n_q_rows=None):
+        lib = _lib.load()
+        if not node_type.is_cuda:
+            raise RuntimeError("pyhgt_amd: graph tensors must live on the GPU (no CPU fallback)")
+        for name, t in (("node_type", node_type), ("edge_index", edge_index), ("edge_type", edge_type)):
+            if t.dtype != torch.int64:
+                raise TypeError("pyhgt_amd: %s must be int64 like the reference's tensors, got %s" % (name, t.dtype))
+        if edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError("edge_index must be [2, E]")
+        self.N = int(node_type.numel())
+        self.E = int(edge_index.size(1))
+        self.T, self.R = int(num_types), int(num_relations)
+        self.NQ = self.N if n_q_rows is None else int(n_q_rows)
+        if edge_type.numel() != self.E or (edge_time is not None and edge_time.numel() != self.E):
+            raise ValueError("edge_type / edge_time must have E entries")
+        node_type = node_type.contiguous()
+        edge_type = edge_type.contiguous()
+        if edge_time is not None:
+            if edge_time.dtype != torch.int64:
+                raise TypeError("pyhgt_amd: edge_time must be int64")
+            edge_time = edge_time.contiguous()
+        sz = _lib.HgtPlanSizes()
+        _lib.check(lib.hgt_plan_sizes_for(self.N, self.E, self.T, self.R, C.byref(sz)), "hgt_plan_sizes_for")
+        dev = node_type.device
+        self.buf = torch.empty(int(sz.plan_bytes), dtype=torch.uint8, device=dev)
+        tmp = torch.empty(int(sz.tmp_bytes), dtype=torch.uint8, device=dev)
+        self.max_items = int(sz.max_items)
+        # edge_index arrives as a (1,2)-strided view (data.py:254): hand the strides over, no copy
+        sr, sc = (edge_index.stride(0), edge_index.stride(1)) if self.E > 0 else (0, 1)
+        _lib.check(lib.hgt_plan_build(_ptr(edge_index), sr, sc, _ptr(edge_type), _ptr(edge_time), _ptr(node_type),
+                                      self.N, self.NQ, self.E, self.T, self.R, _ptr(self.buf), self.buf.numel(),
+                                      _ptr(tmp), tmp.numel(), _stream()), "hgt_plan_build")
+        # tmp is released by the caching allocator only after the stream ran past this point
+        tmp.record_stream(torch.cuda.current_stream())
+        self.device = dev
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+    def row_lists(self):
+        pr = _lib.HgtPlanRows()
+        _lib.check(_lib.load().hgt_plan_row_lists(self.ptr, self.N, self.E, self.T, self.R, C.byref(pr)), "hgt_plan_row_lists")
+        return pr
+
+    def check_indices(self):
+        """Debug aid (synchronises): raise if an edge endpoint was outside [0, N) (the reference
+        would have raised an IndexError inside index_select)."""
+        hdr = self.buf[:8].view(torch.int32).cpu()
+        if int(hdr[1]) != 0:
+            raise IndexError("pyhgt_amd: edge_index contains node ids outside [0, num_nodes)")
+        return int(hdr[0])
+
+    # -- cache: the reference passes the SAME tensors to every layer (model.py:78-79) ------------
+    @classmethod
+    def cached(cls, node_type, edge_index, edge_type, edge_time, num_types, num_relations, n_q_rows=None):
+        tensors = (node_type, edge_index, edge_type, edge_time)
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride())) if t is not None else None for t in tensors)
+        key = key + (int(num_types), int(num_relations), n_q_rows, str(node_type.device))
+        hit = cls._cache.get(key)
+        if hit is not None:
+            cls._cache.move_to_end(key)
+            return hit[0]
+        plan = cls(node_type, edge_index, edge_type, edge_time, num_types, num_relations, n_q_rows)
+        # keep the key tensors alive so their addresses cannot be recycled while the entry lives
+        cls._cache[key] = (plan, tensors)
+        while len(cls._cache) > cls.CACHE_SIZE:
+            cls._cache.popitem(last=False)
+        return plan
+
+    @classmethod
+    def clear_cache(cls):
+        cls._cache.clear()
+
+
+class RelTemporalEncoding(nn.Module):
+    """Parameter container with the reference's names (conv.py:283-299): `emb` = fixed sinusoid
+    table [max_len, n_hid] scaled by 1/sqrt(n_hid), `lin` = Linear(n_hid, n_hid).  HGTConv folds
+    lin(emb[dt]) through W_k / W_v into per-(source type, dt) tables on the GPU
+    (hgt_conv_forward step 3) instead of evaluating it per edge."""
+
+    def __init__(self, n_hid, max_len=240, dropout=0.2):
+        super().__init__()
+        if max_len != _lib.HGT_RTE_LEN:
+            raise ValueError("libhgt_hip is built for max_len = 240 (conv.py:287)")
+        pos = torch.arange(0.0, max_len).unsqueeze(1)
+        freq = torch.exp(torch.arange(0, n_hid, 2) * -(math.log(10000.0) / n_hid))
+        table = nn.Embedding(max_len, n_hid)
+        with torch.no_grad():
+            table.weight[:, 0::2] = torch.sin(pos * freq) / math.sqrt(n_hid)
+            table.weight[:, 1::2] = torch.cos(pos * freq) / math.sqrt(n_hid)
+        self.emb = table
+        self.lin = nn.Linear(n_hid, n_hid)
+
+
+class HGTConv(nn.Module):
+    """Heterogeneous Graph Transformer layer, forward on MI355X.
+
+    Same constructor / parameters / forward as the reference (conv.py:11-58).  Extra keyword-only
+    options: keep_att (export softmax weights into self.att like conv.py:108; off by default
+    because nothing in the reference reads it), precision ("fp32" MFMA, exact fp32 chain).
+    """
+
+    def __init__(self, in_dim, out_dim, num_types, num_relations, n_heads, dropout=0.2, use_norm=True, use_RTE=True,
+                 keep_att=False, precision="fp32", **kwargs):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.num_types, self.num_relations = num_types, num_relations
+        self.total_rel = num_types * num_relations * num_types
+        self.n_heads = n_heads
+        self.d_k = out_dim // n_heads
+        self.sqrt_dk = math.sqrt(self.d_k)
+        self.use_norm, self.use_RTE = use_norm, use_RTE
+        self.keep_att = keep_att
+        self.precision = precision
+        self.att = None
+
+        self.k_linears = nn.ModuleList(nn.Linear(in_dim, out_dim) for _ in range(num_types))
+        self.q_linears = nn.ModuleList(nn.Linear(in_dim, out_dim) for _ in range(num_types))
+        self.v_linears = nn.ModuleList(nn.Linear(in_dim, out_dim) for _ in range(num_types))
+        self.a_linears = nn.ModuleList(nn.Linear(out_dim, out_dim) for _ in range(num_types))
+        self.norms = nn.ModuleList(nn.LayerNorm(out_dim) for _ in range(num_types)) if use_norm else nn.ModuleList()
+        self.relation_pri = nn.Parameter(torch.ones(num_relations, n_heads))
+        bound = math.sqrt(6.0 / (2 * self.d_k))                       # PyG glorot over the two trailing dims
+        self.relation_att = nn.Parameter(torch.empty(num_relations, n_heads, self.d_k, self.d_k).uniform_(-bound, bound))
+        self.relation_msg = nn.Parameter(torch.empty(num_relations, n_heads, self.d_k, self.d_k).uniform_(-bound, bound))
+        self.skip = nn.Parameter(torch.ones(num_types))
+        self.drop = nn.Dropout(dropout)
+        if use_RTE:
+            self.emb = RelTemporalEncoding(in_dim)
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------------------------------
+    def _pack_parameters(self):
+        """Stack the per-type Linear / LayerNorm parameters into the contiguous, head-padded arrays
+        hgt_conv_forward takes (pure data movement; cached until a parameter changes)."""
+        params = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        lay = _lib.layout_for(self.out_dim, self.n_heads)
+        H, dk, dkp, dp = self.n_heads, lay.d_k, lay.dk_pad, lay.d_pad
+        T, din, dout = self.num_types, self.in_dim, self.out_dim
+
+        def pad_rows(w):          # [dout, *] -> [dp, *] (each head's dk rows followed by dkp-dk zero rows)
+            if dkp == dk:
+                return w
+            tail = w.shape[1:]
+            w = w.reshape(H, dk, *tail)
+            z = w.new_zeros(H, dkp - dk, *tail)
+            return torch.cat([w, z], dim=1).reshape(dp, *tail)
+
+        with torch.no_grad():
+            w_qkv = torch.stack([torch.cat([pad_rows(self.q_linears[t].weight), pad_rows(self.k_linears[t].weight),
+                                            pad_rows(self.v_linears[t].weight)], 0) for t in range(T)]).float().contiguous()
+            b_qkv = torch.stack([torch.cat([pad_rows(self.q_linears[t].bias), pad_rows(self.k_linears[t].bias),
+                                            pad_rows(self.v_linears[t].bias)], 0) for t in range(T)]).float().contiguous()
+            w_a = torch.stack([pad_rows(self.a_linears[t].weight.t()).t() for t in range(T)]).float().contiguous()
+            b_a = torch.stack([self.a_linears[t].bias for t in range(T)]).float().contiguous()
+            ln_w = ln_b = None
+            if self.use_norm:
+                ln_w = torch.stack([self.norms[t].weight for t in range(T)]).float().contiguous()
+                ln_b = torch.stack([self.norms[t].bias for t in range(T)]).float().contiguous()
+            packed = dict(lay=lay, w_qkv=w_qkv, b_qkv=b_qkv, w_a=w_a, b_a=b_a, ln_w=ln_w, ln_b=ln_b,
+                          ratt=self.relation_att.detach().float().contiguous(),
+                          rmsg=self.relation_msg.detach().float().contiguous(),
+                          rpri=self.relation_pri.detach().float().contiguous(),
+                          skip=self.skip.detach().float().contiguous())
+            if self.use_RTE:
+                packed.update(rte_emb=self.emb.emb.weight.detach().float().contiguous(),
+                              rte_w=self.emb.lin.weight.detach().float().contiguous(),
+                              rte_b=self.emb.lin.bias.detach().float().contiguous())
+        assert w_qkv.shape == (T, 3 * dp, din) and w_a.shape == (T, dout, dp)
+        self._packed, self._packed_key = packed, key
+        return packed
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, node_inp, node_type, edge_index, edge_type, edge_time=None, plan=None, n_q_rows=None):
+        """node_inp f32[N,in_dim], node_type i64[N], edge_index i64[2,E] (row 0 = source, row 1 =
+        target; any strides), edge_type i64[E], edge_time i64[E] (needed iff use_RTE).
+        Returns f32[N,out_dim] (or [n_q_rows,out_dim] when only the first n_q_rows nodes are targets)."""
+        lib = _lib.load()
+        if not node_inp.is_cuda:
+            raise RuntimeError("pyhgt_amd.HGTConv runs only on a ROCm GPU tensor; there is no CPU fallback "
+                               "(the CPU oracle lives under oracle/ and is test infrastructure)")
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("pyhgt_amd.HGTConv is forward-only (SURVEY.md section 8f-2): call it under "
+                               "torch.no_grad() or in eval() mode")
+        if node_inp.dtype != torch.float32:
+            raise TypeError("node_inp must be float32 (the reference layer is fp32-only, conv.py:68-69)")
+        if self.in_dim != self.out_dim:
+            raise RuntimeError("HGTConv needs in_dim == out_dim for the skip connection (conv.py:131)")
+        if self.use_RTE and edge_time is None:
+            raise ValueError("use_RTE=True needs edge_time (conv.py:91-92)")
+        N = node_inp.size(0)
+        if node_inp.size(1) != self.in_dim or node_type.numel() != N:
+            raise ValueError("node_inp must be [N, in_dim] and node_type [N]")
+        x = node_inp.detach().contiguous()
+        if plan is None:
+            plan = GraphPlan.cached(node_type, edge_index, edge_type, edge_time if self.use_RTE else None,
+                                    self.num_types, self.num_relations, n_q_rows)
+        if plan.N != N or plan.T != self.num_types or plan.R != self.num_relations:
+            raise ValueError("plan was built for a different graph / schema")
+        NQ, E = plan.NQ, plan.E
+        pk = self._pack_parameters()
+        if pk["w_qkv"].device != x.device:
+            raise RuntimeError("module parameters and node_inp are on different devices")
+        nbytes = C.c_uint64()
+        _lib.check(lib.hgt_conv_workspace_bytes(N, E, self.in_dim, self.out_dim, self.num_types, self.num_relations,
+                                                self.n_heads, int(self.use_RTE), C.byref(nbytes)), "hgt_conv_workspace_bytes")
+        ws = _Workspace.get(x.device, nbytes.value)
+        out = torch.empty(NQ, self.out_dim, dtype=torch.float32, device=x.device)
+        att = torch.empty(E, self.n_heads, dtype=torch.float32, device=x.device) if self.keep_att else None
+        ntype = node_type.contiguous()
+
+        a = _lib.HgtConvArgs()
+        a.n_nodes, a.n_edges = N, E
+        a.in_dim, a.out_dim, a.n_types, a.n_relations, a.n_heads = (self.in_dim, self.out_dim, self.num_types,
+                                                                    self.num_relations, self.n_heads)
+        a.use_norm, a.use_rte = int(self.use_norm), int(self.use_RTE)
+        a.precision = {"fp32": 0, "bf16x3": 1}[self.precision]
+        a.want_att = int(self.keep_att)
+        a.n_q_rows = NQ
+        a.x, a.node_type, a.plan = _ptr(x), _ptr(ntype), plan.ptr
+        a.w_qkv, a.b_qkv, a.w_a, a.b_a = _ptr(pk["w_qkv"]), _ptr(pk["b_qkv"]), _ptr(pk["w_a"]), _ptr(pk["b_a"])
+        a.relation_att, a.relation_msg, a.relation_pri = _ptr(pk["ratt"]), _ptr(pk["rmsg"]), _ptr(pk["rpri"])
+        a.skip, a.ln_w, a.ln_b = _ptr(pk["skip"]), _ptr(pk["ln_w"]), _ptr(pk["ln_b"])
+        a.rte_emb, a.rte_w, a.rte_b = _ptr(pk.get("rte_emb")), _ptr(pk.get("rte_w")), _ptr(pk.get("rte_b"))
+        a.workspace, a.workspace_bytes = _ptr(ws), ws.numel()
+        a.out, a.att_out = _ptr(out), _ptr(att)
+        _lib.check(lib.hgt_conv_forward(C.byref(a), _stream()), "hgt_conv_forward")
+        self.att = att
+        return out
+
+    def __repr__(self):
+        return '{}(in_dim={}, out_dim={}, num_types={}, num_types={})'.format(
+            self.__class__.__name__, self.in_dim, self.out_dim, self.num_types, self.num_relations)
+
+
+class GeneralConv(nn.Module):
+    """The reference's layer dispatcher (conv.py:303-323) for the in-scope convolution.  Only
+    conv_name == 'hgt' is part of the MI355X hot path (SURVEY.md section 2, rows 4-5 are out of scope)."""
+
+    def __init__(self, conv_name, in_hid, out_hid, num_types, num_relations, n_heads, dropout, use_norm=True, use_RTE=True):
+        super().__init__()
+        self.conv_name = conv_name
+        if conv_name != 'hgt':
+            raise NotImplementedError("pyhgt_amd implements conv_name='hgt' only; %r is outside the accelerated path" % conv_name)
+        self.base_conv = HGTConv(in_hid, out_hid, num_types, num_relations, n_heads, dropout, use_norm, use_RTE)
+
+    def forward(self, meta_xs, node_type, edge_index, edge_type, edge_time):
+        return self.base_conv(meta_xs, node_type, edge_index, edge_type, edge_time)
+
+
+def install_into(conv_module):
+    """Plug this implementation into the reference: `import pyHGT.conv as c; install_into(c)` makes
+    the reference's GeneralConv / model.GNN construct pyhgt_amd.HGTConv for conv_name='hgt'
+    (GeneralConv looks the class up in its module globals at construction time, conv.py:308)."""
+    conv_module.HGTConv = HGTConv
+    return conv_module

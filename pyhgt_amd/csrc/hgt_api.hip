@@ -1,0 +1,173 @@
+// C-ABI glue: error strings, layout helper and the whole-layer entry point that enqueues every
+// kernel of one HGTConv.forward (conv.py:56-134, eval mode) on the caller's stream.
+#include "hgt_common.h"
+
+namespace {
+
+struct ConvWorkspace {
+    uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p;
+    uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, total;
+};
+
+static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim, int out_dim, int T, int R, int H, int use_rte,
+                                    const hgt_layout& lay) {
+    ConvWorkspace w;
+    uint64_t o = 0;
+    auto take = [&](uint64_t bytes) { uint64_t r = o; o = hgt_align_up(o + bytes, 256); return r; };
+    const uint64_t dp = (uint64_t)lay.d_pad;
+    w.off_q = take((uint64_t)NQ * dp * 4);
+    w.off_k = take((uint64_t)N * dp * 4);
+    w.off_v = take((uint64_t)N * dp * 4);
+    w.off_logits = take((uint64_t)E * H * 4);
+    w.off_agg = take((uint64_t)NQ * dp * 4);
+    w.off_trans = take((uint64_t)NQ * out_dim * 4);
+    w.off_att_t = take((uint64_t)R * H * lay.dk_pad * lay.dk_pad * 4);
+    w.off_msg_p = take((uint64_t)R * H * lay.dk_pad * lay.dk_pad * 4);
+    if (use_rte) {
+        w.off_rte_lin = take((uint64_t)HGT_RTE_LEN * in_dim * 4);
+        w.off_rte_k = take((uint64_t)T * HGT_RTE_LEN * dp * 4);
+        w.off_rte_v = take((uint64_t)T * HGT_RTE_LEN * dp * 4);
+        w.off_rte_rows = take((uint64_t)T * HGT_RTE_LEN * 4);
+        w.off_rte_off = take((uint64_t)(T + 1) * 4);
+    } else {
+        w.off_rte_lin = w.off_rte_k = w.off_rte_v = w.off_rte_rows = w.off_rte_off = 0;
+    }
+    w.total = o;
+    return w;
+}
+
+// rows[i] = i % 240 for i < T*240 ; off[g] = g*240
+__global__ void k_rte_row_lists(int T, int32_t* __restrict__ rows, int32_t* __restrict__ off) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < T * HGT_RTE_LEN) rows[i] = i % HGT_RTE_LEN;
+    if (i <= T) off[i] = i * HGT_RTE_LEN;
+}
+
+}  // namespace
+
+extern "C" const char* hgt_strerror(int code) {
+    switch (code) {
+        case HGT_OK: return "ok";
+        case HGT_ERR_INVALID_ARG: return "invalid argument";
+        case HGT_ERR_UNSUPPORTED: return "unsupported shape (need d % n_heads == 0, 64 % n_heads == 0, n_heads <= 16, d_pad <= 512)";
+        case HGT_ERR_WORKSPACE: return "workspace too small";
+        case HGT_ERR_TOO_LARGE: return "problem exceeds 32-bit plan indices";
+        case HGT_ERR_LAUNCH: return "HIP launch/runtime error";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int hgt_abi_version(void) { return HGT_ABI_VERSION; }
+
+extern "C" int hgt_layout_for(int32_t d_out, int32_t n_heads, hgt_layout* out) {
+    if (!out) return HGT_ERR_INVALID_ARG;
+    int rc = hgt_layout_compute(d_out, n_heads, out);
+    if (rc != HGT_OK) return rc;
+    if (out->vec > 8 || 64 / n_heads < 4) return HGT_ERR_UNSUPPORTED;   // kernels instantiated for vec <= 8, >= 4 lanes per head
+    return HGT_OK;
+}
+
+extern "C" int hgt_conv_workspace_bytes(int64_t n_nodes, int64_t n_edges, int32_t in_dim, int32_t out_dim, int32_t n_types,
+                                        int32_t n_relations, int32_t n_heads, int32_t use_rte, uint64_t* out) {
+    if (!out || n_nodes < 0 || n_edges < 0 || in_dim <= 0) return HGT_ERR_INVALID_ARG;
+    hgt_layout lay;
+    int rc = hgt_layout_for(out_dim, n_heads, &lay);
+    if (rc != HGT_OK) return rc;
+    *out = conv_workspace(n_nodes, n_nodes, n_edges, in_dim, out_dim, n_types, n_relations, n_heads, use_rte, lay).total;
+    return HGT_OK;
+}
+
+extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
+    if (!a) return HGT_ERR_INVALID_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t N = a->n_nodes, E = a->n_edges;
+    const int64_t NQ = (a->n_q_rows > 0 && a->n_q_rows <= N) ? a->n_q_rows : N;
+    const int T = a->n_types, R = a->n_relations, H = a->n_heads, din = a->in_dim, dout = a->out_dim;
+    if (!a->x || !a->node_type || !a->plan || !a->w_qkv || !a->b_qkv || !a->w_a || !a->b_a || !a->relation_att ||
+        !a->relation_msg || !a->relation_pri || !a->skip || !a->workspace || !a->out)
+        return HGT_ERR_INVALID_ARG;
+    if (din != dout) return HGT_ERR_INVALID_ARG;   // the skip connection of conv.py:131 needs in_dim == out_dim
+    if (a->use_norm && (!a->ln_w || !a->ln_b)) return HGT_ERR_INVALID_ARG;
+    if (a->use_rte && (!a->rte_emb || !a->rte_w || !a->rte_b)) return HGT_ERR_INVALID_ARG;
+    if (a->want_att && !a->att_out) return HGT_ERR_INVALID_ARG;
+    hgt_layout lay;
+    int rc = hgt_layout_for(dout, H, &lay);
+    if (rc != HGT_OK) return rc;
+    const int dp = lay.d_pad;
+    ConvWorkspace w = conv_workspace(N, N, E, din, dout, T, R, H, a->use_rte, lay);   // sized for NQ == N (upper bound)
+    if (a->workspace_bytes < w.total) return HGT_ERR_WORKSPACE;
+    if (N == 0) return HGT_OK;
+    char* wb = (char*)a->workspace;
+    float* Q = (float*)(wb + w.off_q);
+    float* K = (float*)(wb + w.off_k);
+    float* V = (float*)(wb + w.off_v);
+    float* logits = (float*)(wb + w.off_logits);
+    float* agg = (float*)(wb + w.off_agg);
+    float* trans = (float*)(wb + w.off_trans);
+    float* att_t = (float*)(wb + w.off_att_t);
+    float* msg_p = (float*)(wb + w.off_msg_p);
+    float* rte_k = nullptr;
+    float* rte_v = nullptr;
+
+    hgt_plan_rows pr;
+    rc = hgt_plan_row_lists(a->plan, N, E, T, R, &pr);
+    if (rc != HGT_OK) return rc;
+
+    // (1) relation matrices: fold pri/sqrt(dk), transpose att, zero-pad heads (conv.py:98-99,104)
+    rc = hgt_relation_pack(a->relation_att, a->relation_msg, a->relation_pri, R, H, lay.d_k, lay.dk_pad, att_t, msg_p, stream);
+    if (rc != HGT_OK) return rc;
+
+    // (2) typed projections once per NODE (conv.py:96-97,103 did them per edge)
+    const int64_t wstride = (int64_t)3 * dp * din;
+    if (NQ == N) {
+        rc = hgt_typed_linear(a->x, din, pr.rows_all, pr.off_all, T, N, din, 3 * dp, a->w_qkv, wstride, a->b_qkv, 3 * dp, Q, K, V, dp, 0,
+                              0, a->precision, stream);
+        if (rc != HGT_OK) return rc;
+    } else {
+        rc = hgt_typed_linear(a->x, din, pr.rows_q, pr.off_q, T, NQ, din, dp, a->w_qkv, wstride, a->b_qkv, 3 * dp, Q, nullptr, nullptr, dp,
+                              0, 0, a->precision, stream);
+        if (rc != HGT_OK) return rc;
+        rc = hgt_typed_linear(a->x, din, pr.rows_all, pr.off_all, T, N, din, 2 * dp, a->w_qkv + (int64_t)dp * din, wstride,
+                              a->b_qkv + dp, 3 * dp, K, V, nullptr, dp, 0, 0, a->precision, stream);
+        if (rc != HGT_OK) return rc;
+    }
+
+    // (3) temporal tables: rte_k[t][p] = (emb[p] W_rte^T + b_rte) W_k[t]^T  (conv.py:91-92,298-299 hoisted off the edges)
+    if (a->use_rte) {
+        float* rte_lin = (float*)(wb + w.off_rte_lin);
+        rte_k = (float*)(wb + w.off_rte_k);
+        rte_v = (float*)(wb + w.off_rte_v);
+        int32_t* rrows = (int32_t*)(wb + w.off_rte_rows);
+        int32_t* roff = (int32_t*)(wb + w.off_rte_off);
+        const int nthr = T * HGT_RTE_LEN;
+        k_rte_row_lists<<<(nthr + 255) / 256, 256, 0, stream>>>(T, rrows, roff);
+        rc = hgt_typed_linear(a->rte_emb, din, rrows, roff, 1, HGT_RTE_LEN, din, din, a->rte_w, 0, a->rte_b, 0, rte_lin, nullptr, nullptr,
+                              din, 1, 0, a->precision, stream);
+        if (rc != HGT_OK) return rc;
+        rc = hgt_typed_linear(rte_lin, din, rrows, roff, T, (int64_t)T * HGT_RTE_LEN, din, 2 * dp, a->w_qkv + (int64_t)dp * din, wstride,
+                              nullptr, 0, rte_k, rte_v, nullptr, dp, 1, 0, a->precision, stream);
+        if (rc != HGT_OK) return rc;
+    }
+
+    // (4) edge phase
+    if (hipMemsetAsync(agg, 0, (size_t)NQ * dp * 4, stream) != hipSuccess) return HGT_ERR_LAUNCH;
+    if (E > 0) {
+        rc = hgt_edge_logits(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, stream);
+        if (rc != HGT_OK) return rc;
+        rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);
+        if (rc != HGT_OK) return rc;
+        rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, stream);
+        if (rc != HGT_OK) return rc;
+        if (a->want_att) {
+            rc = hgt_att_export(a->plan, N, E, T, R, H, logits, a->att_out, stream);
+            if (rc != HGT_OK) return rc;
+        }
+    }
+
+    // (5) update: a_linear(gelu(agg)) -> gated skip -> LayerNorm (conv.py:119-133)
+    rc = hgt_typed_linear(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, a->w_a, (int64_t)dout * dp, a->b_a, dout, trans, nullptr, nullptr,
+                          dout, 0, 1, a->precision, stream);
+    if (rc != HGT_OK) return rc;
+    rc = hgt_node_update(trans, a->x, din, a->node_type, a->skip, a->ln_w, a->ln_b, a->use_norm, NQ, dout, T, a->out, stream);
+    return rc;
+}

@@ -1,0 +1,107 @@
+// Shared definitions of the libhgt_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hgt_hip.h"
+
+#define HGT_TD 64        // destination nodes per tile (sort key = (dst/TD, relation, dst%TD))
+#define HGT_CH 256       // max edges per wavefront work item
+#define HGT_WAVE 64
+
+#define HGT_CHECK_LAUNCH()                          \
+    do {                                            \
+        if (hipGetLastError() != hipSuccess) return HGT_ERR_LAUNCH; \
+    } while (0)
+
+static inline uint64_t hgt_align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+// Device-written header at the start of the plan buffer.
+struct HgtPlanHeader {
+    int32_t n_items;      // number of valid work items (written by the build)
+    int32_t bad_index;    // != 0 if an edge endpoint was outside [0, n_nodes) / target >= n_q_rows
+    int32_t pad[14];
+};
+
+// One wavefront work item: sorted edge positions [beg, end) all in one (dst tile, relation) bucket.
+struct __attribute__((aligned(16))) HgtItem {
+    int32_t beg, end, rel, tile;
+};
+
+// Byte offsets of the arrays inside the plan buffer; a pure function of (N, E, T, R).
+struct HgtPlanLayout {
+    uint64_t off_hdr, off_esrc, off_edst, off_ertei, off_eid, off_segptr, off_items;
+    uint64_t off_rows_all, off_off_all, off_rows_q, off_off_q, total;
+    int64_t n_tiles, n_bins, n_pairs, max_items;
+};
+
+static inline HgtPlanLayout hgt_plan_layout(int64_t N, int64_t E, int32_t T, int32_t R) {
+    HgtPlanLayout L;
+    L.n_tiles = (N + HGT_TD - 1) / HGT_TD;
+    L.n_pairs = L.n_tiles * (R + 1);
+    L.n_bins = L.n_pairs * HGT_TD;
+    L.max_items = L.n_pairs + E / HGT_CH + 1;
+    uint64_t o = 0;
+    auto take = [&](uint64_t bytes) { uint64_t r = o; o = hgt_align_up(o + bytes, 256); return r; };
+    L.off_hdr = take(sizeof(HgtPlanHeader));
+    L.off_esrc = take((uint64_t)E * 4);
+    L.off_edst = take((uint64_t)E * 4);
+    L.off_ertei = take((uint64_t)E * 2);
+    L.off_eid = take((uint64_t)E * 4);
+    L.off_segptr = take((uint64_t)(L.n_bins + 1) * 4);
+    L.off_items = take((uint64_t)L.max_items * sizeof(HgtItem));
+    L.off_rows_all = take((uint64_t)N * 4);
+    L.off_off_all = take((uint64_t)(T + 2) * 4);
+    L.off_rows_q = take((uint64_t)N * 4);
+    L.off_off_q = take((uint64_t)(T + 2) * 4);
+    L.total = o;
+    return L;
+}
+
+struct HgtPlanView {
+    const HgtPlanHeader* hdr;
+    const int32_t* esrc;
+    const int32_t* edst;
+    const uint16_t* ertei;
+    const int32_t* eid;
+    const int32_t* segptr;
+    const HgtItem* items;
+    const int32_t* rows_all;
+    const int32_t* off_all;
+    const int32_t* rows_q;
+    const int32_t* off_q;
+    HgtPlanLayout L;
+};
+
+static inline HgtPlanView hgt_plan_view(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R) {
+    HgtPlanView v;
+    v.L = hgt_plan_layout(N, E, T, R);
+    const char* b = (const char*)plan;
+    v.hdr = (const HgtPlanHeader*)(b + v.L.off_hdr);
+    v.esrc = (const int32_t*)(b + v.L.off_esrc);
+    v.edst = (const int32_t*)(b + v.L.off_edst);
+    v.ertei = (const uint16_t*)(b + v.L.off_ertei);
+    v.eid = (const int32_t*)(b + v.L.off_eid);
+    v.segptr = (const int32_t*)(b + v.L.off_segptr);
+    v.items = (const HgtItem*)(b + v.L.off_items);
+    v.rows_all = (const int32_t*)(b + v.L.off_rows_all);
+    v.off_all = (const int32_t*)(b + v.L.off_off_all);
+    v.rows_q = (const int32_t*)(b + v.L.off_rows_q);
+    v.off_q = (const int32_t*)(b + v.L.off_off_q);
+    return v;
+}
+
+static inline int hgt_layout_compute(int32_t d_out, int32_t n_heads, hgt_layout* o) {
+    if (d_out <= 0 || n_heads <= 0 || d_out % n_heads != 0) return HGT_ERR_INVALID_ARG;
+    if (n_heads > 64 || (64 % n_heads) != 0) return HGT_ERR_UNSUPPORTED;
+    int dk = d_out / n_heads;
+    int lph = 64 / n_heads;                 // lanes per head
+    int vec = 1;
+    while (vec * lph < dk) vec *= 2;
+    if (vec > 16) return HGT_ERR_UNSUPPORTED;
+    o->d_k = dk;
+    o->vec = vec;
+    o->dk_pad = vec * lph;
+    o->d_pad = 64 * vec;
+    return HGT_OK;
+}

@@ -1,0 +1,424 @@
+// Edge phase of HGTConv.forward: relation-aware attention logits, per-target softmax, attention-
+// weighted aggregation.  Replaces conv.py:98-99,104,108-111 + PyG's gathers / scatter-add
+// (conv.py:13,57) without ever materialising an E x d tensor.
+//
+// Algebra (validated against the reference):
+//     s_e,h   = <q_i,h , k_j,h A[r,h]> pri[r,h]/sqrt(dk)  =  <A'[r,h] q_i,h , k_j,h>       (target-side transform)
+//     agg_i,h = sum_e att_e (v_j,h M[r,h])                =  sum_r (sum_{e in (i,r)} att_e v_j,h) M[r,h]
+// so the d_k x d_k relation matrices are applied once per (target, relation) SEGMENT, not per
+// edge, and the per-edge work is one gathered row + a dot (pass 1) or an axpy (pass 2): HBM-bound.
+//
+// Work decomposition: edges are sorted by (dst tile of 64, relation, dst); one 64-lane wavefront
+// takes one work item = <= 256 consecutive edges of one (tile, relation).  All its segments share
+// the relation, so the wave keeps its slice of the relation matrix in REGISTERS (dk_pad*vec floats
+// per lane, 128 for d=256/H=8) for the whole item instead of re-reading 32 KB per segment.
+// Lane l owns `VEC` contiguous floats of a row (one coalesced 64*VEC*4-byte row read per
+// wavefront instruction); head h = l / LPH; per-head dot products are reduced over LPH adjacent
+// lanes with DPP.  Rows for the next UN edges are requested before the current ones are consumed.
+#include "hgt_common.h"
+
+namespace {
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// sum over the LPH adjacent lanes that hold one head; every lane of the group gets the total
+template <int LPH>
+__device__ __forceinline__ float head_allreduce(float v) {
+    if (LPH >= 2) v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+    if (LPH >= 4) v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+    if (LPH >= 8) v += dpp_f<0x141>(v);   // row_half_mirror
+    if (LPH >= 16) v += dpp_f<0x140>(v);  // row_mirror
+    if (LPH >= 32) v += __shfl_xor(v, 16);
+    if (LPH >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&o)[VEC]) {
+    if constexpr (VEC == 1) {
+        o[0] = p[0];
+    } else if constexpr (VEC == 2) {
+        float2 t = *reinterpret_cast<const float2*>(p);
+        o[0] = t.x; o[1] = t.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC / 4; ++i) {
+            float4 t = *reinterpret_cast<const float4*>(p + 4 * i);
+            o[4 * i] = t.x; o[4 * i + 1] = t.y; o[4 * i + 2] = t.z; o[4 * i + 3] = t.w;
+        }
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec_lds(float* p, const float (&o)[VEC]) {
+    if constexpr (VEC == 1) {
+        p[0] = o[0];
+    } else if constexpr (VEC == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2(o[0], o[1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC / 4; ++i) *reinterpret_cast<float4*>(p + 4 * i) = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+    }
+}
+
+// y[i] = sum_j xin[j] * F[j][i]  over one head (DKP inputs, this lane's VEC outputs).
+// xin is spread over the LPH lanes of the head -> bounced through a wave-private LDS row.
+// F comes from registers (HOIST) or from the packed relation matrix in global memory (L1/L2).
+template <int VEC, int DKP, bool HOIST>
+__device__ __forceinline__ void head_matvec(const float (&xv)[VEC], float* bounce, int lane, int h,
+                                            const float (&frag)[HOIST ? DKP : 1][VEC], const float* __restrict__ fglob,
+                                            float (&y)[VEC]) {
+    store_vec_lds<VEC>(bounce + lane * VEC, xv);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) y[i] = 0.0f;
+    const float* xb = bounce + h * DKP;
+#pragma unroll
+    for (int j4 = 0; j4 < DKP / 4; ++j4) {
+        const float4 xx = *reinterpret_cast<const float4*>(xb + 4 * j4);
+        const float xs[4] = {xx.x, xx.y, xx.z, xx.w};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if constexpr (HOIST) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) y[i] = fmaf(xs[jj], frag[4 * j4 + jj][i], y[i]);
+            } else {
+                float f[VEC];
+                load_vec<VEC>(fglob + (4 * j4 + jj) * DKP, f);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) y[i] = fmaf(xs[jj], f[i], y[i]);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();   // the bounce row may be rewritten only after every lane has read it
+}
+
+template <int VEC>
+constexpr int unroll_for() { return VEC <= 4 ? 8 : (VEC == 8 ? 4 : 2); }
+
+// ---------------------------------------------------------------------------------------------
+// pass 1: logits
+// ---------------------------------------------------------------------------------------------
+template <int VEC, int LPH>
+__global__ __launch_bounds__(256) void k_edge_logits(
+    const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
+    const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ Q,
+    const float* __restrict__ K, const float* __restrict__ rteK, const float* __restrict__ attT, float* __restrict__ logits, int R) {
+    constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = unroll_for<VEC>();
+    constexpr bool HOIST = (DKP * VEC <= 128);
+    __shared__ __attribute__((aligned(16))) float s_bounce[4][DP];
+
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blockIdx.x * 4 + wib;
+    if (item >= hdr->n_items) return;
+    const HgtItem it = items[item];
+    const int beg = __builtin_amdgcn_readfirstlane(it.beg), end = __builtin_amdgcn_readfirstlane(it.end);
+    const int rel = __builtin_amdgcn_readfirstlane(it.rel);
+    const int h = lane / LPH, p = lane % LPH;
+
+    if (rel >= R) {   // edges no meta relation claims: logit 0 (conv.py:68)
+        for (int64_t i = (int64_t)beg * H + lane; i < (int64_t)end * H; i += 64) logits[i] = 0.0f;
+        return;
+    }
+
+    float* bounce = s_bounce[wib];
+    const float* __restrict__ fglob = attT + ((int64_t)(rel * H + h) * DKP) * DKP + p * VEC;
+    float frag[HOIST ? DKP : 1][VEC];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int j = 0; j < DKP; ++j) load_vec<VEC>(fglob + j * DKP, frag[j]);
+    }
+
+    int cur_dst = -1;
+    float qt[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) qt[i] = 0.0f;
+
+    for (int base = beg; base < end; base += 64) {
+        const int nb = min(64, end - base);
+        const int li = base + min(lane, nb - 1);
+        const int my_src = esrc[li], my_dst = edst[li];
+        const int my_rte = rteK ? (int)ertei[li] : 0;
+        for (int i0 = 0; i0 < nb; i0 += UN) {
+            float kr[UN][VEC], qr[UN][VEC];
+            int dsts[UN];
+            bool newq[UN];
+            int prev = cur_dst;
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int idx = min(i0 + u, nb - 1);
+                const int s = __builtin_amdgcn_readlane(my_src, idx);
+                const int dd = __builtin_amdgcn_readlane(my_dst, idx);
+                load_vec<VEC>(K + (int64_t)s * DP + lane * VEC, kr[u]);
+                if (rteK) {
+                    const int ri = __builtin_amdgcn_readlane(my_rte, idx);
+                    float t[VEC];
+                    load_vec<VEC>(rteK + (int64_t)ri * DP + lane * VEC, t);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) kr[u][i] += t[i];
+                }
+                dsts[u] = dd;
+                newq[u] = (dd != prev);
+                if (newq[u]) load_vec<VEC>(Q + (int64_t)dd * DP + lane * VEC, qr[u]);
+                prev = dd;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (i0 + u < nb) {
+                    if (newq[u]) {
+                        head_matvec<VEC, DKP, HOIST>(qr[u], bounce, lane, h, frag, fglob, qt);
+                        cur_dst = dsts[u];
+                    }
+                    float part = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) part = fmaf(qt[i], kr[u][i], part);
+                    part = head_allreduce<LPH>(part);
+                    if (p == 0) logits[(int64_t)(base + i0 + u) * H + h] = part;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax over the in-edges of each target, per head (PyG utils.softmax, conv.py:108); in place
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_edge_softmax(const int32_t* __restrict__ segptr, float* __restrict__ s, int64_t NQ,
+                                                      int H, int R) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t dst = idx / H;
+    const int h = (int)(idx % H);
+    if (dst >= NQ) return;
+    const int64_t tile = dst / HGT_TD, dl = dst % HGT_TD;
+    float m = -INFINITY;
+    for (int r = 0; r <= R; ++r) {
+        const int64_t b = (tile * (R + 1) + r) * HGT_TD + dl;
+        const int e0 = segptr[b], e1 = segptr[b + 1];
+        for (int e = e0; e < e1; ++e) m = fmaxf(m, s[(int64_t)e * H + h]);
+    }
+    float z = 0.0f;
+    for (int r = 0; r <= R; ++r) {
+        const int64_t b = (tile * (R + 1) + r) * HGT_TD + dl;
+        const int e0 = segptr[b], e1 = segptr[b + 1];
+        for (int e = e0; e < e1; ++e) z += expf(s[(int64_t)e * H + h] - m);
+    }
+    const float inv = 1.0f / (z + 1e-16f);
+    for (int r = 0; r <= R; ++r) {
+        const int64_t b = (tile * (R + 1) + r) * HGT_TD + dl;
+        const int e0 = segptr[b], e1 = segptr[b + 1];
+        for (int e = e0; e < e1; ++e) {
+            const int64_t o = (int64_t)e * H + h;
+            s[o] = expf(s[o] - m) * inv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass 2: aggregation
+// ---------------------------------------------------------------------------------------------
+template <int VEC, int LPH>
+__global__ __launch_bounds__(256) void k_edge_aggregate(
+    const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
+    const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ att,
+    const float* __restrict__ V, const float* __restrict__ rteV, const float* __restrict__ msgP, float* __restrict__ agg, int R) {
+    constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = unroll_for<VEC>();
+    constexpr bool HOIST = (DKP * VEC <= 128);
+    __shared__ __attribute__((aligned(16))) float s_bounce[4][DP];
+
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blockIdx.x * 4 + wib;
+    if (item >= hdr->n_items) return;
+    const HgtItem it = items[item];
+    const int beg = __builtin_amdgcn_readfirstlane(it.beg), end = __builtin_amdgcn_readfirstlane(it.end);
+    const int rel = __builtin_amdgcn_readfirstlane(it.rel);
+    if (rel >= R) return;   // unclaimed edges carry no message (conv.py:69)
+    const int h = lane / LPH, p = lane % LPH;
+
+    float* bounce = s_bounce[wib];
+    const float* __restrict__ fglob = msgP + ((int64_t)(rel * H + h) * DKP) * DKP + p * VEC;
+    float frag[HOIST ? DKP : 1][VEC];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int j = 0; j < DKP; ++j) load_vec<VEC>(fglob + j * DKP, frag[j]);
+    }
+
+    int cur_dst = -1;
+    float U[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
+
+    auto flush = [&]() {
+        if (cur_dst >= 0) {
+            float z[VEC];
+            head_matvec<VEC, DKP, HOIST>(U, bounce, lane, h, frag, fglob, z);
+            float* o = agg + (int64_t)cur_dst * DP + lane * VEC;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(o + i, z[i]);
+        }
+    };
+
+    for (int base = beg; base < end; base += 64) {
+        const int nb = min(64, end - base);
+        const int li = base + min(lane, nb - 1);
+        const int my_src = esrc[li], my_dst = edst[li];
+        const int my_rte = rteV ? (int)ertei[li] : 0;
+        for (int i0 = 0; i0 < nb; i0 += UN) {
+            float vr[UN][VEC], al[UN];
+            int dsts[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int idx = min(i0 + u, nb - 1);
+                const int s = __builtin_amdgcn_readlane(my_src, idx);
+                dsts[u] = __builtin_amdgcn_readlane(my_dst, idx);
+                load_vec<VEC>(V + (int64_t)s * DP + lane * VEC, vr[u]);
+                al[u] = att[(int64_t)(base + idx) * H + h];
+                if (rteV) {
+                    const int ri = __builtin_amdgcn_readlane(my_rte, idx);
+                    float t[VEC];
+                    load_vec<VEC>(rteV + (int64_t)ri * DP + lane * VEC, t);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) vr[u][i] += t[i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (i0 + u < nb) {
+                    if (dsts[u] != cur_dst) {
+                        flush();
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
+                        cur_dst = dsts[u];
+                    }
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) U[i] = fmaf(al[u], vr[u][i], U[i]);
+                }
+            }
+        }
+    }
+    flush();
+}
+
+__global__ void k_att_export(const int32_t* __restrict__ eid, const float* __restrict__ att, float* __restrict__ out, int64_t E, int H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E * H) return;
+    const int64_t p = i / H;
+    const int h = (int)(i % H);
+    out[(int64_t)eid[p] * H + h] = att[i];
+}
+
+__global__ void k_relation_pack(const float* __restrict__ ratt, const float* __restrict__ rmsg, const float* __restrict__ rpri,
+                                int R, int H, int dk, int dkp, float* __restrict__ attT, float* __restrict__ msgP) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)R * H * dkp * dkp;
+    if (i >= total) return;
+    const int b = (int)(i % dkp), a = (int)((i / dkp) % dkp);
+    const int64_t rh = i / ((int64_t)dkp * dkp);
+    float va = 0.0f, vm = 0.0f;
+    if (a < dk && b < dk) {
+        // attT[r][h][c=a][k=b] = att[r][h][k=b][c=a] * pri / sqrt(dk)
+        va = ratt[(rh * dk + b) * dk + a] * rpri[rh] / sqrtf((float)dk);
+        vm = rmsg[(rh * dk + a) * dk + b];
+    }
+    attT[i] = va;
+    msgP[i] = vm;
+}
+
+template <template <int, int> class Launcher, typename... Args>
+int dispatch_layout(int vec, int lph, Args... args) {
+#define HGT_CASE(V, L) \
+    if (vec == V && lph == L) return Launcher<V, L>::run(args...);
+    HGT_CASE(1, 4) HGT_CASE(2, 4) HGT_CASE(4, 4) HGT_CASE(8, 4)
+    HGT_CASE(1, 8) HGT_CASE(2, 8) HGT_CASE(4, 8) HGT_CASE(8, 8)
+    HGT_CASE(1, 16) HGT_CASE(2, 16) HGT_CASE(4, 16) HGT_CASE(8, 16)
+    HGT_CASE(1, 32) HGT_CASE(2, 32) HGT_CASE(4, 32) HGT_CASE(8, 32)
+    HGT_CASE(1, 64) HGT_CASE(2, 64) HGT_CASE(4, 64) HGT_CASE(8, 64)
+#undef HGT_CASE
+    return HGT_ERR_UNSUPPORTED;
+}
+
+template <int VEC, int LPH>
+struct LaunchLogits {
+    static int run(const HgtPlanView& pv, const float* Q, const float* K, const float* rteK, const float* attT, float* logits,
+                   int R, hipStream_t stream) {
+        const unsigned blocks = (unsigned)((pv.L.max_items + 3) / 4);
+        k_edge_logits<VEC, LPH><<<blocks, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R);
+        return HGT_OK;
+    }
+};
+
+template <int VEC, int LPH>
+struct LaunchAggregate {
+    static int run(const HgtPlanView& pv, const float* att, const float* V, const float* rteV, const float* msgP, float* agg,
+                   int R, hipStream_t stream) {
+        const unsigned blocks = (unsigned)((pv.L.max_items + 3) / 4);
+        k_edge_aggregate<VEC, LPH><<<blocks, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, att, V, rteV, msgP, agg, R);
+        return HGT_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" int hgt_relation_pack(const float* relation_att, const float* relation_msg, const float* relation_pri,
+                                 int32_t R, int32_t H, int32_t d_k, int32_t dk_pad, float* att_t, float* msg_p, void* stream) {
+    if (!relation_att || !relation_msg || !relation_pri || !att_t || !msg_p || R <= 0 || H <= 0 || d_k <= 0 || dk_pad < d_k)
+        return HGT_ERR_INVALID_ARG;
+    const int64_t total = (int64_t)R * H * dk_pad * dk_pad;
+    k_relation_pack<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(relation_att, relation_msg, relation_pri, R, H,
+                                                                                      d_k, dk_pad, att_t, msg_p);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_edge_logits(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                               const float* Q, const float* K, const float* rte_k, const float* att_t, float* logits, void* stream) {
+    if (!plan || !Q || !K || !att_t || !logits || H <= 0 || 64 % H != 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
+    if (E == 0) return HGT_OK;
+    const int lph = 64 / H;
+    if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
+    HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
+    int rc = dispatch_layout<LaunchLogits>(dk_pad / lph, lph, pv, Q, K, rte_k, att_t, logits, (int)R, (hipStream_t)stream);
+    if (rc != HGT_OK) return rc;
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_edge_softmax(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, float* logits_att,
+                                void* stream) {
+    if (!plan || !logits_att || H <= 0) return HGT_ERR_INVALID_ARG;
+    if (E == 0 || N == 0) return HGT_OK;
+    HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
+    const int64_t threads = N * H;
+    k_edge_softmax<<<(unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream>>>(pv.segptr, logits_att, N, H, R);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_edge_aggregate(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                  const float* att, const float* V, const float* rte_v, const float* msg_p, float* agg, void* stream) {
+    if (!plan || !att || !V || !msg_p || !agg || H <= 0 || 64 % H != 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
+    if (E == 0) return HGT_OK;
+    const int lph = 64 / H;
+    if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
+    HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
+    int rc = dispatch_layout<LaunchAggregate>(dk_pad / lph, lph, pv, att, V, rte_v, msg_p, agg, (int)R, (hipStream_t)stream);
+    if (rc != HGT_OK) return rc;
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_att_export(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, const float* att_sorted,
+                              float* att_out, void* stream) {
+    if (!plan || !att_sorted || !att_out || H <= 0) return HGT_ERR_INVALID_ARG;
+    if (E == 0) return HGT_OK;
+    HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
+    k_att_export<<<(unsigned)((E * H + 255) / 256), 256, 0, (hipStream_t)stream>>>(pv.eid, att_sorted, att_out, E, H);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}

@@ -1,0 +1,276 @@
+// Graph plan build: (edge_index, edge_type, edge_time, node_type) -> sorted, compacted edge
+// arrays + segment table + wavefront work items + typed row lists.  One-off per sampled
+// subgraph (shared by every layer); see include/hgt_hip.h for what it replaces in the reference
+// (PyG propagate gathers called from conv.py:57, the mask cube conv.py:71-84, update masks
+// conv.py:121-123).
+//
+// The stable sorts use rocPRIM's device radix sort (ROCm-native primitive, header-only); the
+// key/fill/segment/item kernels are hand-written.  Everything is enqueued on the caller's stream,
+// nothing synchronises; the number of work items stays on the device (HgtPlanHeader::n_items)
+// and consumers launch the host-side upper bound.
+#include <cstring>
+#include <cstdlib>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "hgt_common.h"
+
+namespace {
+
+struct TmpLayout {
+    uint64_t off_keys_in, off_keys_out, off_vals_in, off_vals_out, off_pair_cnt, off_pair_off;
+    uint64_t off_nkeys_in, off_nkeys_out, off_nvals_in, off_sort_tmp, sort_tmp_bytes, total;
+};
+
+static TmpLayout tmp_layout(int64_t N, int64_t E, const HgtPlanLayout& L, uint64_t sort_tmp_bytes) {
+    TmpLayout t;
+    uint64_t o = 0;
+    auto take = [&](uint64_t bytes) { uint64_t r = o; o = hgt_align_up(o + bytes, 256); return r; };
+    t.off_keys_in = take((uint64_t)E * 4);
+    t.off_keys_out = take((uint64_t)E * 4);
+    t.off_vals_in = take((uint64_t)E * 4);
+    t.off_vals_out = take((uint64_t)E * 4);
+    t.off_pair_cnt = take((uint64_t)(L.n_pairs + 1) * 4);
+    t.off_pair_off = take((uint64_t)(L.n_pairs + 1) * 4);
+    t.off_nkeys_in = take((uint64_t)N * 4);
+    t.off_nkeys_out = take((uint64_t)N * 4);
+    t.off_nvals_in = take((uint64_t)N * 4);
+    t.sort_tmp_bytes = sort_tmp_bytes;
+    t.off_sort_tmp = take(sort_tmp_bytes);
+    t.total = o;
+    return t;
+}
+
+static int key_bits(uint64_t n_values) {
+    int b = 1;
+    while (b < 32 && (1ull << b) < n_values) ++b;
+    return b;
+}
+
+// rocPRIM temp-storage requirement (host-side query, no launch).
+static int sort_tmp_query(int64_t N, int64_t E, int32_t T, const HgtPlanLayout& L, uint64_t* bytes) {
+    size_t a = 0, b = 0, c = 0;
+    uint32_t* kp = nullptr;
+    int32_t* vp = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, a, kp, kp, vp, vp, (size_t)(E > 0 ? E : 1), 0, key_bits((uint64_t)L.n_bins),
+                                  (hipStream_t)0) != hipSuccess) return HGT_ERR_LAUNCH;
+    if (rocprim::radix_sort_pairs(nullptr, b, kp, kp, vp, vp, (size_t)(N > 0 ? N : 1), 0, key_bits((uint64_t)T + 1),
+                                  (hipStream_t)0) != hipSuccess) return HGT_ERR_LAUNCH;
+    if (rocprim::exclusive_scan(nullptr, c, vp, vp, 0, (size_t)(L.n_pairs + 1), rocprim::plus<int32_t>(),
+                                (hipStream_t)0) != hipSuccess) return HGT_ERR_LAUNCH;
+    size_t m = a > b ? a : b;
+    m = m > c ? m : c;
+    *bytes = (uint64_t)m + 256;
+    return HGT_OK;
+}
+
+__global__ void k_init_header(HgtPlanHeader* hdr) {
+    if (threadIdx.x == 0) { hdr->n_items = 0; hdr->bad_index = 0; }
+}
+
+// key = ((dst / TD) * (R+1) + rel') * TD + dst % TD ; rel' = R for edges no meta relation claims
+__global__ void k_edge_keys(const int64_t* __restrict__ ei, int64_t sr, int64_t sc, const int64_t* __restrict__ etype,
+                            const int64_t* __restrict__ ntype, int64_t N, int64_t NQ, int64_t E, int T, int R,
+                            uint32_t* __restrict__ keys, int32_t* __restrict__ vals, HgtPlanHeader* hdr) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int64_t src = ei[e * sc];
+    int64_t dst = ei[sr + e * sc];
+    bool bad = false;
+    if (src < 0 || src >= N) { src = 0; bad = true; }
+    if (dst < 0 || dst >= NQ) { dst = 0; bad = true; }
+    if (bad) hdr->bad_index = 1;
+    int64_t ts = ntype[src], td = ntype[dst], r = etype[e];
+    bool claimed = !bad && ts >= 0 && ts < T && td >= 0 && td < T && r >= 0 && r < R;
+    uint32_t rr = claimed ? (uint32_t)r : (uint32_t)R;
+    uint32_t tile = (uint32_t)(dst / HGT_TD), dl = (uint32_t)(dst % HGT_TD);
+    keys[e] = (tile * (uint32_t)(R + 1) + rr) * HGT_TD + dl;
+    vals[e] = (int32_t)e;
+}
+
+__global__ void k_edge_fill(const int64_t* __restrict__ ei, int64_t sr, int64_t sc, const int64_t* __restrict__ etime,
+                            const int64_t* __restrict__ ntype, int64_t N, int64_t NQ, int64_t E, int T,
+                            const int32_t* __restrict__ order, int32_t* __restrict__ esrc, int32_t* __restrict__ edst,
+                            uint16_t* __restrict__ ertei) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= E) return;
+    int32_t e = order[p];
+    int64_t src = ei[(int64_t)e * sc];
+    int64_t dst = ei[sr + (int64_t)e * sc];
+    if (src < 0 || src >= N) src = 0;
+    if (dst < 0 || dst >= NQ) dst = 0;
+    int64_t ts = ntype[src];
+    if (ts < 0 || ts >= T) ts = 0;
+    int64_t tm = etime ? etime[e] : 0;
+    if (tm < 0) tm = 0;
+    if (tm >= HGT_RTE_LEN) tm = HGT_RTE_LEN - 1;
+    esrc[p] = (int32_t)src;
+    edst[p] = (int32_t)dst;
+    ertei[p] = (uint16_t)(ts * HGT_RTE_LEN + tm);
+}
+
+// segptr[b] = first sorted position whose key >= b (lower bound); segptr[n_bins] = E
+__global__ void k_segptr(const uint32_t* __restrict__ keys_sorted, int64_t E, int64_t n_bins, int32_t* __restrict__ segptr) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_bins) return;
+    int64_t lo = 0, hi = E;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)keys_sorted[mid] < b) lo = mid + 1; else hi = mid;
+    }
+    segptr[b] = (int32_t)lo;
+}
+
+__global__ void k_pair_counts(const int32_t* __restrict__ segptr, int64_t n_pairs, int32_t* __restrict__ cnt) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n_pairs) return;
+    if (j == n_pairs) { cnt[j] = 0; return; }
+    int32_t len = segptr[(j + 1) * HGT_TD] - segptr[j * HGT_TD];
+    cnt[j] = (len + HGT_CH - 1) / HGT_CH;
+}
+
+__global__ void k_items(const int32_t* __restrict__ segptr, const int32_t* __restrict__ pair_off, int64_t n_pairs, int R,
+                        HgtItem* __restrict__ items, HgtPlanHeader* hdr) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n_pairs) return;
+    if (j == n_pairs) { hdr->n_items = pair_off[n_pairs]; return; }
+    int32_t beg = segptr[j * HGT_TD], end = segptr[(j + 1) * HGT_TD];
+    int32_t o = pair_off[j];
+    int32_t rel = (int32_t)(j % (R + 1)), tile = (int32_t)(j / (R + 1));
+    for (int32_t b = beg; b < end; b += HGT_CH) {
+        HgtItem it;
+        it.beg = b;
+        it.end = (b + HGT_CH < end) ? b + HGT_CH : end;
+        it.rel = rel;
+        it.tile = tile;
+        items[o++] = it;
+    }
+}
+
+__global__ void k_node_keys(const int64_t* __restrict__ ntype, int64_t N, int T, uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    int64_t t = ntype[n];
+    keys[n] = (t >= 0 && t < T) ? (uint32_t)t : (uint32_t)T;
+    vals[n] = (int32_t)n;
+}
+
+// off[g] = lower bound of g in the sorted type keys, g = 0..T+1
+__global__ void k_type_offsets(const uint32_t* __restrict__ keys_sorted, int64_t N, int T, int32_t* __restrict__ off) {
+    int g = threadIdx.x;
+    if (g > T + 1) return;
+    int64_t lo = 0, hi = N;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)keys_sorted[mid] < g) lo = mid + 1; else hi = mid;
+    }
+    off[g] = (int32_t)lo;
+}
+
+static inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace
+
+extern "C" int hgt_plan_sizes_for(int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                                  hgt_plan_sizes* out) {
+    if (!out || n_nodes < 0 || n_edges < 0 || n_types <= 0 || n_relations <= 0 || n_types > 250) return HGT_ERR_INVALID_ARG;
+    HgtPlanLayout L = hgt_plan_layout(n_nodes, n_edges, n_types, n_relations);
+    if (n_nodes >= (1ll << 31) - HGT_TD || n_edges >= (1ll << 31) - HGT_CH || (uint64_t)L.n_bins >= (1ull << 32) - 1 ||
+        (int64_t)n_types * HGT_RTE_LEN > 65535)
+        return HGT_ERR_TOO_LARGE;
+    uint64_t st = 0;
+    int rc = sort_tmp_query(n_nodes, n_edges, n_types, L, &st);
+    if (rc != HGT_OK) return rc;
+    TmpLayout t = tmp_layout(n_nodes, n_edges, L, st);
+    out->plan_bytes = L.total;
+    out->tmp_bytes = t.total;
+    out->max_items = L.max_items;
+    out->n_bins = L.n_bins;
+    return HGT_OK;
+}
+
+extern "C" int hgt_plan_row_lists(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types,
+                                  int32_t n_relations, hgt_plan_rows* out) {
+    if (!plan || !out) return HGT_ERR_INVALID_ARG;
+    HgtPlanView v = hgt_plan_view(plan, n_nodes, n_edges, n_types, n_relations);
+    out->rows_all = v.rows_all;
+    out->off_all = v.off_all;
+    out->rows_q = v.rows_q;
+    out->off_q = v.off_q;
+    return HGT_OK;
+}
+
+extern "C" int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col,
+                              const int64_t* edge_type, const int64_t* edge_time, const int64_t* node_type,
+                              int64_t N, int64_t NQ, int64_t E, int32_t T, int32_t R,
+                              void* plan, uint64_t plan_bytes, void* tmp, uint64_t tmp_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    hgt_plan_sizes sz;
+    int rc = hgt_plan_sizes_for(N, E, T, R, &sz);
+    if (rc != HGT_OK) return rc;
+    if (!plan || !tmp || !node_type || (E > 0 && (!edge_index || !edge_type)) || NQ < 0 || NQ > N) return HGT_ERR_INVALID_ARG;
+    if (plan_bytes < sz.plan_bytes || tmp_bytes < sz.tmp_bytes) return HGT_ERR_WORKSPACE;
+
+    HgtPlanLayout L = hgt_plan_layout(N, E, T, R);
+    uint64_t st = 0;
+    sort_tmp_query(N, E, T, L, &st);
+    TmpLayout tl = tmp_layout(N, E, L, st);
+    char* pb = (char*)plan;
+    char* tb = (char*)tmp;
+    HgtPlanHeader* hdr = (HgtPlanHeader*)(pb + L.off_hdr);
+    int32_t* esrc = (int32_t*)(pb + L.off_esrc);
+    int32_t* edst = (int32_t*)(pb + L.off_edst);
+    uint16_t* ertei = (uint16_t*)(pb + L.off_ertei);
+    int32_t* eid = (int32_t*)(pb + L.off_eid);
+    int32_t* segptr = (int32_t*)(pb + L.off_segptr);
+    HgtItem* items = (HgtItem*)(pb + L.off_items);
+    int32_t* rows_all = (int32_t*)(pb + L.off_rows_all);
+    int32_t* off_all = (int32_t*)(pb + L.off_off_all);
+    int32_t* rows_q = (int32_t*)(pb + L.off_rows_q);
+    int32_t* off_q = (int32_t*)(pb + L.off_off_q);
+    uint32_t* keys_in = (uint32_t*)(tb + tl.off_keys_in);
+    uint32_t* keys_out = (uint32_t*)(tb + tl.off_keys_out);
+    int32_t* vals_in = (int32_t*)(tb + tl.off_vals_in);
+    int32_t* pair_cnt = (int32_t*)(tb + tl.off_pair_cnt);
+    int32_t* pair_off = (int32_t*)(tb + tl.off_pair_off);
+    uint32_t* nkeys_in = (uint32_t*)(tb + tl.off_nkeys_in);
+    uint32_t* nkeys_out = (uint32_t*)(tb + tl.off_nkeys_out);
+    int32_t* nvals_in = (int32_t*)(tb + tl.off_nvals_in);
+    void* sort_tmp = (void*)(tb + tl.off_sort_tmp);
+    size_t sort_bytes = (size_t)tl.sort_tmp_bytes;
+
+    const int BS = 256;
+    k_init_header<<<1, 64, 0, stream>>>(hdr);
+    if (E > 0) {
+        k_edge_keys<<<nblk(E, BS), BS, 0, stream>>>(edge_index, stride_row, stride_col, edge_type, node_type, N, NQ, E, T, R,
+                                                   keys_in, vals_in, hdr);
+        // stable: equal (tile, rel, dst) keep original edge order -> deterministic per-segment summation order
+        if (rocprim::radix_sort_pairs(sort_tmp, sort_bytes, keys_in, keys_out, vals_in, eid, (size_t)E, 0,
+                                      key_bits((uint64_t)L.n_bins), stream) != hipSuccess) return HGT_ERR_LAUNCH;
+        k_edge_fill<<<nblk(E, BS), BS, 0, stream>>>(edge_index, stride_row, stride_col, edge_time, node_type, N, NQ, E, T,
+                                                   eid, esrc, edst, ertei);
+    }
+    k_segptr<<<nblk(L.n_bins + 1, BS), BS, 0, stream>>>(keys_out, E, L.n_bins, segptr);
+    k_pair_counts<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(segptr, L.n_pairs, pair_cnt);
+    sort_bytes = (size_t)tl.sort_tmp_bytes;
+    if (rocprim::exclusive_scan(sort_tmp, sort_bytes, pair_cnt, pair_off, 0, (size_t)(L.n_pairs + 1),
+                                rocprim::plus<int32_t>(), stream) != hipSuccess) return HGT_ERR_LAUNCH;
+    k_items<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(segptr, pair_off, L.n_pairs, R, items, hdr);
+
+    // typed row lists: all nodes, and target nodes [0, NQ)
+    if (N > 0) {
+        k_node_keys<<<nblk(N, BS), BS, 0, stream>>>(node_type, N, T, nkeys_in, nvals_in);
+        sort_bytes = (size_t)tl.sort_tmp_bytes;
+        if (rocprim::radix_sort_pairs(sort_tmp, sort_bytes, nkeys_in, nkeys_out, nvals_in, rows_all, (size_t)N, 0,
+                                      key_bits((uint64_t)T + 1), stream) != hipSuccess) return HGT_ERR_LAUNCH;
+    }
+    k_type_offsets<<<1, 256, 0, stream>>>(nkeys_out, N, T, off_all);
+    if (NQ > 0) {
+        sort_bytes = (size_t)tl.sort_tmp_bytes;
+        if (rocprim::radix_sort_pairs(sort_tmp, sort_bytes, nkeys_in, nkeys_out, nvals_in, rows_q, (size_t)NQ, 0,
+                                      key_bits((uint64_t)T + 1), stream) != hipSuccess) return HGT_ERR_LAUNCH;
+    }
+    k_type_offsets<<<1, 256, 0, stream>>>(nkeys_out, NQ, T, off_q);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}

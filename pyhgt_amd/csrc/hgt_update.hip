@@ -1,0 +1,104 @@
+// Node update epilogue (conv.py:129-133) and the halo row gather.
+//
+// One 64-lane wavefront per node row: gated skip connection  y = o*sigmoid(skip[t]) + x*(1-sigmoid(skip[t]))
+// followed by the per-type LayerNorm (eps 1e-5, affine).  Rows whose type is outside [0,T) are
+// written as zeros (the reference's zero-initialised `res`, conv.py:120).
+#include "hgt_common.h"
+
+namespace {
+
+constexpr int MAX_PER_LANE = 16;   // d <= 1024
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_node_update(const float* __restrict__ trans, const float* __restrict__ x, int64_t ldx,
+                                                     const int64_t* __restrict__ ntype, const float* __restrict__ skip,
+                                                     const float* __restrict__ lnw, const float* __restrict__ lnb, int use_norm,
+                                                     int64_t N, int d, int T, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int64_t t = ntype[n];
+    float* __restrict__ o = out + n * d;
+    if (t < 0 || t >= T) {
+        for (int c = lane; c < d; c += 64) o[c] = 0.0f;
+        return;
+    }
+    const float a = 1.0f / (1.0f + expf(-skip[t]));
+    const float* __restrict__ tr = trans + n * d;
+    const float* __restrict__ xr = x + n * ldx;
+    float y[MAX_PER_LANE];
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) {
+        const int c = lane + 64 * j;
+        y[j] = 0.0f;
+        if (c < d) {
+            y[j] = tr[c] * a + xr[c] * (1.0f - a);
+            s += y[j];
+        }
+    }
+    if (use_norm) {
+        const float mean = wave_sum(s) / (float)d;
+        float v = 0.0f;
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            const int c = lane + 64 * j;
+            if (c < d) { const float dlt = y[j] - mean; v += dlt * dlt; }
+        }
+        const float rstd = rsqrtf(wave_sum(v) / (float)d + 1e-5f);
+        const float* __restrict__ w = lnw + t * d;
+        const float* __restrict__ b = lnb + t * d;
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            const int c = lane + 64 * j;
+            if (c < d) o[c] = (y[j] - mean) * rstd * w[c] + b[c];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            const int c = lane + 64 * j;
+            if (c < d) o[c] = y[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ idx,
+                                                     int64_t n, int d, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* __restrict__ src = x + (int64_t)idx[i] * ldx;
+    float* __restrict__ dst = out + i * d;
+    if ((d & 3) == 0 && (ldx & 3) == 0) {
+        for (int c = lane * 4; c < d; c += 256) *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
+    } else {
+        for (int c = lane; c < d; c += 64) dst[c] = src[c];
+    }
+}
+
+}  // namespace
+
+extern "C" int hgt_node_update(const float* trans, const float* x, int64_t ldx, const int64_t* node_type, const float* skip,
+                               const float* ln_w, const float* ln_b, int32_t use_norm, int64_t n_nodes, int32_t d,
+                               int32_t n_types, float* out, void* stream) {
+    if (!trans || !x || !node_type || !skip || !out || d <= 0 || n_nodes < 0 || (use_norm && (!ln_w || !ln_b))) return HGT_ERR_INVALID_ARG;
+    if (d > 64 * MAX_PER_LANE) return HGT_ERR_UNSUPPORTED;
+    if (n_nodes == 0) return HGT_OK;
+    k_node_update<<<(unsigned)((n_nodes + 3) / 4), 256, 0, (hipStream_t)stream>>>(trans, x, ldx, node_type, skip, ln_w, ln_b, use_norm,
+                                                                                 n_nodes, d, n_types, out);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_gather_rows(const float* x, int64_t ldx, const int32_t* idx, int64_t n, int32_t d, float* out, void* stream) {
+    if (!x || !idx || !out || d <= 0 || n < 0) return HGT_ERR_INVALID_ARG;
+    if (n == 0) return HGT_OK;
+    k_gather_rows<<<(unsigned)((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(x, ldx, idx, n, d, out);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}

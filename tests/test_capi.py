@@ -1,0 +1,115 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, the ctypes table matches the header, and the host-side mirror keeps the reference's
+parameter names.  No compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from pyhgt_amd import _lib
+from oracle import hgt_oracle as O
+from oracle.reference_loader import reference_available, load_reference_conv
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "hgt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hgt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "libhgt_hip.so lacks %s" % n
+    assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree"
+
+
+def test_abi_version_and_error_strings():
+    lib = _lib.load()
+    assert lib.hgt_abi_version() == 1
+    assert lib.hgt_strerror(0) == b"ok"
+    assert b"invalid" in lib.hgt_strerror(-1)
+
+
+@pytest.mark.parametrize("d,H,exp", [(64, 4, (16, 16, 64, 1)), (256, 8, (32, 32, 256, 4)), (512, 8, (64, 64, 512, 8)),
+                                     (400, 8, (50, 64, 512, 8)), (100, 2, (50, 64, 128, 2)), (32, 2, (16, 32, 64, 1))])
+def test_head_padded_layout(d, H, exp):
+    lay = _lib.layout_for(d, H)
+    assert (lay.d_k, lay.dk_pad, lay.d_pad, lay.vec) == exp
+
+
+def test_layout_errors_are_codes_not_crashes():
+    lay = _lib.HgtLayout()
+    lib = _lib.load()
+    assert lib.hgt_layout_for(65, 4, ctypes.byref(lay)) == -1       # d % heads != 0
+    assert lib.hgt_layout_for(96, 3, ctypes.byref(lay)) == -2       # 64 % heads != 0
+    assert lib.hgt_layout_for(64, 4, None) == -1
+    with pytest.raises(RuntimeError):
+        _lib.layout_for(96, 3)
+
+
+def test_conv_args_struct_matches_header_field_order():
+    text = open(os.path.join(ROOT, "include", "hgt_hip.h")).read()
+    body = text[text.index("typedef struct hgt_conv_args"):text.index("} hgt_conv_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for name in decl.split(","):
+            fields.append(re.findall(r"([A-Za-z_0-9]+)\s*$", name.strip())[0])
+    assert fields == [f[0] for f in _lib.HgtConvArgs._fields_]
+
+
+def test_module_keeps_reference_state_dict_names():
+    from pyhgt_amd import HGTConv
+    T, R, H, d = 3, 4, 4, 64
+    layer = HGTConv(d, d, T, R, H, 0.2, True, True)
+    sd = O.make_state_dict(d, d, T, R, H, True, True, seed=0)
+    assert set(layer.state_dict().keys()) == set(sd.keys())
+    for k, v in layer.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    assert sum(p.numel() for p in layer.parameters()) == 78035        # SURVEY appendix B probe of the reference
+    layer.load_state_dict(sd)
+    # RTE table is the reference's sinusoid (conv.py:289-294)
+    fresh = HGTConv(d, d, T, R, H).emb.emb.weight
+    assert torch.allclose(fresh, O.sinusoid_table(d), atol=1e-7)
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+def test_state_dict_names_equal_the_live_reference():
+    from pyhgt_amd import HGTConv
+    conv = load_reference_conv()
+    for use_norm, use_rte in ((True, True), (False, False)):
+        ref = conv.HGTConv(32, 32, 2, 3, 4, 0.2, use_norm, use_rte)
+        ours = HGTConv(32, 32, 2, 3, 4, 0.2, use_norm, use_rte)
+        rs, os_ = ref.state_dict(), ours.state_dict()
+        assert list(rs.keys()) == list(os_.keys())
+        assert all(rs[k].shape == os_[k].shape for k in rs)
+        ours.load_state_dict(rs)
+        assert repr(ours) == repr(ref)
+
+
+def test_cpu_input_fails_loudly():
+    from pyhgt_amd import HGTConv
+    layer = HGTConv(16, 16, 2, 2, 2, use_RTE=False).eval()
+    x = torch.randn(4, 16)
+    nt = torch.zeros(4, dtype=torch.long)
+    ei = torch.zeros(2, 3, dtype=torch.long)
+    et = torch.zeros(3, dtype=torch.long)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer(x, nt, ei, et)
+
+
+def test_general_conv_rejects_out_of_scope_layers():
+    from pyhgt_amd import GeneralConv
+    GeneralConv('hgt', 16, 16, 2, 2, 2, 0.2)
+    with pytest.raises(NotImplementedError):
+        GeneralConv('gcn', 16, 16, 2, 2, 2, 0.2)
