@@ -1,0 +1,258 @@
+#!/usr/bin/env python
+"""HGTConv forward benchmark (BASELINE.json metric: edges/s + achieved HBM GB/s).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one HGTConv.forward (eval mode, fp32, plan cached -- the reference reuses one sampled
+graph for all layers and `repeat` optimisation steps, model.py:78-79 / train_paper_field.py:240)
+over a synthetic typed graph that is already resident in HBM.
+  N = 1 : BASELINE.json configs[1]: T=4 R=8, 1M nodes / 10M edges, d=256, H=8, 4-argument form
+          (use_RTE=False), LayerNorm on.
+  N > 1 : weak scaling -- every rank owns 1M target nodes and their 10M in-edges; sources are
+          uniform over all N*1M nodes; halo source rows come over one RCCL all-to-all per step
+          (pyhgt_amd/dist.py); value = total edges of all ranks / max-over-ranks time.
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant kernel,
+timed with HIP events on the launch stream during the timed steps) and `cpu_baseline` (the CPU
+port of the reference algorithm, oracle/hgt_oracle.py, on a bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+PHASES = ["project_qkv", "edge_logits", "edge_softmax", "edge_aggregate", "a_linear", "node_update"]
+
+
+def algorithmic_bytes(N, E, d, use_rte):
+    """SURVEY.md section 8(d) minimal-traffic model, split per kernel:
+    whole layer = E*(8d+24) + N*(28d+8) (+8E with RTE)."""
+    per = {
+        "project_qkv": N * (16 * d + 8),             # read x, write Q,K,V, node_type
+        "edge_logits": E * (4 * d + 12 + (4 if use_rte else 0)) + N * 4 * d,   # K row + ids per edge, Q row per target
+        "edge_softmax": 0,
+        "edge_aggregate": E * (4 * d + 12 + (4 if use_rte else 0)),             # V row + ids per edge
+        "a_linear": 0,
+        "node_update": N * 8 * d,                    # read x (skip), write out
+    }
+    per["layer"] = sum(per.values())
+    return per
+
+
+class HipEvents:
+    """hipEvent_t through ctypes on libamdhip64 (events are recorded on the launch stream by
+    hgt_conv_forward itself, include/hgt_hip.h `phase_events`)."""
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [C.c_void_p]
+
+    def make_set(self, n):
+        arr = (C.c_void_p * n)()
+        for i in range(n):
+            ev = C.c_void_p()
+            assert self.hip.hipEventCreate(C.byref(ev)) == 0
+            arr[i] = ev
+        return arr
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_float()
+        self.hip.hipEventSynchronize(b)
+        rc = self.hip.hipEventElapsedTime(C.byref(ms), a, b)
+        assert rc == 0, "hipEventElapsedTime rc=%d" % rc
+        return float(ms.value)
+
+
+def cpu_baseline(d, H, T, R):
+    """The reference-cost CPU port on a bounded sample of the c2 recipe (1/10 scale)."""
+    from oracle import hgt_oracle as O
+    from pyhgt_amd.synth import synthetic_typed_graph
+    N, E = 100_000, 1_000_000
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = O.make_state_dict(d, d, T, R, H, True, False, seed=0)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=0)
+    with torch.no_grad():
+        O.forward_meta_relation_port(sd, T, R, H, x[:2000], nt[:2000], ei[:, :0], et[:0], None, use_RTE=False)  # warm
+        t0 = time.time()
+        reps = 0
+        while reps < 2 or (time.time() - t0 < 10.0 and reps < 4):
+            O.forward_meta_relation_port(sd, T, R, H, x, nt, ei, et, None, use_RTE=False)
+            reps += 1
+        dt = (time.time() - t0) / reps
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": E / dt, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "c2 recipe at 1/10 scale (T4 R8 N=100k E=1M d=%d H=%d, use_RTE=False), %d forwards of "
+                      "oracle.forward_meta_relation_port, %.1f s each" % (d, H, reps, dt),
+            "cpu_model": cpu_model, "host_cores": cores}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nodes-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--edges-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=256)
+    ap.add_argument("--heads", type=int, default=8)
+    ap.add_argument("--types", type=int, default=4)
+    ap.add_argument("--relations", type=int, default=8)
+    ap.add_argument("--rte", action="store_true", help="5-argument form with temporal encoding")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="fp32")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pyhgt_amd import HGTConv, GraphPlan
+    from pyhgt_amd import _lib
+
+    d, H, T, R = args.dim, args.heads, args.types, args.relations
+    Nl, El = args.nodes_per_gpu, args.edges_per_gpu
+    use_rte = bool(args.rte)
+
+    # ---------------- synthetic inputs, generated on the device (SURVEY.md section 8d recipe) -------------
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    Ng = Nl * world                                            # global node count
+    node_type_own = torch.randint(0, T, (Nl,), generator=g, device=dev).sort().values
+    x_own = torch.randn(Nl, d, generator=g, device=dev)
+    src_global = torch.randint(0, Ng, (El,), generator=g, device=dev)
+    dst_local = torch.randint(0, Nl, (El,), generator=g, device=dev)
+    edge_type = torch.randint(0, R, (El,), generator=g, device=dev)
+    edge_time = torch.randint(0, 240, (El,), generator=g, device=dev) if use_rte else None
+
+    torch.manual_seed(0)
+    layer = HGTConv(d, d, T, R, H, 0.2, True, use_rte, precision=args.precision).eval()
+    with torch.no_grad():
+        layer.relation_pri.uniform_(0.5, 1.5)
+        layer.skip.normal_()
+    layer = layer.to(dev)
+
+    ev = HipEvents()
+    if world == 1:
+        edge_index = torch.stack([src_global, dst_local], dim=1).t()       # (1,2)-strided view like data.py:254
+        t0 = time.time()
+        plan = GraphPlan(node_type_own, edge_index, edge_type, edge_time, T, R)
+        torch.cuda.synchronize()
+        plan_ms = (time.time() - t0) * 1e3
+        t0 = time.time()
+        plan = GraphPlan(node_type_own, edge_index, edge_type, edge_time, T, R)
+        torch.cuda.synchronize()
+        plan_ms = min(plan_ms, (time.time() - t0) * 1e3)
+
+        def step(events=None):
+            return layer(x_own, node_type_own, edge_index, edge_type, edge_time, plan=plan, phase_events=events)
+        barrier = lambda: None
+    else:
+        from pyhgt_amd.dist import PartitionedGraph
+        import torch.distributed as dist
+        pg = PartitionedGraph(node_type_own, src_global, dst_local, edge_type, edge_time, T, R, Nl, rank, world)
+        plan_ms = None
+
+        def step(events=None):
+            return pg.forward(layer, x_own, phase_events=events)
+        barrier = dist.barrier
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        event_sets = [ev.make_set(_lib.HGT_N_PHASE_EVENTS) for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = step(event_sets[i])
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    total_edges = El * world
+    value = total_edges / (elapsed / args.steps)
+
+    # per-kernel time from the HIP events recorded inside the timed steps (this rank)
+    phase_ms = {p: 0.0 for p in PHASES}
+    for es in event_sets:
+        for i, p in enumerate(PHASES):
+            phase_ms[p] += ev.elapsed_ms(es[i], es[i + 1])
+    phase_ms = {p: v / args.steps for p, v in phase_ms.items()}
+    n_local_nodes = Nl if world == 1 else pg.n_local
+    alg = algorithmic_bytes(Nl, El, d, use_rte)
+    dom = max(("edge_logits", "edge_aggregate", "project_qkv"), key=lambda p: phase_ms[p])
+    ach = alg[dom] / (phase_ms[dom] * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.isfile(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": round(phase_ms[dom], 4),
+                "layer_achieved_GBs": round(alg["layer"] / (ms_per_step * 1e-3) / 1e9, 1),
+                "layer_frac": round(alg["layer"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "phase_ms": {p: round(v, 4) for p, v in phase_ms.items()}}
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(d, H, T, R)
+        line = {
+            "metric": "HGTConv forward edges/sec", "value": value, "unit": "edges/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: synthetic %d-type/%d-relation graph, %d nodes / %d edges per GPU, "
+                                   "d=%d, n_heads=%d, use_RTE=%s, use_norm=True, plan cached" % (T, R, Nl, El, d, H, use_rte),
+                       "nodes_per_gpu": Nl, "edges_per_gpu": El, "local_nodes_incl_halo": int(n_local_nodes),
+                       "parallelism": "single" if world == 1 else "dst-partition x%d + RCCL all-to-all halo" % world,
+                       "plan_build_ms": plan_ms, "precision": args.precision},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -204,7 +204,15 @@ typedef struct hgt_conv_args {
     uint64_t workspace_bytes;
     float* out;                  /* [n_nodes][out_dim]                         */
     float* att_out;              /* [n_edges][n_heads] or NULL                 */
+    /* optional instrumentation: HOST array of HGT_N_PHASE_EVENTS hipEvent_t handles, recorded on the
+     * stream at the phase boundaries listed below (NULL = no events)           */
+    void* const* phase_events;
 } hgt_conv_args;
+
+/* phase boundaries at which hgt_conv_forward records phase_events[i]:
+ *   0 start | 1 relation pack + Q/K/V (+ temporal tables) done | 2 logits done | 3 softmax done |
+ *   4 aggregate (+ att export) done | 5 a_linear done | 6 node update done                      */
+#define HGT_N_PHASE_EVENTS 7
 
 int hgt_conv_workspace_bytes(int64_t n_nodes, int64_t n_edges, int32_t in_dim, int32_t out_dim,
                              int32_t n_types, int32_t n_relations, int32_t n_heads, int32_t use_rte,

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhgt_hip.so")
 
 HGT_RTE_LEN = 240
+HGT_N_PHASE_EVENTS = 7
 
 
 class HgtLayout(C.Structure):
@@ -39,6 +40,7 @@ class HgtConvArgs(C.Structure):
         ("rte_emb", C.c_void_p), ("rte_w", C.c_void_p), ("rte_b", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64),
         ("out", C.c_void_p), ("att_out", C.c_void_p),
+        ("phase_events", C.c_void_p),
     ]
 
 

@@ -236,7 +236,8 @@ class HGTConv(nn.Module):
         return packed
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, node_inp, node_type, edge_index, edge_type, edge_time=None, plan=None, n_q_rows=None):
+    def forward(self, node_inp, node_type, edge_index, edge_type, edge_time=None, plan=None, n_q_rows=None,
+                phase_events=None):
         """node_inp f32[N,in_dim], node_type i64[N], edge_index i64[2,E] (row 0 = source, row 1 =
         target; any strides), edge_type i64[E], edge_time i64[E] (needed iff use_RTE).
         Returns f32[N,out_dim] (or [n_q_rows,out_dim] when only the first n_q_rows nodes are targets)."""
@@ -289,6 +290,8 @@ class HGTConv(nn.Module):
         a.rte_emb, a.rte_w, a.rte_b = _ptr(pk.get("rte_emb")), _ptr(pk.get("rte_w")), _ptr(pk.get("rte_b"))
         a.workspace, a.workspace_bytes = _ptr(ws), ws.numel()
         a.out, a.att_out = _ptr(out), _ptr(att)
+        if phase_events is not None:      # ctypes array of HGT_N_PHASE_EVENTS hipEvent_t (bench.py instrumentation)
+            a.phase_events = C.cast(phase_events, C.c_void_p)
         _lib.check(lib.hgt_conv_forward(C.byref(a), _stream()), "hgt_conv_forward")
         self.att = att
         return out

@@ -109,6 +109,10 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     float* rte_k = nullptr;
     float* rte_v = nullptr;
 
+    auto mark = [&](int i) {
+        if (a->phase_events && a->phase_events[i]) (void)hipEventRecord((hipEvent_t)a->phase_events[i], stream);
+    };
+    mark(0);
     hgt_plan_rows pr;
     rc = hgt_plan_row_lists(a->plan, N, E, T, R, &pr);
     if (rc != HGT_OK) return rc;
@@ -149,13 +153,16 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
         if (rc != HGT_OK) return rc;
     }
 
+    mark(1);
     // (4) edge phase
     if (hipMemsetAsync(agg, 0, (size_t)NQ * dp * 4, stream) != hipSuccess) return HGT_ERR_LAUNCH;
     if (E > 0) {
         rc = hgt_edge_logits(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, stream);
         if (rc != HGT_OK) return rc;
+        mark(2);
         rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);
         if (rc != HGT_OK) return rc;
+        mark(3);
         rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, stream);
         if (rc != HGT_OK) return rc;
         if (a->want_att) {
@@ -164,10 +171,14 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
         }
     }
 
+    if (E == 0) { mark(2); mark(3); }
+    mark(4);
     // (5) update: a_linear(gelu(agg)) -> gated skip -> LayerNorm (conv.py:119-133)
     rc = hgt_typed_linear(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, a->w_a, (int64_t)dout * dp, a->b_a, dout, trans, nullptr, nullptr,
                           dout, 0, 1, a->precision, stream);
     if (rc != HGT_OK) return rc;
+    mark(5);
     rc = hgt_node_update(trans, a->x, din, a->node_type, a->skip, a->ln_w, a->ln_b, a->use_norm, NQ, dout, T, a->out, stream);
+    mark(6);
     return rc;
 }
