@@ -143,8 +143,9 @@ int hgt_relation_pack(const float* relation_att, const float* relation_msg, cons
  *                      sorted edge position p (conv.py:98-99); unclaimed edges get 0
  *   hgt_edge_softmax   in place: s -> exp(s - max_i) / (sum_i exp(s - max_i) + 1e-16) over all
  *                      in-edges of each target, per head (PyG softmax, conv.py:108)
- *   hgt_edge_aggregate agg[i] += (sum_{e in (i,rel)} att_e (V[src] + rte_v[...])) M[rel]
- *                      (conv.py:104,109-111 + scatter-add); agg must be zero on entry
+ *   hgt_edge_aggregate agg[i] = sum_rel (sum_{e in (i,rel)} att_e (V[src] + rte_v[...])) M[rel]
+ *                      (conv.py:104,109-111 + scatter-add) for every target i < n_q_rows (isolated
+ *                      targets get 0); apply_gelu != 0 stores gelu(agg) instead (conv.py:119)
  *   hgt_att_export     att_out[original edge id][h] = att[p][h]   (self.att, conv.py:108)
  * rte_k / rte_v: [n_types*240][d_pad] tables or NULL.
  * ---------------------------------------------------------------------------------------------- */
@@ -155,7 +156,7 @@ int hgt_edge_softmax(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t
                      int32_t n_heads, float* logits_att, void* stream);
 int hgt_edge_aggregate(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                        int32_t n_heads, int32_t dk_pad, const float* att, const float* V, const float* rte_v,
-                       const float* msg_p, float* agg, void* stream);
+                       const float* msg_p, float* agg, int64_t n_q_rows, int32_t apply_gelu, void* stream);
 int hgt_att_export(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                    int32_t n_heads, const float* att_sorted, float* att_out, void* stream);
 

@@ -89,7 +89,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     if (din != dout) return HGT_ERR_INVALID_ARG;   // the skip connection of conv.py:131 needs in_dim == out_dim
     if (a->use_norm && (!a->ln_w || !a->ln_b)) return HGT_ERR_INVALID_ARG;
     if (a->use_rte && (!a->rte_emb || !a->rte_w || !a->rte_b)) return HGT_ERR_INVALID_ARG;
-    if (a->want_att && !a->att_out) return HGT_ERR_INVALID_ARG;
+    if (a->want_att && E > 0 && !a->att_out) return HGT_ERR_INVALID_ARG;
     hgt_layout lay;
     int rc = hgt_layout_for(dout, H, &lay);
     if (rc != HGT_OK) return rc;
@@ -155,7 +155,6 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
 
     mark(1);
     // (4) edge phase
-    if (hipMemsetAsync(agg, 0, (size_t)NQ * dp * 4, stream) != hipSuccess) return HGT_ERR_LAUNCH;
     if (E > 0) {
         rc = hgt_edge_logits(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, stream);
         if (rc != HGT_OK) return rc;
@@ -163,8 +162,6 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
         rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);
         if (rc != HGT_OK) return rc;
         mark(3);
-        rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, stream);
-        if (rc != HGT_OK) return rc;
         if (a->want_att) {
             rc = hgt_att_export(a->plan, N, E, T, R, H, logits, a->att_out, stream);
             if (rc != HGT_OK) return rc;
@@ -172,10 +169,13 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     }
 
     if (E == 0) { mark(2); mark(3); }
+    // aggregation also runs for E == 0: it writes the zero rows of isolated targets; stores gelu(agg) (conv.py:119)
+    rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ, 1, stream);
+    if (rc != HGT_OK) return rc;
     mark(4);
     // (5) update: a_linear(gelu(agg)) -> gated skip -> LayerNorm (conv.py:119-133)
     rc = hgt_typed_linear(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, a->w_a, (int64_t)dout * dp, a->b_a, dout, trans, nullptr, nullptr,
-                          dout, 0, 1, a->precision, stream);
+                          dout, 0, 0, a->precision, stream);
     if (rc != HGT_OK) return rc;
     mark(5);
     rc = hgt_node_update(trans, a->x, din, a->node_type, a->skip, a->ln_w, a->ln_b, a->use_norm, NQ, dout, T, a->out, stream);

@@ -30,7 +30,7 @@ struct __attribute__((aligned(16))) HgtItem {
 
 // Byte offsets of the arrays inside the plan buffer; a pure function of (N, E, T, R).
 struct HgtPlanLayout {
-    uint64_t off_hdr, off_esrc, off_edst, off_ertei, off_eid, off_segptr, off_items;
+    uint64_t off_hdr, off_esrc, off_edst, off_ertei, off_eid, off_segptr, off_items, off_tile_items;
     uint64_t off_rows_all, off_off_all, off_rows_q, off_off_q, total;
     int64_t n_tiles, n_bins, n_pairs, max_items;
 };
@@ -50,6 +50,7 @@ static inline HgtPlanLayout hgt_plan_layout(int64_t N, int64_t E, int32_t T, int
     L.off_eid = take((uint64_t)E * 4);
     L.off_segptr = take((uint64_t)(L.n_bins + 1) * 4);
     L.off_items = take((uint64_t)L.max_items * sizeof(HgtItem));
+    L.off_tile_items = take((uint64_t)(L.n_tiles + 1) * 4);
     L.off_rows_all = take((uint64_t)N * 4);
     L.off_off_all = take((uint64_t)(T + 2) * 4);
     L.off_rows_q = take((uint64_t)N * 4);
@@ -66,6 +67,7 @@ struct HgtPlanView {
     const int32_t* eid;
     const int32_t* segptr;
     const HgtItem* items;
+    const int32_t* tile_items;   // items of dst tile t = items[tile_items[t] .. tile_items[t+1])
     const int32_t* rows_all;
     const int32_t* off_all;
     const int32_t* rows_q;
@@ -84,6 +86,7 @@ static inline HgtPlanView hgt_plan_view(const void* plan, int64_t N, int64_t E, 
     v.eid = (const int32_t*)(b + v.L.off_eid);
     v.segptr = (const int32_t*)(b + v.L.off_segptr);
     v.items = (const HgtItem*)(b + v.L.off_items);
+    v.tile_items = (const int32_t*)(b + v.L.off_tile_items);
     v.rows_all = (const int32_t*)(b + v.L.off_rows_all);
     v.off_all = (const int32_t*)(b + v.L.off_off_all);
     v.rows_q = (const int32_t*)(b + v.L.off_rows_q);

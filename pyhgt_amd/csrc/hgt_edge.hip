@@ -220,89 +220,124 @@ __global__ __launch_bounds__(256) void k_edge_softmax(const int32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// pass 2: aggregation
+// pass 2: aggregation.  One workgroup (4 waves) per destination tile of 64 nodes; the tile's
+// accumulator [64][DP] lives in LDS (64 KB at d=256, two workgroups per CU), every wave walks
+// work items of the tile (any relation), keeps U = sum att*v of the current (target, relation)
+// segment in registers, applies M[rel] at the segment end and adds the result into the LDS tile
+// (ds_add_f32; "planar" layout [row][i][lane] so the 64 lanes hit 64 distinct banks).  The tile is
+// written once with plain coalesced stores -- no global atomics, no zero-fill pass over agg.
 // ---------------------------------------------------------------------------------------------
 template <int VEC, int LPH>
 __global__ __launch_bounds__(256) void k_edge_aggregate(
-    const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
+    const HgtItem* __restrict__ items, const int32_t* __restrict__ tile_items, const int32_t* __restrict__ esrc,
     const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ att,
-    const float* __restrict__ V, const float* __restrict__ rteV, const float* __restrict__ msgP, float* __restrict__ agg, int R) {
+    const float* __restrict__ V, const float* __restrict__ rteV, const float* __restrict__ msgP, float* __restrict__ agg,
+    int R, int64_t NQ, int apply_gelu) {
     constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = unroll_for<VEC>();
     constexpr bool HOIST = (DKP * VEC <= 128);
+    __shared__ __attribute__((aligned(16))) float s_tile[HGT_TD * DP];
     __shared__ __attribute__((aligned(16))) float s_bounce[4][DP];
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = blockIdx.x * 4 + wib;
-    if (item >= hdr->n_items) return;
-    const HgtItem it = items[item];
-    const int beg = __builtin_amdgcn_readfirstlane(it.beg), end = __builtin_amdgcn_readfirstlane(it.end);
-    const int rel = __builtin_amdgcn_readfirstlane(it.rel);
-    if (rel >= R) return;   // unclaimed edges carry no message (conv.py:69)
+    const int tile = blockIdx.x;
     const int h = lane / LPH, p = lane % LPH;
 
+    for (int i = threadIdx.x * 4; i < HGT_TD * DP; i += 256 * 4) *reinterpret_cast<float4*>(&s_tile[i]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    const int it0 = tile_items[tile], it1 = tile_items[tile + 1];
     float* bounce = s_bounce[wib];
-    const float* __restrict__ fglob = msgP + ((int64_t)(rel * H + h) * DKP) * DKP + p * VEC;
-    float frag[HOIST ? DKP : 1][VEC];
-    if constexpr (HOIST) {
-#pragma unroll
-        for (int j = 0; j < DKP; ++j) load_vec<VEC>(fglob + j * DKP, frag[j]);
-    }
+    for (int item = it0 + wib; item < it1; item += 4) {
+        const HgtItem it = items[item];
+        const int beg = __builtin_amdgcn_readfirstlane(it.beg), end = __builtin_amdgcn_readfirstlane(it.end);
+        const int rel = __builtin_amdgcn_readfirstlane(it.rel);
+        if (rel >= R) continue;   // unclaimed edges carry no message (conv.py:69)
 
-    int cur_dst = -1;
-    float U[VEC];
+        const float* __restrict__ fglob = msgP + ((int64_t)(rel * H + h) * DKP) * DKP + p * VEC;
+        float frag[HOIST ? DKP : 1][VEC];
+        if constexpr (HOIST) {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
-
-    auto flush = [&]() {
-        if (cur_dst >= 0) {
-            float z[VEC];
-            head_matvec<VEC, DKP, HOIST>(U, bounce, lane, h, frag, fglob, z);
-            float* o = agg + (int64_t)cur_dst * DP + lane * VEC;
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(o + i, z[i]);
+            for (int j = 0; j < DKP; ++j) load_vec<VEC>(fglob + j * DKP, frag[j]);
         }
-    };
 
-    for (int base = beg; base < end; base += 64) {
-        const int nb = min(64, end - base);
-        const int li = base + min(lane, nb - 1);
-        const int my_src = esrc[li], my_dst = edst[li];
-        const int my_rte = rteV ? (int)ertei[li] : 0;
-        for (int i0 = 0; i0 < nb; i0 += UN) {
-            float vr[UN][VEC], al[UN];
-            int dsts[UN];
+        int cur_dst = -1;
+        float U[VEC];
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int idx = min(i0 + u, nb - 1);
-                const int s = __builtin_amdgcn_readlane(my_src, idx);
-                dsts[u] = __builtin_amdgcn_readlane(my_dst, idx);
-                load_vec<VEC>(V + (int64_t)s * DP + lane * VEC, vr[u]);
-                al[u] = att[(int64_t)(base + idx) * H + h];
-                if (rteV) {
-                    const int ri = __builtin_amdgcn_readlane(my_rte, idx);
-                    float t[VEC];
-                    load_vec<VEC>(rteV + (int64_t)ri * DP + lane * VEC, t);
+        for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
+
+        auto flush = [&]() {
+            if (cur_dst >= 0) {
+                float z[VEC];
+                head_matvec<VEC, DKP, HOIST>(U, bounce, lane, h, frag, fglob, z);
+                float* o = s_tile + (cur_dst - tile * HGT_TD) * DP + lane;
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) vr[u][i] += t[i];
-                }
+                for (int i = 0; i < VEC; ++i) __hip_atomic_fetch_add(o + i * 64, z[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+        };
+
+        for (int base = beg; base < end; base += 64) {
+            const int nb = min(64, end - base);
+            const int li = base + min(lane, nb - 1);
+            const int my_src = esrc[li], my_dst = edst[li];
+            const int my_rte = rteV ? (int)ertei[li] : 0;
+            for (int i0 = 0; i0 < nb; i0 += UN) {
+                float vr[UN][VEC], al[UN];
+                int dsts[UN];
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                if (i0 + u < nb) {
-                    if (dsts[u] != cur_dst) {
-                        flush();
+                for (int u = 0; u < UN; ++u) {
+                    const int idx = min(i0 + u, nb - 1);
+                    const int s = __builtin_amdgcn_readlane(my_src, idx);
+                    dsts[u] = __builtin_amdgcn_readlane(my_dst, idx);
+                    load_vec<VEC>(V + (int64_t)s * DP + lane * VEC, vr[u]);
+                    al[u] = att[(int64_t)(base + idx) * H + h];
+                    if (rteV) {
+                        const int ri = __builtin_amdgcn_readlane(my_rte, idx);
+                        float t[VEC];
+                        load_vec<VEC>(rteV + (int64_t)ri * DP + lane * VEC, t);
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
-                        cur_dst = dsts[u];
+                        for (int i = 0; i < VEC; ++i) vr[u][i] += t[i];
                     }
+                }
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) U[i] = fmaf(al[u], vr[u][i], U[i]);
+                for (int u = 0; u < UN; ++u) {
+                    if (i0 + u < nb) {
+                        if (dsts[u] != cur_dst) {
+                            flush();
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
+                            cur_dst = dsts[u];
+                        }
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) U[i] = fmaf(al[u], vr[u][i], U[i]);
+                    }
                 }
             }
         }
+        flush();
     }
-    flush();
+    __syncthreads();
+
+    // tile write-out: row r of the tile by wave r % 4; un-permute the planar layout
+    for (int r = wib; r < HGT_TD; r += 4) {
+        const int64_t row = (int64_t)tile * HGT_TD + r;
+        if (row >= NQ) break;
+        float o[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            o[i] = s_tile[r * DP + i * 64 + lane];
+            if (apply_gelu) o[i] = 0.5f * o[i] * (1.0f + erff(o[i] * 0.70710678118654752440f));
+        }
+        float* g = agg + row * DP + lane * VEC;
+        if constexpr (VEC == 1) {
+            g[0] = o[0];
+        } else if constexpr (VEC == 2) {
+            *reinterpret_cast<float2*>(g) = make_float2(o[0], o[1]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC / 4; ++i) *reinterpret_cast<float4*>(g + 4 * i) = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+        }
+    }
 }
 
 __global__ void k_att_export(const int32_t* __restrict__ eid, const float* __restrict__ att, float* __restrict__ out, int64_t E, int H) {
@@ -356,9 +391,10 @@ struct LaunchLogits {
 template <int VEC, int LPH>
 struct LaunchAggregate {
     static int run(const HgtPlanView& pv, const float* att, const float* V, const float* rteV, const float* msgP, float* agg,
-                   int R, hipStream_t stream) {
-        const unsigned blocks = (unsigned)((pv.L.max_items + 3) / 4);
-        k_edge_aggregate<VEC, LPH><<<blocks, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, att, V, rteV, msgP, agg, R);
+                   int R, int64_t NQ, int apply_gelu, hipStream_t stream) {
+        const int64_t tiles = (NQ + HGT_TD - 1) / HGT_TD;
+        k_edge_aggregate<VEC, LPH><<<(unsigned)tiles, 256, 0, stream>>>(pv.items, pv.tile_items, pv.esrc, pv.edst, pv.ertei, att, V,
+                                                                        rteV, msgP, agg, R, NQ, apply_gelu);
         return HGT_OK;
     }
 };
@@ -401,13 +437,16 @@ extern "C" int hgt_edge_softmax(const void* plan, int64_t N, int64_t E, int32_t 
 }
 
 extern "C" int hgt_edge_aggregate(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
-                                  const float* att, const float* V, const float* rte_v, const float* msg_p, float* agg, void* stream) {
-    if (!plan || !att || !V || !msg_p || !agg || H <= 0 || 64 % H != 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
-    if (E == 0) return HGT_OK;
+                                  const float* att, const float* V, const float* rte_v, const float* msg_p, float* agg,
+                                  int64_t n_q_rows, int32_t apply_gelu, void* stream) {
+    if (!plan || !V || !msg_p || !agg || (E > 0 && !att) || H <= 0 || 64 % H != 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
+    const int64_t NQ = (n_q_rows > 0 && n_q_rows <= N) ? n_q_rows : N;
+    if (NQ == 0) return HGT_OK;
     const int lph = 64 / H;
     if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
     HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
-    int rc = dispatch_layout<LaunchAggregate>(dk_pad / lph, lph, pv, att, V, rte_v, msg_p, agg, (int)R, (hipStream_t)stream);
+    int rc = dispatch_layout<LaunchAggregate>(dk_pad / lph, lph, pv, att, V, rte_v, msg_p, agg, (int)R, NQ, (int)apply_gelu,
+                                              (hipStream_t)stream);
     if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();
     return HGT_OK;

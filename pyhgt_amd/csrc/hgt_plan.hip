@@ -130,9 +130,10 @@ __global__ void k_pair_counts(const int32_t* __restrict__ segptr, int64_t n_pair
 }
 
 __global__ void k_items(const int32_t* __restrict__ segptr, const int32_t* __restrict__ pair_off, int64_t n_pairs, int R,
-                        HgtItem* __restrict__ items, HgtPlanHeader* hdr) {
+                        HgtItem* __restrict__ items, int32_t* __restrict__ tile_items, HgtPlanHeader* hdr) {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j > n_pairs) return;
+    if (j % (R + 1) == 0) tile_items[j / (R + 1)] = pair_off[j];   // includes the end sentinel at j == n_pairs
     if (j == n_pairs) { hdr->n_items = pair_off[n_pairs]; return; }
     int32_t beg = segptr[j * HGT_TD], end = segptr[(j + 1) * HGT_TD];
     int32_t o = pair_off[j];
@@ -224,6 +225,7 @@ extern "C" int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int
     int32_t* eid = (int32_t*)(pb + L.off_eid);
     int32_t* segptr = (int32_t*)(pb + L.off_segptr);
     HgtItem* items = (HgtItem*)(pb + L.off_items);
+    int32_t* tile_items = (int32_t*)(pb + L.off_tile_items);
     int32_t* rows_all = (int32_t*)(pb + L.off_rows_all);
     int32_t* off_all = (int32_t*)(pb + L.off_off_all);
     int32_t* rows_q = (int32_t*)(pb + L.off_rows_q);
@@ -255,7 +257,7 @@ extern "C" int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int
     sort_bytes = (size_t)tl.sort_tmp_bytes;
     if (rocprim::exclusive_scan(sort_tmp, sort_bytes, pair_cnt, pair_off, 0, (size_t)(L.n_pairs + 1),
                                 rocprim::plus<int32_t>(), stream) != hipSuccess) return HGT_ERR_LAUNCH;
-    k_items<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(segptr, pair_off, L.n_pairs, R, items, hdr);
+    k_items<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(segptr, pair_off, L.n_pairs, R, items, tile_items, hdr);
 
     // typed row lists: all nodes, and target nodes [0, NQ)
     if (N > 0) {

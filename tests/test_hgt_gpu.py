@@ -166,12 +166,13 @@ def _plan_arrays(plan):
     eid = take(E * 4, np.int32, E)
     segptr = take((n_bins + 1) * 4, np.int32, n_bins + 1)
     items = take(max_items * 16, np.int32, max_items * 4).reshape(-1, 4)
+    tile_items = take((n_tiles + 1) * 4, np.int32, n_tiles + 1)
     rows_all = take(N * 4, np.int32, N)
     off_all = take((T + 2) * 4, np.int32, T + 2)
     rows_q = take(N * 4, np.int32, N)
     off_q = take((T + 2) * 4, np.int32, T + 2)
     return dict(n_items=int(hdr[0]), bad=int(hdr[1]), esrc=esrc, edst=edst, ertei=ertei, eid=eid, segptr=segptr,
-                items=items, rows_all=rows_all, off_all=off_all, rows_q=rows_q, off_q=off_q, n_bins=n_bins)
+                items=items, tile_items=tile_items, rows_all=rows_all, off_all=off_all, rows_q=rows_q, off_q=off_q, n_bins=n_bins)
 
 
 @pytest.mark.parametrize("sorted_types,skew", [(True, 0.0), (False, 1.2)])
@@ -200,6 +201,7 @@ def test_plan_is_bit_exact(sorted_types, skew):
     pair = key[order] // 64
     assert np.array_equal(pair[it[:, 0]], pair[it[:, 1] - 1])
     assert np.array_equal(pair[it[:, 0]], it[:, 3] * (R + 1) + it[:, 2])
+    assert np.array_equal(p["tile_items"], np.searchsorted(it[:, 3], np.arange(len(p["tile_items"]))).astype(np.int32))
     assert np.array_equal(p["rows_all"], np.argsort(nt.numpy(), kind="stable").astype(np.int32))
     assert np.array_equal(p["off_all"][:T + 1], np.searchsorted(np.sort(nt.numpy()), np.arange(T + 1)).astype(np.int32))
     assert np.array_equal(p["rows_q"], p["rows_all"]) and np.array_equal(p["off_q"], p["off_all"])
