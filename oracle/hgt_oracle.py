@@ -118,12 +118,14 @@ def _segment_softmax(s, dst, n_nodes):
     return p / (z[dst] + 1e-16)
 
 
-def _update(sd, agg, x, node_type, num_types, use_norm, dtype):
-    """conv.py:114-134 (eval mode: dropout is the identity)."""
+def _update(sd, agg, x, node_type, num_types, use_norm, dtype, library_ops=False):
+    """conv.py:114-134 (eval mode: dropout is the identity).  library_ops=True uses the same
+    torch.nn.functional calls as the reference (F.gelu, LayerNorm) -- for the timed port; the
+    checker keeps the explicit formulas."""
     N, d = agg.shape
     Wa = _stack(sd, "a_linears.%d.weight", num_types, dtype)
     ba = _stack(sd, "a_linears.%d.bias", num_types, dtype)
-    g = _gelu_erf(agg)                                              # conv.py:119
+    g = torch.nn.functional.gelu(agg) if library_ops else _gelu_erf(agg)   # conv.py:119
     out = torch.zeros(N, d, dtype=dtype)                            # conv.py:120
     alpha = torch.sigmoid(sd["skip"].to(dtype))                     # conv.py:129
     for t in range(num_types):
@@ -133,7 +135,8 @@ def _update(sd, agg, x, node_type, num_types, use_norm, dtype):
         o = g[rows] @ Wa[t].T + ba[t]                               # conv.py:125
         y = o * alpha[t] + x[rows] * (1.0 - alpha[t])               # conv.py:131/133
         if use_norm:
-            y = _layer_norm(y, sd["norms.%d.weight" % t].to(dtype), sd["norms.%d.bias" % t].to(dtype))
+            w, b = sd["norms.%d.weight" % t].to(dtype), sd["norms.%d.bias" % t].to(dtype)
+            y = torch.nn.functional.layer_norm(y, (d,), w, b, 1e-5) if library_ops else _layer_norm(y, w, b)
         out[rows] = y
     return out
 
@@ -278,5 +281,5 @@ def forward_meta_relation_port(sd, num_types, num_relations, n_heads, x, node_ty
     att = _segment_softmax(logits, dst, N) if E > 0 else logits
     res = (msg * att.unsqueeze(-1)).reshape(E, d)
     agg = torch.zeros(N, d, dtype=dtype).index_add_(0, dst, res)
-    out = _update(sd, agg, x, node_type.long(), T, use_norm, dtype)
+    out = _update(sd, agg, x, node_type.long(), T, use_norm, dtype, library_ops=True)
     return (out, att) if return_att else out

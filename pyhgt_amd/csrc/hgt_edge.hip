@@ -220,39 +220,45 @@ __global__ __launch_bounds__(256) void k_edge_softmax(const int32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// pass 2: aggregation.  One workgroup (4 waves) per destination tile of 64 nodes; the tile's
-// accumulator [64][DP] lives in LDS (64 KB at d=256, two workgroups per CU), every wave walks
-// work items of the tile (any relation), keeps U = sum att*v of the current (target, relation)
-// segment in registers, applies M[rel] at the segment end and adds the result into the LDS tile
-// (ds_add_f32; "planar" layout [row][i][lane] so the 64 lanes hit 64 distinct banks).  The tile is
-// written once with plain coalesced stores -- no global atomics, no zero-fill pass over agg.
+// pass 2: aggregation.  One WAVEFRONT owns a sub-tile of 16 consecutive target nodes and walks all
+// relations of it in ascending order: for relation r its edges are the contiguous sorted range
+// segptr[(tile, r, 16*sub)] .. segptr[(tile, r, 16*sub+16)].  The wave keeps U = sum att*v of the
+// current (target, relation) segment in registers, applies M[r] (register-resident slice, re-read
+// from L2 once per (sub-tile, relation)) at the segment end and adds the result into a WAVE-PRIVATE
+// LDS accumulator [16][DP] ("planar" [row][i][lane] layout: the 64 lanes of a ds_add_f32 hit 64
+// distinct banks).  No atomics between waves, no barriers, no zero-fill of agg, and the summation
+// order is fixed (relations ascending, edges in stable sorted order) -> bitwise reproducible.
+// Rows are written once with plain coalesced stores (optionally through gelu, conv.py:119).
 // ---------------------------------------------------------------------------------------------
+constexpr int HGT_SUB = 16;   // targets per wavefront
+
 template <int VEC, int LPH>
 __global__ __launch_bounds__(256) void k_edge_aggregate(
-    const HgtItem* __restrict__ items, const int32_t* __restrict__ tile_items, const int32_t* __restrict__ esrc,
-    const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ att,
-    const float* __restrict__ V, const float* __restrict__ rteV, const float* __restrict__ msgP, float* __restrict__ agg,
-    int R, int64_t NQ, int apply_gelu) {
+    const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
+    const uint16_t* __restrict__ ertei, const float* __restrict__ att, const float* __restrict__ V,
+    const float* __restrict__ rteV, const float* __restrict__ msgP, float* __restrict__ agg, int R, int64_t NQ, int apply_gelu) {
     constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = unroll_for<VEC>();
     constexpr bool HOIST = (DKP * VEC <= 128);
-    __shared__ __attribute__((aligned(16))) float s_tile[HGT_TD * DP];
+    __shared__ __attribute__((aligned(16))) float s_acc[4][HGT_SUB * DP];
     __shared__ __attribute__((aligned(16))) float s_bounce[4][DP];
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tile = blockIdx.x;
+    const int64_t row0 = (int64_t)tile * HGT_TD + wib * HGT_SUB;
+    if (row0 >= NQ) return;
     const int h = lane / LPH, p = lane % LPH;
-
-    for (int i = threadIdx.x * 4; i < HGT_TD * DP; i += 256 * 4) *reinterpret_cast<float4*>(&s_tile[i]) = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-
-    const int it0 = tile_items[tile], it1 = tile_items[tile + 1];
+    float* acc = s_acc[wib];
     float* bounce = s_bounce[wib];
-    for (int item = it0 + wib; item < it1; item += 4) {
-        const HgtItem it = items[item];
-        const int beg = __builtin_amdgcn_readfirstlane(it.beg), end = __builtin_amdgcn_readfirstlane(it.end);
-        const int rel = __builtin_amdgcn_readfirstlane(it.rel);
-        if (rel >= R) continue;   // unclaimed edges carry no message (conv.py:69)
+
+#pragma unroll
+    for (int j = 0; j < HGT_SUB * VEC / 4; ++j) *reinterpret_cast<float4*>(&acc[j * 256 + lane * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int rel = 0; rel < R; ++rel) {
+        const int64_t b0 = ((int64_t)tile * (R + 1) + rel) * HGT_TD + wib * HGT_SUB;
+        const int beg = __builtin_amdgcn_readfirstlane(segptr[b0]);
+        const int end = __builtin_amdgcn_readfirstlane(segptr[b0 + HGT_SUB]);
+        if (beg == end) continue;
 
         const float* __restrict__ fglob = msgP + ((int64_t)(rel * H + h) * DKP) * DKP + p * VEC;
         float frag[HOIST ? DKP : 1][VEC];
@@ -270,9 +276,9 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
             if (cur_dst >= 0) {
                 float z[VEC];
                 head_matvec<VEC, DKP, HOIST>(U, bounce, lane, h, frag, fglob, z);
-                float* o = s_tile + (cur_dst - tile * HGT_TD) * DP + lane;
+                float* o = acc + (cur_dst - (int)row0) * DP + lane;
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) __hip_atomic_fetch_add(o + i * 64, z[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int i = 0; i < VEC; ++i) o[i * 64] += z[i];   // wave-private: plain read-modify-write
             }
         };
 
@@ -316,16 +322,15 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
         }
         flush();
     }
-    __syncthreads();
 
-    // tile write-out: row r of the tile by wave r % 4; un-permute the planar layout
-    for (int r = wib; r < HGT_TD; r += 4) {
-        const int64_t row = (int64_t)tile * HGT_TD + r;
+    // write-out: un-permute the planar layout, one coalesced row store per wave instruction
+    for (int r = 0; r < HGT_SUB; ++r) {
+        const int64_t row = row0 + r;
         if (row >= NQ) break;
         float o[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            o[i] = s_tile[r * DP + i * 64 + lane];
+            o[i] = acc[r * DP + i * 64 + lane];
             if (apply_gelu) o[i] = 0.5f * o[i] * (1.0f + erff(o[i] * 0.70710678118654752440f));
         }
         float* g = agg + row * DP + lane * VEC;
@@ -393,8 +398,8 @@ struct LaunchAggregate {
     static int run(const HgtPlanView& pv, const float* att, const float* V, const float* rteV, const float* msgP, float* agg,
                    int R, int64_t NQ, int apply_gelu, hipStream_t stream) {
         const int64_t tiles = (NQ + HGT_TD - 1) / HGT_TD;
-        k_edge_aggregate<VEC, LPH><<<(unsigned)tiles, 256, 0, stream>>>(pv.items, pv.tile_items, pv.esrc, pv.edst, pv.ertei, att, V,
-                                                                        rteV, msgP, agg, R, NQ, apply_gelu);
+        k_edge_aggregate<VEC, LPH><<<(unsigned)tiles, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, att, V, rteV, msgP, agg,
+                                                                        R, NQ, apply_gelu);
         return HGT_OK;
     }
 };

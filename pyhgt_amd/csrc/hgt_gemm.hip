@@ -158,6 +158,11 @@ __global__ __launch_bounds__(256) void k_typed_linear_f32(
 
 }  // namespace
 
+int hgt_typed_linear_bf16x3_launch(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
+                                   int64_t n_rows, int32_t k, int32_t n_out, const float* W, int64_t wgs, const float* bias,
+                                   int64_t bgs, float* out0, float* out1, float* out2, int32_t block_cols, int32_t by_pos,
+                                   int32_t prologue, int vec_ok, hipStream_t stream);
+
 extern "C" int hgt_typed_linear(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off,
                                 int32_t n_groups, int64_t n_rows, int32_t k, int32_t n_out,
                                 const float* W, int64_t w_group_stride, const float* bias, int64_t b_group_stride,
@@ -168,7 +173,7 @@ extern "C" int hgt_typed_linear(const float* x, int64_t ldx, const int32_t* rows
     const int n_blocks_out = (n_out + block_cols - 1) / block_cols;
     if (n_blocks_out > 3 || (n_blocks_out > 1 && !out1) || (n_blocks_out > 2 && !out2)) return HGT_ERR_INVALID_ARG;
     if (prologue != 0 && prologue != 1) return HGT_ERR_INVALID_ARG;
-    if (precision != 0) return HGT_ERR_UNSUPPORTED;   // split-bf16 path: not built yet
+    if (precision != 0 && precision != 1) return HGT_ERR_INVALID_ARG;
     if (n_rows == 0) return HGT_OK;
     hipStream_t stream = (hipStream_t)stream_;
     // group sizes are device data: launch the upper bound on row tiles, surplus workgroups exit
@@ -177,6 +182,9 @@ extern "C" int hgt_typed_linear(const float* x, int64_t ldx, const int32_t* rows
     dim3 grid((unsigned)row_tiles, (unsigned)((n_out + BN - 1) / BN));
     const int vec_ok = (ldx % 4 == 0) && (k % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)W & 15) == 0) &&
                        (w_group_stride % 4 == 0);
+    if (precision == 1)
+        return hgt_typed_linear_bf16x3_launch(x, ldx, rows, group_off, n_groups, n_rows, k, n_out, W, w_group_stride, bias,
+                                              b_group_stride, out0, out1, out2, block_cols, out_by_position, prologue, vec_ok, stream);
     if (prologue == 0)
         k_typed_linear_f32<0><<<grid, 256, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out, W, w_group_stride, bias,
                                                         b_group_stride, out0, out1, out2, block_cols, out_by_position, vec_ok);

@@ -17,8 +17,8 @@ TOL = 1e-4
 DEV = "cuda:0"
 
 
-def _layer_from(sd, d, T, R, H, use_norm, use_RTE, keep_att=True):
-    layer = HGTConv(d, d, T, R, H, 0.2, use_norm, use_RTE, keep_att=keep_att).eval()
+def _layer_from(sd, d, T, R, H, use_norm, use_RTE, keep_att=True, precision="fp32"):
+    layer = HGTConv(d, d, T, R, H, 0.2, use_norm, use_RTE, keep_att=keep_att, precision=precision).eval()
     layer.load_state_dict(sd)
     return layer.to(DEV)
 
@@ -45,6 +45,15 @@ def test_matches_reference_golden(golden):
     assert (att - g["att"]).abs().max().item() < 1e-5
 
 
+def test_split_bf16_precision_matches_reference_golden(golden):
+    """precision="bf16x3" (3-term split-bf16 MFMA for the typed linears) must meet the same 1e-4 bound."""
+    g = golden
+    layer = _layer_from(g["sd"], g["d"], g["T"], g["R"], g["H"], g["use_norm"], g["use_RTE"], precision="bf16x3")
+    out, att = _run(layer, g["x"], g["node_type"], g["edge_index"], g["edge_type"], g["edge_time"])
+    assert (out - g["out"]).abs().max().item() < TOL
+    assert (att - g["att"]).abs().max().item() < 1e-5
+
+
 # ------------------------------------------------------------------ (b) oracle on seeded inputs
 CASES = [
     # N, E, d, H, T, R, use_norm, use_RTE, graph kwargs
@@ -60,17 +69,20 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
-def test_matches_oracle(case):
+def test_matches_oracle(case, precision):
     N, E, d, H, T, R, use_norm, use_RTE, gk = case
     sd = O.make_state_dict(d, d, T, R, H, use_norm, use_RTE, seed=N + E)
     x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=E + 1, **gk)
     ref, att_ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, use_norm=use_norm, use_RTE=use_RTE,
                                          dtype=torch.float64, return_att=True)
-    layer = _layer_from(sd, d, T, R, H, use_norm, use_RTE)
+    layer = _layer_from(sd, d, T, R, H, use_norm, use_RTE, precision=precision)
     out, att = _run(layer, x, nt, ei, et, tm if use_RTE else None)
-    assert (out.double() - ref).abs().max().item() < TOL
-    assert (att.double() - att_ref).abs().max().item() < 1e-5
+    err, err_att = (out.double() - ref).abs().max().item(), (att.double() - att_ref).abs().max().item()
+    print("case N=%d E=%d d=%d H=%d %s: max|out| err %.2e, att err %.2e" % (N, E, d, H, precision, err, err_att))
+    assert err < TOL
+    assert err_att < 1e-5
 
 
 def test_no_edges_and_isolated_targets():
@@ -218,8 +230,9 @@ def test_plan_flags_out_of_range_node_ids():
 
 
 # ------------------------------------------------------------------ kernels in isolation
+@pytest.mark.parametrize("precision,tol", [(0, 2e-5), (1, 1e-4)])
 @pytest.mark.parametrize("k,n_out,prologue", [(256, 768, 0), (64, 192, 0), (400, 400, 1), (129, 96, 0), (512, 512, 1)])
-def test_typed_linear_against_torch_fp32(k, n_out, prologue):
+def test_typed_linear_against_torch_fp32(k, n_out, prologue, precision, tol):
     lib = _lib.load()
     T, N = 3, 1000
     g = torch.Generator().manual_seed(k + n_out)
@@ -237,11 +250,13 @@ def test_typed_linear_against_torch_fp32(k, n_out, prologue):
     xd, Wd, bd, rd, od = _to_dev(x, W, b, rows, off)
     out = torch.zeros(N, n_out, device=DEV)
     rc = lib.hgt_typed_linear(xd.data_ptr(), k, rd.data_ptr(), od.data_ptr(), T, N, k, n_out, Wd.data_ptr(), n_out * k,
-                              bd.data_ptr(), n_out, out.data_ptr(), 0, 0, n_out, 0, prologue, 0,
+                              bd.data_ptr(), n_out, out.data_ptr(), 0, 0, n_out, 0, prologue, precision,
                               torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     torch.cuda.synchronize()
-    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+    err = (out.cpu().double() - ref).abs().max().item()
+    print("typed_linear k=%d n=%d precision=%d err %.2e" % (k, n_out, precision, err))
+    assert err < tol
 
 
 def test_gather_rows_bit_exact():
