@@ -117,13 +117,25 @@ int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride
  *   out0..2   the n_out columns are split into blocks of block_cols columns, block c is written
  *             to out{c}[row * block_cols + col]; row = rows[p] (out_by_position = 0) or p (= 1)
  *   prologue  0 = none, 1 = exact (erf) GELU applied to x on load (conv.py:119)
- *   precision 0 = fp32 MFMA (exact fp32 FMA chain), 1 = 3-term split-bf16 MFMA
+ *   precision must be 0 (fp32 MFMA, exact fp32 FMA chain); the split-bf16 variant is below
  * ---------------------------------------------------------------------------------------------- */
 int hgt_typed_linear(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off,
                      int32_t n_groups, int64_t n_rows, int32_t k, int32_t n_out,
                      const float* W, int64_t w_group_stride, const float* bias, int64_t b_group_stride,
                      float* out0, float* out1, float* out2, int32_t block_cols,
                      int32_t out_by_position, int32_t prologue, int32_t precision, void* stream);
+
+/* Split-bf16 x3 variant of the typed linear layer (same contract as hgt_typed_linear): operands are
+ * split into bf16 hi+mid terms and a product is evaluated as mid*hi + hi*mid + hi*hi on the bf16 matrix
+ * cores with fp32 accumulation (relative error of a product <= ~3*2^-18).  W is split and tiled once per
+ * forward by hgt_split_weights into a caller-owned buffer of hgt_split_weights_bytes() bytes. */
+int hgt_split_weights_bytes(int32_t n_groups, int32_t k, int32_t n_out, uint64_t* out_host);
+int hgt_split_weights(const float* W, int64_t w_group_stride, int32_t n_groups, int32_t k, int32_t n_out,
+                      void* w_split, void* stream);
+int hgt_typed_linear_bf16x3(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off,
+                            int32_t n_groups, int64_t n_rows, int32_t k, int32_t n_out, const void* w_split,
+                            const float* bias, int64_t b_group_stride, float* out0, float* out1, float* out2,
+                            int32_t block_cols, int32_t out_by_position, int32_t prologue, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Relation parameter packing (per forward, R*H*dk*dk elements):
@@ -143,9 +155,12 @@ int hgt_relation_pack(const float* relation_att, const float* relation_msg, cons
  *                      sorted edge position p (conv.py:98-99); unclaimed edges get 0
  *   hgt_edge_softmax   in place: s -> exp(s - max_i) / (sum_i exp(s - max_i) + 1e-16) over all
  *                      in-edges of each target, per head (PyG softmax, conv.py:108)
- *   hgt_edge_aggregate agg[i] = sum_rel (sum_{e in (i,rel)} att_e (V[src] + rte_v[...])) M[rel]
- *                      (conv.py:104,109-111 + scatter-add) for every target i < n_q_rows (isolated
- *                      targets get 0); apply_gelu != 0 stores gelu(agg) instead (conv.py:119)
+ *   hgt_edge_aggregate takes the RAW logits of hgt_edge_logits and evaluates the per-target softmax
+ *                      online (same formula as above) while aggregating:
+ *                      agg[i] = sum_rel (sum_{e in (i,rel)} att_e (V[src] + rte_v[...])) M[rel]
+ *                      (conv.py:104,108-111 + scatter-add) for every target i < n_q_rows (isolated
+ *                      targets get 0); apply_gelu != 0 stores gelu(agg) instead (conv.py:119).
+ *                      hgt_edge_softmax is only needed to materialise att for hgt_att_export.
  *   hgt_att_export     att_out[original edge id][h] = att[p][h]   (self.att, conv.py:108)
  * rte_k / rte_v: [n_types*240][d_pad] tables or NULL.
  * ---------------------------------------------------------------------------------------------- */
@@ -155,7 +170,7 @@ int hgt_edge_logits(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t 
 int hgt_edge_softmax(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                      int32_t n_heads, float* logits_att, void* stream);
 int hgt_edge_aggregate(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
-                       int32_t n_heads, int32_t dk_pad, const float* att, const float* V, const float* rte_v,
+                       int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
                        const float* msg_p, float* agg, int64_t n_q_rows, int32_t apply_gelu, void* stream);
 int hgt_att_export(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                    int32_t n_heads, const float* att_sorted, float* att_out, void* stream);

@@ -56,6 +56,10 @@ SIGNATURES = {
     "hgt_plan_build": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _u64, _vp, _u64, _vp]),
     "hgt_typed_linear": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                                    _i32, _i32, _i32, _i32, _vp]),
+    "hgt_split_weights_bytes": (C.c_int, [_i32, _i32, _i32, C.POINTER(_u64)]),
+    "hgt_split_weights": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "hgt_typed_linear_bf16x3": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp,
+                                          _i32, _i32, _i32, _vp]),
     "hgt_relation_pack": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "hgt_edge_logits": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hgt_edge_softmax": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),

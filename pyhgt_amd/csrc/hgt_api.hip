@@ -6,7 +6,7 @@ namespace {
 
 struct ConvWorkspace {
     uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p;
-    uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, total;
+    uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, off_ws_qkv, off_ws_a, off_ws_rte, total;
 };
 
 static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim, int out_dim, int T, int R, int H, int use_rte,
@@ -32,6 +32,15 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
     } else {
         w.off_rte_lin = w.off_rte_k = w.off_rte_v = w.off_rte_rows = w.off_rte_off = 0;
     }
+    // split-bf16 weight tiles (precision = 1); sized unconditionally, they are small
+    uint64_t b = 0;
+    hgt_split_weights_bytes(T, in_dim, 3 * lay.d_pad, &b);
+    w.off_ws_qkv = take(b);
+    // shared by the a_linear / Q-only / temporal K|V splits (used one after the other on the stream)
+    hgt_split_weights_bytes(T, in_dim > lay.d_pad ? in_dim : lay.d_pad, 2 * lay.d_pad > out_dim ? 2 * lay.d_pad : out_dim, &b);
+    w.off_ws_a = take(b);
+    hgt_split_weights_bytes(1, in_dim, in_dim, &b);
+    w.off_ws_rte = take(use_rte ? b : 0);
     w.total = o;
     return w;
 }
@@ -121,18 +130,32 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     rc = hgt_relation_pack(a->relation_att, a->relation_msg, a->relation_pri, R, H, lay.d_k, lay.dk_pad, att_t, msg_p, stream);
     if (rc != HGT_OK) return rc;
 
+    // typed linear dispatch: exact fp32 MFMA, or split-bf16 x3 with weights split+tiled into the workspace
+    const bool split = (a->precision == 1);
+    auto linear = [&](const float* xin, int64_t ldx, const int32_t* rws, const int32_t* goff, int ng, int64_t nrows, int kk, int nout,
+                      const float* Wp, int64_t wgs, const float* bp, int64_t bgs, float* o0, float* o1, float* o2, int bcols,
+                      int by_pos, void* wsplit) -> int {
+        if (!split)
+            return hgt_typed_linear(xin, ldx, rws, goff, ng, nrows, kk, nout, Wp, wgs, bp, bgs, o0, o1, o2, bcols, by_pos, 0, 0, stream);
+        int r2 = hgt_split_weights(Wp, wgs, ng, kk, nout, wsplit, stream);
+        if (r2 != HGT_OK) return r2;
+        return hgt_typed_linear_bf16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos, 0, stream);
+    };
+    void* ws_qkv = wb + w.off_ws_qkv;
+    void* ws_a = wb + w.off_ws_a;
+
     // (2) typed projections once per NODE (conv.py:96-97,103 did them per edge)
     const int64_t wstride = (int64_t)3 * dp * din;
     if (NQ == N) {
-        rc = hgt_typed_linear(a->x, din, pr.rows_all, pr.off_all, T, N, din, 3 * dp, a->w_qkv, wstride, a->b_qkv, 3 * dp, Q, K, V, dp, 0,
-                              0, a->precision, stream);
+        rc = linear(a->x, din, pr.rows_all, pr.off_all, T, N, din, 3 * dp, a->w_qkv, wstride, a->b_qkv, 3 * dp, Q, K, V, dp, 0, ws_qkv);
         if (rc != HGT_OK) return rc;
     } else {
-        rc = hgt_typed_linear(a->x, din, pr.rows_q, pr.off_q, T, NQ, din, dp, a->w_qkv, wstride, a->b_qkv, 3 * dp, Q, nullptr, nullptr, dp,
-                              0, 0, a->precision, stream);
+        // halo rows (>= NQ) only need K and V.  The split tiles of the full [Q|K|V] weight serve both launches:
+        // Q = columns [0,dp) -> its own split; K|V = columns [dp,3dp)
+        rc = linear(a->x, din, pr.rows_q, pr.off_q, T, NQ, din, dp, a->w_qkv, wstride, a->b_qkv, 3 * dp, Q, nullptr, nullptr, dp, 0, ws_a);
         if (rc != HGT_OK) return rc;
-        rc = hgt_typed_linear(a->x, din, pr.rows_all, pr.off_all, T, N, din, 2 * dp, a->w_qkv + (int64_t)dp * din, wstride,
-                              a->b_qkv + dp, 3 * dp, K, V, nullptr, dp, 0, 0, a->precision, stream);
+        rc = linear(a->x, din, pr.rows_all, pr.off_all, T, N, din, 2 * dp, a->w_qkv + (int64_t)dp * din, wstride, a->b_qkv + dp, 3 * dp,
+                    K, V, nullptr, dp, 0, ws_qkv);
         if (rc != HGT_OK) return rc;
     }
 
@@ -145,37 +168,36 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
         int32_t* roff = (int32_t*)(wb + w.off_rte_off);
         const int nthr = T * HGT_RTE_LEN;
         k_rte_row_lists<<<(nthr + 255) / 256, 256, 0, stream>>>(T, rrows, roff);
-        rc = hgt_typed_linear(a->rte_emb, din, rrows, roff, 1, HGT_RTE_LEN, din, din, a->rte_w, 0, a->rte_b, 0, rte_lin, nullptr, nullptr,
-                              din, 1, 0, a->precision, stream);
+        rc = linear(a->rte_emb, din, rrows, roff, 1, HGT_RTE_LEN, din, din, a->rte_w, 0, a->rte_b, 0, rte_lin, nullptr, nullptr, din, 1,
+                    wb + w.off_ws_rte);
         if (rc != HGT_OK) return rc;
-        rc = hgt_typed_linear(rte_lin, din, rrows, roff, T, (int64_t)T * HGT_RTE_LEN, din, 2 * dp, a->w_qkv + (int64_t)dp * din, wstride,
-                              nullptr, 0, rte_k, rte_v, nullptr, dp, 1, 0, a->precision, stream);
+        // the K|V split tiles are already in ws_qkv only when NQ == N used the full 3*dp weight; re-split the K|V part (tiny)
+        rc = linear(rte_lin, din, rrows, roff, T, (int64_t)T * HGT_RTE_LEN, din, 2 * dp, a->w_qkv + (int64_t)dp * din, wstride, nullptr, 0,
+                    rte_k, rte_v, nullptr, dp, 1, ws_a);
         if (rc != HGT_OK) return rc;
     }
 
     mark(1);
-    // (4) edge phase
+    // (4) edge phase: logits, then softmax fused into the aggregation (online, per target sub-tile)
     if (E > 0) {
         rc = hgt_edge_logits(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, stream);
         if (rc != HGT_OK) return rc;
-        mark(2);
-        rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);
-        if (rc != HGT_OK) return rc;
-        mark(3);
-        if (a->want_att) {
-            rc = hgt_att_export(a->plan, N, E, T, R, H, logits, a->att_out, stream);
-            if (rc != HGT_OK) return rc;
-        }
     }
-
-    if (E == 0) { mark(2); mark(3); }
-    // aggregation also runs for E == 0: it writes the zero rows of isolated targets; stores gelu(agg) (conv.py:119)
+    mark(2);
+    mark(3);
+    // runs for E == 0 too: it writes the zero rows of isolated targets; stores gelu(agg) (conv.py:119)
     rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ, 1, stream);
     if (rc != HGT_OK) return rc;
+    if (a->want_att && E > 0) {   // self.att (conv.py:108): normalise the logits in place and un-sort them
+        rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);
+        if (rc != HGT_OK) return rc;
+        rc = hgt_att_export(a->plan, N, E, T, R, H, logits, a->att_out, stream);
+        if (rc != HGT_OK) return rc;
+    }
     mark(4);
     // (5) update: a_linear(gelu(agg)) -> gated skip -> LayerNorm (conv.py:119-133)
-    rc = hgt_typed_linear(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, a->w_a, (int64_t)dout * dp, a->b_a, dout, trans, nullptr, nullptr,
-                          dout, 0, 0, a->precision, stream);
+    rc = linear(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, a->w_a, (int64_t)dout * dp, a->b_a, dout, trans, nullptr, nullptr, dout, 0,
+                ws_a);
     if (rc != HGT_OK) return rc;
     mark(5);
     rc = hgt_node_update(trans, a->x, din, a->node_type, a->skip, a->ln_w, a->ln_b, a->use_norm, NQ, dout, T, a->out, stream);

@@ -220,27 +220,36 @@ __global__ __launch_bounds__(256) void k_edge_softmax(const int32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// pass 2: aggregation.  One WAVEFRONT owns a sub-tile of 16 consecutive target nodes and walks all
-// relations of it in ascending order: for relation r its edges are the contiguous sorted range
-// segptr[(tile, r, 16*sub)] .. segptr[(tile, r, 16*sub+16)].  The wave keeps U = sum att*v of the
-// current (target, relation) segment in registers, applies M[r] (register-resident slice, re-read
-// from L2 once per (sub-tile, relation)) at the segment end and adds the result into a WAVE-PRIVATE
-// LDS accumulator [16][DP] ("planar" [row][i][lane] layout: the 64 lanes of a ds_add_f32 hit 64
-// distinct banks).  No atomics between waves, no barriers, no zero-fill of agg, and the summation
-// order is fixed (relations ascending, edges in stable sorted order) -> bitwise reproducible.
+// pass 2: softmax + aggregation.  One WAVEFRONT owns a sub-tile of 16 consecutive target nodes and
+// walks all relations of it in ascending order: for relation r its edges are the contiguous sorted
+// range segptr[(tile, r, 16*sub)] .. segptr[(tile, r, 16*sub+16)].  Because the wave sees EVERY
+// in-edge of its targets, the per-target softmax (conv.py:108) is evaluated online, with no separate
+// normalisation pass over the logits:
+//   * inside a (target, relation) segment: running max m, running sum l and U = sum exp(s-m) v in
+//     registers (rescaled when the max grows);
+//   * at the segment end: z = U M[r] (register-resident slice of M[r], re-read from L2 once per
+//     (sub-tile, relation)), then merged into the target's state kept in WAVE-PRIVATE LDS:
+//     acc = acc*exp(m_t - m') + z*exp(m - m'), l_t likewise ("planar" [row][i][lane] layout: the 64
+//     lanes of an LDS access hit 64 distinct banks);
+//   * at the end: agg = acc / (l_t + 1e-16)  -- identical to PyG's exp(s-max)/(sum exp(s-max)+1e-16)
+//     because the final running max is the true max.  Unclaimed edges (bucket R) count with logit 0
+//     and no message (conv.py:68-69).
+// No atomics, no barriers, no zero-fill of agg; fixed summation order -> bitwise reproducible.
 // Rows are written once with plain coalesced stores (optionally through gelu, conv.py:119).
 // ---------------------------------------------------------------------------------------------
-constexpr int HGT_SUB = 16;   // targets per wavefront
+constexpr int HGT_SUB = 16;       // targets per wavefront
+constexpr float HGT_NEG = -1.0e30f;
 
 template <int VEC, int LPH>
 __global__ __launch_bounds__(256) void k_edge_aggregate(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
-    const uint16_t* __restrict__ ertei, const float* __restrict__ att, const float* __restrict__ V,
+    const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
     const float* __restrict__ rteV, const float* __restrict__ msgP, float* __restrict__ agg, int R, int64_t NQ, int apply_gelu) {
     constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = unroll_for<VEC>();
     constexpr bool HOIST = (DKP * VEC <= 128);
     __shared__ __attribute__((aligned(16))) float s_acc[4][HGT_SUB * DP];
     __shared__ __attribute__((aligned(16))) float s_bounce[4][DP];
+    __shared__ float s_ml[4][2][HGT_SUB * 16];   // running max / sum per (target, head); H <= 16
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -250,35 +259,52 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
     const int h = lane / LPH, p = lane % LPH;
     float* acc = s_acc[wib];
     float* bounce = s_bounce[wib];
+    float* s_m = s_ml[wib][0];
+    float* s_l = s_ml[wib][1];
 
 #pragma unroll
     for (int j = 0; j < HGT_SUB * VEC / 4; ++j) *reinterpret_cast<float4*>(&acc[j * 256 + lane * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < HGT_SUB * 16 / 64; ++j) { s_m[j * 64 + lane] = HGT_NEG; s_l[j * 64 + lane] = 0.0f; }
 
-    for (int rel = 0; rel < R; ++rel) {
+    for (int rel = 0; rel <= R; ++rel) {
         const int64_t b0 = ((int64_t)tile * (R + 1) + rel) * HGT_TD + wib * HGT_SUB;
         const int beg = __builtin_amdgcn_readfirstlane(segptr[b0]);
         const int end = __builtin_amdgcn_readfirstlane(segptr[b0 + HGT_SUB]);
         if (beg == end) continue;
+        const bool claimed = rel < R;   // bucket R: logit 0, no message
 
-        const float* __restrict__ fglob = msgP + ((int64_t)(rel * H + h) * DKP) * DKP + p * VEC;
+        const float* __restrict__ fglob = msgP + ((int64_t)((claimed ? rel : 0) * H + h) * DKP) * DKP + p * VEC;
         float frag[HOIST ? DKP : 1][VEC];
         if constexpr (HOIST) {
+            if (claimed) {
 #pragma unroll
-            for (int j = 0; j < DKP; ++j) load_vec<VEC>(fglob + j * DKP, frag[j]);
+                for (int j = 0; j < DKP; ++j) load_vec<VEC>(fglob + j * DKP, frag[j]);
+            }
         }
 
         int cur_dst = -1;
-        float U[VEC];
+        float U[VEC], m_seg = HGT_NEG, l_seg = 0.0f;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
 
         auto flush = [&]() {
             if (cur_dst >= 0) {
                 float z[VEC];
-                head_matvec<VEC, DKP, HOIST>(U, bounce, lane, h, frag, fglob, z);
-                float* o = acc + (cur_dst - (int)row0) * DP + lane;
+                if (claimed) {
+                    head_matvec<VEC, DKP, HOIST>(U, bounce, lane, h, frag, fglob, z);
+                } else {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) o[i * 64] += z[i];   // wave-private: plain read-modify-write
+                    for (int i = 0; i < VEC; ++i) z[i] = 0.0f;
+                }
+                const int dl = cur_dst - (int)row0;
+                const float m_t = s_m[dl * 16 + h], l_t = s_l[dl * 16 + h];
+                const float m_new = fmaxf(m_t, m_seg);
+                const float ca = __expf(m_t - m_new), cb = __expf(m_seg - m_new);
+                float* o = acc + dl * DP + lane;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) o[i * 64] = o[i * 64] * ca + z[i] * cb;   // wave-private read-modify-write
+                if (p == 0) { s_m[dl * 16 + h] = m_new; s_l[dl * 16 + h] = l_t * ca + l_seg * cb; }
             }
         };
 
@@ -288,21 +314,27 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
             const int my_src = esrc[li], my_dst = edst[li];
             const int my_rte = rteV ? (int)ertei[li] : 0;
             for (int i0 = 0; i0 < nb; i0 += UN) {
-                float vr[UN][VEC], al[UN];
+                float vr[UN][VEC], sl[UN];
                 int dsts[UN];
 #pragma unroll
                 for (int u = 0; u < UN; ++u) {
                     const int idx = min(i0 + u, nb - 1);
                     const int s = __builtin_amdgcn_readlane(my_src, idx);
                     dsts[u] = __builtin_amdgcn_readlane(my_dst, idx);
-                    load_vec<VEC>(V + (int64_t)s * DP + lane * VEC, vr[u]);
-                    al[u] = att[(int64_t)(base + idx) * H + h];
-                    if (rteV) {
-                        const int ri = __builtin_amdgcn_readlane(my_rte, idx);
-                        float t[VEC];
-                        load_vec<VEC>(rteV + (int64_t)ri * DP + lane * VEC, t);
+                    if (claimed) {
+                        load_vec<VEC>(V + (int64_t)s * DP + lane * VEC, vr[u]);
+                        sl[u] = logits[(int64_t)(base + idx) * H + h];
+                        if (rteV) {
+                            const int ri = __builtin_amdgcn_readlane(my_rte, idx);
+                            float t[VEC];
+                            load_vec<VEC>(rteV + (int64_t)ri * DP + lane * VEC, t);
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) vr[u][i] += t[i];
+                            for (int i = 0; i < VEC; ++i) vr[u][i] += t[i];
+                        }
+                    } else {
+                        sl[u] = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) vr[u][i] = 0.0f;
                     }
                 }
 #pragma unroll
@@ -312,10 +344,16 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
                             flush();
 #pragma unroll
                             for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
+                            m_seg = HGT_NEG;
+                            l_seg = 0.0f;
                             cur_dst = dsts[u];
                         }
+                        const float m_new = fmaxf(m_seg, sl[u]);
+                        const float sc = __expf(m_seg - m_new), pe = __expf(sl[u] - m_new);
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) U[i] = fmaf(al[u], vr[u][i], U[i]);
+                        for (int i = 0; i < VEC; ++i) U[i] = fmaf(U[i], sc, pe * vr[u][i]);
+                        l_seg = fmaf(l_seg, sc, pe);
+                        m_seg = m_new;
                     }
                 }
             }
@@ -323,14 +361,15 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
         flush();
     }
 
-    // write-out: un-permute the planar layout, one coalesced row store per wave instruction
+    // write-out: normalise, un-permute the planar layout, one coalesced row store per wave instruction
     for (int r = 0; r < HGT_SUB; ++r) {
         const int64_t row = row0 + r;
         if (row >= NQ) break;
+        const float inv = 1.0f / (s_l[r * 16 + h] + 1e-16f);
         float o[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            o[i] = acc[r * DP + i * 64 + lane];
+            o[i] = acc[r * DP + i * 64 + lane] * inv;
             if (apply_gelu) o[i] = 0.5f * o[i] * (1.0f + erff(o[i] * 0.70710678118654752440f));
         }
         float* g = agg + row * DP + lane * VEC;
@@ -395,10 +434,10 @@ struct LaunchLogits {
 
 template <int VEC, int LPH>
 struct LaunchAggregate {
-    static int run(const HgtPlanView& pv, const float* att, const float* V, const float* rteV, const float* msgP, float* agg,
+    static int run(const HgtPlanView& pv, const float* logits, const float* V, const float* rteV, const float* msgP, float* agg,
                    int R, int64_t NQ, int apply_gelu, hipStream_t stream) {
         const int64_t tiles = (NQ + HGT_TD - 1) / HGT_TD;
-        k_edge_aggregate<VEC, LPH><<<(unsigned)tiles, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, att, V, rteV, msgP, agg,
+        k_edge_aggregate<VEC, LPH><<<(unsigned)tiles, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgP, agg,
                                                                         R, NQ, apply_gelu);
         return HGT_OK;
     }
@@ -442,15 +481,15 @@ extern "C" int hgt_edge_softmax(const void* plan, int64_t N, int64_t E, int32_t 
 }
 
 extern "C" int hgt_edge_aggregate(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
-                                  const float* att, const float* V, const float* rte_v, const float* msg_p, float* agg,
+                                  const float* logits, const float* V, const float* rte_v, const float* msg_p, float* agg,
                                   int64_t n_q_rows, int32_t apply_gelu, void* stream) {
-    if (!plan || !V || !msg_p || !agg || (E > 0 && !att) || H <= 0 || 64 % H != 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
+    if (!plan || !V || !msg_p || !agg || (E > 0 && !logits) || H <= 0 || 64 % H != 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
     const int64_t NQ = (n_q_rows > 0 && n_q_rows <= N) ? n_q_rows : N;
     if (NQ == 0) return HGT_OK;
     const int lph = 64 / H;
     if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
     HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
-    int rc = dispatch_layout<LaunchAggregate>(dk_pad / lph, lph, pv, att, V, rte_v, msg_p, agg, (int)R, NQ, (int)apply_gelu,
+    int rc = dispatch_layout<LaunchAggregate>(dk_pad / lph, lph, pv, logits, V, rte_v, msg_p, agg, (int)R, NQ, (int)apply_gelu,
                                               (hipStream_t)stream);
     if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();

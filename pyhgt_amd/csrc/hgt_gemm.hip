@@ -28,13 +28,21 @@ template <int PROLOGUE>
 __global__ __launch_bounds__(256) void k_typed_linear_f32(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off,
     int n_groups, int k, int n_out, const float* __restrict__ W, int64_t wgs, const float* __restrict__ bias, int64_t bgs,
-    float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos, int vec_ok) {
+    float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos, int vec_ok,
+    int n_col_tiles) {
     __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
     __shared__ int s_rid[BM];
 
     // which (group, row tile) is this workgroup?  group sizes live on the device (no host sync)
-    const int slot = blockIdx.x;
+    // XCD-aware 1-D grid: hardware places block b on XCD b % 8.  Logical tile id l = (b % 8) * per + b / 8 gives
+    // every XCD a contiguous run of logical tiles, and the column tiles of one row tile are consecutive l,
+    // so the x rows of a row tile are fetched from HBM once and re-read from that XCD's L2 by its other
+    // column tiles (without this each column tile streamed x from HBM again: 6x for the Q|K|V launch).
+    const int per_xcd = gridDim.x >> 3;
+    const int ltile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int slot = ltile / n_col_tiles;
+    const int col_tile = ltile - slot * n_col_tiles;
     int g = 0, gbeg = 0, gend = 0, tiles_before = 0;
     for (; g < n_groups; ++g) {
         gbeg = group_off[g];
@@ -46,7 +54,7 @@ __global__ __launch_bounds__(256) void k_typed_linear_f32(
     if (g >= n_groups) return;
     const int row0 = gbeg + (slot - tiles_before) * BM;
     const int nrows = min(BM, gend - row0);
-    const int col0 = blockIdx.y * BN;
+    const int col0 = col_tile * BN;
     const float* __restrict__ Wg = W + (int64_t)g * wgs;
 
     const int tid = threadIdx.x;
@@ -158,11 +166,6 @@ __global__ __launch_bounds__(256) void k_typed_linear_f32(
 
 }  // namespace
 
-int hgt_typed_linear_bf16x3_launch(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
-                                   int64_t n_rows, int32_t k, int32_t n_out, const float* W, int64_t wgs, const float* bias,
-                                   int64_t bgs, float* out0, float* out1, float* out2, int32_t block_cols, int32_t by_pos,
-                                   int32_t prologue, int vec_ok, hipStream_t stream);
-
 extern "C" int hgt_typed_linear(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off,
                                 int32_t n_groups, int64_t n_rows, int32_t k, int32_t n_out,
                                 const float* W, int64_t w_group_stride, const float* bias, int64_t b_group_stride,
@@ -173,24 +176,24 @@ extern "C" int hgt_typed_linear(const float* x, int64_t ldx, const int32_t* rows
     const int n_blocks_out = (n_out + block_cols - 1) / block_cols;
     if (n_blocks_out > 3 || (n_blocks_out > 1 && !out1) || (n_blocks_out > 2 && !out2)) return HGT_ERR_INVALID_ARG;
     if (prologue != 0 && prologue != 1) return HGT_ERR_INVALID_ARG;
-    if (precision != 0 && precision != 1) return HGT_ERR_INVALID_ARG;
+    if (precision != 0) return HGT_ERR_INVALID_ARG;   // split-bf16: hgt_split_weights + hgt_typed_linear_bf16x3
     if (n_rows == 0) return HGT_OK;
     hipStream_t stream = (hipStream_t)stream_;
     // group sizes are device data: launch the upper bound on row tiles, surplus workgroups exit
     const int64_t row_tiles = (n_rows + BM - 1) / BM + n_groups;
     if (row_tiles > 0x7fffffffLL) return HGT_ERR_TOO_LARGE;
-    dim3 grid((unsigned)row_tiles, (unsigned)((n_out + BN - 1) / BN));
+    const int n_col_tiles = (n_out + BN - 1) / BN;
+    const int64_t total_tiles = row_tiles * n_col_tiles;
+    if (total_tiles > 0x7ffffff0LL) return HGT_ERR_TOO_LARGE;
+    const unsigned grid = (unsigned)((total_tiles + 7) / 8 * 8);   // multiple of 8 for the XCD remap; surplus blocks exit
     const int vec_ok = (ldx % 4 == 0) && (k % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)W & 15) == 0) &&
                        (w_group_stride % 4 == 0);
-    if (precision == 1)
-        return hgt_typed_linear_bf16x3_launch(x, ldx, rows, group_off, n_groups, n_rows, k, n_out, W, w_group_stride, bias,
-                                              b_group_stride, out0, out1, out2, block_cols, out_by_position, prologue, vec_ok, stream);
     if (prologue == 0)
         k_typed_linear_f32<0><<<grid, 256, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out, W, w_group_stride, bias,
-                                                        b_group_stride, out0, out1, out2, block_cols, out_by_position, vec_ok);
+                                                        b_group_stride, out0, out1, out2, block_cols, out_by_position, vec_ok, n_col_tiles);
     else
         k_typed_linear_f32<1><<<grid, 256, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out, W, w_group_stride, bias,
-                                                        b_group_stride, out0, out1, out2, block_cols, out_by_position, vec_ok);
+                                                        b_group_stride, out0, out1, out2, block_cols, out_by_position, vec_ok, n_col_tiles);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }

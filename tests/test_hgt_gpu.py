@@ -231,7 +231,7 @@ def test_plan_flags_out_of_range_node_ids():
 
 # ------------------------------------------------------------------ kernels in isolation
 @pytest.mark.parametrize("precision,tol", [(0, 2e-5), (1, 1e-4)])
-@pytest.mark.parametrize("k,n_out,prologue", [(256, 768, 0), (64, 192, 0), (400, 400, 1), (129, 96, 0), (512, 512, 1)])
+@pytest.mark.parametrize("k,n_out,prologue", [(256, 768, 0), (64, 192, 0), (400, 400, 1), (129, 96, 0), (512, 1536, 1), (256, 256, 0)])
 def test_typed_linear_against_torch_fp32(k, n_out, prologue, precision, tol):
     lib = _lib.load()
     T, N = 3, 1000
@@ -248,13 +248,25 @@ def test_typed_linear_against_torch_fp32(k, n_out, prologue, precision, tol):
         m = nt == t
         ref[m] = xin[m].double() @ W[t].double().T + b[t].double()
     xd, Wd, bd, rd, od = _to_dev(x, W, b, rows, off)
-    out = torch.zeros(N, n_out, device=DEV)
-    rc = lib.hgt_typed_linear(xd.data_ptr(), k, rd.data_ptr(), od.data_ptr(), T, N, k, n_out, Wd.data_ptr(), n_out * k,
-                              bd.data_ptr(), n_out, out.data_ptr(), 0, 0, n_out, 0, prologue, precision,
-                              torch.cuda.current_stream().cuda_stream)
+    nblk = 3 if n_out % 3 == 0 and n_out >= 192 else 1        # exercise the Q|K|V column-block outputs
+    bc = n_out // nblk
+    outs = [torch.zeros(N, bc, device=DEV) for _ in range(nblk)]
+    optr = [o.data_ptr() for o in outs] + [0, 0]
+    st = torch.cuda.current_stream().cuda_stream
+    if precision == 0:
+        rc = lib.hgt_typed_linear(xd.data_ptr(), k, rd.data_ptr(), od.data_ptr(), T, N, k, n_out, Wd.data_ptr(), n_out * k,
+                                  bd.data_ptr(), n_out, optr[0], optr[1], optr[2], bc, 0, prologue, 0, st)
+    else:
+        nb = C.c_uint64()
+        assert lib.hgt_split_weights_bytes(T, k, n_out, C.byref(nb)) == 0
+        ws = torch.empty(nb.value, dtype=torch.uint8, device=DEV)
+        assert lib.hgt_split_weights(Wd.data_ptr(), n_out * k, T, k, n_out, ws.data_ptr(), st) == 0
+        rc = lib.hgt_typed_linear_bf16x3(xd.data_ptr(), k, rd.data_ptr(), od.data_ptr(), T, N, k, n_out, ws.data_ptr(),
+                                         bd.data_ptr(), n_out, optr[0], optr[1], optr[2], bc, 0, prologue, st)
     assert rc == 0
     torch.cuda.synchronize()
-    err = (out.cpu().double() - ref).abs().max().item()
+    out = torch.cat([o.cpu() for o in outs], dim=1)
+    err = (out.double() - ref).abs().max().item()
     print("typed_linear k=%d n=%d precision=%d err %.2e" % (k, n_out, precision, err))
     assert err < tol
 

@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the typed linear kernels alone (development aid, not the judged bench)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pyhgt_amd import _lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--k", type=int, default=256)
+    ap.add_argument("--n-out", type=int, default=768)
+    ap.add_argument("--types", type=int, default=4)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--which", default="both")
+    ap.add_argument("--bypos", type=int, default=0)
+    args = ap.parse_args()
+    lib = _lib.load()
+    dev = "cuda:0"
+    N, k, n_out, T = args.rows, args.k, args.n_out, args.types
+    x = torch.randn(N, k, device=dev)
+    W = torch.randn(T, n_out, k, device=dev) / k ** 0.5
+    b = torch.randn(T, n_out, device=dev)
+    nt = torch.randint(0, T, (N,), device=dev).sort().values
+    rows = torch.arange(N, device=dev, dtype=torch.int32)
+    off = torch.searchsorted(nt, torch.arange(T + 1, device=dev)).int()
+    nblk = 3 if n_out % 3 == 0 else 1
+    bc = n_out // nblk
+    outs = [torch.empty(N, bc, device=dev) for _ in range(nblk)]
+    optr = [o.data_ptr() for o in outs] + [0, 0]
+    st = torch.cuda.current_stream().cuda_stream
+    nb = C.c_uint64()
+    lib.hgt_split_weights_bytes(T, k, n_out, C.byref(nb))
+    ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+
+    def run_fp32():
+        assert lib.hgt_typed_linear(x.data_ptr(), k, rows.data_ptr(), off.data_ptr(), T, N, k, n_out, W.data_ptr(), n_out * k,
+                                    b.data_ptr(), n_out, optr[0], optr[1], optr[2], bc, 0, 0, 0, st) == 0
+
+    def run_split():
+        assert lib.hgt_split_weights(W.data_ptr(), n_out * k, T, k, n_out, ws.data_ptr(), st) == 0
+        assert lib.hgt_typed_linear_bf16x3(x.data_ptr(), k, rows.data_ptr(), off.data_ptr(), T, N, k, n_out, ws.data_ptr(),
+                                           b.data_ptr(), n_out, optr[0], optr[1], optr[2], bc, args.bypos, 0, st) == 0
+
+    for name, fn in (("fp32", run_fp32), ("bf16x3", run_split)):
+        if args.which not in ("both", name):
+            continue
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.iters
+        gb = (N * k * 4 + N * n_out * 4) / 1e9
+        print("%-7s rows=%d k=%d n_out=%d: %.3f ms  %.1f TFLOP/s(fp32-equivalent)  %.2f TB/s(min traffic)" % (
+            name, N, k, n_out, ms, 2.0 * N * k * n_out / ms / 1e9, gb / ms))
+
+
+if __name__ == "__main__":
+    main()
