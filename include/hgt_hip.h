@@ -137,6 +137,18 @@ int hgt_typed_linear_bf16x3(const float* x, int64_t ldx, const int32_t* rows, co
                             const float* bias, int64_t b_group_stride, float* out0, float* out1, float* out2,
                             int32_t block_cols, int32_t out_by_position, int32_t prologue, void* stream);
 
+/* a_linear (conv.py:125) with the node update (conv.py:129-133, see hgt_node_update) fused into its epilogue:
+ *   out[n] = LN_t( (agg[n] @ W_a[t]^T + b_a[t]) * sigmoid(skip[t]) + x_skip[n] * (1 - sigmoid(skip[t])) )
+ * for the rows of every group; split-bf16 x3 MFMA; needs n_out <= 256 and n_out % 4 == 0 (HGT_ERR_UNSUPPORTED
+ * otherwise -> use hgt_typed_linear[_bf16x3] + hgt_node_update).  Rows of no group are not written: hgt_zero_rows. */
+int hgt_linear_update_bf16x3(const float* agg, int64_t ld_agg, const int32_t* rows, const int32_t* group_off,
+                             int32_t n_groups, int64_t n_rows, int32_t k, int32_t n_out, const void* w_split,
+                             const float* bias, int64_t b_group_stride, const float* x_skip, int64_t ld_skip,
+                             const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm, float* out,
+                             void* stream);
+/* out[rows[i]][0..d) = 0 for i in [range[0], range[1]) -- range is a DEVICE array of two int32 */
+int hgt_zero_rows(const int32_t* rows, const int32_t* range, int32_t d, float* out, void* stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Relation parameter packing (per forward, R*H*dk*dk elements):
  *   att_t[r][h][c][k] = relation_att[r][h][k][c] * relation_pri[r][h] / sqrt(d_k)   (zero padded)

@@ -60,6 +60,9 @@ SIGNATURES = {
     "hgt_split_weights": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "hgt_typed_linear_bf16x3": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp,
                                           _i32, _i32, _i32, _vp]),
+    "hgt_linear_update_bf16x3": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
+                                           _i32, _vp, _vp]),
+    "hgt_zero_rows": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "hgt_relation_pack": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "hgt_edge_logits": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hgt_edge_softmax": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),

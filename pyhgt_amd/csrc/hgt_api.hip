@@ -196,11 +196,22 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     }
     mark(4);
     // (5) update: a_linear(gelu(agg)) -> gated skip -> LayerNorm (conv.py:119-133)
-    rc = linear(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, a->w_a, (int64_t)dout * dp, a->b_a, dout, trans, nullptr, nullptr, dout, 0,
-                ws_a);
-    if (rc != HGT_OK) return rc;
-    mark(5);
-    rc = hgt_node_update(trans, a->x, din, a->node_type, a->skip, a->ln_w, a->ln_b, a->use_norm, NQ, dout, T, a->out, stream);
+    const bool fuse_update = split && dout <= 256 && (dout & 3) == 0 && (din & 3) == 0;
+    if (fuse_update) {
+        rc = hgt_split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_a, stream);
+        if (rc != HGT_OK) return rc;
+        rc = hgt_linear_update_bf16x3(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, ws_a, a->b_a, dout, a->x, din, a->skip, a->ln_w,
+                                      a->ln_b, a->use_norm, a->out, stream);
+        if (rc != HGT_OK) return rc;
+        mark(5);
+        rc = hgt_zero_rows(pr.rows_q, pr.off_q + T, dout, a->out, stream);   // nodes of unknown type -> 0 (conv.py:120)
+    } else {
+        rc = linear(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, a->w_a, (int64_t)dout * dp, a->b_a, dout, trans, nullptr, nullptr, dout,
+                    0, ws_a);
+        if (rc != HGT_OK) return rc;
+        mark(5);
+        rc = hgt_node_update(trans, a->x, din, a->node_type, a->skip, a->ln_w, a->ln_b, a->use_norm, NQ, dout, T, a->out, stream);
+    }
     mark(6);
     return rc;
 }

@@ -9,17 +9,19 @@
 // fp32 operands.  Opt-in (HGTConv(precision="bf16x3")), parity-tested at the same 1e-4 bound.
 //
 // Shape of the problem: M = millions of node rows, K = d (256), N = 3d: output-heavy and, with the
-// MFMA cost cut 5x, bound by HBM and by latency -- a k-loop that re-fetches a 128-B piece of every
-// x row per step (the fp32 kernel in hgt_gemm.hip) spends its time waiting.  So here:
+// MFMA cost cut 5x, bound by HBM and by latency/synchronisation -- a k-loop with LDS-staged tiles and
+// one or two barriers per k-step (hgt_gemm.hip) spends most of its time waiting.  So here:
 //   * a workgroup (8 waves) owns 64 rows and ALL output columns: the 64 x K slab of x is read from
-//     HBM exactly once, as whole 1 KB rows, split to bf16 hi/mid ONCE and kept in LDS (66 KB);
-//   * W is pre-split and pre-tiled by hgt_split_weights into contiguous 16 KB [256 cols][32 k] tiles
-//     (hi and mid planes), L2-resident (1.5 MB), streamed through a double-buffered LDS ring with the
-//     next tile's global loads in flight under the current tile's MFMAs; one barrier per k-step;
-//   * waves are laid out 2 (rows) x 4 (cols): each wave owns a 32 x 64 strip of the 64 x 256 pass,
-//     A fragments are shared by its two 32x32 tiles (6 MFMAs per 6 ds_read_b128).
-// LDS row strides (528 B for A, 80 B for B) put the 16 lanes of a ds_read_b128 group on 16
-// distinct 4-bank slots (conflict free).
+//     HBM exactly once, as whole 1 KB rows, split to bf16 hi/mid ONCE and kept in LDS (66 KB, so two
+//     workgroups share a CU and one's slab load / epilogue overlaps the other's MFMAs);
+//   * W never goes through LDS: hgt_split_weights pre-splits it and stores it in MFMA-FRAGMENT order
+//     ([pass][k-chunk][plane][32-column tile][lane][8 bf16]), so a wave's B fragment is one coalesced
+//     1 KB load straight into registers from the L2-resident 1.5 MB image, prefetched four k-chunks
+//     ahead in named register stages;
+//   * every wave owns a 64-row x 32-column strip of the current 256-column pass: A fragments (2 row
+//     tiles x hi/mid) come from the read-only LDS slab, 6 MFMAs per 4 ds_read_b128 + 2 global loads,
+//     and -- because nothing is written to LDS in the main loop -- there is NO barrier in it.
+// The 528 B LDS row stride puts the 16 lanes of a ds_read_b128 group on 16 distinct 4-bank slots.
 #include "hgt_common.h"
 
 namespace {
@@ -28,14 +30,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 64;          // rows per workgroup
-constexpr int BNP = 256;        // output columns per pass
-constexpr int BK = 32;          // k per streamed W tile
+constexpr int BNP = 256;        // output columns per pass (8 waves x 32)
+constexpr int KC = 16;          // k per MFMA (v_mfma_f32_32x32x16_bf16)
 constexpr int KP = 256;         // k panel kept in LDS
 constexpr int A_STRIDE = KP * 2 + 16;   // bytes
-constexpr int B_STRIDE = BK * 2 + 16;   // bytes
 constexpr int A_PLANE = BM * A_STRIDE;          // 33792
-constexpr int B_PLANE = BNP * B_STRIDE;         // 20480
-constexpr int W_TILE_ELEMS = BNP * BK;          // bf16 elements per (plane) tile
+constexpr int W_PLANE_ELEMS = BNP * KC;         // bf16 elements per plane of one (pass, k-chunk) tile = 8 x 64 x 8
 
 __device__ __forceinline__ float gelu_erf_(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
@@ -59,37 +59,243 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid) {
     mid = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
 }
 
-// W [n_groups][n_out][k] fp32 -> tiles [g][pass][kstep][plane][256][32] bf16, zero padded
-__global__ void k_split_weights(const float* __restrict__ W, int64_t wgs, int n_groups, int k, int n_out, int n_pass, int n_kstep,
+// W [n_groups][n_out][k] fp32 -> [g][pass][kchunk][plane][col tile 8][lane 64][8] bf16 (zero padded): the 8 bf16 of
+// (col tile ct, lane l) are W[pass*256 + ct*32 + (l&31)][kchunk*16 + (l>>5)*8 .. +8] = one lane's B fragment.
+__global__ void k_split_weights(const float* __restrict__ W, int64_t wgs, int n_groups, int k, int n_out, int n_pass, int n_kc,
                                 unsigned short* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t per_group = (int64_t)n_pass * n_kstep * W_TILE_ELEMS;
+    const int64_t per_group = (int64_t)n_pass * n_kc * W_PLANE_ELEMS;
     if (i >= per_group * n_groups) return;
     const int g = (int)(i / per_group);
     int64_t r = i - (int64_t)g * per_group;
-    const int kk = (int)(r % BK);
-    r /= BK;
-    const int row = (int)(r % BNP);
-    r /= BNP;
-    const int ks = (int)(r % n_kstep);
-    const int pass = (int)(r / n_kstep);
-    const int n = pass * BNP + row, kidx = ks * BK + kk;
+    const int e = (int)(r % 8);
+    r /= 8;
+    const int l = (int)(r % 64);
+    r /= 64;
+    const int ct = (int)(r % 8);
+    r /= 8;
+    const int kc = (int)(r % n_kc);
+    const int pass = (int)(r / n_kc);
+    const int n = pass * BNP + ct * 32 + (l & 31), kidx = kc * KC + (l >> 5) * 8 + e;
     float v = 0.0f;
     if (n < n_out && kidx < k) v = W[(int64_t)g * wgs + (int64_t)n * k + kidx];
     const unsigned short h = bf16_rne(v);
     const unsigned short m = bf16_rne(v - bf16_to_f32(h));
-    const int64_t tile = (((int64_t)g * n_pass + pass) * n_kstep + ks) * 2;
-    out[(tile + 0) * W_TILE_ELEMS + row * BK + kk] = h;
-    out[(tile + 1) * W_TILE_ELEMS + row * BK + kk] = m;
+    const int64_t tile = (((int64_t)g * n_pass + pass) * n_kc + kc) * 2;
+    const int within = (ct * 64 + l) * 8 + e;
+    out[(tile + 0) * W_PLANE_ELEMS + within] = h;
+    out[(tile + 1) * W_PLANE_ELEMS + within] = m;
 }
 
 template <int PROLOGUE>
-__global__ __launch_bounds__(512, 2) void k_typed_linear_split(
+__device__ __forceinline__ void load_a_panel(int kp0, int tid, const int (&a_rid)[8], const float* __restrict__ x, int64_t ldx, int k,
+                                             int vec_ok, unsigned char* sA) {
+    float4 av[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int f = tid + 512 * j;
+        const int kk = kp0 + (f & 63) * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int rid = a_rid[j];
+        if (rid >= 0 && kk < k) {
+            const float* px = x + (int64_t)rid * ldx + kk;
+            if (vec_ok && kk + 3 < k) {
+                a = *reinterpret_cast<const float4*>(px);
+            } else {
+                a.x = px[0];
+                if (kk + 1 < k) a.y = px[1];
+                if (kk + 2 < k) a.z = px[2];
+                if (kk + 3 < k) a.w = px[3];
+            }
+            if (PROLOGUE == 1) { a.x = gelu_erf_(a.x); a.y = gelu_erf_(a.y); a.z = gelu_erf_(a.z); a.w = gelu_erf_(a.w); }
+        }
+        av[j] = a;
+    }
+    __syncthreads();   // every wave is done reading the previous panel
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int f = tid + 512 * j;
+        const int r = f >> 6, cb = (f & 63) * 8;
+        uint2 hi, mid;
+        split4(av[j], hi, mid);
+        *reinterpret_cast<uint2*>(sA + r * A_STRIDE + cb) = hi;
+        *reinterpret_cast<uint2*>(sA + A_PLANE + r * A_STRIDE + cb) = mid;
+    }
+    __syncthreads();   // panel visible
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// 4x4 transpose between the 4 lanes of a quad and 4 registers: lane j reg i <- lane i reg j
+__device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, bool o1, bool o2) {
+    float t;
+    t = dpp_mov_f<0xB1>(o1 ? v0 : v1); if (o1) v0 = t; else v1 = t;    // quad_perm [1,0,3,2]
+    t = dpp_mov_f<0xB1>(o1 ? v2 : v3); if (o1) v2 = t; else v3 = t;
+    t = dpp_mov_f<0x4E>(o2 ? v0 : v2); if (o2) v0 = t; else v2 = t;    // quad_perm [2,3,0,1]
+    t = dpp_mov_f<0x4E>(o2 ? v1 : v3); if (o2) v1 = t; else v3 = t;
+}
+
+// epilogue of one 256-column pass.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// Narrow (4 B per lane) stores are issue-bound, so each group of 4 registers (4 consecutive rows, one column per lane)
+// is transposed inside the lane quad: afterwards a lane holds 4 consecutive COLUMNS of one row and writes one 16 B
+// store (one wave instruction = 8 rows x 128 B) -- 4x fewer store instructions.
+__device__ __forceinline__ void store_pass(f32x16 (&acc)[2], int pass, int wave, int lane, int g, int n_out, int nrows, int row0,
+                                           const int* s_rid, const float* __restrict__ bias, int64_t bgs, float* __restrict__ out0,
+                                           float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos) {
+    const bool wide = ((n_out | block_cols) & 3) == 0;
+    if (wide) {
+        const int col = pass * BNP + wave * 32 + ((lane & 31) >> 2) * 4;      // first of this lane's 4 columns after the transpose
+        const bool col_ok = col < n_out;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col_ok && bias) b4 = *reinterpret_cast<const float4*>(bias + (int64_t)g * bgs + col);
+        const int blk = col_ok ? col / block_cols : 0, cc = col - blk * block_cols;
+        float* __restrict__ ob = (blk == 0) ? out0 : ((blk == 1) ? out1 : out2);
+        const bool o1 = lane & 1, o2 = lane & 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v0 = acc[j][4 * q], v1 = acc[j][4 * q + 1], v2 = acc[j][4 * q + 2], v3 = acc[j][4 * q + 3];
+                quad_transpose(v0, v1, v2, v3, o1, o2);
+                const int rt = j * 32 + (lane & 3) + 8 * q + 4 * (lane >> 5);
+                if (col_ok && rt < nrows) {
+                    const int64_t orow = by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
+                    *reinterpret_cast<float4*>(ob + orow * block_cols + cc) = make_float4(v0 + b4.x, v1 + b4.y, v2 + b4.z, v3 + b4.w);
+                }
+            }
+        }
+    } else {
+        const int col = pass * BNP + wave * 32 + (lane & 31);
+        const bool col_ok = col < n_out;
+        const float bcol = (col_ok && bias) ? bias[(int64_t)g * bgs + col] : 0.0f;
+        const int blk = col_ok ? col / block_cols : 0, cc = col - blk * block_cols;
+        float* __restrict__ ob = (blk == 0) ? out0 : ((blk == 1) ? out1 : out2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rt = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (col_ok && rt < nrows) {
+                    const int64_t orow = by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
+                    ob[orow * block_cols + cc] = acc[j][r] + bcol;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+}
+
+struct UpdateArgs {
+    const float* xs;      // skip-connection input rows [*, ldxs]
+    int64_t ldxs;
+    const float* skip;    // [n_groups]
+    const float* lnw;     // [n_groups][n_out] or nullptr
+    const float* lnb;
+    int use_norm;
+};
+
+__device__ __forceinline__ float strided8_sum(float v) {   // sum over the 8 lanes {j, j+4, ..., j+28} of a 32-lane half
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    return v;
+}
+
+// Fused node update (conv.py:129-133) as the epilogue of the a_linear GEMM, single 256-column pass:
+//   y = (acc + b) * sigmoid(skip[t]) + x * (1 - sigmoid(skip[t]));  out = LayerNorm_t(y)  (two-pass mean/variance)
+// A row's 256 columns live in 8 waves x 8 lanes; partial sums meet in a small LDS table (the A slab is dead by then).
+__device__ __forceinline__ void store_pass_update(f32x16 (&acc)[2], int wave, int lane, int g, int n_out, int nrows, const int* s_rid,
+                                                  const float* __restrict__ bias, int64_t bgs, float* __restrict__ out,
+                                                  const UpdateArgs& u, float* s_red) {
+    const int col = wave * 32 + ((lane & 31) >> 2) * 4;
+    const bool col_ok = col < n_out;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col_ok && bias) b4 = *reinterpret_cast<const float4*>(bias + (int64_t)g * bgs + col);
+    const float alpha = 1.0f / (1.0f + expf(-u.skip[g]));
+    const bool o1 = lane & 1, o2 = lane & 2;
+    const float inv_n = 1.0f / (float)n_out;
+    float y[8][4];
+    int64_t orow[8];
+    int rts[8];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v0 = acc[j][4 * q], v1 = acc[j][4 * q + 1], v2 = acc[j][4 * q + 2], v3 = acc[j][4 * q + 3];
+            quad_transpose(v0, v1, v2, v3, o1, o2);
+            const int rt = j * 32 + (lane & 3) + 8 * q + 4 * (lane >> 5);
+            const int s = j * 4 + q;
+            rts[s] = rt;
+            orow[s] = (rt < nrows) ? (int64_t)s_rid[rt] : -1;
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col_ok && orow[s] >= 0) xv = *reinterpret_cast<const float4*>(u.xs + orow[s] * u.ldxs + col);
+            y[s][0] = col_ok ? (v0 + b4.x) * alpha + xv.x * (1.0f - alpha) : 0.0f;
+            y[s][1] = col_ok ? (v1 + b4.y) * alpha + xv.y * (1.0f - alpha) : 0.0f;
+            y[s][2] = col_ok ? (v2 + b4.z) * alpha + xv.z * (1.0f - alpha) : 0.0f;
+            y[s][3] = col_ok ? (v3 + b4.w) * alpha + xv.w * (1.0f - alpha) : 0.0f;
+        }
+    }
+    if (u.use_norm) {
+        // pass 1: mean
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float ps = strided8_sum(y[s][0] + y[s][1] + y[s][2] + y[s][3]);
+            if (((lane & 31) >> 2) == 0) s_red[rts[s] * 8 + wave] = ps;
+        }
+        __syncthreads();
+        float mean[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(&s_red[rts[s] * 8]);
+            const float4 b = *reinterpret_cast<const float4*>(&s_red[rts[s] * 8 + 4]);
+            mean[s] = (a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w) * inv_n;
+        }
+        __syncthreads();
+        // pass 2: variance
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float d0 = y[s][0] - mean[s], d1 = y[s][1] - mean[s], d2 = y[s][2] - mean[s], d3 = y[s][3] - mean[s];
+            if (!col_ok) d0 = d1 = d2 = d3 = 0.0f;
+            const float ps = strided8_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+            if (((lane & 31) >> 2) == 0) s_red[rts[s] * 8 + wave] = ps;
+        }
+        __syncthreads();
+        float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f), c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col_ok) {
+            w4 = *reinterpret_cast<const float4*>(u.lnw + (int64_t)g * n_out + col);
+            c4 = *reinterpret_cast<const float4*>(u.lnb + (int64_t)g * n_out + col);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(&s_red[rts[s] * 8]);
+            const float4 b = *reinterpret_cast<const float4*>(&s_red[rts[s] * 8 + 4]);
+            const float rstd = rsqrtf((a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w) * inv_n + 1e-5f);
+            if (col_ok && orow[s] >= 0)
+                *reinterpret_cast<float4*>(out + orow[s] * n_out + col) =
+                    make_float4((y[s][0] - mean[s]) * rstd * w4.x + c4.x, (y[s][1] - mean[s]) * rstd * w4.y + c4.y,
+                                (y[s][2] - mean[s]) * rstd * w4.z + c4.z, (y[s][3] - mean[s]) * rstd * w4.w + c4.w);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            if (col_ok && orow[s] >= 0)
+                *reinterpret_cast<float4*>(out + orow[s] * n_out + col) = make_float4(y[s][0], y[s][1], y[s][2], y[s][3]);
+    }
+}
+
+template <int PROLOGUE, bool UPD>
+__global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off,
     int n_groups, int k, int n_out, const unsigned short* __restrict__ wsplit, const float* __restrict__ bias, int64_t bgs,
-    float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos, int vec_ok) {
+    float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos, int vec_ok,
+    UpdateArgs upd) {
     __shared__ __attribute__((aligned(16))) unsigned char sA[2 * A_PLANE];        // [plane][64][528]
-    __shared__ __attribute__((aligned(16))) unsigned char sB[2 * 2 * B_PLANE];    // [buf][plane][256][80]
     __shared__ int s_rid[BM];
 
     const int slot = blockIdx.x;
@@ -110,154 +316,85 @@ __global__ __launch_bounds__(512, 2) void k_typed_linear_split(
     __syncthreads();
 
     const int n_pass = (n_out + BNP - 1) / BNP;
-    const int n_kstep = (k + BK - 1) / BK;
+    const int n_kc = ((k + KC - 1) / KC + 3) & ~3;   // padded to a multiple of 4 k-chunks
     const int n_panel = (k + KP - 1) / KP;
-    const unsigned short* __restrict__ wg = wsplit + (int64_t)g * n_pass * n_kstep * 2 * W_TILE_ELEMS;
-
+    const int total = n_pass * n_kc;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
     const int frow = lane & 31, khalf = lane >> 5;
+    // this wave's B fragments: plane stride W_PLANE_ELEMS, tile stride 2 * W_PLANE_ELEMS (bf16 elements)
+    const unsigned short* __restrict__ wfrag = wsplit + (int64_t)g * total * 2 * W_PLANE_ELEMS + (wave * 64 + lane) * 8;
 
-    // this thread's 8 float4 of the A slab: f = tid + 512*j -> row f>>6, float4 column f&63
-    int a_rid[8];
+    int a_rid[8];   // this thread's 8 float4 of the A slab: f = tid + 512*j -> row f>>6, float4 column f&63
 #pragma unroll
     for (int j = 0; j < 8; ++j) a_rid[j] = s_rid[(tid + 512 * j) >> 6];
 
-    // The W tiles of this row tile form ONE linear stream of n_pass * n_kstep tiles (tile-major layout written
-    // by hgt_split_weights).  They are prefetched FOUR k-steps ahead into four named register stages
-    // (an L2 round trip is ~1 us, one k-step of MFMA work only ~0.4 us), staged through a 2-deep LDS ring.
-    const int total = n_pass * n_kstep;
     f32x16 acc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
-    // W chunk handled by this thread: row slot q = tid>>2 is permuted inside each block of 8 rows
-    // (0,4,1,5,2,6,3,7) so that the two rows written by one 8-lane ds_write_b128 group are 4 apart:
-    // 4 * 80 B = 16 banks (mod 32) -> the group covers all 32 banks once (the natural order was 2-way).
-    const int q_ = tid >> 2;
-    const int brow = (q_ & ~7) + ((q_ & 1) << 2) + ((q_ >> 1) & 3);
-    const int gch0 = brow * 4 + (tid & 3);                            // chunk index inside the 16 KB plane tile
-    const int bo0 = brow * B_STRIDE + (tid & 3) * 16;                 // LDS offset of that chunk
-    const int bo1 = (brow + 128) * B_STRIDE + (tid & 3) * 16;         // ... of chunk gch0 + 512
-
-    uint4 s0a, s0b, s0c, s0d, s1a, s1b, s1c, s1d, s2a, s2b, s2c, s2d, s3a, s3b, s3c, s3d;
-#define HGT_LOAD_STAGE(S, T)                                                                  \
-    if ((T) < total) {                                                                        \
-        const unsigned short* t_ = wg + (int64_t)(T) * 2 * W_TILE_ELEMS;                      \
-        s##S##a = *reinterpret_cast<const uint4*>(t_ + gch0 * 8);                             \
-        s##S##b = *reinterpret_cast<const uint4*>(t_ + (gch0 + 512) * 8);                     \
-        s##S##c = *reinterpret_cast<const uint4*>(t_ + W_TILE_ELEMS + gch0 * 8);              \
-        s##S##d = *reinterpret_cast<const uint4*>(t_ + W_TILE_ELEMS + (gch0 + 512) * 8);      \
+    // B fragment stream: k-chunk T of the flattened (pass, k-chunk) sequence, prefetched 4 ahead in 4 named stages.
+    // n_kc is a multiple of 4 (hgt_split_weights zero-pads K to a multiple of 64, the A slab is zero-filled
+    // beyond k), so the 4-step body needs no guards and a pass boundary always falls between bodies.
+    bf16x8 s0h, s0m, s1h, s1m, s2h, s2m, s3h, s3m;
+#define HGT_LOAD_STAGE(S, T)                                                                          \
+    {                                                                                                 \
+        const unsigned short* t_ = wfrag + (int64_t)min((T), total - 1) * 2 * W_PLANE_ELEMS;          \
+        s##S##h = *reinterpret_cast<const bf16x8*>(t_);                                               \
+        s##S##m = *reinterpret_cast<const bf16x8*>(t_ + W_PLANE_ELEMS);                               \
     }
     HGT_LOAD_STAGE(0, 0)
     HGT_LOAD_STAGE(1, 1)
     HGT_LOAD_STAGE(2, 2)
     HGT_LOAD_STAGE(3, 3)
 
-    auto load_a_panel = [&](int kp0) {
-        float4 av[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int f = tid + 512 * j;
-            const int kk = kp0 + (f & 63) * 4;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int rid = a_rid[j];
-            if (rid >= 0 && kk < k) {
-                const float* px = x + (int64_t)rid * ldx + kk;
-                if (vec_ok && kk + 3 < k) {
-                    a = *reinterpret_cast<const float4*>(px);
-                } else {
-                    a.x = px[0];
-                    if (kk + 1 < k) a.y = px[1];
-                    if (kk + 2 < k) a.z = px[2];
-                    if (kk + 3 < k) a.w = px[3];
-                }
-                if (PROLOGUE == 1) { a.x = gelu_erf_(a.x); a.y = gelu_erf_(a.y); a.z = gelu_erf_(a.z); a.w = gelu_erf_(a.w); }
-            }
-            av[j] = a;
-        }
-        __syncthreads();   // readers of the previous panel are done
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int f = tid + 512 * j;
-            const int r = f >> 6, cb = (f & 63) * 8;
-            uint2 hi, mid;
-            split4(av[j], hi, mid);
-            *reinterpret_cast<uint2*>(sA + r * A_STRIDE + cb) = hi;
-            *reinterpret_cast<uint2*>(sA + A_PLANE + r * A_STRIDE + cb) = mid;
-        }
-    };
+    load_a_panel<PROLOGUE>(0, tid, a_rid, x, ldx, k, vec_ok, sA);
 
-    auto epilogue = [&](int pass) {
-        // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = pass * BNP + wn * 64 + j * 32 + (lane & 31);
-            if (col < n_out) {
-                const float bcol = bias ? bias[(int64_t)g * bgs + col] : 0.0f;
-                const int blk = col / block_cols, cc = col - blk * block_cols;
-                float* __restrict__ ob = (blk == 0) ? out0 : ((blk == 1) ? out1 : out2);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rt = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (rt < nrows && !(by_pos & 2 && acc[j][r] != 12345.0f)) {
-                        const int64_t orow = (by_pos & 1) ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
-                        ob[orow * block_cols + cc] = acc[j][r] + bcol;
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-        }
-    };
-
-#define HGT_STEP(S, T)                                                                                              \
-    if ((T) < total) {                                                                                              \
-        const int pass_ = (T) / n_kstep, ksg_ = (T) - pass_ * n_kstep;        /* k-step inside the row of tiles */  \
-        const int ksp_ = ksg_ & (KP / BK - 1);                                /* k-step inside the A panel */       \
-        if (ksp_ == 0 && (n_panel > 1 || (T) == 0)) load_a_panel((ksg_ / (KP / BK)) * KP);                          \
-        unsigned char* bb = sB + ((T) & 1) * 2 * B_PLANE;                                                           \
-        *reinterpret_cast<uint4*>(bb + bo0) = s##S##a;                                                              \
-        *reinterpret_cast<uint4*>(bb + bo1) = s##S##b;                                                              \
-        *reinterpret_cast<uint4*>(bb + B_PLANE + bo0) = s##S##c;                                                    \
-        *reinterpret_cast<uint4*>(bb + B_PLANE + bo1) = s##S##d;                                                    \
-        __syncthreads(); /* tile T (and a fresh A panel) visible; ring slot (T+1)&1 is free again */                \
-        HGT_LOAD_STAGE(S, (T) + 4)                                                                                  \
-        _Pragma("unroll") for (int kc = 0; kc < BK / 16; ++kc) {                                                    \
-            const int ao = (wm * 32 + frow) * A_STRIDE + (ksp_ * BK + kc * 16 + khalf * 8) * 2;                     \
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(sA + ao);                                            \
-            const bf16x8 am = *reinterpret_cast<const bf16x8*>(sA + A_PLANE + ao);                                  \
-            const int bo_ = (wn * 64 + frow) * B_STRIDE + (kc * 16 + khalf * 8) * 2;                                 \
-            const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(bb + bo_);                                          \
-            const bf16x8 bm0 = *reinterpret_cast<const bf16x8*>(bb + B_PLANE + bo_);                                \
-            const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(bb + bo_ + 32 * B_STRIDE);                          \
-            const bf16x8 bm1 = *reinterpret_cast<const bf16x8*>(bb + B_PLANE + bo_ + 32 * B_STRIDE);                \
-            /* small terms first, hi*hi last; the two accumulators alternate so dependent MFMAs are 2 apart */      \
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh0, acc[0], 0, 0, 0);                             \
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh1, acc[1], 0, 0, 0);                             \
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm0, acc[0], 0, 0, 0);                             \
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm1, acc[1], 0, 0, 0);                             \
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc[0], 0, 0, 0);                             \
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc[1], 0, 0, 0);                             \
-        }                                                                                                           \
-        if (ksg_ == n_kstep - 1) epilogue(pass_);                                                                   \
+#define HGT_STEP(S, T, KCP)                                                                                        \
+    {                                                                                                              \
+        const int ao = frow * A_STRIDE + ((KCP) * KC + khalf * 8) * 2;                                             \
+        const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(sA + ao);                                              \
+        const bf16x8 am0 = *reinterpret_cast<const bf16x8*>(sA + A_PLANE + ao);                                    \
+        const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(sA + ao + 32 * A_STRIDE);                              \
+        const bf16x8 am1 = *reinterpret_cast<const bf16x8*>(sA + A_PLANE + ao + 32 * A_STRIDE);                    \
+        const bf16x8 bh = s##S##h, bm = s##S##m;                                                                   \
+        HGT_LOAD_STAGE(S, (T) + 4)                                                                                 \
+        /* small terms first, hi*hi last; the two accumulators alternate */                                        \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, bh, acc[0], 0, 0, 0);                                \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, bh, acc[1], 0, 0, 0);                                \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bm, acc[0], 0, 0, 0);                                \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bm, acc[1], 0, 0, 0);                                \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[0], 0, 0, 0);                                \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1], 0, 0, 0);                                \
     }
 
-    for (int t0 = 0; t0 < total; t0 += 4) {
-        HGT_STEP(0, t0)
-        HGT_STEP(1, t0 + 1)
-        HGT_STEP(2, t0 + 2)
-        HGT_STEP(3, t0 + 3)
+    for (int pass = 0; pass < n_pass; ++pass) {
+        for (int panel = 0; panel < n_panel; ++panel) {
+            if (n_panel > 1 && (pass | panel) != 0) load_a_panel<PROLOGUE>(panel * KP, tid, a_rid, x, ldx, k, vec_ok, sA);
+            const int nkc_p = min(KP / KC, n_kc - panel * (KP / KC));
+            const int tbase = pass * n_kc + panel * (KP / KC);
+            for (int kq = 0; kq < nkc_p; kq += 4) {
+                HGT_STEP(0, tbase + kq, kq)
+                HGT_STEP(1, tbase + kq + 1, kq + 1)
+                HGT_STEP(2, tbase + kq + 2, kq + 2)
+                HGT_STEP(3, tbase + kq + 3, kq + 3)
+            }
+        }
+        if constexpr (UPD) {
+            __syncthreads();   // every wave left the MFMA loop: the A slab can be reused as the reduction table
+            store_pass_update(acc, wave, lane, g, n_out, nrows, s_rid, bias, bgs, out0, upd, reinterpret_cast<float*>(sA));
+        } else {
+            store_pass(acc, pass, wave, lane, g, n_out, nrows, row0, s_rid, bias, bgs, out0, out1, out2, block_cols, by_pos);
+        }
     }
 #undef HGT_STEP
 #undef HGT_LOAD_STAGE
 }
 
-static inline void split_dims(int k, int n_out, int* n_pass, int* n_kstep) {
+static inline void split_dims(int k, int n_out, int* n_pass, int* n_kc) {
     *n_pass = (n_out + BNP - 1) / BNP;
-    *n_kstep = (k + BK - 1) / BK;
+    *n_kc = ((k + KC - 1) / KC + 3) & ~3;   // k-chunks padded to a multiple of 4 (zero tiles)
 }
 
 }  // namespace
@@ -266,7 +403,7 @@ extern "C" int hgt_split_weights_bytes(int32_t n_groups, int32_t k, int32_t n_ou
     if (!out || n_groups <= 0 || k <= 0 || n_out <= 0) return HGT_ERR_INVALID_ARG;
     int n_pass, n_kstep;
     split_dims(k, n_out, &n_pass, &n_kstep);
-    *out = (uint64_t)n_groups * n_pass * n_kstep * 2 * W_TILE_ELEMS * 2;
+    *out = (uint64_t)n_groups * n_pass * n_kstep * 2 * W_PLANE_ELEMS * 2;
     return HGT_OK;
 }
 
@@ -275,7 +412,7 @@ extern "C" int hgt_split_weights(const float* W, int64_t w_group_stride, int32_t
     if (!W || !w_split || n_groups <= 0 || k <= 0 || n_out <= 0) return HGT_ERR_INVALID_ARG;
     int n_pass, n_kstep;
     split_dims(k, n_out, &n_pass, &n_kstep);
-    const int64_t total = (int64_t)n_groups * n_pass * n_kstep * W_TILE_ELEMS;
+    const int64_t total = (int64_t)n_groups * n_pass * n_kstep * W_PLANE_ELEMS;
     k_split_weights<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, w_group_stride, n_groups, k, n_out, n_pass, n_kstep,
                                                                                      (unsigned short*)w_split);
     HGT_CHECK_LAUNCH();
@@ -296,14 +433,37 @@ extern "C" int hgt_typed_linear_bf16x3(const float* x, int64_t ldx, const int32_
     const int64_t row_tiles = (n_rows + BM - 1) / BM + n_groups;   // device-side group sizes: launch the upper bound
     if (row_tiles > 0x7fffffffLL) return HGT_ERR_TOO_LARGE;
     const int vec_ok = (ldx % 4 == 0) && (k % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    UpdateArgs noupd = {nullptr, 0, nullptr, nullptr, nullptr, 0};
     if (prologue == 0)
-        k_typed_linear_split<0><<<(unsigned)row_tiles, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
-                                                                         (const unsigned short*)w_split, bias, b_group_stride, out0,
-                                                                         out1, out2, block_cols, out_by_position, vec_ok);
+        k_typed_linear_split<0, false><<<(unsigned)row_tiles, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
+                                                                                (const unsigned short*)w_split, bias, b_group_stride,
+                                                                                out0, out1, out2, block_cols, out_by_position, vec_ok, noupd);
     else
-        k_typed_linear_split<1><<<(unsigned)row_tiles, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
-                                                                         (const unsigned short*)w_split, bias, b_group_stride, out0,
-                                                                         out1, out2, block_cols, out_by_position, vec_ok);
+        k_typed_linear_split<1, false><<<(unsigned)row_tiles, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
+                                                                                (const unsigned short*)w_split, bias, b_group_stride,
+                                                                                out0, out1, out2, block_cols, out_by_position, vec_ok, noupd);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+// a_linear + gated skip + LayerNorm in one kernel (n_out <= 256, n_out % 4 == 0): see store_pass_update.
+extern "C" int hgt_linear_update_bf16x3(const float* agg, int64_t ld_agg, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
+                                        int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias,
+                                        int64_t b_group_stride, const float* x_skip, int64_t ld_skip, const float* skip,
+                                        const float* ln_w, const float* ln_b, int32_t use_norm, float* out, void* stream_) {
+    if (!agg || !rows || !group_off || !w_split || !x_skip || !skip || !out || n_groups <= 0 || n_rows < 0 || k <= 0 || n_out <= 0)
+        return HGT_ERR_INVALID_ARG;
+    if (use_norm && (!ln_w || !ln_b)) return HGT_ERR_INVALID_ARG;
+    if (n_out > BNP || (n_out & 3) != 0 || (ld_skip & 3) != 0 || ((uintptr_t)x_skip & 15) != 0) return HGT_ERR_UNSUPPORTED;
+    if (n_rows == 0) return HGT_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t row_tiles = (n_rows + BM - 1) / BM + n_groups;
+    if (row_tiles > 0x7fffffffLL) return HGT_ERR_TOO_LARGE;
+    const int vec_ok = (ld_agg % 4 == 0) && (k % 4 == 0) && (((uintptr_t)agg & 15) == 0);
+    UpdateArgs u = {x_skip, ld_skip, skip, ln_w, ln_b, use_norm};
+    k_typed_linear_split<0, true><<<(unsigned)row_tiles, 512, 0, stream>>>(agg, ld_agg, rows, group_off, n_groups, k, n_out,
+                                                                           (const unsigned short*)w_split, bias, b_group_stride, out,
+                                                                           nullptr, nullptr, n_out, 0, vec_ok, u);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }

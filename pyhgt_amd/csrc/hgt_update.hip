@@ -81,7 +81,25 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ x
     }
 }
 
+// out[rows[i]] = 0 for i in [off[0], off[1]) (device-side range): rows whose node type no group claims (conv.py:120)
+__global__ __launch_bounds__(256) void k_zero_rows(const int32_t* __restrict__ rows, const int32_t* __restrict__ off, int d,
+                                                   float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int beg = off[0], end = off[1];
+    for (int i = beg + blockIdx.x * 4 + (threadIdx.x >> 6); i < end; i += gridDim.x * 4) {
+        float* o = out + (int64_t)rows[i] * d;
+        for (int c = lane; c < d; c += 64) o[c] = 0.0f;
+    }
+}
+
 }  // namespace
+
+extern "C" int hgt_zero_rows(const int32_t* rows, const int32_t* range, int32_t d, float* out, void* stream) {
+    if (!rows || !range || !out || d <= 0) return HGT_ERR_INVALID_ARG;
+    k_zero_rows<<<64, 256, 0, (hipStream_t)stream>>>(rows, range, d, out);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
 
 extern "C" int hgt_node_update(const float* trans, const float* x, int64_t ldx, const int64_t* node_type, const float* skip,
                                const float* ln_w, const float* ln_b, int32_t use_norm, int64_t n_nodes, int32_t d,
