@@ -71,13 +71,15 @@ template <int VEC, int DKP, bool HOIST>
 __device__ __forceinline__ void head_matvec(const float (&xv)[VEC], float* bounce, int lane, int h,
                                             const float (&frag)[HOIST ? DKP : 1][VEC], const float* __restrict__ fglob,
                                             float (&y)[VEC]) {
-    store_vec_lds<VEC>(bounce + lane * VEC, xv);
+    // head h's DKP inputs live at h*(DKP+4): the +4 floats of padding put the (up to 4) heads that one
+    // ds_read_b128 lane group reads on different banks (unpadded, heads 0/2 and 1/3 collided: 2-way conflict)
+    store_vec_lds<VEC>(bounce + lane * VEC + (lane / (DKP / VEC)) * 4, xv);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int i = 0; i < VEC; ++i) y[i] = 0.0f;
-    const float* xb = bounce + h * DKP;
+    const float* xb = bounce + h * (DKP + 4);
 #pragma unroll
     for (int j4 = 0; j4 < DKP / 4; ++j4) {
         const float4 xx = *reinterpret_cast<const float4*>(xb + 4 * j4);
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void k_edge_logits(
     const float* __restrict__ K, const float* __restrict__ rteK, const float* __restrict__ attT, float* __restrict__ logits, int R) {
     constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = unroll_for<VEC>();
     constexpr bool HOIST = (DKP * VEC <= 128);
-    __shared__ __attribute__((aligned(16))) float s_bounce[4][DP];
+    __shared__ __attribute__((aligned(16))) float s_bounce[4][DP + 4 * (64 / LPH)];
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
     constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = unroll_for<VEC>();
     constexpr bool HOIST = (DKP * VEC <= 128);
     __shared__ __attribute__((aligned(16))) float s_acc[4][HGT_SUB * DP];
-    __shared__ __attribute__((aligned(16))) float s_bounce[4][DP];
+    __shared__ __attribute__((aligned(16))) float s_bounce[4][DP + 4 * (64 / LPH)];
     __shared__ float s_ml[4][2][HGT_SUB * 16];   // running max / sum per (target, head); H <= 16
 
     const int lane = threadIdx.x & 63;

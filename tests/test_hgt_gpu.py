@@ -155,6 +155,54 @@ def test_two_layer_stack_shares_one_plan():
     assert (h.cpu() - ref).abs().max().item() < TOL
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_source_only_halo_rows(precision):
+    """Destination partitioning (pyhgt_amd/dist.py): nodes >= n_q_rows are source-only halo rows -- they get K/V
+    projections but no Q / aggregation / update; the first n_q_rows outputs must equal the full-graph result."""
+    T, R, H, d, N, NQ, E = 3, 4, 4, 64, 3000, 1000, 20000
+    sd = O.make_state_dict(d, d, T, R, H, True, True, seed=31)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=32, sorted_types=False)
+    ei = ei.clone()
+    ei[1] = ei[1] % NQ                                   # every target is an owned node
+    ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, dtype=torch.float64)
+    layer = _layer_from(sd, d, T, R, H, True, True, keep_att=False, precision=precision)
+    GraphPlan.clear_cache()
+    with torch.no_grad():
+        out = layer(*_to_dev(x, nt, ei, et, tm), n_q_rows=NQ)
+    assert out.shape == (NQ, d)
+    assert (out.cpu().double() - ref[:NQ]).abs().max().item() < TOL
+
+
+def test_partitioned_graph_on_gpu_single_rank():
+    """pyhgt_amd.dist on the real device path (RCCL all_to_all_single, HIP halo pack) with world_size 1;
+    world_size 2/3 index logic is covered on CPU over gloo (tests/test_dist_gloo.py)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from pyhgt_amd.dist import PartitionedGraph
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        T, R, H, d, N, E = 3, 4, 4, 64, 2000, 16000
+        sd = O.make_state_dict(d, d, T, R, H, True, True, seed=41)
+        x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=42)
+        ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, dtype=torch.float64)
+        layer = _layer_from(sd, d, T, R, H, True, True, keep_att=False)
+        xs, nts, eis, ets, tms = _to_dev(x, nt, ei, et, tm)
+        pg = PartitionedGraph(nts, eis[0].contiguous(), eis[1].contiguous(), ets, tms, T, R, N, 0, 1)
+        assert pg.n_own == N and pg.n_local == N
+        with torch.no_grad():
+            out = pg.forward(layer, xs)
+        assert (out.cpu().double() - ref).abs().max().item() < TOL
+    finally:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------ integer work: bit exact
 def _plan_arrays(plan):
     """Mirror of hgt_plan_layout() in pyhgt_amd/csrc/hgt_common.h (256-byte aligned arrays)."""
