@@ -87,39 +87,45 @@ __global__ void k_split_weights(const float* __restrict__ W, int64_t wgs, int n_
     out[(tile + 1) * W_PLANE_ELEMS + within] = m;
 }
 
+// Load one K panel of the 64-row x slab: whole rows, split into bf16 hi/mid planes ONCE, stored to LDS.
+// Done in two halves of 4 float4 per thread to keep the live register set small (the kernel is capped at 128 VGPRs
+// so that two workgroups fit a CU; an 8-deep version spilled ~230 B per lane to scratch = +2.9 GB of HBM traffic at c2).
 template <int PROLOGUE>
-__device__ __forceinline__ void load_a_panel(int kp0, int tid, const int (&a_rid)[8], const float* __restrict__ x, int64_t ldx, int k,
-                                             int vec_ok, unsigned char* sA) {
-    float4 av[8];
+__device__ __forceinline__ void load_a_panel(int kp0, int tid, const int* s_rid, const float* __restrict__ x, int64_t ldx, int k,
+                                             int vec_ok, unsigned char* sA, bool wait_readers) {
+    if (wait_readers) __syncthreads();   // every wave is done reading the previous panel
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int f = tid + 512 * j;
-        const int kk = kp0 + (f & 63) * 4;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int rid = a_rid[j];
-        if (rid >= 0 && kk < k) {
-            const float* px = x + (int64_t)rid * ldx + kk;
-            if (vec_ok && kk + 3 < k) {
-                a = *reinterpret_cast<const float4*>(px);
-            } else {
-                a.x = px[0];
-                if (kk + 1 < k) a.y = px[1];
-                if (kk + 2 < k) a.z = px[2];
-                if (kk + 3 < k) a.w = px[3];
+    for (int half = 0; half < 2; ++half) {
+        float4 av[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 512 * (half * 4 + j);
+            const int kk = kp0 + (f & 63) * 4;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int rid = s_rid[f >> 6];
+            if (rid >= 0 && kk < k) {
+                const float* px = x + (int64_t)rid * ldx + kk;
+                if (vec_ok && kk + 3 < k) {
+                    a = *reinterpret_cast<const float4*>(px);
+                } else {
+                    a.x = px[0];
+                    if (kk + 1 < k) a.y = px[1];
+                    if (kk + 2 < k) a.z = px[2];
+                    if (kk + 3 < k) a.w = px[3];
+                }
+                if (PROLOGUE == 1) { a.x = gelu_erf_(a.x); a.y = gelu_erf_(a.y); a.z = gelu_erf_(a.z); a.w = gelu_erf_(a.w); }
             }
-            if (PROLOGUE == 1) { a.x = gelu_erf_(a.x); a.y = gelu_erf_(a.y); a.z = gelu_erf_(a.z); a.w = gelu_erf_(a.w); }
+            av[j] = a;
         }
-        av[j] = a;
-    }
-    __syncthreads();   // every wave is done reading the previous panel
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int f = tid + 512 * j;
-        const int r = f >> 6, cb = (f & 63) * 8;
-        uint2 hi, mid;
-        split4(av[j], hi, mid);
-        *reinterpret_cast<uint2*>(sA + r * A_STRIDE + cb) = hi;
-        *reinterpret_cast<uint2*>(sA + A_PLANE + r * A_STRIDE + cb) = mid;
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 512 * (half * 4 + j);
+            const int r = f >> 6, cb = (f & 63) * 8;
+            uint2 hi, mid;
+            split4(av[j], hi, mid);
+            *reinterpret_cast<uint2*>(sA + r * A_STRIDE + cb) = hi;
+            *reinterpret_cast<uint2*>(sA + A_PLANE + r * A_STRIDE + cb) = mid;
+        }
     }
     __syncthreads();   // panel visible
 }
@@ -324,20 +330,22 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     // this wave's B fragments: plane stride W_PLANE_ELEMS, tile stride 2 * W_PLANE_ELEMS (bf16 elements)
     const unsigned short* __restrict__ wfrag = wsplit + (int64_t)g * total * 2 * W_PLANE_ELEMS + (wave * 64 + lane) * 8;
 
-    int a_rid[8];   // this thread's 8 float4 of the A slab: f = tid + 512*j -> row f>>6, float4 column f&63
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a_rid[j] = s_rid[(tid + 512 * j) >> 6];
-
     f32x16 acc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
-    // B fragment stream: k-chunk T of the flattened (pass, k-chunk) sequence, prefetched 4 ahead in 4 named stages.
+    // B fragment stream: k-chunk T of the flattened (pass, k-chunk) sequence, prefetched HGT_NSTAGE ahead in named register stages.
     // n_kc is a multiple of 4 (hgt_split_weights zero-pads K to a multiple of 64, the A slab is zero-filled
     // beyond k), so the 4-step body needs no guards and a pass boundary always falls between bodies.
-    bf16x8 s0h, s0m, s1h, s1m, s2h, s2m, s3h, s3m;
+#ifndef HGT_NSTAGE
+#define HGT_NSTAGE 2   // measured: 2 stages (1.83 ms at c2) beat 4 (1.88 ms): fewer live registers -> fewer spills at the 128-VGPR cap
+#endif
+    bf16x8 s0h, s0m, s1h, s1m;
+#if HGT_NSTAGE == 4
+    bf16x8 s2h, s2m, s3h, s3m;
+#endif
 #define HGT_LOAD_STAGE(S, T)                                                                          \
     {                                                                                                 \
         const unsigned short* t_ = wfrag + (int64_t)min((T), total - 1) * 2 * W_PLANE_ELEMS;          \
@@ -346,10 +354,12 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     }
     HGT_LOAD_STAGE(0, 0)
     HGT_LOAD_STAGE(1, 1)
+#if HGT_NSTAGE == 4
     HGT_LOAD_STAGE(2, 2)
     HGT_LOAD_STAGE(3, 3)
+#endif
 
-    load_a_panel<PROLOGUE>(0, tid, a_rid, x, ldx, k, vec_ok, sA);
+    load_a_panel<PROLOGUE>(0, tid, s_rid, x, ldx, k, vec_ok, sA, false);
 
 #define HGT_STEP(S, T, KCP)                                                                                        \
     {                                                                                                              \
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
         const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(sA + ao + 32 * A_STRIDE);                              \
         const bf16x8 am1 = *reinterpret_cast<const bf16x8*>(sA + A_PLANE + ao + 32 * A_STRIDE);                    \
         const bf16x8 bh = s##S##h, bm = s##S##m;                                                                   \
-        HGT_LOAD_STAGE(S, (T) + 4)                                                                                 \
+        HGT_LOAD_STAGE(S, (T) + HGT_NSTAGE)                                                                        \
         /* small terms first, hi*hi last; the two accumulators alternate */                                        \
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, bh, acc[0], 0, 0, 0);                                \
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, bh, acc[1], 0, 0, 0);                                \
@@ -371,14 +381,21 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
 
     for (int pass = 0; pass < n_pass; ++pass) {
         for (int panel = 0; panel < n_panel; ++panel) {
-            if (n_panel > 1 && (pass | panel) != 0) load_a_panel<PROLOGUE>(panel * KP, tid, a_rid, x, ldx, k, vec_ok, sA);
+            if (n_panel > 1 && (pass | panel) != 0) load_a_panel<PROLOGUE>(panel * KP, tid, s_rid, x, ldx, k, vec_ok, sA, true);
             const int nkc_p = min(KP / KC, n_kc - panel * (KP / KC));
             const int tbase = pass * n_kc + panel * (KP / KC);
             for (int kq = 0; kq < nkc_p; kq += 4) {
+#if HGT_NSTAGE == 4
                 HGT_STEP(0, tbase + kq, kq)
                 HGT_STEP(1, tbase + kq + 1, kq + 1)
                 HGT_STEP(2, tbase + kq + 2, kq + 2)
                 HGT_STEP(3, tbase + kq + 3, kq + 3)
+#else
+                HGT_STEP(0, tbase + kq, kq)
+                HGT_STEP(1, tbase + kq + 1, kq + 1)
+                HGT_STEP(0, tbase + kq + 2, kq + 2)
+                HGT_STEP(1, tbase + kq + 3, kq + 3)
+#endif
             }
         }
         if constexpr (UPD) {

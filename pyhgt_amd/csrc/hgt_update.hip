@@ -114,8 +114,8 @@ extern "C" int hgt_node_update(const float* trans, const float* x, int64_t ldx, 
 }
 
 extern "C" int hgt_gather_rows(const float* x, int64_t ldx, const int32_t* idx, int64_t n, int32_t d, float* out, void* stream) {
-    if (!x || !idx || !out || d <= 0 || n < 0) return HGT_ERR_INVALID_ARG;
     if (n == 0) return HGT_OK;
+    if (!x || !idx || !out || d <= 0 || n < 0) return HGT_ERR_INVALID_ARG;
     k_gather_rows<<<(unsigned)((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(x, ldx, idx, n, d, out);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
