@@ -67,6 +67,8 @@ SIGNATURES = {
     "hgt_edge_logits": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hgt_edge_softmax": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "hgt_edge_aggregate": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "hgt_relation_frag": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "hgt_edge_aggregate_mfma": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "hgt_att_export": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "hgt_node_update": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "hgt_gather_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
