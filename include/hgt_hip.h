@@ -184,17 +184,6 @@ int hgt_edge_softmax(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t
 int hgt_edge_aggregate(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                        int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
                        const float* msg_p, float* agg, int64_t n_q_rows, int32_t apply_gelu, void* stream);
-/* Matrix-core variants of the edge kernels: the d_k x d_k relation transforms are batched over the 16 targets
- * of a sub-tile and run as fp32 MFMA (exact fp32 FMA chains) instead of one VALU mat-vec per (target, relation).
- * hgt_relation_frag re-orders the packed matrices of hgt_relation_pack into MFMA B-fragment order
- * ([R][H][dk_pad/16][dk_pad/16][64 lanes][4]).  Same contracts as hgt_edge_logits / hgt_edge_aggregate.
- * HGT_ERR_UNSUPPORTED when dk_pad % 16 != 0 or the fragments of one relation do not fit in registers
- * (callers then use the VALU variants). */
-int hgt_relation_frag(const float* att_t, const float* msg_p, int32_t n_relations, int32_t n_heads, int32_t dk_pad,
-                      float* att_f, float* msg_f, void* stream);
-int hgt_edge_aggregate_mfma(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
-                            int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
-                            const float* msg_f, float* agg, int64_t n_q_rows, int32_t apply_gelu, void* stream);
 int hgt_att_export(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                    int32_t n_heads, const float* att_sorted, float* att_out, void* stream);
 

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhgt_hip.so")
+LIB_PATH = os.environ.get("HGT_LIB_PATH", os.path.join(_HERE, "lib", "libhgt_hip.so"))   # override: development A/B builds
 
 HGT_RTE_LEN = 240
 HGT_N_PHASE_EVENTS = 7
@@ -67,8 +67,6 @@ SIGNATURES = {
     "hgt_edge_logits": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hgt_edge_softmax": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "hgt_edge_aggregate": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
-    "hgt_relation_frag": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "hgt_edge_aggregate_mfma": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "hgt_att_export": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "hgt_node_update": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "hgt_gather_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),

@@ -1,13 +1,11 @@
 // C-ABI glue: error strings, layout helper and the whole-layer entry point that enqueues every
 // kernel of one HGTConv.forward (conv.py:56-134, eval mode) on the caller's stream.
-#include <cstdlib>
-
 #include "hgt_common.h"
 
 namespace {
 
 struct ConvWorkspace {
-    uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p, off_att_f, off_msg_f;
+    uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p;
     uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, off_ws_qkv, off_ws_a, off_ws_rte, total;
 };
 
@@ -25,8 +23,6 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
     w.off_trans = take((uint64_t)NQ * out_dim * 4);
     w.off_att_t = take((uint64_t)R * H * lay.dk_pad * lay.dk_pad * 4);
     w.off_msg_p = take((uint64_t)R * H * lay.dk_pad * lay.dk_pad * 4);
-    w.off_att_f = take((uint64_t)R * H * lay.dk_pad * lay.dk_pad * 4);
-    w.off_msg_f = take((uint64_t)R * H * lay.dk_pad * lay.dk_pad * 4);
     if (use_rte) {
         w.off_rte_lin = take((uint64_t)HGT_RTE_LEN * in_dim * 4);
         w.off_rte_k = take((uint64_t)T * HGT_RTE_LEN * dp * 4);
@@ -119,8 +115,6 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     float* trans = (float*)(wb + w.off_trans);
     float* att_t = (float*)(wb + w.off_att_t);
     float* msg_p = (float*)(wb + w.off_msg_p);
-    float* att_f = (float*)(wb + w.off_att_f);
-    float* msg_f = (float*)(wb + w.off_msg_f);
     float* rte_k = nullptr;
     float* rte_v = nullptr;
 
@@ -135,14 +129,6 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     // (1) relation matrices: fold pri/sqrt(dk), transpose att, zero-pad heads (conv.py:98-99,104)
     rc = hgt_relation_pack(a->relation_att, a->relation_msg, a->relation_pri, R, H, lay.d_k, lay.dk_pad, att_t, msg_p, stream);
     if (rc != HGT_OK) return rc;
-    // MFMA B-fragment order for the matrix-core edge kernels (when the head layout supports them)
-    const char* mf_env = getenv("HGT_EDGE_MFMA");
-    bool edge_mfma = !(mf_env && mf_env[0] == '0');
-    if (edge_mfma) {
-        rc = hgt_relation_frag(att_t, msg_p, R, H, lay.dk_pad, att_f, msg_f, stream);
-        if (rc == HGT_ERR_UNSUPPORTED) edge_mfma = false;
-        else if (rc != HGT_OK) return rc;
-    }
 
     // typed linear dispatch: exact fp32 MFMA, or split-bf16 x3 with weights split+tiled into the workspace
     const bool split = (a->precision == 1);
@@ -200,9 +186,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     mark(2);
     mark(3);
     // runs for E == 0 too: it writes the zero rows of isolated targets; stores gelu(agg) (conv.py:119)
-    rc = HGT_ERR_UNSUPPORTED;
-    if (edge_mfma) rc = hgt_edge_aggregate_mfma(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_f, agg, NQ, 1, stream);
-    if (rc == HGT_ERR_UNSUPPORTED) rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ, 1, stream);
+    rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ, 1, stream);
     if (rc != HGT_OK) return rc;
     if (a->want_att && E > 0) {   // self.att (conv.py:108): normalise the logits in place and un-sort them
         rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);

@@ -5,8 +5,12 @@
 
 #include "../../include/hgt_hip.h"
 
-#define HGT_TD 64        // destination nodes per tile (sort key = (dst/TD, relation, dst%TD))
+#ifndef HGT_TD
+#define HGT_TD 64        // destination nodes per tile (sort key = (dst/TD, relation, dst%TD)); multiple of 64
+#endif
+#ifndef HGT_CH
 #define HGT_CH 256       // max edges per wavefront work item
+#endif
 #define HGT_WAVE 64
 
 #define HGT_CHECK_LAUNCH()                          \

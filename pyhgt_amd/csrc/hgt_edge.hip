@@ -106,12 +106,20 @@ constexpr int unroll_for() { return VEC <= 4 ? 8 : (VEC == 8 ? 4 : 2); }
 // ---------------------------------------------------------------------------------------------
 // pass 1: logits
 // ---------------------------------------------------------------------------------------------
-template <int VEC, int LPH>
+template <int VEC, int LPH, bool RTE>
 __global__ __launch_bounds__(256) void k_edge_logits(
     const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
     const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ Q,
-    const float* __restrict__ K, const float* __restrict__ rteK, const float* __restrict__ attT, float* __restrict__ logits, int R) {
-    constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = unroll_for<VEC>();
+    const float* __restrict__ K, const float* __restrict__ rteK, const float* __restrict__ attT, float* __restrict__ logits, int R,
+    int HT) {
+    // A wave covers DP = 64*VEC consecutive floats of a row = H = 64/LPH heads.  When the row has more heads (HT > H),
+    // blockIdx.y selects the head group: used when the full-width relation fragment (dk_pad*vec floats per lane) would
+    // not fit in registers (d = 512: 512 floats) -- narrower slices keep it register-resident.
+    // With temporal encoding the table rows get their own slots (added at use), so the batch is half as deep.
+    constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = RTE ? unroll_for<VEC>() / 2 : unroll_for<VEC>();
+    const int hg = blockIdx.y;
+    const int64_t ld = (int64_t)HT * DKP;   // row stride of Q/K/V/rte tables in floats
+    const int co = hg * DP;                 // first column of this head group
     constexpr bool HOIST = (DKP * VEC <= 128);
     __shared__ __attribute__((aligned(16))) float s_bounce[4][DP + 4 * (64 / LPH)];
 
@@ -125,12 +133,12 @@ __global__ __launch_bounds__(256) void k_edge_logits(
     const int h = lane / LPH, p = lane % LPH;
 
     if (rel >= R) {   // edges no meta relation claims: logit 0 (conv.py:68)
-        for (int64_t i = (int64_t)beg * H + lane; i < (int64_t)end * H; i += 64) logits[i] = 0.0f;
+        for (int64_t i = (int64_t)beg * H + lane; i < (int64_t)end * H; i += 64) logits[(i / H) * HT + hg * H + (i % H)] = 0.0f;
         return;
     }
 
     float* bounce = s_bounce[wib];
-    const float* __restrict__ fglob = attT + ((int64_t)(rel * H + h) * DKP) * DKP + p * VEC;
+    const float* __restrict__ fglob = attT + ((int64_t)(rel * HT + hg * H + h) * DKP) * DKP + p * VEC;
     float frag[HOIST ? DKP : 1][VEC];
     if constexpr (HOIST) {
 #pragma unroll
@@ -146,9 +154,9 @@ __global__ __launch_bounds__(256) void k_edge_logits(
         const int nb = min(64, end - base);
         const int li = base + min(lane, nb - 1);
         const int my_src = esrc[li], my_dst = edst[li];
-        const int my_rte = rteK ? (int)ertei[li] : 0;
+        const int my_rte = RTE ? (int)ertei[li] : 0;
         for (int i0 = 0; i0 < nb; i0 += UN) {
-            float kr[UN][VEC], qr[UN][VEC];
+            float kr[UN][VEC], qr[UN][VEC], tr[RTE ? UN : 1][VEC];
             int dsts[UN];
             bool newq[UN];
             int prev = cur_dst;
@@ -157,17 +165,14 @@ __global__ __launch_bounds__(256) void k_edge_logits(
                 const int idx = min(i0 + u, nb - 1);
                 const int s = __builtin_amdgcn_readlane(my_src, idx);
                 const int dd = __builtin_amdgcn_readlane(my_dst, idx);
-                load_vec<VEC>(K + (int64_t)s * DP + lane * VEC, kr[u]);
-                if (rteK) {
+                load_vec<VEC>(K + (int64_t)s * ld + co + lane * VEC, kr[u]);
+                if constexpr (RTE) {
                     const int ri = __builtin_amdgcn_readlane(my_rte, idx);
-                    float t[VEC];
-                    load_vec<VEC>(rteK + (int64_t)ri * DP + lane * VEC, t);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) kr[u][i] += t[i];
+                    load_vec<VEC>(rteK + (int64_t)ri * ld + co + lane * VEC, tr[u]);
                 }
                 dsts[u] = dd;
                 newq[u] = (dd != prev);
-                if (newq[u]) load_vec<VEC>(Q + (int64_t)dd * DP + lane * VEC, qr[u]);
+                if (newq[u]) load_vec<VEC>(Q + (int64_t)dd * ld + co + lane * VEC, qr[u]);
                 prev = dd;
             }
 #pragma unroll
@@ -179,9 +184,13 @@ __global__ __launch_bounds__(256) void k_edge_logits(
                     }
                     float part = 0.0f;
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) part = fmaf(qt[i], kr[u][i], part);
+                    for (int i = 0; i < VEC; ++i) {
+                        float kv = kr[u][i];
+                        if constexpr (RTE) kv += tr[u][i];
+                        part = fmaf(qt[i], kv, part);
+                    }
                     part = head_allreduce<LPH>(part);
-                    if (p == 0) logits[(int64_t)(base + i0 + u) * H + h] = part;
+                    if (p == 0) logits[(int64_t)(base + i0 + u) * HT + hg * H + h] = part;
                 }
             }
         }
@@ -242,12 +251,16 @@ __global__ __launch_bounds__(256) void k_edge_softmax(const int32_t* __restrict_
 constexpr int HGT_SUB = 16;       // targets per wavefront
 constexpr float HGT_NEG = -1.0e30f;
 
-template <int VEC, int LPH>
+template <int VEC, int LPH, bool RTE>
 __global__ __launch_bounds__(256) void k_edge_aggregate(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
-    const float* __restrict__ rteV, const float* __restrict__ msgP, float* __restrict__ agg, int R, int64_t NQ, int apply_gelu) {
-    constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = unroll_for<VEC>();
+    const float* __restrict__ rteV, const float* __restrict__ msgP, float* __restrict__ agg, int R, int64_t NQ, int apply_gelu,
+    int HT) {
+    constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = RTE ? unroll_for<VEC>() / 2 : unroll_for<VEC>();
+    const int hg = blockIdx.y;              // head group (see k_edge_logits)
+    const int64_t ld = (int64_t)HT * DKP;
+    const int co = hg * DP;
     constexpr bool HOIST = (DKP * VEC <= 128);
     __shared__ __attribute__((aligned(16))) float s_acc[4][HGT_SUB * DP];
     __shared__ __attribute__((aligned(16))) float s_bounce[4][DP + 4 * (64 / LPH)];
@@ -255,9 +268,11 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = blockIdx.x;
-    const int64_t row0 = (int64_t)tile * HGT_TD + wib * HGT_SUB;
+    // a workgroup covers 64 consecutive targets (4 waves x 16); the plan's destination tile may be larger
+    const int64_t row0 = (int64_t)blockIdx.x * 64 + wib * HGT_SUB;
     if (row0 >= NQ) return;
+    const int tile = (int)(row0 / HGT_TD);
+    const int within = (int)(row0 % HGT_TD);
     const int h = lane / LPH, p = lane % LPH;
     float* acc = s_acc[wib];
     float* bounce = s_bounce[wib];
@@ -270,13 +285,13 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
     for (int j = 0; j < HGT_SUB * 16 / 64; ++j) { s_m[j * 64 + lane] = HGT_NEG; s_l[j * 64 + lane] = 0.0f; }
 
     for (int rel = 0; rel <= R; ++rel) {
-        const int64_t b0 = ((int64_t)tile * (R + 1) + rel) * HGT_TD + wib * HGT_SUB;
+        const int64_t b0 = ((int64_t)tile * (R + 1) + rel) * HGT_TD + within;
         const int beg = __builtin_amdgcn_readfirstlane(segptr[b0]);
         const int end = __builtin_amdgcn_readfirstlane(segptr[b0 + HGT_SUB]);
         if (beg == end) continue;
         const bool claimed = rel < R;   // bucket R: logit 0, no message
 
-        const float* __restrict__ fglob = msgP + ((int64_t)((claimed ? rel : 0) * H + h) * DKP) * DKP + p * VEC;
+        const float* __restrict__ fglob = msgP + ((int64_t)((claimed ? rel : 0) * HT + hg * H + h) * DKP) * DKP + p * VEC;
         float frag[HOIST ? DKP : 1][VEC];
         if constexpr (HOIST) {
             if (claimed) {
@@ -314,9 +329,9 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
             const int nb = min(64, end - base);
             const int li = base + min(lane, nb - 1);
             const int my_src = esrc[li], my_dst = edst[li];
-            const int my_rte = rteV ? (int)ertei[li] : 0;
+            const int my_rte = RTE ? (int)ertei[li] : 0;
             for (int i0 = 0; i0 < nb; i0 += UN) {
-                float vr[UN][VEC], sl[UN];
+                float vr[UN][VEC], sl[UN], tr[RTE ? UN : 1][VEC];
                 int dsts[UN];
 #pragma unroll
                 for (int u = 0; u < UN; ++u) {
@@ -324,19 +339,20 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
                     const int s = __builtin_amdgcn_readlane(my_src, idx);
                     dsts[u] = __builtin_amdgcn_readlane(my_dst, idx);
                     if (claimed) {
-                        load_vec<VEC>(V + (int64_t)s * DP + lane * VEC, vr[u]);
-                        sl[u] = logits[(int64_t)(base + idx) * H + h];
-                        if (rteV) {
+                        load_vec<VEC>(V + (int64_t)s * ld + co + lane * VEC, vr[u]);
+                        sl[u] = logits[(int64_t)(base + idx) * HT + hg * H + h];
+                        if constexpr (RTE) {
                             const int ri = __builtin_amdgcn_readlane(my_rte, idx);
-                            float t[VEC];
-                            load_vec<VEC>(rteV + (int64_t)ri * DP + lane * VEC, t);
-#pragma unroll
-                            for (int i = 0; i < VEC; ++i) vr[u][i] += t[i];
+                            load_vec<VEC>(rteV + (int64_t)ri * ld + co + lane * VEC, tr[u]);
                         }
                     } else {
                         sl[u] = 0.0f;
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) vr[u][i] = 0.0f;
+                        if constexpr (RTE) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) tr[u][i] = 0.0f;
+                        }
                     }
                 }
 #pragma unroll
@@ -353,7 +369,11 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
                         const float m_new = fmaxf(m_seg, sl[u]);
                         const float sc = __expf(m_seg - m_new), pe = __expf(sl[u] - m_new);
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) U[i] = fmaf(U[i], sc, pe * vr[u][i]);
+                        for (int i = 0; i < VEC; ++i) {
+                            float vv = vr[u][i];
+                            if constexpr (RTE) vv += tr[u][i];
+                            U[i] = fmaf(U[i], sc, pe * vv);
+                        }
                         l_seg = fmaf(l_seg, sc, pe);
                         m_seg = m_new;
                     }
@@ -374,7 +394,7 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
             o[i] = acc[r * DP + i * 64 + lane] * inv;
             if (apply_gelu) o[i] = 0.5f * o[i] * (1.0f + erff(o[i] * 0.70710678118654752440f));
         }
-        float* g = agg + row * DP + lane * VEC;
+        float* g = agg + row * ld + co + lane * VEC;
         if constexpr (VEC == 1) {
             g[0] = o[0];
         } else if constexpr (VEC == 2) {
@@ -427,9 +447,13 @@ int dispatch_layout(int vec, int lph, Args... args) {
 template <int VEC, int LPH>
 struct LaunchLogits {
     static int run(const HgtPlanView& pv, const float* Q, const float* K, const float* rteK, const float* attT, float* logits,
-                   int R, hipStream_t stream) {
+                   int R, int HT, hipStream_t stream) {
         const unsigned blocks = (unsigned)((pv.L.max_items + 3) / 4);
-        k_edge_logits<VEC, LPH><<<blocks, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R);
+        dim3 grid(blocks, (unsigned)(HT / (64 / LPH)));
+        if (rteK)
+            k_edge_logits<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT);
+        else
+            k_edge_logits<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT);
         return HGT_OK;
     }
 };
@@ -437,13 +461,28 @@ struct LaunchLogits {
 template <int VEC, int LPH>
 struct LaunchAggregate {
     static int run(const HgtPlanView& pv, const float* logits, const float* V, const float* rteV, const float* msgP, float* agg,
-                   int R, int64_t NQ, int apply_gelu, hipStream_t stream) {
-        const int64_t tiles = (NQ + HGT_TD - 1) / HGT_TD;
-        k_edge_aggregate<VEC, LPH><<<(unsigned)tiles, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgP, agg,
-                                                                        R, NQ, apply_gelu);
+                   int R, int64_t NQ, int apply_gelu, int HT, hipStream_t stream) {
+        const int64_t tiles = (NQ + 63) / 64;
+        dim3 grid((unsigned)tiles, (unsigned)(HT / (64 / LPH)));
+        if (rteV)
+            k_edge_aggregate<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgP, agg, R,
+                                                                       NQ, apply_gelu, HT);
+        else
+            k_edge_aggregate<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgP, agg, R,
+                                                                        NQ, apply_gelu, HT);
         return HGT_OK;
     }
 };
+
+// Head-group split: the smallest power of two that makes the per-lane relation fragment (dk_pad * vec / split floats)
+// fit in 128 registers; 1 for every layout up to d = 256 / 8 heads.  Measured at c2 (d=256): a split of 2 is slower
+// (logits 2.86 vs 2.75 ms, aggregate 4.19 vs 3.42 ms), so it is only used when the fragment cannot be hoisted
+// (d = 512 / d_k = 64: 37 ms -> see DESIGN.md).
+static int head_split_for(int vec_full, int lph_full, int dk_pad) {
+    int s = 1;
+    while (dk_pad * (vec_full / s) > 128 && (vec_full / s) > 1 && lph_full * s * 2 <= 64) s *= 2;
+    return s;
+}
 
 }  // namespace
 
@@ -465,7 +504,8 @@ extern "C" int hgt_edge_logits(const void* plan, int64_t N, int64_t E, int32_t T
     const int lph = 64 / H;
     if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
     HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
-    int rc = dispatch_layout<LaunchLogits>(dk_pad / lph, lph, pv, Q, K, rte_k, att_t, logits, (int)R, (hipStream_t)stream);
+    const int sp = head_split_for(dk_pad / lph, lph, dk_pad);
+    int rc = dispatch_layout<LaunchLogits>(dk_pad / lph / sp, lph * sp, pv, Q, K, rte_k, att_t, logits, (int)R, (int)H, (hipStream_t)stream);
     if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();
     return HGT_OK;
@@ -491,8 +531,9 @@ extern "C" int hgt_edge_aggregate(const void* plan, int64_t N, int64_t E, int32_
     const int lph = 64 / H;
     if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
     HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
-    int rc = dispatch_layout<LaunchAggregate>(dk_pad / lph, lph, pv, logits, V, rte_v, msg_p, agg, (int)R, NQ, (int)apply_gelu,
-                                              (hipStream_t)stream);
+    const int sp = head_split_for(dk_pad / lph, lph, dk_pad);
+    int rc = dispatch_layout<LaunchAggregate>(dk_pad / lph / sp, lph * sp, pv, logits, V, rte_v, msg_p, agg, (int)R, NQ, (int)apply_gelu,
+                                              (int)H, (hipStream_t)stream);
     if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();
     return HGT_OK;
