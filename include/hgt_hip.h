@@ -62,10 +62,10 @@ int hgt_layout_for(int32_t d_out, int32_t n_heads, hgt_layout* out_host);
  * tensors for every layer, model.py:78-79).  Replaces, for the whole layer, PyG's per-call
  * index_select gathers (MessagePassing.propagate, called at conv.py:57), the T*T*R boolean mask
  * cube and its host syncs (conv.py:71-84) and the per-type masks of update() (conv.py:121-123):
- *   - edges stably sorted by (dst / 64, relation, dst % 64), ids compacted int64 -> int32,
+ *   - edges stably sorted by (dst / TD, relation, dst % TD) (TD = tile size, hgt_plan_constants), ids int64 -> int32,
  *     source-type*240 + edge_time folded into one uint16 per edge;
  *   - a segment table over (dst tile, relation, dst) and a list of wavefront work items
- *     (<= 256 consecutive edges of one (dst tile, relation));
+ *     (a bounded run of consecutive edges of one (dst tile, relation));
  *   - nodes stably sorted by type (row lists for the typed linears) + per-type offsets.
  * Edges whose relation id or endpoint node types fall outside [0,R) / [0,T) go to an extra
  * "unclaimed" relation bucket: logit 0, message 0, still part of the softmax -- the behaviour of
@@ -75,11 +75,13 @@ typedef struct hgt_plan_sizes {
     uint64_t plan_bytes;   /* persistent plan buffer                         */
     uint64_t tmp_bytes;    /* scratch needed only during hgt_plan_build      */
     int64_t  max_items;    /* upper bound on wavefront work items            */
-    int64_t  n_bins;       /* (dst tiles) * (R+1) * 64                       */
+    int64_t  n_bins;       /* (dst tiles) * (R+1) * tile size                */
 } hgt_plan_sizes;
 
 int hgt_plan_sizes_for(int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                        hgt_plan_sizes* out_host);
+/* build-time constants of the plan: destination tile size and the edge cap of one work item */
+int hgt_plan_constants(int32_t* tile_nodes_host, int32_t* item_edges_host);
 
 /* Row lists exported by a built plan (device pointers INTO the plan buffer), for hgt_typed_linear:
  *   rows_all / off_all : all n_nodes nodes stably sorted by type, int32[n_nodes] / int32[T+2]

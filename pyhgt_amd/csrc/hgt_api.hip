@@ -137,6 +137,8 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
                       int by_pos, void* wsplit) -> int {
         if (!split)
             return hgt_typed_linear(xin, ldx, rws, goff, ng, nrows, kk, nout, Wp, wgs, bp, bgs, o0, o1, o2, bcols, by_pos, 0, 0, stream);
+        if (((nout | bcols) & 3) != 0)   // the split kernel stores 16 B per lane: odd widths take the exact fp32 kernel
+            return hgt_typed_linear(xin, ldx, rws, goff, ng, nrows, kk, nout, Wp, wgs, bp, bgs, o0, o1, o2, bcols, by_pos, 0, 0, stream);
         int r2 = hgt_split_weights(Wp, wgs, ng, kk, nout, wsplit, stream);
         if (r2 != HGT_OK) return r2;
         return hgt_typed_linear_bf16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos, 0, stream);

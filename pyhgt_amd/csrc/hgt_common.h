@@ -6,10 +6,12 @@
 #include "../../include/hgt_hip.h"
 
 #ifndef HGT_TD
-#define HGT_TD 64        // destination nodes per tile (sort key = (dst/TD, relation, dst%TD)); multiple of 64
+#define HGT_TD 256       // destination nodes per tile (sort key = (dst/TD, relation, dst%TD)); multiple of 64.
+                         // measured at c2: 64 -> 2.76 ms, 128 -> 2.69 ms, 256 -> 2.65 ms for the logits kernel (longer work items
+                         // amortise the per-item relation-fragment load); the aggregation kernel walks 16-target sub-tiles either way
 #endif
 #ifndef HGT_CH
-#define HGT_CH 256       // max edges per wavefront work item
+#define HGT_CH 512       // max edges per wavefront work item
 #endif
 #define HGT_WAVE 64
 

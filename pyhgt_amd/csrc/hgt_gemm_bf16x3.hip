@@ -151,43 +151,23 @@ __device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, 
 __device__ __forceinline__ void store_pass(f32x16 (&acc)[2], int pass, int wave, int lane, int g, int n_out, int nrows, int row0,
                                            const int* s_rid, const float* __restrict__ bias, int64_t bgs, float* __restrict__ out0,
                                            float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos) {
-    const bool wide = ((n_out | block_cols) & 3) == 0;
-    if (wide) {
-        const int col = pass * BNP + wave * 32 + ((lane & 31) >> 2) * 4;      // first of this lane's 4 columns after the transpose
-        const bool col_ok = col < n_out;
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (col_ok && bias) b4 = *reinterpret_cast<const float4*>(bias + (int64_t)g * bgs + col);
-        const int blk = col_ok ? col / block_cols : 0, cc = col - blk * block_cols;
-        float* __restrict__ ob = (blk == 0) ? out0 : ((blk == 1) ? out1 : out2);
-        const bool o1 = lane & 1, o2 = lane & 2;
+    const int col = pass * BNP + wave * 32 + ((lane & 31) >> 2) * 4;      // first of this lane's 4 columns after the transpose
+    const bool col_ok = col < n_out;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col_ok && bias) b4 = *reinterpret_cast<const float4*>(bias + (int64_t)g * bgs + col);
+    const int blk = col_ok ? col / block_cols : 0, cc = col - blk * block_cols;
+    float* __restrict__ ob = (blk == 0) ? out0 : ((blk == 1) ? out1 : out2);
+    const bool o1 = lane & 1, o2 = lane & 2;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v0 = acc[j][4 * q], v1 = acc[j][4 * q + 1], v2 = acc[j][4 * q + 2], v3 = acc[j][4 * q + 3];
-                quad_transpose(v0, v1, v2, v3, o1, o2);
-                const int rt = j * 32 + (lane & 3) + 8 * q + 4 * (lane >> 5);
-                if (col_ok && rt < nrows) {
-                    const int64_t orow = by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
-                    *reinterpret_cast<float4*>(ob + orow * block_cols + cc) = make_float4(v0 + b4.x, v1 + b4.y, v2 + b4.z, v3 + b4.w);
-                }
-            }
-        }
-    } else {
-        const int col = pass * BNP + wave * 32 + (lane & 31);
-        const bool col_ok = col < n_out;
-        const float bcol = (col_ok && bias) ? bias[(int64_t)g * bgs + col] : 0.0f;
-        const int blk = col_ok ? col / block_cols : 0, cc = col - blk * block_cols;
-        float* __restrict__ ob = (blk == 0) ? out0 : ((blk == 1) ? out1 : out2);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rt = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (col_ok && rt < nrows) {
-                    const int64_t orow = by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
-                    ob[orow * block_cols + cc] = acc[j][r] + bcol;
-                }
+        for (int q = 0; q < 4; ++q) {
+            float v0 = acc[j][4 * q], v1 = acc[j][4 * q + 1], v2 = acc[j][4 * q + 2], v3 = acc[j][4 * q + 3];
+            quad_transpose(v0, v1, v2, v3, o1, o2);
+            const int rt = j * 32 + (lane & 3) + 8 * q + 4 * (lane >> 5);
+            if (col_ok && rt < nrows) {
+                const int64_t orow = by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
+                *reinterpret_cast<float4*>(ob + orow * block_cols + cc) = make_float4(v0 + b4.x, v1 + b4.y, v2 + b4.z, v3 + b4.w);
             }
         }
     }
@@ -226,72 +206,73 @@ __device__ __forceinline__ void store_pass_update(f32x16 (&acc)[2], int wave, in
     const float alpha = 1.0f / (1.0f + expf(-u.skip[g]));
     const bool o1 = lane & 1, o2 = lane & 2;
     const float inv_n = 1.0f / (float)n_out;
-    float y[8][4];
-    int64_t orow[8];
-    int rts[8];
+    float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f), c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (u.use_norm && col_ok) {
+        w4 = *reinterpret_cast<const float4*>(u.lnw + (int64_t)g * n_out + col);
+        c4 = *reinterpret_cast<const float4*>(u.lnb + (int64_t)g * n_out + col);
+    }
+    // the two 32-row halves one after the other: half the live registers (so two workgroups still fit a CU)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+        float y[4][4];
+        int64_t orow[4];
+        int rts[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float v0 = acc[j][4 * q], v1 = acc[j][4 * q + 1], v2 = acc[j][4 * q + 2], v3 = acc[j][4 * q + 3];
             quad_transpose(v0, v1, v2, v3, o1, o2);
             const int rt = j * 32 + (lane & 3) + 8 * q + 4 * (lane >> 5);
-            const int s = j * 4 + q;
-            rts[s] = rt;
-            orow[s] = (rt < nrows) ? (int64_t)s_rid[rt] : -1;
+            rts[q] = rt;
+            orow[q] = (rt < nrows) ? (int64_t)s_rid[rt] : -1;
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col_ok && orow[s] >= 0) xv = *reinterpret_cast<const float4*>(u.xs + orow[s] * u.ldxs + col);
-            y[s][0] = col_ok ? (v0 + b4.x) * alpha + xv.x * (1.0f - alpha) : 0.0f;
-            y[s][1] = col_ok ? (v1 + b4.y) * alpha + xv.y * (1.0f - alpha) : 0.0f;
-            y[s][2] = col_ok ? (v2 + b4.z) * alpha + xv.z * (1.0f - alpha) : 0.0f;
-            y[s][3] = col_ok ? (v3 + b4.w) * alpha + xv.w * (1.0f - alpha) : 0.0f;
+            if (col_ok && orow[q] >= 0) xv = *reinterpret_cast<const float4*>(u.xs + orow[q] * u.ldxs + col);
+            y[q][0] = col_ok ? (v0 + b4.x) * alpha + xv.x * (1.0f - alpha) : 0.0f;
+            y[q][1] = col_ok ? (v1 + b4.y) * alpha + xv.y * (1.0f - alpha) : 0.0f;
+            y[q][2] = col_ok ? (v2 + b4.z) * alpha + xv.z * (1.0f - alpha) : 0.0f;
+            y[q][3] = col_ok ? (v3 + b4.w) * alpha + xv.w * (1.0f - alpha) : 0.0f;
         }
-    }
-    if (u.use_norm) {
-        // pass 1: mean
+        if (u.use_norm) {
+            // pass 1: mean
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const float ps = strided8_sum(y[s][0] + y[s][1] + y[s][2] + y[s][3]);
-            if (((lane & 31) >> 2) == 0) s_red[rts[s] * 8 + wave] = ps;
-        }
-        __syncthreads();
-        float mean[8];
+            for (int q = 0; q < 4; ++q) {
+                const float ps = strided8_sum(y[q][0] + y[q][1] + y[q][2] + y[q][3]);
+                if (((lane & 31) >> 2) == 0) s_red[rts[q] * 8 + wave] = ps;
+            }
+            __syncthreads();
+            float mean[4];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const float4 a = *reinterpret_cast<const float4*>(&s_red[rts[s] * 8]);
-            const float4 b = *reinterpret_cast<const float4*>(&s_red[rts[s] * 8 + 4]);
-            mean[s] = (a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w) * inv_n;
-        }
-        __syncthreads();
-        // pass 2: variance
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = *reinterpret_cast<const float4*>(&s_red[rts[q] * 8]);
+                const float4 b = *reinterpret_cast<const float4*>(&s_red[rts[q] * 8 + 4]);
+                mean[q] = (a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w) * inv_n;
+            }
+            __syncthreads();
+            // pass 2: variance
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            float d0 = y[s][0] - mean[s], d1 = y[s][1] - mean[s], d2 = y[s][2] - mean[s], d3 = y[s][3] - mean[s];
-            if (!col_ok) d0 = d1 = d2 = d3 = 0.0f;
-            const float ps = strided8_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
-            if (((lane & 31) >> 2) == 0) s_red[rts[s] * 8 + wave] = ps;
-        }
-        __syncthreads();
-        float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f), c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (col_ok) {
-            w4 = *reinterpret_cast<const float4*>(u.lnw + (int64_t)g * n_out + col);
-            c4 = *reinterpret_cast<const float4*>(u.lnb + (int64_t)g * n_out + col);
-        }
+            for (int q = 0; q < 4; ++q) {
+                float d0 = y[q][0] - mean[q], d1 = y[q][1] - mean[q], d2 = y[q][2] - mean[q], d3 = y[q][3] - mean[q];
+                if (!col_ok) d0 = d1 = d2 = d3 = 0.0f;
+                const float ps = strided8_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+                if (((lane & 31) >> 2) == 0) s_red[rts[q] * 8 + wave] = ps;
+            }
+            __syncthreads();
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const float4 a = *reinterpret_cast<const float4*>(&s_red[rts[s] * 8]);
-            const float4 b = *reinterpret_cast<const float4*>(&s_red[rts[s] * 8 + 4]);
-            const float rstd = rsqrtf((a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w) * inv_n + 1e-5f);
-            if (col_ok && orow[s] >= 0)
-                *reinterpret_cast<float4*>(out + orow[s] * n_out + col) =
-                    make_float4((y[s][0] - mean[s]) * rstd * w4.x + c4.x, (y[s][1] - mean[s]) * rstd * w4.y + c4.y,
-                                (y[s][2] - mean[s]) * rstd * w4.z + c4.z, (y[s][3] - mean[s]) * rstd * w4.w + c4.w);
-        }
-    } else {
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = *reinterpret_cast<const float4*>(&s_red[rts[q] * 8]);
+                const float4 b = *reinterpret_cast<const float4*>(&s_red[rts[q] * 8 + 4]);
+                const float rstd = rsqrtf((a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w) * inv_n + 1e-5f);
+                if (col_ok && orow[q] >= 0)
+                    *reinterpret_cast<float4*>(out + orow[q] * n_out + col) =
+                        make_float4((y[q][0] - mean[q]) * rstd * w4.x + c4.x, (y[q][1] - mean[q]) * rstd * w4.y + c4.y,
+                                    (y[q][2] - mean[q]) * rstd * w4.z + c4.z, (y[q][3] - mean[q]) * rstd * w4.w + c4.w);
+            }
+            __syncthreads();   // s_red is reused by the second half
+        } else {
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
-            if (col_ok && orow[s] >= 0)
-                *reinterpret_cast<float4*>(out + orow[s] * n_out + col) = make_float4(y[s][0], y[s][1], y[s][2], y[s][3]);
+            for (int q = 0; q < 4; ++q)
+                if (col_ok && orow[q] >= 0)
+                    *reinterpret_cast<float4*>(out + orow[q] * n_out + col) = make_float4(y[q][0], y[q][1], y[q][2], y[q][3]);
+        }
     }
 }
 
@@ -445,6 +426,7 @@ extern "C" int hgt_typed_linear_bf16x3(const float* x, int64_t ldx, const int32_
     const int n_blocks_out = (n_out + block_cols - 1) / block_cols;
     if (n_blocks_out > 3 || (n_blocks_out > 1 && !out1) || (n_blocks_out > 2 && !out2)) return HGT_ERR_INVALID_ARG;
     if (prologue != 0 && prologue != 1) return HGT_ERR_INVALID_ARG;
+    if (((n_out | block_cols) & 3) != 0) return HGT_ERR_UNSUPPORTED;   // 16-byte epilogue stores; use hgt_typed_linear (fp32) instead
     if (n_rows == 0) return HGT_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t row_tiles = (n_rows + BM - 1) / BM + n_groups;   // device-side group sizes: launch the upper bound

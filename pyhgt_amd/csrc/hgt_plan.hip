@@ -190,6 +190,13 @@ extern "C" int hgt_plan_sizes_for(int64_t n_nodes, int64_t n_edges, int32_t n_ty
     return HGT_OK;
 }
 
+extern "C" int hgt_plan_constants(int32_t* tile_nodes, int32_t* item_edges) {
+    if (!tile_nodes || !item_edges) return HGT_ERR_INVALID_ARG;
+    *tile_nodes = HGT_TD;
+    *item_edges = HGT_CH;
+    return HGT_OK;
+}
+
 extern "C" int hgt_plan_row_lists(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types,
                                   int32_t n_relations, hgt_plan_rows* out) {
     if (!plan || !out) return HGT_ERR_INVALID_ARG;

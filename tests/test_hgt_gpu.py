@@ -204,13 +204,20 @@ def test_partitioned_graph_on_gpu_single_rank():
 
 
 # ------------------------------------------------------------------ integer work: bit exact
+def _plan_constants():
+    td, ch = C.c_int32(), C.c_int32()
+    assert _lib.load().hgt_plan_constants(C.byref(td), C.byref(ch)) == 0
+    return td.value, ch.value
+
+
 def _plan_arrays(plan):
     """Mirror of hgt_plan_layout() in pyhgt_amd/csrc/hgt_common.h (256-byte aligned arrays)."""
     N, E, T, R = plan.N, plan.E, plan.T, plan.R
-    n_tiles = (N + 63) // 64
+    TD, CH = _plan_constants()
+    n_tiles = (N + TD - 1) // TD
     n_pairs = n_tiles * (R + 1)
-    n_bins = n_pairs * 64
-    max_items = n_pairs + E // 256 + 1
+    n_bins = n_pairs * TD
+    max_items = n_pairs + E // CH + 1
     raw = plan.buf.cpu().numpy()
     off = [0]
 
@@ -246,7 +253,8 @@ def test_plan_is_bit_exact(sorted_types, skew):
     p = _plan_arrays(plan)
     src, dst = ei[0].numpy(), ei[1].numpy()
     rel = np.where(et.numpy() < R, et.numpy(), R)
-    key = ((dst // 64) * (R + 1) + rel) * 64 + dst % 64
+    TD, CH = _plan_constants()
+    key = ((dst // TD) * (R + 1) + rel) * TD + dst % TD
     order = np.argsort(key, kind="stable")
     assert p["bad"] == 0
     assert np.array_equal(p["eid"], order.astype(np.int32))
@@ -257,8 +265,8 @@ def test_plan_is_bit_exact(sorted_types, skew):
     # work items tile the sorted edge array, never straddle a (tile, relation) bucket, <= 256 edges
     it = p["items"][:p["n_items"]]
     assert it[0, 0] == 0 and it[-1, 1] == E and np.array_equal(it[1:, 0], it[:-1, 1])
-    assert (it[:, 1] - it[:, 0]).max() <= 256 and (it[:, 1] - it[:, 0]).min() >= 1
-    pair = key[order] // 64
+    assert (it[:, 1] - it[:, 0]).max() <= CH and (it[:, 1] - it[:, 0]).min() >= 1
+    pair = key[order] // TD
     assert np.array_equal(pair[it[:, 0]], pair[it[:, 1] - 1])
     assert np.array_equal(pair[it[:, 0]], it[:, 3] * (R + 1) + it[:, 2])
     assert np.array_equal(p["tile_items"], np.searchsorted(it[:, 3], np.arange(len(p["tile_items"]))).astype(np.int32))
@@ -311,6 +319,9 @@ def test_typed_linear_against_torch_fp32(k, n_out, prologue, precision, tol):
         assert lib.hgt_split_weights(Wd.data_ptr(), n_out * k, T, k, n_out, ws.data_ptr(), st) == 0
         rc = lib.hgt_typed_linear_bf16x3(xd.data_ptr(), k, rd.data_ptr(), od.data_ptr(), T, N, k, n_out, ws.data_ptr(),
                                          bd.data_ptr(), n_out, optr[0], optr[1], optr[2], bc, 0, prologue, st)
+        if n_out % 4 != 0:
+            assert rc == -2        # documented: odd widths are not supported by the 16-byte-store epilogue
+            return
     assert rc == 0
     torch.cuda.synchronize()
     out = torch.cat([o.cpu() for o in outs], dim=1)
