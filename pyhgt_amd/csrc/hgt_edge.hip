@@ -362,20 +362,32 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
                             flush();
 #pragma unroll
                             for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
-                            m_seg = HGT_NEG;
+                            m_seg = sl[u];   // reference point of the segment: its first logit (not necessarily the max)
                             l_seg = 0.0f;
                             cur_dst = dsts[u];
                         }
-                        const float m_new = fmaxf(m_seg, sl[u]);
-                        const float sc = __expf(m_seg - m_new), pe = __expf(sl[u] - m_new);
+                        // Deferred rescaling: weights are exp(s - m_seg) relative to the segment's reference; the reference
+                        // is only moved (and U, l rescaled) when a logit exceeds it by more than 40 (exp(40) ~ 2e17 is far
+                        // from fp32 overflow), which is a wave-uniform rare branch.  Any reference gives the same softmax:
+                        // the merge below and the final division are invariant to it.
+                        float dlt = sl[u] - m_seg;
+                        if (__builtin_amdgcn_ballot_w64(dlt > 40.0f) != 0) {
+                            const float m_new = fmaxf(m_seg, sl[u]);
+                            const float sc = __expf(m_seg - m_new);
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) U[i] *= sc;
+                            l_seg *= sc;
+                            m_seg = m_new;
+                            dlt = sl[u] - m_seg;
+                        }
+                        const float pe = __expf(dlt);
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) {
                             float vv = vr[u][i];
                             if constexpr (RTE) vv += tr[u][i];
-                            U[i] = fmaf(U[i], sc, pe * vv);
+                            U[i] = fmaf(pe, vv, U[i]);
                         }
-                        l_seg = fmaf(l_seg, sc, pe);
-                        m_seg = m_new;
+                        l_seg += pe;
                     }
                 }
             }

@@ -85,6 +85,26 @@ def test_matches_oracle(case, precision):
     assert err_att < 1e-5
 
 
+def test_large_logit_spread_forces_softmax_rereference():
+    """The aggregation kernel re-references its running softmax only when a logit exceeds the segment's reference by
+    more than 40 (deferred rescaling).  Blow the logits up (relation_pri x 60, multi-edge segments via few targets)
+    so that branch is taken, and compare with the fp64 oracle."""
+    T, R, H, d, N, E = 2, 2, 4, 64, 400, 12000
+    sd = O.make_state_dict(d, d, T, R, H, True, False, seed=51)
+    sd["relation_pri"] = sd["relation_pri"] * 60.0
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=52)
+    ei = ei.clone()
+    ei[1] = ei[1] % 40                                   # 40 targets x 2 relations -> ~150 edges per segment
+    ref, att_ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, None, use_RTE=False, dtype=torch.float64, return_att=True)
+    s_spread = float((att_ref.max(0).values.log() - att_ref.clamp_min(1e-300).min(0).values.log()).max())
+    assert s_spread > 60.0                               # the input really spans more than the threshold
+    layer = _layer_from(sd, d, T, R, H, True, False)
+    out, att = _run(layer, x, nt, ei, et, None)
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < TOL
+    assert (att.double() - att_ref).abs().max().item() < 1e-4   # logits ~ 1e2: fp32 logit rounding alone is ~1e-5
+
+
 def test_no_edges_and_isolated_targets():
     T, R, H, d = 3, 2, 4, 64
     sd = O.make_state_dict(d, d, T, R, H, True, False, seed=1)
