@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--types", type=int, default=4)
     ap.add_argument("--relations", type=int, default=8)
     ap.add_argument("--rte", action="store_true", help="5-argument form with temporal encoding")
+    ap.add_argument("--dst-skew", type=float, default=0.0, help="secondary variant: Zipf exponent a in (0,1) of the target in-degree distribution (hubs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
                     help="typed linears: 3-term split-bf16 MFMA with fp32 accumulation (default; parity-tested at 1e-4) "
@@ -172,6 +173,10 @@ def main():
     x_own = torch.randn(Nl, d, generator=g, device=dev)
     src_global = torch.randint(0, Ng, (El,), generator=g, device=dev)
     dst_local = torch.randint(0, Nl, (El,), generator=g, device=dev)
+    if args.dst_skew > 0.0:   # hub targets (SURVEY.md section 8d secondary variant)
+        # Zipf-like: P(rank k) ~ k^-a with a = dst_skew in (0,1); rank 0 gets ~E*(1-a)/N^(1-a) edges
+        u = torch.rand(El, generator=g, device=dev)
+        dst_local = (Nl * u ** (1.0 / (1.0 - args.dst_skew))).long().clamp(0, Nl - 1)
     edge_type = torch.randint(0, R, (El,), generator=g, device=dev)
     edge_time = torch.randint(0, 240, (El,), generator=g, device=dev) if use_rte else None
 
