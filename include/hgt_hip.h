@@ -185,7 +185,11 @@ int hgt_edge_softmax(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t
                      int32_t n_heads, float* logits_att, void* stream);
 int hgt_edge_aggregate(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                        int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
-                       const float* msg_p, float* agg, int64_t n_q_rows, int32_t apply_gelu, void* stream);
+                       const float* msg_p, float* agg, int64_t n_q_rows, int32_t apply_gelu, void* hub_ws, void* stream);
+/* hub_ws: scratch of hgt_hub_workspace_bytes() bytes for targets with more than 1024 in-edges ("hubs"): their edge
+ * ranges are split over many wavefronts (max / sum-exp / weighted sum accumulated with atomics) instead of being
+ * walked by the one wavefront that owns their 16-target sub-tile.  NULL = no hub path (correct, slow on hubs). */
+int hgt_hub_workspace_bytes(int64_t n_edges, int32_t n_heads, int32_t dk_pad, uint64_t* out_host);
 int hgt_att_export(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                    int32_t n_heads, const float* att_sorted, float* att_out, void* stream);
 

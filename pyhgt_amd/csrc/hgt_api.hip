@@ -1,11 +1,13 @@
 // C-ABI glue: error strings, layout helper and the whole-layer entry point that enqueues every
 // kernel of one HGTConv.forward (conv.py:56-134, eval mode) on the caller's stream.
+#include <cstdlib>
+
 #include "hgt_common.h"
 
 namespace {
 
 struct ConvWorkspace {
-    uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p;
+    uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p, off_hub;
     uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, off_ws_qkv, off_ws_a, off_ws_rte, total;
 };
 
@@ -23,6 +25,9 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
     w.off_trans = take((uint64_t)NQ * out_dim * 4);
     w.off_att_t = take((uint64_t)R * H * lay.dk_pad * lay.dk_pad * 4);
     w.off_msg_p = take((uint64_t)R * H * lay.dk_pad * lay.dk_pad * 4);
+    uint64_t hb = 0;
+    hgt_hub_workspace_bytes(E, H, lay.dk_pad, &hb);
+    w.off_hub = take(hb);
     if (use_rte) {
         w.off_rte_lin = take((uint64_t)HGT_RTE_LEN * in_dim * 4);
         w.off_rte_k = take((uint64_t)T * HGT_RTE_LEN * dp * 4);
@@ -188,7 +193,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     mark(2);
     mark(3);
     // runs for E == 0 too: it writes the zero rows of isolated targets; stores gelu(agg) (conv.py:119)
-    rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ, 1, stream);
+    rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ, 1, getenv("HGT_NO_HUB") ? nullptr : (void*)(wb + w.off_hub), stream);
     if (rc != HGT_OK) return rc;
     if (a->want_att && E > 0) {   // self.att (conv.py:108): normalise the logits in place and un-sort them
         rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);

@@ -14,6 +14,9 @@
 #define HGT_CH 512       // max edges per wavefront work item
 #endif
 #define HGT_WAVE 64
+#ifndef HGT_HUB_DEG
+#define HGT_HUB_DEG 1024  // targets with more in-edges are "hubs": aggregated by many wavefronts (hgt_edge.hip, hub path)
+#endif
 
 #define HGT_CHECK_LAUNCH()                          \
     do {                                            \
@@ -26,7 +29,8 @@ static inline uint64_t hgt_align_up(uint64_t v, uint64_t a) { return (v + a - 1)
 struct HgtPlanHeader {
     int32_t n_items;      // number of valid work items (written by the build)
     int32_t bad_index;    // != 0 if an edge endpoint was outside [0, n_nodes) / target >= n_q_rows
-    int32_t pad[14];
+    int32_t n_hubs;       // number of hub targets (in-degree > HGT_HUB_DEG), see hub_slot / hub_list
+    int32_t pad[13];
 };
 
 // One wavefront work item: sorted edge positions [beg, end) all in one (dst tile, relation) bucket.
@@ -37,8 +41,8 @@ struct __attribute__((aligned(16))) HgtItem {
 // Byte offsets of the arrays inside the plan buffer; a pure function of (N, E, T, R).
 struct HgtPlanLayout {
     uint64_t off_hdr, off_esrc, off_edst, off_ertei, off_eid, off_segptr, off_items, off_tile_items;
-    uint64_t off_rows_all, off_off_all, off_rows_q, off_off_q, total;
-    int64_t n_tiles, n_bins, n_pairs, max_items;
+    uint64_t off_rows_all, off_off_all, off_rows_q, off_off_q, off_hub_slot, off_hub_list, total;
+    int64_t n_tiles, n_bins, n_pairs, max_items, max_hubs;
 };
 
 static inline HgtPlanLayout hgt_plan_layout(int64_t N, int64_t E, int32_t T, int32_t R) {
@@ -61,6 +65,9 @@ static inline HgtPlanLayout hgt_plan_layout(int64_t N, int64_t E, int32_t T, int
     L.off_off_all = take((uint64_t)(T + 2) * 4);
     L.off_rows_q = take((uint64_t)N * 4);
     L.off_off_q = take((uint64_t)(T + 2) * 4);
+    L.max_hubs = E / HGT_HUB_DEG + 1;
+    L.off_hub_slot = take((uint64_t)N * 4);
+    L.off_hub_list = take((uint64_t)L.max_hubs * 4);
     L.total = o;
     return L;
 }
@@ -78,6 +85,8 @@ struct HgtPlanView {
     const int32_t* off_all;
     const int32_t* rows_q;
     const int32_t* off_q;
+    const int32_t* hub_slot;   // [N]: index into the hub buffers or -1
+    const int32_t* hub_list;   // [n_hubs]: target id of each hub
     HgtPlanLayout L;
 };
 
@@ -97,6 +106,8 @@ static inline HgtPlanView hgt_plan_view(const void* plan, int64_t N, int64_t E, 
     v.off_all = (const int32_t*)(b + v.L.off_off_all);
     v.rows_q = (const int32_t*)(b + v.L.off_rows_q);
     v.off_q = (const int32_t*)(b + v.L.off_off_q);
+    v.hub_slot = (const int32_t*)(b + v.L.off_hub_slot);
+    v.hub_list = (const int32_t*)(b + v.L.off_hub_list);
     return v;
 }
 

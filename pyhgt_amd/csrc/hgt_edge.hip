@@ -251,20 +251,17 @@ __global__ __launch_bounds__(256) void k_edge_softmax(const int32_t* __restrict_
 constexpr int HGT_SUB = 16;       // targets per wavefront
 constexpr float HGT_NEG = -1.0e30f;
 
-template <int VEC, int LPH, bool RTE>
-__global__ __launch_bounds__(256) void k_edge_aggregate(
+template <int VEC, int LPH, bool RTE, bool HUBS>
+__device__ __forceinline__ void aggregate_subtile(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
     const float* __restrict__ rteV, const float* __restrict__ msgP, float* __restrict__ agg, int R, int64_t NQ, int apply_gelu,
-    int HT) {
+    int HT, unsigned hub_mask, float (&s_acc)[4][16 * 64 * VEC], float (&s_bounce)[4][64 * VEC + 4 * (64 / LPH)], float (&s_ml)[4][2][16 * 16]) {
     constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = RTE ? unroll_for<VEC>() / 2 : unroll_for<VEC>();
     const int hg = blockIdx.y;              // head group (see k_edge_logits)
     const int64_t ld = (int64_t)HT * DKP;
     const int co = hg * DP;
     constexpr bool HOIST = (DKP * VEC <= 128);
-    __shared__ __attribute__((aligned(16))) float s_acc[4][HGT_SUB * DP];
-    __shared__ __attribute__((aligned(16))) float s_bounce[4][DP + 4 * (64 / LPH)];
-    __shared__ float s_ml[4][2][HGT_SUB * 16];   // running max / sum per (target, head); H <= 16
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -285,9 +282,18 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
     for (int j = 0; j < HGT_SUB * 16 / 64; ++j) { s_m[j * 64 + lane] = HGT_NEG; s_l[j * 64 + lane] = 0.0f; }
 
     for (int rel = 0; rel <= R; ++rel) {
-        const int64_t b0 = ((int64_t)tile * (R + 1) + rel) * HGT_TD + within;
-        const int beg = __builtin_amdgcn_readfirstlane(segptr[b0]);
-        const int end = __builtin_amdgcn_readfirstlane(segptr[b0 + HGT_SUB]);
+      const int64_t b0 = ((int64_t)tile * (R + 1) + rel) * HGT_TD + within;
+      // maximal runs [dl0, dl1) of non-hub targets: one run covering the whole sub-tile unless it contains a hub
+      for (int dl0 = 0; dl0 < HGT_SUB;) {
+        int dl1 = HGT_SUB;
+        if constexpr (HUBS) {
+            if ((hub_mask >> dl0) & 1u) { ++dl0; continue; }
+            dl1 = dl0 + 1;
+            while (dl1 < HGT_SUB && !((hub_mask >> dl1) & 1u)) ++dl1;
+        }
+        const int beg = __builtin_amdgcn_readfirstlane(segptr[b0 + dl0]);
+        const int end = __builtin_amdgcn_readfirstlane(segptr[b0 + dl1]);
+        dl0 = dl1;
         if (beg == end) continue;
         const bool claimed = rel < R;   // bucket R: logit 0, no message
 
@@ -393,12 +399,14 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
             }
         }
         flush();
+      }
     }
 
     // write-out: normalise, un-permute the planar layout, one coalesced row store per wave instruction
     for (int r = 0; r < HGT_SUB; ++r) {
         const int64_t row = row0 + r;
         if (row >= NQ) break;
+        if (HUBS && ((hub_mask >> r) & 1u)) continue;   // written by k_hub_finalize
         const float inv = 1.0f / (s_l[r * 16 + h] + 1e-16f);
         float o[VEC];
 #pragma unroll
@@ -414,6 +422,208 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
         } else {
 #pragma unroll
             for (int i = 0; i < VEC / 4; ++i) *reinterpret_cast<float4*>(g + 4 * i) = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+        }
+    }
+}
+
+// Sub-tiles without a hub target (all of them on c2) take the HUBS = false instantiation: its loop nest is the plain
+// "one range per relation" walk (the run logic costs ~4 % when it is compiled into the hot path).
+template <int VEC, int LPH, bool RTE>
+__global__ __launch_bounds__(256) void k_edge_aggregate(
+    const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
+    const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
+    const float* __restrict__ rteV, const float* __restrict__ msgP, float* __restrict__ agg, int R, int64_t NQ, int apply_gelu,
+    int HT, const int32_t* __restrict__ hub_slot) {
+    __shared__ __attribute__((aligned(16))) float s_acc[4][16 * 64 * VEC];
+    __shared__ __attribute__((aligned(16))) float s_bounce[4][64 * VEC + 4 * (64 / LPH)];
+    __shared__ float s_ml[4][2][16 * 16];   // running max / sum per (target, head); H <= 16
+    // hub targets (in-degree > HGT_HUB_DEG, plan) are aggregated by the hub kernels below; this wave skips them
+    unsigned hub_mask = 0;
+    if (hub_slot) {
+        const int lane = threadIdx.x & 63;
+        const int64_t rr = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 6) * 16 + (lane & 15);
+        const bool is_hub = (lane < 16) && (rr < NQ) && (hub_slot[rr] >= 0);
+        hub_mask = (unsigned)(__builtin_amdgcn_ballot_w64(is_hub) & 0xFFFFull);
+    }
+    if (hub_mask == 0)
+        aggregate_subtile<VEC, LPH, RTE, false>(segptr, esrc, edst, ertei, logits, V, rteV, msgP, agg, R, NQ, apply_gelu, HT, 0u, s_acc,
+                                                s_bounce, s_ml);
+    else
+        aggregate_subtile<VEC, LPH, RTE, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgP, agg, R, NQ, apply_gelu, HT, hub_mask,
+                                               s_acc, s_bounce, s_ml);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hub path.  A target with more than HGT_HUB_DEG in-edges would make the single wavefront that owns its sub-tile
+// walk all of them (Zipf targets: 8 -> 190 ms at c2 size).  Hubs are therefore skipped by k_edge_aggregate and
+// handled by a fixed grid of wavefronts that split every (hub, relation) edge range into HUB_CHUNKS pieces:
+//   k_hub_max        max logit per (hub, head)  (wave reduce + one atomicMax per head and piece)
+//   k_hub_accumulate sum exp(s - m) and (sum exp(s - m) V[src]) M[rel] per piece, atomically added to the hub's
+//                    fp32 accumulators (any reference m gives the same softmax; m = max(max logit, 0) covers the
+//                    unclaimed bucket, whose logits are 0)
+//   k_hub_finalize   agg[hub] = gelu(acc / (l + 1e-16))
+// All three exit immediately when the plan found no hub (hdr->n_hubs == 0).
+// ---------------------------------------------------------------------------------------------
+constexpr int HUB_CHUNKS = 64;
+constexpr int HUB_GRID_WAVES = 8192;
+
+__device__ __forceinline__ int f2ord(float f) { const int b = __builtin_bit_cast(int, f); return b ^ ((b >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float ord2f(int o) { return __builtin_bit_cast(float, o ^ ((o >> 31) & 0x7fffffff)); }
+
+struct HubBuffers {
+    int* mx;      // [max_hubs][HT] ordered-int max logit
+    float* l;     // [max_hubs][HT]
+    float* acc;   // [max_hubs][HT * DKP]
+};
+
+__global__ void k_hub_init(const HgtPlanHeader* __restrict__ hdr, HubBuffers hb, int HT, int dfull) {
+    const int n = hdr->n_hubs;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = 2 * HT + dfull;
+    if (i >= (int64_t)n * per) return;
+    const int slot = (int)(i / per), r = (int)(i % per);
+    if (r < HT) hb.mx[slot * HT + r] = f2ord(-1.0e30f);
+    else if (r < 2 * HT) hb.l[slot * HT + r - HT] = 0.0f;
+    else hb.acc[(int64_t)slot * dfull + r - 2 * HT] = 0.0f;
+}
+
+// work id w -> (hub slot, relation bucket, piece); edges [pb, pe) of that piece
+__device__ __forceinline__ bool hub_piece(int w, int n_hubs, int R, const int32_t* __restrict__ hub_list,
+                                          const int32_t* __restrict__ segptr, int& slot, int& rel, int& pb, int& pe) {
+    const int per_hub = (R + 1) * HUB_CHUNKS;
+    slot = w / per_hub;
+    if (slot >= n_hubs) return false;
+    const int r2 = w - slot * per_hub;
+    rel = r2 / HUB_CHUNKS;
+    const int c = r2 - rel * HUB_CHUNKS;
+    const int64_t dst = hub_list[slot];
+    const int64_t b = ((dst / HGT_TD) * (R + 1) + rel) * HGT_TD + dst % HGT_TD;
+    const int beg = segptr[b], end = segptr[b + 1];
+    const int len = end - beg, piece = (len + HUB_CHUNKS - 1) / HUB_CHUNKS;
+    pb = beg + c * piece;
+    pe = min(end, pb + piece);
+    return pb < pe;
+}
+
+__global__ __launch_bounds__(256) void k_hub_max(const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ hub_list,
+                                                 const int32_t* __restrict__ segptr, const float* __restrict__ logits, int R, int HT,
+                                                 HubBuffers hb) {
+    const int n_hubs = hdr->n_hubs;
+    if (n_hubs == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int epw = 64 / HT;                       // edges per wave iteration
+    const int hh = lane % HT, eo = lane / HT;
+    const int total = n_hubs * (R + 1) * HUB_CHUNKS;
+    for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < total; w += gridDim.x * 4) {
+        int slot, rel, pb, pe;
+        if (!hub_piece(w, n_hubs, R, hub_list, segptr, slot, rel, pb, pe)) continue;
+        float m = -1.0e30f;
+        if (rel < R) {
+            for (int e = pb + eo; e < pe; e += epw) m = fmaxf(m, logits[(int64_t)e * HT + hh]);
+        } else {
+            m = 0.0f;                              // unclaimed bucket: logits are 0
+        }
+        for (int sft = HT; sft < 64; sft <<= 1) m = fmaxf(m, __shfl_xor(m, sft));
+        if (lane < HT) atomicMax(&hb.mx[slot * HT + hh], f2ord(m));
+    }
+}
+
+template <int VEC, int LPH, bool RTE>
+__global__ __launch_bounds__(256) void k_hub_accumulate(
+    const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ hub_list, const int32_t* __restrict__ segptr,
+    const int32_t* __restrict__ esrc, const uint16_t* __restrict__ ertei, const float* __restrict__ logits,
+    const float* __restrict__ V, const float* __restrict__ rteV, const float* __restrict__ msgP, int R, int HT, HubBuffers hb) {
+    constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = RTE ? unroll_for<VEC>() / 2 : unroll_for<VEC>();
+    constexpr bool HOIST = (DKP * VEC <= 128);
+    __shared__ __attribute__((aligned(16))) float s_bounce[4][DP + 4 * (64 / LPH)];
+    const int n_hubs = hdr->n_hubs;
+    if (n_hubs == 0) return;
+    const int hg = blockIdx.y;
+    const int64_t ld = (int64_t)HT * DKP;
+    const int co = hg * DP;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane / LPH, p = lane % LPH;
+    float* bounce = s_bounce[wib];
+    const int total = n_hubs * (R + 1) * HUB_CHUNKS;
+    for (int w = blockIdx.x * 4 + wib; w < total; w += gridDim.x * 4) {
+        int slot, rel, pb, pe;
+        if (!hub_piece(w, n_hubs, R, hub_list, segptr, slot, rel, pb, pe)) continue;
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        rel = __builtin_amdgcn_readfirstlane(rel);
+        pb = __builtin_amdgcn_readfirstlane(pb);
+        pe = __builtin_amdgcn_readfirstlane(pe);
+        const float mref = fmaxf(ord2f(hb.mx[slot * HT + hg * H + h]), 0.0f);
+        float l_part = 0.0f;
+        if (rel >= R) {                            // unclaimed: logit 0, no message
+            l_part = (float)(pe - pb) * __expf(0.0f - mref);
+            if (p == 0) atomicAdd(&hb.l[slot * HT + hg * H + h], l_part);
+            continue;
+        }
+        const float* __restrict__ fglob = msgP + ((int64_t)(rel * HT + hg * H + h) * DKP) * DKP + p * VEC;
+        float frag[HOIST ? DKP : 1][VEC];
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int j = 0; j < DKP; ++j) load_vec<VEC>(fglob + j * DKP, frag[j]);
+        }
+        float U[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
+        for (int base = pb; base < pe; base += 64) {
+            const int nb = min(64, pe - base);
+            const int li = base + min(lane, nb - 1);
+            const int my_src = esrc[li];
+            const int my_rte = RTE ? (int)ertei[li] : 0;
+            for (int i0 = 0; i0 < nb; i0 += UN) {
+                float vr[UN][VEC], sl[UN], tr[RTE ? UN : 1][VEC];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int idx = min(i0 + u, nb - 1);
+                    const int s = __builtin_amdgcn_readlane(my_src, idx);
+                    load_vec<VEC>(V + (int64_t)s * ld + co + lane * VEC, vr[u]);
+                    sl[u] = logits[(int64_t)(base + idx) * HT + hg * H + h];
+                    if constexpr (RTE) {
+                        const int ri = __builtin_amdgcn_readlane(my_rte, idx);
+                        load_vec<VEC>(rteV + (int64_t)ri * ld + co + lane * VEC, tr[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    if (i0 + u < nb) {
+                        const float pe_ = __expf(sl[u] - mref);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            float vv = vr[u][i];
+                            if constexpr (RTE) vv += tr[u][i];
+                            U[i] = fmaf(pe_, vv, U[i]);
+                        }
+                        l_part += pe_;
+                    }
+                }
+            }
+        }
+        float z[VEC];
+        head_matvec<VEC, DKP, HOIST>(U, bounce, lane, h, frag, fglob, z);
+        float* o = hb.acc + (int64_t)slot * ld + co + lane * VEC;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(o + i, z[i]);
+        if (p == 0) unsafeAtomicAdd(&hb.l[slot * HT + hg * H + h], l_part);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hub_finalize(const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ hub_list,
+                                                      HubBuffers hb, float* __restrict__ agg, int HT, int dkp, int64_t NQ,
+                                                      int apply_gelu) {
+    const int n_hubs = hdr->n_hubs;
+    const int lane = threadIdx.x & 63;
+    const int dfull = HT * dkp;
+    for (int slot = blockIdx.x * 4 + (threadIdx.x >> 6); slot < n_hubs; slot += gridDim.x * 4) {
+        const int64_t row = hub_list[slot];
+        if (row >= NQ) continue;
+        for (int c = lane; c < dfull; c += 64) {
+            float v = hb.acc[(int64_t)slot * dfull + c] / (hb.l[slot * HT + c / dkp] + 1e-16f);
+            if (apply_gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            agg[row * dfull + c] = v;
         }
     }
 }
@@ -473,15 +683,31 @@ struct LaunchLogits {
 template <int VEC, int LPH>
 struct LaunchAggregate {
     static int run(const HgtPlanView& pv, const float* logits, const float* V, const float* rteV, const float* msgP, float* agg,
-                   int R, int64_t NQ, int apply_gelu, int HT, hipStream_t stream) {
+                   int R, int64_t NQ, int apply_gelu, int HT, HubBuffers hb, hipStream_t stream) {
         const int64_t tiles = (NQ + 63) / 64;
-        dim3 grid((unsigned)tiles, (unsigned)(HT / (64 / LPH)));
+        const unsigned ny = (unsigned)(HT / (64 / LPH));
+        dim3 grid((unsigned)tiles, ny);
+        const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
         if (rteV)
             k_edge_aggregate<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgP, agg, R,
-                                                                       NQ, apply_gelu, HT);
+                                                                       NQ, apply_gelu, HT, hub_slot);
         else
             k_edge_aggregate<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgP, agg, R,
-                                                                        NQ, apply_gelu, HT);
+                                                                        NQ, apply_gelu, HT, hub_slot);
+        if (hb.mx) {   // hub path: a fixed grid, every wave returns at once when the plan has no hub
+            const int dkp = VEC * LPH;
+            const int64_t cells = (int64_t)pv.L.max_hubs * (2 * HT + HT * dkp);
+            k_hub_init<<<(unsigned)((cells + 255) / 256), 256, 0, stream>>>(pv.hdr, hb, HT, HT * dkp);
+            k_hub_max<<<HUB_GRID_WAVES / 4, 256, 0, stream>>>(pv.hdr, pv.hub_list, pv.segptr, logits, R, HT, hb);
+            dim3 hgrid(HUB_GRID_WAVES / 4, ny);
+            if (rteV)
+                k_hub_accumulate<VEC, LPH, true><<<hgrid, 256, 0, stream>>>(pv.hdr, pv.hub_list, pv.segptr, pv.esrc, pv.ertei, logits, V,
+                                                                            rteV, msgP, R, HT, hb);
+            else
+                k_hub_accumulate<VEC, LPH, false><<<hgrid, 256, 0, stream>>>(pv.hdr, pv.hub_list, pv.segptr, pv.esrc, pv.ertei, logits, V,
+                                                                             rteV, msgP, R, HT, hb);
+            k_hub_finalize<<<256, 256, 0, stream>>>(pv.hdr, pv.hub_list, hb, agg, HT, dkp, NQ, apply_gelu);
+        }
         return HGT_OK;
     }
 };
@@ -534,18 +760,35 @@ extern "C" int hgt_edge_softmax(const void* plan, int64_t N, int64_t E, int32_t 
     return HGT_OK;
 }
 
+extern "C" int hgt_hub_workspace_bytes(int64_t n_edges, int32_t n_heads, int32_t dk_pad, uint64_t* out) {
+    if (!out || n_edges < 0 || n_heads <= 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
+    const uint64_t max_hubs = (uint64_t)(n_edges / HGT_HUB_DEG + 1);
+    *out = hgt_align_up(max_hubs * n_heads * 4, 256) * 2 + hgt_align_up(max_hubs * n_heads * dk_pad * 4, 256);
+    return HGT_OK;
+}
+
 extern "C" int hgt_edge_aggregate(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
                                   const float* logits, const float* V, const float* rte_v, const float* msg_p, float* agg,
-                                  int64_t n_q_rows, int32_t apply_gelu, void* stream) {
+                                  int64_t n_q_rows, int32_t apply_gelu, void* hub_ws, void* stream) {
     if (!plan || !V || !msg_p || !agg || (E > 0 && !logits) || H <= 0 || 64 % H != 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
     const int64_t NQ = (n_q_rows > 0 && n_q_rows <= N) ? n_q_rows : N;
     if (NQ == 0) return HGT_OK;
     const int lph = 64 / H;
     if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
     HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
+    HubBuffers hb = {nullptr, nullptr, nullptr};
+    if (hub_ws && E > 0) {
+        const uint64_t max_hubs = (uint64_t)pv.L.max_hubs;
+        char* b = (char*)hub_ws;
+        hb.mx = (int*)b;
+        b += hgt_align_up(max_hubs * H * 4, 256);
+        hb.l = (float*)b;
+        b += hgt_align_up(max_hubs * H * 4, 256);
+        hb.acc = (float*)b;
+    }
     const int sp = head_split_for(dk_pad / lph, lph, dk_pad);
     int rc = dispatch_layout<LaunchAggregate>(dk_pad / lph / sp, lph * sp, pv, logits, V, rte_v, msg_p, agg, (int)R, NQ, (int)apply_gelu,
-                                              (int)H, (hipStream_t)stream);
+                                              (int)H, hb, (hipStream_t)stream);
     if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();
     return HGT_OK;

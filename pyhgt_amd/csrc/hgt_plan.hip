@@ -65,7 +65,7 @@ static int sort_tmp_query(int64_t N, int64_t E, int32_t T, const HgtPlanLayout& 
 }
 
 __global__ void k_init_header(HgtPlanHeader* hdr) {
-    if (threadIdx.x == 0) { hdr->n_items = 0; hdr->bad_index = 0; }
+    if (threadIdx.x == 0) { hdr->n_items = 0; hdr->bad_index = 0; hdr->n_hubs = 0; }
 }
 
 // key = ((dst / TD) * (R+1) + rel') * TD + dst % TD ; rel' = R for edges no meta relation claims
@@ -146,6 +146,26 @@ __global__ void k_items(const int32_t* __restrict__ segptr, const int32_t* __res
         it.tile = tile;
         items[o++] = it;
     }
+}
+
+// hub targets: in-degree (over all relation buckets) above HGT_HUB_DEG.  They get a slot in the hub buffers and are
+// aggregated by many wavefronts (one per work item) instead of the single wavefront that owns their sub-tile.
+__global__ void k_hub_detect(const int32_t* __restrict__ segptr, int64_t N, int R, int32_t* __restrict__ hub_slot,
+                             int32_t* __restrict__ hub_list, HgtPlanHeader* hdr) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int64_t tile = n / HGT_TD, dl = n % HGT_TD;
+    int deg = 0;
+    for (int r = 0; r <= R; ++r) {
+        const int64_t b = (tile * (R + 1) + r) * HGT_TD + dl;
+        deg += segptr[b + 1] - segptr[b];
+    }
+    int slot = -1;
+    if (deg > HGT_HUB_DEG) {
+        slot = atomicAdd(&hdr->n_hubs, 1);
+        hub_list[slot] = (int32_t)n;
+    }
+    hub_slot[n] = slot;
 }
 
 __global__ void k_node_keys(const int64_t* __restrict__ ntype, int64_t N, int T, uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
@@ -237,6 +257,8 @@ extern "C" int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int
     int32_t* off_all = (int32_t*)(pb + L.off_off_all);
     int32_t* rows_q = (int32_t*)(pb + L.off_rows_q);
     int32_t* off_q = (int32_t*)(pb + L.off_off_q);
+    int32_t* hub_slot = (int32_t*)(pb + L.off_hub_slot);
+    int32_t* hub_list = (int32_t*)(pb + L.off_hub_list);
     uint32_t* keys_in = (uint32_t*)(tb + tl.off_keys_in);
     uint32_t* keys_out = (uint32_t*)(tb + tl.off_keys_out);
     int32_t* vals_in = (int32_t*)(tb + tl.off_vals_in);
@@ -265,6 +287,7 @@ extern "C" int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int
     if (rocprim::exclusive_scan(sort_tmp, sort_bytes, pair_cnt, pair_off, 0, (size_t)(L.n_pairs + 1),
                                 rocprim::plus<int32_t>(), stream) != hipSuccess) return HGT_ERR_LAUNCH;
     k_items<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(segptr, pair_off, L.n_pairs, R, items, tile_items, hdr);
+    if (N > 0) k_hub_detect<<<nblk(N, BS), BS, 0, stream>>>(segptr, N, R, hub_slot, hub_list, hdr);
 
     // typed row lists: all nodes, and target nodes [0, NQ)
     if (N > 0) {

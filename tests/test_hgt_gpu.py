@@ -105,6 +105,30 @@ def test_large_logit_spread_forces_softmax_rereference():
     assert (att.double() - att_ref).abs().max().item() < 1e-4   # logits ~ 1e2: fp32 logit rounding alone is ~1e-5
 
 
+@pytest.mark.parametrize("use_RTE", [False, True])
+def test_hub_targets_take_the_split_path(use_RTE):
+    """Targets with more than 1024 in-edges are aggregated by the hub kernels (edge ranges split over many
+    wavefronts, fp32 atomics); everything else stays on the one-wavefront-per-sub-tile path."""
+    T, R, H, d, N, E = 3, 4, 4, 64, 3000, 40000
+    sd = O.make_state_dict(d, d, T, R, H, True, use_RTE, seed=61)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=62)
+    ei = ei.clone()
+    ei[1, :9000] = 5                    # hub 1: 9000 in-edges, all relations
+    ei[1, 9000:12500] = 777             # hub 2
+    ei[1, 12500:13600] = 2999           # hub 3: just over the threshold, last node
+    et = et.clone()
+    et[100:400] = R + 3                 # some unclaimed edges into hub 1 (logit 0, no message)
+    ref, att_ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm if use_RTE else None, use_RTE=use_RTE,
+                                         dtype=torch.float64, return_att=True)
+    layer = _layer_from(sd, d, T, R, H, True, use_RTE)
+    out, att = _run(layer, x, nt, ei, et, tm if use_RTE else None)
+    plan = GraphPlan(*_to_dev(nt, ei, et, tm if use_RTE else None), T, R)
+    torch.cuda.synchronize()
+    assert int(plan.buf[:12].view(torch.int32).cpu()[2]) == 3          # three hubs detected
+    assert (out.double() - ref).abs().max().item() < TOL
+    assert (att.double() - att_ref).abs().max().item() < 1e-5
+
+
 def test_no_edges_and_isolated_targets():
     T, R, H, d = 3, 2, 4, 64
     sd = O.make_state_dict(d, d, T, R, H, True, False, seed=1)
