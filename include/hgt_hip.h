@@ -203,6 +203,9 @@ int hgt_node_update(const float* trans, const float* x, int64_t ldx, const int64
                     const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm,
                     int64_t n_nodes, int32_t d, int32_t n_types, float* out, void* stream);
 
+/* x[i] = tanh(x[i]) in place: the activation of the typed input adapter of model.GNN (model.py:70-76) */
+int hgt_tanh_inplace(float* x, int64_t n, void* stream);
+
 /* row gather used to pack halo rows for the multi-GPU exchange: out[i] = x[idx[i]] */
 int hgt_gather_rows(const float* x, int64_t ldx, const int32_t* idx, int64_t n, int32_t d, float* out, void* stream);
 

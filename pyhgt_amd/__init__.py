@@ -4,5 +4,6 @@ Drop-in for the reference layer pyHGT/conv.py::HGTConv (same constructor, parame
 forward signature) backed by hand-written HIP kernels behind a C ABI (include/hgt_hip.h).
 """
 from .conv import HGTConv, GeneralConv, RelTemporalEncoding, GraphPlan, install_into  # noqa: F401
+from .model import GNN  # noqa: F401
 
-__all__ = ["HGTConv", "GeneralConv", "RelTemporalEncoding", "GraphPlan", "install_into"]
+__all__ = ["HGTConv", "GeneralConv", "RelTemporalEncoding", "GraphPlan", "install_into", "GNN"]

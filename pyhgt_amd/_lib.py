@@ -71,6 +71,7 @@ SIGNATURES = {
     "hgt_hub_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_u64)]),
     "hgt_att_export": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "hgt_node_update": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
+    "hgt_tanh_inplace": (C.c_int, [_vp, _i64, _vp]),
     "hgt_gather_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "hgt_conv_workspace_bytes": (C.c_int, [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_u64)]),
     "hgt_conv_forward": (C.c_int, [C.POINTER(HgtConvArgs), _vp]),

@@ -92,7 +92,26 @@ __global__ __launch_bounds__(256) void k_zero_rows(const int32_t* __restrict__ r
     }
 }
 
+__global__ void k_tanh_inplace(float* __restrict__ x, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float4 v = *reinterpret_cast<float4*>(x + i);
+        v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+        *reinterpret_cast<float4*>(x + i) = v;
+    } else {
+        for (int64_t j = i; j < n; ++j) x[j] = tanhf(x[j]);
+    }
+}
+
 }  // namespace
+
+extern "C" int hgt_tanh_inplace(float* x, int64_t n, void* stream) {
+    if (n == 0) return HGT_OK;
+    if (!x || n < 0 || ((uintptr_t)x & 15) != 0) return HGT_ERR_INVALID_ARG;
+    k_tanh_inplace<<<(unsigned)((n / 4 + 256) / 256), 256, 0, (hipStream_t)stream>>>(x, n);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
 
 extern "C" int hgt_zero_rows(const int32_t* rows, const int32_t* range, int32_t d, float* out, void* stream) {
     if (!rows || !range || !out || d <= 0) return HGT_ERR_INVALID_ARG;

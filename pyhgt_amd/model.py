@@ -1,0 +1,75 @@
+"""Host-side mirror of the reference's GNN wrapper ("next" row 1).
+
+`GNN` keeps the constructor, attribute / state_dict names and forward signature of
+/root/reference/pyHGT/model.py:54-80: a typed input adapter (`adapt_ws[t]` Linear + tanh, model.py:70-76)
+followed by `n_layers` GeneralConv('hgt') layers that all receive the same graph tensors (model.py:78-79).
+The adapter runs on the same typed-linear kernels as the layers (no per-type boolean masks, no host sync --
+the reference syncs once per type at model.py:73), and one GraphPlan is built for the whole stack.
+Forward only (eval mode: both dropouts are the identity).  Classifier / Matcher heads stay the reference's.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .conv import GeneralConv, GraphPlan, _ptr, _stream
+
+__all__ = ["GNN"]
+
+
+class GNN(nn.Module):
+    def __init__(self, in_dim, n_hid, num_types, num_relations, n_heads, n_layers, dropout=0.2, conv_name='hgt',
+                 prev_norm=False, last_norm=False, use_RTE=True):
+        super().__init__()
+        self.gcs = nn.ModuleList()
+        self.num_types = num_types
+        self.in_dim = in_dim
+        self.n_hid = n_hid
+        self.adapt_ws = nn.ModuleList(nn.Linear(in_dim, n_hid) for _ in range(num_types))
+        self.drop = nn.Dropout(dropout)
+        for _ in range(n_layers - 1):
+            self.gcs.append(GeneralConv(conv_name, n_hid, n_hid, num_types, num_relations, n_heads, dropout,
+                                        use_norm=prev_norm, use_RTE=use_RTE))
+        self.gcs.append(GeneralConv(conv_name, n_hid, n_hid, num_types, num_relations, n_heads, dropout,
+                                    use_norm=last_norm, use_RTE=use_RTE))
+        self._packed = None
+        self._packed_key = None
+
+    def _pack_adapter(self):
+        params = [p for lin in self.adapt_ws for p in lin.parameters()]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed is None or self._packed_key != key:
+            with torch.no_grad():
+                w = torch.stack([lin.weight for lin in self.adapt_ws]).float().contiguous()   # [T, n_hid, in_dim]
+                b = torch.stack([lin.bias for lin in self.adapt_ws]).float().contiguous()     # [T, n_hid]
+            self._packed, self._packed_key = (w, b), key
+        return self._packed
+
+    def forward(self, node_feature, node_type, edge_time, edge_index, edge_type):
+        """Same argument order as the reference (model.py:69): note edge_time comes third."""
+        lib = _lib.load()
+        if not node_feature.is_cuda:
+            raise RuntimeError("pyhgt_amd.GNN runs only on a ROCm GPU tensor; there is no CPU fallback")
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("pyhgt_amd.GNN is forward-only: call it under torch.no_grad() or in eval() mode")
+        x = node_feature.detach().float().contiguous()
+        N = x.size(0)
+        conv0 = self.gcs[0].base_conv
+        plan = GraphPlan.cached(node_type, edge_index, edge_type, edge_time if conv0.use_RTE else None,
+                                conv0.num_types, conv0.num_relations)
+        rows = plan.row_lists()
+        w, b = self._pack_adapter()
+        T, n_hid, in_dim = self.num_types, self.n_hid, self.in_dim
+        h = torch.empty(N, n_hid, dtype=torch.float32, device=x.device)
+        st = _stream()
+        # typed adapter: exact fp32 MFMA kernel (in_dim is arbitrary, e.g. 129 or 1169: not a multiple of 4)
+        _lib.check(lib.hgt_typed_linear(_ptr(x), in_dim, rows.rows_all, rows.off_all, T, N, in_dim, n_hid, _ptr(w), n_hid * in_dim,
+                                        _ptr(b), n_hid, _ptr(h), 0, 0, n_hid, 0, 0, 0, st), "hgt_typed_linear(adapter)")
+        # nodes whose type no adapter claims stay zero like the reference's zero-initialised `res` (model.py:70);
+        # rows_all[off_all[T] .. off_all[T+1]) are exactly those nodes
+        _lib.check(lib.hgt_zero_rows(rows.rows_all, rows.off_all + 4 * T, n_hid, _ptr(h), st), "hgt_zero_rows")
+        _lib.check(lib.hgt_tanh_inplace(_ptr(h), N * n_hid, st), "hgt_tanh_inplace")
+        for gc in self.gcs:
+            h = gc.base_conv(h, node_type, edge_index, edge_type, edge_time, plan=plan)
+        return h

@@ -113,3 +113,22 @@ def test_general_conv_rejects_out_of_scope_layers():
     GeneralConv('hgt', 16, 16, 2, 2, 2, 0.2)
     with pytest.raises(NotImplementedError):
         GeneralConv('gcn', 16, 16, 2, 2, 2, 0.2)
+
+
+def test_gnn_wrapper_matches_reference_parameter_count():
+    """ogbn-mag/README.md:30: 21,173,389 parameters for GNN(129, 512, 4, 9, 8, 4, norms on, RTE) + Classifier(512, 349)."""
+    from pyhgt_amd import GNN
+    gnn = GNN(129, 512, 4, 9, 8, 4, prev_norm=True, last_norm=True, use_RTE=True)
+    assert sum(p.numel() for p in gnn.parameters()) + (512 * 349 + 349) == 21173389
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+def test_gnn_state_dict_names_equal_the_live_reference():
+    from oracle.reference_loader import load_reference_model
+    from pyhgt_amd import GNN
+    ref = load_reference_model().GNN(32, 64, 3, 4, 4, 2, prev_norm=True, last_norm=False, use_RTE=True)
+    ours = GNN(32, 64, 3, 4, 4, 2, prev_norm=True, last_norm=False, use_RTE=True)
+    rs, os_ = ref.state_dict(), ours.state_dict()
+    assert list(rs.keys()) == list(os_.keys())
+    assert all(rs[k].shape == os_[k].shape for k in rs)
+    ours.load_state_dict(rs)
