@@ -190,14 +190,6 @@ int hgt_edge_aggregate(const void* plan, int64_t n_nodes, int64_t n_edges, int32
  * ranges are split over many wavefronts (max / sum-exp / weighted sum accumulated with atomics) instead of being
  * walked by the one wavefront that owns their 16-target sub-tile.  NULL = no hub path (correct, slow on hubs). */
 int hgt_hub_workspace_bytes(int64_t n_edges, int32_t n_heads, int32_t dk_pad, uint64_t* out_host);
-/* Split-bf16 matrix-core variant of hgt_edge_logits for the (dk_pad = 32, 8 heads) layout: the A'[rel] q transforms of
- * 16 (target, relation) segments at a time run as one small GEMM on v_mfma_f32_16x16x32_bf16 (3 MFMAs per tile,
- * fp32 accumulate) instead of one fp32 VALU mat-vec per segment.  att_bf = hgt_relation_pack_bf16(att_t): A'^T split
- * into bf16 hi/mid, MFMA-fragment order, n_relations * n_heads * 4096 bytes.  HGT_ERR_UNSUPPORTED for other layouts. */
-int hgt_relation_pack_bf16(const float* att_t, int32_t n_relations, int32_t n_heads, int32_t dk_pad, void* att_bf, void* stream);
-int hgt_edge_logits_bf16x3(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
-                           int32_t n_heads, int32_t dk_pad, const float* Q, const float* K, const float* rte_k,
-                           const void* att_bf, float* logits, void* stream);
 int hgt_att_export(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                    int32_t n_heads, const float* att_sorted, float* att_out, void* stream);
 

@@ -7,7 +7,7 @@
 namespace {
 
 struct ConvWorkspace {
-    uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p, off_hub, off_att_bf;
+    uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p, off_hub;
     uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, off_ws_qkv, off_ws_a, off_ws_rte, total;
 };
 
@@ -28,7 +28,6 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
     uint64_t hb = 0;
     hgt_hub_workspace_bytes(E, H, lay.dk_pad, &hb);
     w.off_hub = take(hb);
-    w.off_att_bf = take((uint64_t)R * H * 4096);
     if (use_rte) {
         w.off_rte_lin = take((uint64_t)HGT_RTE_LEN * in_dim * 4);
         w.off_rte_k = take((uint64_t)T * HGT_RTE_LEN * dp * 4);
@@ -188,13 +187,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     mark(1);
     // (4) edge phase: logits, then softmax fused into the aggregation (online, per target sub-tile)
     if (E > 0) {
-        // split-bf16 mode + (d_k 32, 8 heads): relation transforms batched on the matrix cores; otherwise fp32 VALU mat-vecs
-        rc = HGT_ERR_UNSUPPORTED;
-        if (split && !getenv("HGT_LOGITS_VALU")) {
-            rc = hgt_relation_pack_bf16(att_t, R, H, lay.dk_pad, wb + w.off_att_bf, stream);
-            if (rc == HGT_OK) rc = hgt_edge_logits_bf16x3(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, wb + w.off_att_bf, logits, stream);
-        }
-        if (rc == HGT_ERR_UNSUPPORTED) rc = hgt_edge_logits(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, stream);
+        rc = hgt_edge_logits(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, stream);
         if (rc != HGT_OK) return rc;
     }
     mark(2);
