@@ -150,10 +150,6 @@ __global__ __launch_bounds__(256) void k_edge_logits(
 #pragma unroll
     for (int i = 0; i < VEC; ++i) qt[i] = 0.0f;
 
-#ifndef HGT_PIPE
-#define HGT_PIPE 1
-#endif
-#if HGT_PIPE
     // Software pipeline: two half-batches (A, B) of HB edges.  The loads of the NEXT half-batch are issued before the
     // current one is consumed, so the mat-vec / dot work of one half overlaps the gather latency of the other.  Every
     // issue is unconditional and of fixed size (indices clamped to the chunk, the Q row is fetched for every edge, not
@@ -209,56 +205,6 @@ __global__ __launch_bounds__(256) void k_edge_logits(
 #undef HGT_PROCESS
     }
 }
-
-#else
-    for (int base = beg; base < end; base += 64) {
-        const int nb = min(64, end - base);
-        const int li = base + min(lane, nb - 1);
-        const int my_src = esrc[li], my_dst = edst[li];
-        const int my_rte = RTE ? (int)ertei[li] : 0;
-        for (int i0 = 0; i0 < nb; i0 += UN) {
-            float kr[UN][VEC], qr[UN][VEC], tr[RTE ? UN : 1][VEC];
-            int dsts[UN];
-            bool newq[UN];
-            int prev = cur_dst;
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int idx = min(i0 + u, nb - 1);
-                const int s = __builtin_amdgcn_readlane(my_src, idx);
-                const int dd = __builtin_amdgcn_readlane(my_dst, idx);
-                load_vec<VEC>(K + (int64_t)s * ld + co + lane * VEC, kr[u]);
-                if constexpr (RTE) {
-                    const int ri = __builtin_amdgcn_readlane(my_rte, idx);
-                    load_vec<VEC>(rteK + (int64_t)ri * ld + co + lane * VEC, tr[u]);
-                }
-                dsts[u] = dd;
-                newq[u] = (dd != prev);
-                if (newq[u]) load_vec<VEC>(Q + (int64_t)dd * ld + co + lane * VEC, qr[u]);
-                prev = dd;
-            }
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                if (i0 + u < nb) {
-                    if (newq[u]) {
-                        head_matvec<VEC, DKP, HOIST>(qr[u], bounce, lane, h, frag, fglob, qt);
-                        cur_dst = dsts[u];
-                    }
-                    float part = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) {
-                        float kv = kr[u][i];
-                        if constexpr (RTE) kv += tr[u][i];
-                        part = fmaf(qt[i], kv, part);
-                    }
-                    part = head_allreduce<LPH>(part);
-                    if (p == 0) logits[(int64_t)(base + i0 + u) * HT + hg * H + h] = part;
-                }
-            }
-        }
-    }
-}
-
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // softmax over the in-edges of each target, per head (PyG utils.softmax, conv.py:108); in place

@@ -23,6 +23,12 @@
 //     and -- because nothing is written to LDS in the main loop -- there is NO barrier in it.
 // The 528 B LDS row stride puts the 16 lanes of a ds_read_b128 group on 16 distinct 4-bank slots.
 #include "hgt_common.h"
+#include <algorithm>
+#include <cstdlib>
+
+#ifndef PC_DBG
+#define PC_DBG 0   // development switches for timing experiments; 0 in the product build
+#endif
 
 namespace {
 
@@ -151,7 +157,11 @@ __device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, 
 __device__ __forceinline__ void store_pass(f32x16 (&acc)[2], int pass, int wave, int lane, int g, int n_out, int nrows, int row0,
                                            const int* s_rid, const float* __restrict__ bias, int64_t bgs, float* __restrict__ out0,
                                            float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos) {
+#if PC_DBG & 16
+    const int col = pass * BNP + wave * 32 + (lane & 7) * 4;   // timing experiment only: WRONG placement, coalesced pattern
+#else
     const int col = pass * BNP + wave * 32 + ((lane & 31) >> 2) * 4;      // first of this lane's 4 columns after the transpose
+#endif
     const bool col_ok = col < n_out;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col_ok && bias) b4 = *reinterpret_cast<const float4*>(bias + (int64_t)g * bgs + col);
@@ -164,7 +174,11 @@ __device__ __forceinline__ void store_pass(f32x16 (&acc)[2], int pass, int wave,
         for (int q = 0; q < 4; ++q) {
             float v0 = acc[j][4 * q], v1 = acc[j][4 * q + 1], v2 = acc[j][4 * q + 2], v3 = acc[j][4 * q + 3];
             quad_transpose(v0, v1, v2, v3, o1, o2);
+#if PC_DBG & 16
+            const int rt = j * 32 + 8 * q + (lane >> 3);
+#else
             const int rt = j * 32 + (lane & 3) + 8 * q + 4 * (lane >> 5);
+#endif
             if (col_ok && rt < nrows) {
                 const int64_t orow = by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
                 *reinterpret_cast<float4*>(ob + orow * block_cols + cc) = make_float4(v0 + b4.x, v1 + b4.y, v2 + b4.z, v3 + b4.w);
@@ -390,12 +404,503 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
 #undef HGT_LOAD_STAGE
 }
 
+// =============================================================================================
+// Persistent producer / consumer variant (k <= 256: the whole K extent is one LDS slab).
+//
+// Why: the kernel above has at most two workgroups per CU and every one of them runs its phases
+// back to back (row ids -> 64 KB slab from HBM -> MFMA loop -> epilogue), so HBM idles while a
+// workgroup computes and the matrix cores idle while it loads.  A next-tile prefetch through
+// registers does not help: s_waitcnt vmcnt retires IN ORDER, so the first B-fragment wait of the
+// MFMA loop would also wait for the older slab loads.  The loads therefore move to their own waves:
+//   * one workgroup per CU (grid = #CUs), looping over 64-row tiles  t = blockIdx.x, += gridDim.x;
+//   * waves 0..7 (two per SIMD) are CONSUMERS: the MFMA loop + epilogue of tile i out of slab[i&1];
+//   * waves 8..11 (one per SIMD) are PRODUCERS: they keep the 64 KB of tile i+2 in flight in
+//     registers, and split + store tile i+1 into slab[(i+1)&1] while the consumers work on tile i;
+//   * one workgroup barrier per tile hands slab[(i+1)&1] over (plus two inside the LayerNorm
+//     epilogue of the fused update; the producers simply arrive at those as well).
+// LDS: 2 x 66 KB slabs + row ids + the LayerNorm tables = 137 KB.  VGPR budget 168 (3 waves/SIMD).
+// =============================================================================================
+#ifndef PC_PRIO
+#define PC_PRIO 0
+#endif
+#ifndef PC_TRACE
+#define PC_TRACE 0
+#endif
+#if PC_TRACE
+// development aid: per-phase shader-clock totals of consumer wave 0 / producer wave 8 of every workgroup
+__device__ unsigned long long pc_trace[16];
+#define PC_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PC_TADD(slot, from, to) if (trace_me) atomicAdd(&pc_trace[slot], (to) - (from))
+#else
+#define PC_T(var)
+#define PC_TADD(slot, from, to)
+#endif
+constexpr int PC_CONS = 8, PC_PROD = 4, PC_THREADS = 64 * (PC_CONS + PC_PROD);
+constexpr int PC_AREGS = BM * (KP / 4) / (64 * PC_PROD);   // float4 per producer lane per tile = 16
+
+__device__ __forceinline__ bool tile_lookup(int t, const int32_t* __restrict__ group_off, int n_groups, int& g, int& row0, int& nrows) {
+    int before = 0;
+    for (g = 0; g < n_groups; ++g) {
+        const int gb = group_off[g], ge = group_off[g + 1];
+        const int nt = (ge - gb + BM - 1) / BM;
+        if (t < before + nt) {
+            row0 = gb + (t - before) * BM;
+            nrows = min(BM, ge - row0);
+            return true;
+        }
+        before += nt;
+    }
+    return false;
+}
+
+// producer: request the rows of one tile (wave pw fetches rows pw, pw+4, ..., one coalesced 1 KB row per instruction).
+// Fast path: 16 unconditional back-to-back 16 B loads (absent rows read row 0 and are zeroed in pc_commit); written
+// with per-row conditions hipcc lowers the whole thing to 4 B loads behind branches (measured: 47k cycles per tile).
+__device__ __forceinline__ void pc_issue(float4 (&a)[PC_AREGS], int& v_rid, int pw, int lane, int row0, int nrows,
+                                         const int32_t* __restrict__ rows, const float* __restrict__ x, int64_t ldx, int k, int vec_ok) {
+    const int myrow = pw + PC_PROD * lane;   // lanes 0..15 carry the 16 row ids of this wave
+    v_rid = (lane < PC_AREGS && myrow < nrows) ? rows[row0 + myrow] : -1;
+    const int kk = lane * 4;
+    if (vec_ok) {   // k % 4 == 0: a lane is entirely inside or entirely outside the row
+        if (kk < k && !(PC_DBG & 2)) {
+#pragma unroll
+            for (int j = 0; j < PC_AREGS; ++j) {
+                const int rid = max(__builtin_amdgcn_readlane(v_rid, j), 0);
+                a[j] = *reinterpret_cast<const float4*>(x + (int64_t)rid * ldx + kk);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PC_AREGS; ++j) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < PC_AREGS; ++j) {
+        const int rid = __builtin_amdgcn_readlane(v_rid, j);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rid >= 0 && kk < k) {
+            const float* px = x + (int64_t)rid * ldx + kk;
+            v.x = px[0];
+            if (kk + 1 < k) v.y = px[1];
+            if (kk + 2 < k) v.z = px[2];
+            if (kk + 3 < k) v.w = px[3];
+        }
+        a[j] = v;
+    }
+}
+
+template <int PROLOGUE>
+__device__ __forceinline__ void pc_commit(const float4 (&a)[PC_AREGS], int v_rid, int pw, int lane, unsigned char* slab, int* rid_out) {
+    if (lane < PC_AREGS) rid_out[pw + PC_PROD * lane] = v_rid;
+#pragma unroll
+    for (int j = 0; j < PC_AREGS; ++j) {
+        float4 v = a[j];
+        if (__builtin_amdgcn_readlane(v_rid, j) < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);   // row beyond the tile
+        if (PROLOGUE == 1) { v.x = gelu_erf_(v.x); v.y = gelu_erf_(v.y); v.z = gelu_erf_(v.z); v.w = gelu_erf_(v.w); }
+        uint2 hi, mid;
+        split4(v, hi, mid);
+        unsigned char* p = slab + (pw + PC_PROD * j) * A_STRIDE + lane * 8;
+        *reinterpret_cast<uint2*>(p) = hi;
+        *reinterpret_cast<uint2*>(p + A_PLANE) = mid;
+    }
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Output rows are written with stores the compiler does not see (inline asm).  Reason: a CU retires only ~10 B/clk of
+// stores (measured: 64 KB per pass = 6.5-9k cycles of epilogue with the matrix cores idle), so the stores of pass p are
+// spread over the MFMA loop of pass p+1, one every other k-chunk.  With visible stores pending, hipcc must treat
+// vmcnt as unordered and turns every B-fragment wait of that loop into vmcnt(0).  With hidden stores it keeps emitting
+// vmcnt(N), N = younger LOADS -- still sufficient: loads return in order, so a pending target load implies N+1
+// pending loads, i.e. counter > N.  Pending stores only make the wait a little stricter than necessary.
+__device__ __forceinline__ void hidden_store16(float* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" : : "v"(p), "v"(v));
+}
+
+// workgroup barrier that orders LDS only (a __syncthreads() would also drain every outstanding global load AND store)
+__device__ __forceinline__ void pc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct PendingRows {     // one pass worth of finished output of this lane: 8 x (row, 4 consecutive columns)
+    f32x4 v[8];
+    float* base;         // column offset already applied; nullptr = this lane's columns are out of range
+    int ld;              // row stride in floats
+    // the output row of register group u is looked up again when the store is issued (8 fewer live registers):
+    const int* rid;      // LDS row-id table of the tile the rows belong to (three tables rotate, see s_rid)
+    int row0, nrows, by_pos;
+    __device__ __forceinline__ int row(int u, int lane) const {
+        const int rt = (u >> 2) * 32 + (lane & 3) + 8 * (u & 3) + 4 * (lane >> 5);
+        return (base != nullptr && rt < nrows) ? (by_pos ? row0 + rt : rid[rt]) : -1;
+    }
+};
+
+// Fused node update (conv.py:129-133), both 32-row halves at once, two barriers:
+//   y = (acc + b) * sigmoid(skip[t]) + x * (1 - sigmoid(skip[t]));  out = LayerNorm_t(y)  (two-pass mean / variance)
+__device__ __forceinline__ void pc_store_update(f32x16 (&acc)[2], int wave, int lane, int g, int n_out, int nrows, const int* s_rid,
+                                                const float* __restrict__ bias, int64_t bgs, float* __restrict__ out,
+                                                const UpdateArgs& u, float* s_sum, float* s_var, PendingRows& pr) {
+    const int col = wave * 32 + ((lane & 31) >> 2) * 4;
+    const bool col_ok = col < n_out;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col_ok && bias) b4 = *reinterpret_cast<const float4*>(bias + (int64_t)g * bgs + col);
+    const float alpha = 1.0f / (1.0f + expf(-u.skip[g]));
+    const bool o1 = lane & 1, o2 = lane & 2;
+    const float inv_n = 1.0f / (float)n_out;
+    float y[8][4];
+    // row of register group jq = (half, q): rt0 + 32*half + 8*q; its node id is re-read from LDS where needed
+    // (keeping the eight ids in registers spills at the 168-VGPR cap)
+    const int rt0 = (lane & 3) + 4 * (lane >> 5);
+#define PC_OROW(JQ) ((rt0 + 32 * ((JQ) >> 2) + 8 * ((JQ)&3)) < nrows ? s_rid[rt0 + 32 * ((JQ) >> 2) + 8 * ((JQ)&3)] : -1)
+    // the skip rows in two groups of four 16 B loads (all eight at once costs 16 more live registers: spills at the 168 cap)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float4 xv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int jq = half * 4 + q;
+            xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int orow = PC_OROW(jq);
+            if (col_ok && orow >= 0) xv[q] = *reinterpret_cast<const float4*>(u.xs + (int64_t)orow * u.ldxs + col);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int jq = half * 4 + q;
+            float v0 = acc[half][4 * q], v1 = acc[half][4 * q + 1], v2 = acc[half][4 * q + 2], v3 = acc[half][4 * q + 3];
+            quad_transpose(v0, v1, v2, v3, o1, o2);
+            y[jq][0] = col_ok ? (v0 + b4.x) * alpha + xv[q].x * (1.0f - alpha) : 0.0f;
+            y[jq][1] = col_ok ? (v1 + b4.y) * alpha + xv[q].y * (1.0f - alpha) : 0.0f;
+            y[jq][2] = col_ok ? (v2 + b4.z) * alpha + xv[q].z * (1.0f - alpha) : 0.0f;
+            y[jq][3] = col_ok ? (v3 + b4.w) * alpha + xv[q].w * (1.0f - alpha) : 0.0f;
+        }
+    }
+    if (!u.use_norm) {
+#pragma unroll
+        for (int jq = 0; jq < 8; ++jq) {
+            pr.v[jq] = f32x4{y[jq][0], y[jq][1], y[jq][2], y[jq][3]};
+        }
+        pr.base = col_ok ? out + col : nullptr;
+        pr.ld = n_out;
+        pc_barrier();
+        pc_barrier();
+        return;
+    }
+    // a row's columns live in 8 waves x 8 lanes: lane-strided sums, then one table entry per (row, wave)
+#pragma unroll
+    for (int jq = 0; jq < 8; ++jq) {
+        const int rt = (jq >> 2) * 32 + (lane & 3) + 8 * (jq & 3) + 4 * (lane >> 5);
+        const float ps = strided8_sum(y[jq][0] + y[jq][1] + y[jq][2] + y[jq][3]);
+        if (((lane & 31) >> 2) == 0) s_sum[rt * 8 + wave] = ps;
+    }
+    pc_barrier();
+#pragma unroll
+    for (int jq = 0; jq < 8; ++jq) {
+        const int rt = (jq >> 2) * 32 + (lane & 3) + 8 * (jq & 3) + 4 * (lane >> 5);
+        const float4 a = *reinterpret_cast<const float4*>(&s_sum[rt * 8]);
+        const float4 b = *reinterpret_cast<const float4*>(&s_sum[rt * 8 + 4]);
+        const float mean = (a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w) * inv_n;
+        y[jq][0] -= mean; y[jq][1] -= mean; y[jq][2] -= mean; y[jq][3] -= mean;   // y is centred from here on
+        float d0 = y[jq][0], d1 = y[jq][1], d2 = y[jq][2], d3 = y[jq][3];
+        if (!col_ok) d0 = d1 = d2 = d3 = 0.0f;
+        const float ps = strided8_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+        if (((lane & 31) >> 2) == 0) s_var[rt * 8 + wave] = ps;
+    }
+    pc_barrier();
+    float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f), c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col_ok) {   // loaded this late on purpose: 8 fewer registers live across the two reductions
+        w4 = *reinterpret_cast<const float4*>(u.lnw + (int64_t)g * n_out + col);
+        c4 = *reinterpret_cast<const float4*>(u.lnb + (int64_t)g * n_out + col);
+    }
+#pragma unroll
+    for (int jq = 0; jq < 8; ++jq) {
+        const int rt = (jq >> 2) * 32 + (lane & 3) + 8 * (jq & 3) + 4 * (lane >> 5);
+        const float4 a = *reinterpret_cast<const float4*>(&s_var[rt * 8]);
+        const float4 b = *reinterpret_cast<const float4*>(&s_var[rt * 8 + 4]);
+        const float rstd = rsqrtf((a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w) * inv_n + 1e-5f);
+        pr.v[jq] = f32x4{y[jq][0] * rstd * w4.x + c4.x, y[jq][1] * rstd * w4.y + c4.y, y[jq][2] * rstd * w4.z + c4.z,
+                         y[jq][3] * rstd * w4.w + c4.w};
+    }
+    pr.base = col_ok ? out + col : nullptr;
+    pr.ld = n_out;
+}
+#undef PC_OROW
+
+// one 256-column pass of the plain linear layer: bias, 4x4 quad transpose (see store_pass), rows parked in PendingRows
+__device__ __forceinline__ void pc_stage_pass(f32x16 (&acc)[2], int pass, int wave, int lane, int g, int n_out, int nrows, int row0,
+                                              const int* s_rid, const float* __restrict__ bias, int64_t bgs, float* __restrict__ out0,
+                                              float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos,
+                                              PendingRows& pr) {
+    const int col = pass * BNP + wave * 32 + ((lane & 31) >> 2) * 4;
+    const bool col_ok = col < n_out;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col_ok && bias) b4 = *reinterpret_cast<const float4*>(bias + (int64_t)g * bgs + col);
+    const int blk = col_ok ? col / block_cols : 0, cc = col - blk * block_cols;
+    float* __restrict__ ob = (blk == 0) ? out0 : ((blk == 1) ? out1 : out2);
+    const bool o1 = lane & 1, o2 = lane & 2;
+#pragma unroll
+    for (int jq = 0; jq < 8; ++jq) {
+        const int j = jq >> 2, q = jq & 3;
+        float v0 = acc[j][4 * q], v1 = acc[j][4 * q + 1], v2 = acc[j][4 * q + 2], v3 = acc[j][4 * q + 3];
+        quad_transpose(v0, v1, v2, v3, o1, o2);
+        pr.v[jq] = f32x4{v0 + b4.x, v1 + b4.y, v2 + b4.z, v3 + b4.w};
+    }
+    pr.base = col_ok ? ob + cc : nullptr;
+    pr.ld = block_cols;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+}
+
+template <int PROLOGUE, bool UPD>
+__global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
+    const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off,
+    int n_groups, int k, int n_out, const unsigned short* __restrict__ wsplit, const float* __restrict__ bias, int64_t bgs,
+    float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos, int vec_ok,
+    UpdateArgs upd) {
+    __shared__ __attribute__((aligned(16))) unsigned char sA[2][2 * A_PLANE];   // [slab][plane][64][528]
+    __shared__ int s_rid[3][BM];   // three tables: the parked rows of tile i are written while tile i+2 is being loaded
+    __shared__ __attribute__((aligned(16))) float s_red[2][2][BM * 8];          // [parity][sum|var][row][wave]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // number of tiles of this workgroup (the same value in every wave: barrier counts must agree)
+    int total_tiles = 0;
+    for (int g = 0; g < n_groups; ++g) total_tiles += (group_off[g + 1] - group_off[g] + BM - 1) / BM;
+    const int first = blockIdx.x, stride = gridDim.x;
+    const int n_mine = (total_tiles > first) ? (total_tiles - first + stride - 1) / stride : 0;
+    if (n_mine == 0) return;
+#if PC_PRIO
+    // producers first (short bursts that keep HBM busy); consumer waves 0..3 ahead of 4..7 so that the two consumer waves
+    // of a SIMD drift half a pass apart: one drains its stores (vmcnt(0)) while the other owns the matrix core
+    if (wave >= PC_CONS) __builtin_amdgcn_s_setprio(3);
+    else if (wave < 4) __builtin_amdgcn_s_setprio(2);
+#endif
+
+    if (wave >= PC_CONS) {
+        // ------------------------------------------------ producers
+        const int pw = wave - PC_CONS;
+        // lane id from mbcnt: reusing the consumers' `lane` keeps it live across their whole code and costs a spill
+        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        float4 a[PC_AREGS];
+        int v_rid, g, row0, nrows;
+        tile_lookup(first, group_off, n_groups, g, row0, nrows);
+        pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
+        pc_commit<PROLOGUE>(a, v_rid, pw, lane, sA[0], s_rid[0]);
+        if (n_mine > 1) {
+            tile_lookup(first + stride, group_off, n_groups, g, row0, nrows);
+            pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
+        }
+        pc_barrier();                                   // B_0
+#if PC_TRACE
+        const bool trace_me = (pw == 0 && lane == 0);
+#endif
+        for (int i = 0; i < n_mine; ++i) {
+            PC_T(p0);
+            if (i + 1 < n_mine) {
+#if PC_TRACE
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+                PC_T(p1);
+                pc_commit<PROLOGUE>(a, v_rid, pw, lane, sA[(i + 1) & 1], s_rid[(i + 1) % 3]);
+                PC_T(p2);
+                if (i + 2 < n_mine) {
+                    tile_lookup(first + (i + 2) * stride, group_off, n_groups, g, row0, nrows);
+                    pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
+                }
+                PC_T(p3);
+                PC_TADD(8, p0, p1);    // producer: wait for the loads
+                PC_TADD(9, p1, p2);    // producer: split + LDS store
+                PC_TADD(10, p2, p3);   // producer: issue next
+            }
+            PC_T(p4);
+            if constexpr (UPD) {
+                pc_barrier();
+                pc_barrier();
+            }
+            if (i + 1 < n_mine) pc_barrier();           // B_{i+1}
+            PC_T(p5);
+            PC_TADD(11, p4, p5);       // producer: barriers
+        }
+        return;
+    }
+
+    // ---------------------------------------------------- consumers
+    const int lane = tid & 63;
+    const int n_pass = (n_out + BNP - 1) / BNP;
+    const int n_kc = ((k + KC - 1) / KC + 3) & ~3;
+    const int total = n_pass * n_kc;
+    const int frow = lane & 31, khalf = lane >> 5;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    PendingRows pr;
+    bool have_pend = false;   // wave-uniform
+#pragma unroll
+    for (int u = 0; u < 8; ++u) pr.v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    pr.base = nullptr;
+    pr.ld = 0;
+    pr.rid = s_rid[0];
+    pr.row0 = pr.nrows = pr.by_pos = 0;
+#define PC_STORE(U)                                                                                   \
+    if (have_pend && !(PC_DBG & 4)) {                                                                 \
+        const int r_ = pr.row(U, lane);                                                               \
+        if (r_ >= 0) hidden_store16(pr.base + (int64_t)r_ * pr.ld, pr.v[U]);                          \
+    }
+#if PC_TRACE
+    const bool trace_me = (wave == 0 && lane == 0);
+#endif
+
+    for (int i = 0; i < n_mine; ++i) {
+        int g, row0, nrows;
+        tile_lookup(first + i * stride, group_off, n_groups, g, row0, nrows);
+        const unsigned short* __restrict__ wfrag = wsplit + (int64_t)g * total * 2 * W_PLANE_ELEMS + (wave * 64 + lane) * 8;
+        bf16x8 s0h, s0m, s1h, s1m, s2h, s2m, s3h, s3m;
+#define PC_LOAD_STAGE(S, T)                                                                           \
+    {                                                                                                 \
+        const unsigned short* t_ = wfrag + (int64_t)min((T), total - 1) * 2 * W_PLANE_ELEMS;          \
+        s##S##h = *reinterpret_cast<const bf16x8*>(t_);                                               \
+        s##S##m = *reinterpret_cast<const bf16x8*>(t_ + W_PLANE_ELEMS);                               \
+    }
+        // B fragments are prefetched NST k-chunks ahead (the fused-update variant has fewer registers to spare)
+        constexpr int NST = UPD ? 2 : 4;
+        PC_T(c0);
+        PC_LOAD_STAGE(0, 0)
+        PC_LOAD_STAGE(1, 1)
+        if constexpr (NST == 4) {
+            PC_LOAD_STAGE(2, 2)
+            PC_LOAD_STAGE(3, 3)
+        }
+        pc_barrier();                                      // B_i: slab[i&1] holds tile i
+        PC_T(c1);
+        PC_TADD(0, c0, c1);            // consumer: tile barrier
+        PC_TADD(7, c0 - c0, c0 - c0 + 1);   // tiles
+        const unsigned char* slab = sA[i & 1] + frow * A_STRIDE + khalf * 16;
+        // A fragments (2 row tiles x hi/mid) are read one k-chunk ahead, into alternating register sets
+        bf16x8 e_h0, e_m0, e_h1, e_m1, o_h0, o_m0, o_h1, o_m1;
+#define PC_LOAD_A(P, KCP)                                                                              \
+    {                                                                                                 \
+        const unsigned char* a_ = slab + (KCP) * (KC * 2);                                            \
+        P##_h0 = *reinterpret_cast<const bf16x8*>(a_);                                                \
+        P##_m0 = *reinterpret_cast<const bf16x8*>(a_ + A_PLANE);                                      \
+        P##_h1 = *reinterpret_cast<const bf16x8*>(a_ + 32 * A_STRIDE);                                \
+        P##_m1 = *reinterpret_cast<const bf16x8*>(a_ + A_PLANE + 32 * A_STRIDE);                      \
+    }
+        // One k-chunk: 6 MFMAs (small terms first, hi*hi last; the two accumulators alternate).  The sched barriers pin
+        // the order "next A fragments -> MFMAs -> refill of the consumed B stage": left alone, hipcc sinks all the B
+        // loads of the 4-step body to its end (a stall at the top of every body), and a refill issued BEFORE the
+        // stage's last use gets a fresh register plus a v_mov rotation of all stages that waits for every load.
+#define PC_STEP(S, T, P, PN, KNEXT)                                                                                \
+    {                                                                                                              \
+        PC_LOAD_A(PN, KNEXT)                                                                                       \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m0, s##S##h, acc[0], 0, 0, 0);                        \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m1, s##S##h, acc[1], 0, 0, 0);                        \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##m, acc[0], 0, 0, 0);                        \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##m, acc[1], 0, 0, 0);                        \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##h, acc[0], 0, 0, 0);                        \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##h, acc[1], 0, 0, 0);                        \
+        if (!(PC_DBG & 1)) PC_LOAD_STAGE(S, (T) + NST)                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); /* 4 DS reads    */                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0); /* 6 MFMAs       */                                     \
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0); /* 2 VMEM reads  */                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    }
+        // 4 k-chunks + two of the previous pass's parked output rows
+#define PC_BODY(B)                                                                                                 \
+    {                                                                                                              \
+        const int kq = 4 * (B);                                                                                    \
+        const int knext = (kq + 4 == n_kc) ? 0 : kq + 4; /* the next pass starts over on the same slab */          \
+        if constexpr (NST == 4) {                                                                                  \
+            PC_STEP(0, tbase + kq, e, o, kq + 1)                                                                   \
+            PC_STEP(1, tbase + kq + 1, o, e, kq + 2)                                                               \
+            PC_STORE(2 * (B))                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+            PC_STEP(2, tbase + kq + 2, e, o, kq + 3)                                                               \
+            PC_STEP(3, tbase + kq + 3, o, e, knext)                                                                \
+            PC_STORE(2 * (B) + 1)                                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+        } else {                                                                                                   \
+            PC_STEP(0, tbase + kq, e, o, kq + 1)                                                                   \
+            PC_STEP(1, tbase + kq + 1, o, e, kq + 2)                                                               \
+            PC_STORE(2 * (B))                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+            PC_STEP(0, tbase + kq + 2, e, o, kq + 3)                                                               \
+            PC_STEP(1, tbase + kq + 3, o, e, knext)                                                                \
+            PC_STORE(2 * (B) + 1)                                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+        }                                                                                                          \
+    }
+        PC_LOAD_A(e, 0)
+        for (int pass = 0; pass < n_pass; ++pass) {
+            const int tbase = pass * n_kc;
+            PC_T(c3);
+            PC_BODY(0)
+            if (n_kc > 4) PC_BODY(1)
+            if (n_kc > 8) PC_BODY(2)
+            if (n_kc > 12) PC_BODY(3)
+            // k < 256: the bodies that did not run leave their rows behind
+            if (n_kc <= 12) { PC_STORE(6) PC_STORE(7) }
+            if (n_kc <= 8) { PC_STORE(4) PC_STORE(5) }
+            if (n_kc <= 4) { PC_STORE(2) PC_STORE(3) }
+            PC_T(c4);
+            PC_TADD(2, c3, c4);        // consumer: MFMA loop (+ the parked stores of the previous pass)
+            if constexpr (UPD) {
+                pc_store_update(acc, wave, lane, g, n_out, nrows, s_rid[i % 3], bias, bgs, out0, upd, s_red[i & 1][0], s_red[i & 1][1], pr);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+            } else {
+                pc_stage_pass(acc, pass, wave, lane, g, n_out, nrows, row0, s_rid[i % 3], bias, bgs, out0, out1, out2, block_cols, by_pos, pr);
+            }
+            have_pend = true;
+            pr.rid = s_rid[i % 3];
+            pr.row0 = row0;
+            pr.nrows = nrows;
+            pr.by_pos = UPD ? 0 : by_pos;
+            PC_T(c5);
+            PC_TADD(3, c4, c5);        // consumer: epilogue arithmetic
+        }
+#undef PC_LOAD_A
+#undef PC_STEP
+#undef PC_BODY
+#undef PC_LOAD_STAGE
+    }
+    // the rows of the very last pass
+    PC_STORE(0) PC_STORE(1) PC_STORE(2) PC_STORE(3) PC_STORE(4) PC_STORE(5) PC_STORE(6) PC_STORE(7)
+#undef PC_STORE
+}
+
+static int pc_grid() {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n_cu = v;
+#if PC_TRACE
+        if (const char* e = getenv("HGT_PC_GRID")) n_cu = atoi(e);   // development aid
+#endif
+    }
+    return n_cu;
+}
+
 static inline void split_dims(int k, int n_out, int* n_pass, int* n_kc) {
     *n_pass = (n_out + BNP - 1) / BNP;
     *n_kc = ((k + KC - 1) / KC + 3) & ~3;   // k-chunks padded to a multiple of 4 (zero tiles)
 }
 
 }  // namespace
+
+#if PC_TRACE
+extern "C" int hgt_debug_pc_trace(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pc_trace), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pc_trace), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int hgt_split_weights_bytes(int32_t n_groups, int32_t k, int32_t n_out, uint64_t* out) {
     if (!out || n_groups <= 0 || k <= 0 || n_out <= 0) return HGT_ERR_INVALID_ARG;
@@ -433,6 +938,19 @@ extern "C" int hgt_typed_linear_bf16x3(const float* x, int64_t ldx, const int32_
     if (row_tiles > 0x7fffffffLL) return HGT_ERR_TOO_LARGE;
     const int vec_ok = (ldx % 4 == 0) && (k % 4 == 0) && (((uintptr_t)x & 15) == 0);
     UpdateArgs noupd = {nullptr, 0, nullptr, nullptr, nullptr, 0};
+    if (k <= KP) {   // persistent producer/consumer kernel, one workgroup per CU
+        const unsigned grid = (unsigned)std::min<int64_t>(row_tiles, pc_grid());
+        if (prologue == 0)
+            k_typed_linear_pc<0, false><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
+                                                                         (const unsigned short*)w_split, bias, b_group_stride, out0, out1,
+                                                                         out2, block_cols, out_by_position, vec_ok, noupd);
+        else
+            k_typed_linear_pc<1, false><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
+                                                                         (const unsigned short*)w_split, bias, b_group_stride, out0, out1,
+                                                                         out2, block_cols, out_by_position, vec_ok, noupd);
+        HGT_CHECK_LAUNCH();
+        return HGT_OK;
+    }
     if (prologue == 0)
         k_typed_linear_split<0, false><<<(unsigned)row_tiles, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
                                                                                 (const unsigned short*)w_split, bias, b_group_stride,
@@ -460,6 +978,14 @@ extern "C" int hgt_linear_update_bf16x3(const float* agg, int64_t ld_agg, const 
     if (row_tiles > 0x7fffffffLL) return HGT_ERR_TOO_LARGE;
     const int vec_ok = (ld_agg % 4 == 0) && (k % 4 == 0) && (((uintptr_t)agg & 15) == 0);
     UpdateArgs u = {x_skip, ld_skip, skip, ln_w, ln_b, use_norm};
+    if (k <= KP) {
+        const unsigned grid = (unsigned)std::min<int64_t>(row_tiles, pc_grid());
+        k_typed_linear_pc<0, true><<<grid, PC_THREADS, 0, stream>>>(agg, ld_agg, rows, group_off, n_groups, k, n_out,
+                                                                    (const unsigned short*)w_split, bias, b_group_stride, out, nullptr,
+                                                                    nullptr, n_out, 0, vec_ok, u);
+        HGT_CHECK_LAUNCH();
+        return HGT_OK;
+    }
     k_typed_linear_split<0, true><<<(unsigned)row_tiles, 512, 0, stream>>>(agg, ld_agg, rows, group_off, n_groups, k, n_out,
                                                                            (const unsigned short*)w_split, bias, b_group_stride, out,
                                                                            nullptr, nullptr, n_out, 0, vec_ok, u);

@@ -61,6 +61,17 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.iters
         gb = (N * k * 4 + N * n_out * 4) / 1e9
+        if name == "bf16x3" and hasattr(lib, "hgt_debug_pc_trace"):   # development builds with -DPC_TRACE=1 only
+            buf = (C.c_uint64 * 16)()
+            lib.hgt_debug_pc_trace(buf, 1)
+            fn()
+            torch.cuda.synchronize()
+            lib.hgt_debug_pc_trace(buf, 1)
+            v = list(buf)
+            tiles = max(1, v[7])
+            names = {0: "cons barrier", 1: "cons drain", 2: "cons mfma loop", 3: "cons epilogue", 8: "prod wait loads",
+                     9: "prod commit", 10: "prod issue", 11: "prod barriers"}
+            print("  trace (cycles per tile, wave 0 / wave 8): " + ", ".join("%s=%d" % (names[i], v[i] // tiles) for i in sorted(names)))
         print("%-7s rows=%d k=%d n_out=%d: %.3f ms  %.1f TFLOP/s(fp32-equivalent)  %.2f TB/s(min traffic)" % (
             name, N, k, n_out, ms, 2.0 * N * k * n_out / ms / 1e9, gb / ms))
 
