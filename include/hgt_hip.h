@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HGT_ABI_VERSION 1
+#define HGT_ABI_VERSION 2
 
 /* error codes */
 #define HGT_OK 0
@@ -203,6 +203,13 @@ int hgt_node_update(const float* trans, const float* x, int64_t ldx, const int64
                     const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm,
                     int64_t n_nodes, int32_t d, int32_t n_types, float* out, void* stream);
 
+/* Generalised form used by DenseHGTConv (conv.py:250-274): skip == NULL -> plain residual y = trans[n] + x[n]
+ * (conv.py:259,271); ln_shared != 0 -> one LayerNorm for every type (out_norm, conv.py:272), ln_w/ln_b are [d].
+ * out may alias x (every row is read completely before it is written). */
+int hgt_node_update_ex(const float* trans, const float* x, int64_t ldx, const int64_t* node_type,
+                       const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm, int32_t ln_shared,
+                       int64_t n_nodes, int32_t d, int32_t n_types, float* out, void* stream);
+
 /* x[i] = tanh(x[i]) in place: the activation of the typed input adapter of model.GNN (model.py:70-76) */
 int hgt_tanh_inplace(float* x, int64_t n, void* stream);
 
@@ -244,6 +251,16 @@ typedef struct hgt_conv_args {
     /* optional instrumentation: HOST array of HGT_N_PHASE_EVENTS hipEvent_t handles, recorded on the
      * stream at the phase boundaries listed below (NULL = no events)           */
     void* const* phase_events;
+    /* ABI 2: update_mode 0 = HGTConv.update (conv.py:114-134); 1 = DenseHGTConv.update (conv.py:250-274):
+     *   y1 = LN_t(a_linear_t(agg) + x)   (no gelu on agg, no gate; `skip` is ignored)
+     *   out = out_norm(out_linear(gelu(mid_linear(y1))) + y1)      (weights shared by all types)   */
+    int32_t update_mode;
+    const float* mid_w;          /* [2*out_dim][out_dim]                       */
+    const float* mid_b;          /* [2*out_dim]                                */
+    const float* out_w;          /* [out_dim][2*out_dim]                       */
+    const float* out_b;          /* [out_dim]                                  */
+    const float* out_ln_w;       /* [out_dim]                                  */
+    const float* out_ln_b;       /* [out_dim]                                  */
 } hgt_conv_args;
 
 /* phase boundaries at which hgt_conv_forward records phase_events[i]:

@@ -37,14 +37,23 @@ CASES = {
     "isolated_empty_type": dict(N=800, E=400, d=32, H=4, T=4, R=2, use_norm=True, use_RTE=False,
                                 gk={}, drop_type=2),
     "schema": dict(N=700, E=5000, d=64, H=4, T=4, R=9, use_norm=True, use_RTE=True, gk=dict(schema=True)),
+    # DenseHGTConv (conv.py:143-280): same message(), dense update
+    "dense_rte_norm": dict(N=500, E=4000, d=64, H=4, T=3, R=4, use_norm=True, use_RTE=True, gk={}, dense=True),
+    "dense_plain_d256": dict(N=300, E=2500, d=256, H=8, T=2, R=3, use_norm=False, use_RTE=False, gk={}, dense=True),
 }
+
+
+# fixed per-case seeds (the first eight are "100 + index in sorted order" of the original case list)
+SEEDS = {"c1_full": 100, "d256_h8": 101, "dk50": 102, "hubs_unsorted": 103, "isolated_empty_type": 104, "schema": 105,
+         "small_plain": 106, "small_rte_norm": 107, "dense_rte_norm": 108, "dense_plain_d256": 109}
 
 
 def build_case(name, c, seed):
     x, nt, ei, et, tm = synthetic_typed_graph(c["N"], c["E"], c["d"], c["T"], c["R"], seed=seed, **c["gk"])
     if "drop_type" in c:  # a node type with zero nodes (conv.py:83,123 skip paths)
         nt = torch.where(nt == c["drop_type"], torch.full_like(nt, c["drop_type"] + 1), nt)
-    sd = O.make_state_dict(c["d"], c["d"], c["T"], c["R"], c["H"], c["use_norm"], c["use_RTE"], seed=seed + 1000)
+    sd = O.make_state_dict(c["d"], c["d"], c["T"], c["R"], c["H"], c["use_norm"], c["use_RTE"], seed=seed + 1000,
+                           dense=c.get("dense", False))
     return sd, x, nt, ei, et, tm
 
 
@@ -52,9 +61,13 @@ def main():
     conv = load_reference_conv()
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
-    for k, (name, c) in enumerate(sorted(CASES.items())):
-        sd, x, nt, ei, et, tm = build_case(name, c, seed=100 + k)
-        layer = conv.HGTConv(c["d"], c["d"], c["T"], c["R"], c["H"], 0.2, c["use_norm"], c["use_RTE"]).eval()
+    only = set(sys.argv[1:])          # optional: regenerate just the named cases
+    for name, c in sorted(CASES.items()):
+        if only and name not in only:
+            continue
+        sd, x, nt, ei, et, tm = build_case(name, c, seed=SEEDS[name])
+        cls = conv.DenseHGTConv if c.get("dense", False) else conv.HGTConv
+        layer = cls(c["d"], c["d"], c["T"], c["R"], c["H"], 0.2, c["use_norm"], c["use_RTE"]).eval()
         layer.load_state_dict(sd)
         with torch.no_grad():
             out = layer(x, nt, ei, et, tm)
@@ -64,8 +77,8 @@ def main():
             node_feature=x.numpy(), node_type=nt.numpy().astype(np.int32),
             edge_index=ei.contiguous().numpy().astype(np.int32), edge_type=et.numpy().astype(np.int16),
             edge_time=tm.numpy().astype(np.int16), out=out.numpy(), att=att.numpy(),
-            meta=np.array([c["N"], c["E"], c["d"], c["H"], c["T"], c["R"], int(c["use_norm"]), int(c["use_RTE"])],
-                          dtype=np.int64),
+            meta=np.array([c["N"], c["E"], c["d"], c["H"], c["T"], c["R"], int(c["use_norm"]), int(c["use_RTE"]),
+                           int(c.get("dense", False))], dtype=np.int64),
             strided=np.array([int(c["gk"].get("strided_edge_index", True))]),
         )
         path = os.path.join(outdir, name + ".npz")

@@ -54,7 +54,7 @@ def sinusoid_table(n_hid, max_len=RTE_MAX_LEN, dtype=torch.float32):
 
 
 def make_state_dict(in_dim, out_dim, num_types, num_relations, n_heads,
-                    use_norm=True, use_RTE=True, seed=0, randomize_gates=True):
+                    use_norm=True, use_RTE=True, seed=0, randomize_gates=True, dense=False):
     """Random parameters in the reference's state_dict layout.
 
     Distributions mirror the reference init (Linear: U(+-1/sqrt(fan_in));
@@ -91,6 +91,16 @@ def make_state_dict(in_dim, out_dim, num_types, num_relations, n_heads,
         b = 1.0 / math.sqrt(in_dim)
         sd["emb.lin.weight"] = uni((in_dim, in_dim), b)
         sd["emb.lin.bias"] = uni((in_dim,), b)
+    if dense:   # DenseHGTConv (conv.py:143-191): no `skip`; shared mid/out linears + out_norm
+        del sd["skip"]
+        b = 1.0 / math.sqrt(out_dim)
+        sd["mid_linear.weight"] = uni((2 * out_dim, out_dim), b)
+        sd["mid_linear.bias"] = uni((2 * out_dim,), b)
+        b = 1.0 / math.sqrt(2 * out_dim)
+        sd["out_linear.weight"] = uni((out_dim, 2 * out_dim), b)
+        sd["out_linear.bias"] = uni((out_dim,), b)
+        sd["out_norm.weight"] = 1.0 + 0.1 * uni((out_dim,), 1.0)
+        sd["out_norm.bias"] = 0.1 * uni((out_dim,), 1.0)
     return sd
 
 
@@ -141,13 +151,36 @@ def _update(sd, agg, x, node_type, num_types, use_norm, dtype, library_ops=False
     return out
 
 
+def _update_dense(sd, agg, x, node_type, num_types, use_norm, dtype):
+    """DenseHGTConv.update, conv.py:250-274 (eval mode): per type  y1 = LN_t(a_linear_t(agg) + x)  (no gelu on
+    the aggregate, no gate), then the shared dense layer  out = out_norm(out_linear(gelu(mid_linear(y1))) + y1)."""
+    N, d = agg.shape
+    Wa = _stack(sd, "a_linears.%d.weight", num_types, dtype)
+    ba = _stack(sd, "a_linears.%d.bias", num_types, dtype)
+    Wm, bm = sd["mid_linear.weight"].to(dtype), sd["mid_linear.bias"].to(dtype)
+    Wo, bo = sd["out_linear.weight"].to(dtype), sd["out_linear.bias"].to(dtype)
+    wn, bn = sd["out_norm.weight"].to(dtype), sd["out_norm.bias"].to(dtype)
+    out = torch.zeros(N, d, dtype=dtype)                            # conv.py:255
+    for t in range(num_types):
+        rows = (node_type == t).nonzero(as_tuple=True)[0]
+        if rows.numel() == 0:
+            continue
+        y1 = agg[rows] @ Wa[t].T + ba[t] + x[rows]                  # conv.py:259
+        if use_norm:
+            y1 = _layer_norm(y1, sd["norms.%d.weight" % t].to(dtype), sd["norms.%d.bias" % t].to(dtype))   # conv.py:264
+        y2 = _gelu_erf(y1 @ Wm.T + bm) @ Wo.T + bo + y1             # conv.py:271
+        out[rows] = _layer_norm(y2, wn, bn)                         # conv.py:272
+    return out
+
+
 # --------------------------------------------------------------------------
 # entry point 1: node-level closed form (the parity checker)
 # --------------------------------------------------------------------------
 def forward_closed_form(sd, num_types, num_relations, n_heads, x, node_type, edge_index,
                         edge_type, edge_time=None, use_norm=True, use_RTE=True,
-                        dtype=torch.float64, return_att=False, return_agg=False):
-    """One HGTConv forward (eval mode).  Math follows conv.py:60-134:
+                        dtype=torch.float64, return_att=False, return_agg=False, dense=False):
+    """One HGTConv (or, with dense=True, DenseHGTConv: same message(), conv.py:197-248, update of conv.py:250-274)
+    forward (eval mode).  Math follows conv.py:60-134:
 
       q_e = W_q[tau(i)] x_i + b          (conv.py:73-77,96)
       k_e = W_k[tau(j)] (x_j + RTE(dt_e)) + b   (conv.py:91-92,97)
@@ -225,7 +258,7 @@ def forward_closed_form(sd, num_types, num_relations, n_heads, x, node_type, edg
         att = s
     msg = (vp * att.unsqueeze(-1)).reshape(E, d)
     agg = torch.zeros(N, d, dtype=dtype).index_add_(0, dst, msg)
-    out = _update(sd, agg, x, ntype, T, use_norm, dtype)
+    out = (_update_dense if dense else _update)(sd, agg, x, ntype, T, use_norm, dtype)
     res = [out]
     if return_att:
         res.append(att)

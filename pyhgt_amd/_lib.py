@@ -41,6 +41,9 @@ class HgtConvArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64),
         ("out", C.c_void_p), ("att_out", C.c_void_p),
         ("phase_events", C.c_void_p),
+        ("update_mode", C.c_int32),
+        ("mid_w", C.c_void_p), ("mid_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p),
+        ("out_ln_w", C.c_void_p), ("out_ln_b", C.c_void_p),
     ]
 
 
@@ -71,6 +74,7 @@ SIGNATURES = {
     "hgt_hub_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_u64)]),
     "hgt_att_export": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "hgt_node_update": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
+    "hgt_node_update_ex": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp]),
     "hgt_tanh_inplace": (C.c_int, [_vp, _i64, _vp]),
     "hgt_gather_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "hgt_conv_workspace_bytes": (C.c_int, [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_u64)]),
@@ -93,7 +97,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.hgt_abi_version() != 1:
+        if lib.hgt_abi_version() != 2:
             raise RuntimeError("pyhgt_amd: ABI version mismatch in %s" % LIB_PATH)
         _lib = lib
     return _lib

@@ -184,12 +184,24 @@ class HGTConv(nn.Module):
         bound = math.sqrt(6.0 / (2 * self.d_k))                       # PyG glorot over the two trailing dims
         self.relation_att = nn.Parameter(torch.empty(num_relations, n_heads, self.d_k, self.d_k).uniform_(-bound, bound))
         self.relation_msg = nn.Parameter(torch.empty(num_relations, n_heads, self.d_k, self.d_k).uniform_(-bound, bound))
-        self.skip = nn.Parameter(torch.ones(num_types))
+        self._init_update_parameters(num_types, out_dim)
         self.drop = nn.Dropout(dropout)
         if use_RTE:
             self.emb = RelTemporalEncoding(in_dim)
         self._packed = None
         self._packed_key = None
+
+    _UPDATE_MODE = 0     # hgt_conv_args.update_mode
+
+    def _init_update_parameters(self, num_types, out_dim):
+        self.skip = nn.Parameter(torch.ones(num_types))                 # conv.py:47
+
+    def _pack_update_parameters(self):
+        return dict(skip=self.skip.detach().float().contiguous())
+
+    def _set_update_args(self, a, pk):
+        a.update_mode = self._UPDATE_MODE
+        a.skip = _ptr(pk["skip"])
 
     # ------------------------------------------------------------------------------------------
     def _pack_parameters(self):
@@ -225,8 +237,8 @@ class HGTConv(nn.Module):
             packed = dict(lay=lay, w_qkv=w_qkv, b_qkv=b_qkv, w_a=w_a, b_a=b_a, ln_w=ln_w, ln_b=ln_b,
                           ratt=self.relation_att.detach().float().contiguous(),
                           rmsg=self.relation_msg.detach().float().contiguous(),
-                          rpri=self.relation_pri.detach().float().contiguous(),
-                          skip=self.skip.detach().float().contiguous())
+                          rpri=self.relation_pri.detach().float().contiguous())
+            packed.update(self._pack_update_parameters())
             if self.use_RTE:
                 packed.update(rte_emb=self.emb.emb.weight.detach().float().contiguous(),
                               rte_w=self.emb.lin.weight.detach().float().contiguous(),
@@ -286,7 +298,8 @@ class HGTConv(nn.Module):
         a.x, a.node_type, a.plan = _ptr(x), _ptr(ntype), plan.ptr
         a.w_qkv, a.b_qkv, a.w_a, a.b_a = _ptr(pk["w_qkv"]), _ptr(pk["b_qkv"]), _ptr(pk["w_a"]), _ptr(pk["b_a"])
         a.relation_att, a.relation_msg, a.relation_pri = _ptr(pk["ratt"]), _ptr(pk["rmsg"]), _ptr(pk["rpri"])
-        a.skip, a.ln_w, a.ln_b = _ptr(pk["skip"]), _ptr(pk["ln_w"]), _ptr(pk["ln_b"])
+        a.ln_w, a.ln_b = _ptr(pk["ln_w"]), _ptr(pk["ln_b"])
+        self._set_update_args(a, pk)
         a.rte_emb, a.rte_w, a.rte_b = _ptr(pk.get("rte_emb")), _ptr(pk.get("rte_w")), _ptr(pk.get("rte_b"))
         a.workspace, a.workspace_bytes = _ptr(ws), ws.numel()
         a.out, a.att_out = _ptr(out), _ptr(att)
@@ -301,16 +314,48 @@ class HGTConv(nn.Module):
             self.__class__.__name__, self.in_dim, self.out_dim, self.num_types, self.num_relations)
 
 
+class DenseHGTConv(HGTConv):
+    """The reference's DenseHGTConv (conv.py:143-280): message() is HGTConv's (conv.py:197-248), update() differs
+    (conv.py:250-274):
+
+        y1  = LayerNorm_t(a_linear_t(agg) + x)          no gelu on the aggregate, plain residual, no `skip` gate
+        out = out_norm(out_linear(gelu(mid_linear(y1))) + y1)            one dense layer shared by all types
+
+    Same parameter names as the reference (no `skip`; mid_linear, out_linear, out_norm added)."""
+
+    _UPDATE_MODE = 1
+
+    def _init_update_parameters(self, num_types, out_dim):
+        self.mid_linear = nn.Linear(out_dim, out_dim * 2)               # conv.py:189
+        self.out_linear = nn.Linear(out_dim * 2, out_dim)               # conv.py:190
+        self.out_norm = nn.LayerNorm(out_dim)                           # conv.py:191
+
+    def _pack_update_parameters(self):
+        f = lambda t: t.detach().float().contiguous()
+        return dict(mid_w=f(self.mid_linear.weight), mid_b=f(self.mid_linear.bias), out_w=f(self.out_linear.weight),
+                    out_b=f(self.out_linear.bias), out_ln_w=f(self.out_norm.weight), out_ln_b=f(self.out_norm.bias))
+
+    def _set_update_args(self, a, pk):
+        a.update_mode = self._UPDATE_MODE
+        a.skip = None
+        a.mid_w, a.mid_b, a.out_w, a.out_b = _ptr(pk["mid_w"]), _ptr(pk["mid_b"]), _ptr(pk["out_w"]), _ptr(pk["out_b"])
+        a.out_ln_w, a.out_ln_b = _ptr(pk["out_ln_w"]), _ptr(pk["out_ln_b"])
+
+
 class GeneralConv(nn.Module):
-    """The reference's layer dispatcher (conv.py:303-323) for the in-scope convolution.  Only
-    conv_name == 'hgt' is part of the MI355X hot path (SURVEY.md section 2, rows 4-5 are out of scope)."""
+    """The reference's layer dispatcher (conv.py:303-323) for the in-scope convolutions: 'hgt' and 'dense_hgt'
+    ('gcn' / 'gat' are PyG's own layers and out of scope)."""
 
     def __init__(self, conv_name, in_hid, out_hid, num_types, num_relations, n_heads, dropout, use_norm=True, use_RTE=True):
         super().__init__()
         self.conv_name = conv_name
-        if conv_name != 'hgt':
-            raise NotImplementedError("pyhgt_amd implements conv_name='hgt' only; %r is outside the accelerated path" % conv_name)
-        self.base_conv = HGTConv(in_hid, out_hid, num_types, num_relations, n_heads, dropout, use_norm, use_RTE)
+        if conv_name == 'hgt':
+            self.base_conv = HGTConv(in_hid, out_hid, num_types, num_relations, n_heads, dropout, use_norm, use_RTE)
+        elif conv_name == 'dense_hgt':
+            self.base_conv = DenseHGTConv(in_hid, out_hid, num_types, num_relations, n_heads, dropout, use_norm, use_RTE)
+        else:
+            raise NotImplementedError("pyhgt_amd implements conv_name 'hgt' and 'dense_hgt'; %r is outside the accelerated path"
+                                      % conv_name)
 
     def forward(self, meta_xs, node_type, edge_index, edge_type, edge_time):
         return self.base_conv(meta_xs, node_type, edge_index, edge_type, edge_time)
@@ -321,4 +366,5 @@ def install_into(conv_module):
     the reference's GeneralConv / model.GNN construct pyhgt_amd.HGTConv for conv_name='hgt'
     (GeneralConv looks the class up in its module globals at construction time, conv.py:308)."""
     conv_module.HGTConv = HGTConv
+    conv_module.DenseHGTConv = DenseHGTConv
     return conv_module

@@ -8,7 +8,7 @@ namespace {
 
 struct ConvWorkspace {
     uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p, off_hub;
-    uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, off_ws_qkv, off_ws_a, off_ws_rte, total;
+    uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, off_ws_qkv, off_ws_a, off_ws_rte, off_off2, total;
 };
 
 static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim, int out_dim, int T, int R, int H, int use_rte,
@@ -46,8 +46,14 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
     w.off_ws_a = take(b);
     hgt_split_weights_bytes(1, in_dim, in_dim, &b);
     w.off_ws_rte = take(use_rte ? b : 0);
+    w.off_off2 = take(256);
     w.total = o;
     return w;
+}
+
+// off2 = {0, off_q[T]}: all rows of a valid type as ONE group (the shared dense layer of DenseHGTConv)
+__global__ void k_single_group(const int32_t* __restrict__ off_q, int T, int32_t* __restrict__ off2) {
+    if (threadIdx.x == 0) { off2[0] = 0; off2[1] = off_q[T]; }
 }
 
 // rows[i] = i % 240 for i < T*240 ; off[g] = g*240
@@ -98,12 +104,15 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     const int64_t NQ = (a->n_q_rows > 0 && a->n_q_rows <= N) ? a->n_q_rows : N;
     const int T = a->n_types, R = a->n_relations, H = a->n_heads, din = a->in_dim, dout = a->out_dim;
     if (!a->x || !a->node_type || !a->plan || !a->w_qkv || !a->b_qkv || !a->w_a || !a->b_a || !a->relation_att ||
-        !a->relation_msg || !a->relation_pri || !a->skip || !a->workspace || !a->out)
+        !a->relation_msg || !a->relation_pri || (!a->skip && a->update_mode == 0) || !a->workspace || !a->out)
         return HGT_ERR_INVALID_ARG;
     if (din != dout) return HGT_ERR_INVALID_ARG;   // the skip connection of conv.py:131 needs in_dim == out_dim
     if (a->use_norm && (!a->ln_w || !a->ln_b)) return HGT_ERR_INVALID_ARG;
     if (a->use_rte && (!a->rte_emb || !a->rte_w || !a->rte_b)) return HGT_ERR_INVALID_ARG;
     if (a->want_att && E > 0 && !a->att_out) return HGT_ERR_INVALID_ARG;
+    const bool dense = (a->update_mode == 1);
+    if (a->update_mode != 0 && a->update_mode != 1) return HGT_ERR_INVALID_ARG;
+    if (dense && (!a->mid_w || !a->mid_b || !a->out_w || !a->out_b || !a->out_ln_w || !a->out_ln_b)) return HGT_ERR_INVALID_ARG;
     hgt_layout lay;
     int rc = hgt_layout_for(dout, H, &lay);
     if (rc != HGT_OK) return rc;
@@ -139,14 +148,14 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     const bool split = (a->precision == 1);
     auto linear = [&](const float* xin, int64_t ldx, const int32_t* rws, const int32_t* goff, int ng, int64_t nrows, int kk, int nout,
                       const float* Wp, int64_t wgs, const float* bp, int64_t bgs, float* o0, float* o1, float* o2, int bcols,
-                      int by_pos, void* wsplit) -> int {
+                      int by_pos, void* wsplit, int prologue = 0) -> int {
         if (!split)
-            return hgt_typed_linear(xin, ldx, rws, goff, ng, nrows, kk, nout, Wp, wgs, bp, bgs, o0, o1, o2, bcols, by_pos, 0, 0, stream);
+            return hgt_typed_linear(xin, ldx, rws, goff, ng, nrows, kk, nout, Wp, wgs, bp, bgs, o0, o1, o2, bcols, by_pos, prologue, 0, stream);
         if (((nout | bcols) & 3) != 0)   // the split kernel stores 16 B per lane: odd widths take the exact fp32 kernel
-            return hgt_typed_linear(xin, ldx, rws, goff, ng, nrows, kk, nout, Wp, wgs, bp, bgs, o0, o1, o2, bcols, by_pos, 0, 0, stream);
+            return hgt_typed_linear(xin, ldx, rws, goff, ng, nrows, kk, nout, Wp, wgs, bp, bgs, o0, o1, o2, bcols, by_pos, prologue, 0, stream);
         int r2 = hgt_split_weights(Wp, wgs, ng, kk, nout, wsplit, stream);
         if (r2 != HGT_OK) return r2;
-        return hgt_typed_linear_bf16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos, 0, stream);
+        return hgt_typed_linear_bf16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos, prologue, stream);
     };
     void* ws_qkv = wb + w.off_ws_qkv;
     void* ws_a = wb + w.off_ws_a;
@@ -193,7 +202,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     mark(2);
     mark(3);
     // runs for E == 0 too: it writes the zero rows of isolated targets; stores gelu(agg) (conv.py:119)
-    rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ, 1, getenv("HGT_NO_HUB") ? nullptr : (void*)(wb + w.off_hub), stream);
+    rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ, dense ? 0 : 1, getenv("HGT_NO_HUB") ? nullptr : (void*)(wb + w.off_hub), stream);
     if (rc != HGT_OK) return rc;
     if (a->want_att && E > 0) {   // self.att (conv.py:108): normalise the logits in place and un-sort them
         rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);
@@ -203,8 +212,30 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     }
     mark(4);
     // (5) update: a_linear(gelu(agg)) -> gated skip -> LayerNorm (conv.py:119-133)
-    const bool fuse_update = split && dout <= 256 && (dout & 3) == 0 && (din & 3) == 0;
-    if (fuse_update) {
+    const bool fuse_update = !dense && split && dout <= 256 && (dout & 3) == 0 && (din & 3) == 0;
+    if (dense) {
+        // DenseHGTConv.update (conv.py:250-274): no gelu on the aggregate, plain residual, then the shared dense layer
+        rc = linear(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, a->w_a, (int64_t)dout * dp, a->b_a, dout, trans, nullptr, nullptr, dout,
+                    0, ws_a);
+        if (rc != HGT_OK) return rc;
+        mark(5);
+        // y1 = LN_t(a_linear(agg) + x), kept in `out`
+        rc = hgt_node_update_ex(trans, a->x, din, a->node_type, nullptr, a->ln_w, a->ln_b, a->use_norm, 0, NQ, dout, T, a->out, stream);
+        if (rc != HGT_OK) return rc;
+        int32_t* off2 = (int32_t*)(wb + w.off_off2);
+        k_single_group<<<1, 64, 0, stream>>>(pr.off_q, T, off2);
+        // mid = mid_linear(y1): [NQ][2*dout] in the (dead) Q|K region; gelu is applied where out_linear loads it
+        float* mid = Q;
+        if (w.off_k != w.off_q + (uint64_t)N * dp * 4 || 2 * dout > 2 * dp) return HGT_ERR_WORKSPACE;
+        rc = linear(a->out, dout, pr.rows_q, off2, 1, NQ, dout, 2 * dout, a->mid_w, 0, a->mid_b, 0, mid, nullptr, nullptr, 2 * dout, 0,
+                    ws_a);
+        if (rc != HGT_OK) return rc;
+        rc = linear(mid, 2 * dout, pr.rows_q, off2, 1, NQ, 2 * dout, dout, a->out_w, 0, a->out_b, 0, trans, nullptr, nullptr, dout, 0,
+                    ws_a, 1);
+        if (rc != HGT_OK) return rc;
+        // out = out_norm(out_linear(...) + y1), in place over y1
+        rc = hgt_node_update_ex(trans, a->out, dout, a->node_type, nullptr, a->out_ln_w, a->out_ln_b, 1, 1, NQ, dout, T, a->out, stream);
+    } else if (fuse_update) {
         rc = hgt_split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_a, stream);
         if (rc != HGT_OK) return rc;
         rc = hgt_linear_update_bf16x3(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, ws_a, a->b_a, dout, a->x, din, a->skip, a->ln_w,

@@ -18,7 +18,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(256) void k_node_update(const float* __restrict__ trans, const float* __restrict__ x, int64_t ldx,
                                                      const int64_t* __restrict__ ntype, const float* __restrict__ skip,
                                                      const float* __restrict__ lnw, const float* __restrict__ lnb, int use_norm,
-                                                     int64_t N, int d, int T, float* __restrict__ out) {
+                                                     int ln_shared, int64_t N, int d, int T, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -28,7 +28,9 @@ __global__ __launch_bounds__(256) void k_node_update(const float* __restrict__ t
         for (int c = lane; c < d; c += 64) o[c] = 0.0f;
         return;
     }
-    const float a = 1.0f / (1.0f + expf(-skip[t]));
+    // gated skip of HGTConv (conv.py:129-131) or, without a gate, the plain residual of DenseHGTConv (conv.py:259,271)
+    const float a = skip ? 1.0f / (1.0f + expf(-skip[t])) : 1.0f;
+    const float a1 = skip ? 1.0f - a : 1.0f;
     const float* __restrict__ tr = trans + n * d;
     const float* __restrict__ xr = x + n * ldx;
     float y[MAX_PER_LANE];
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(256) void k_node_update(const float* __restrict__ t
         const int c = lane + 64 * j;
         y[j] = 0.0f;
         if (c < d) {
-            y[j] = tr[c] * a + xr[c] * (1.0f - a);
+            y[j] = tr[c] * a + xr[c] * a1;
             s += y[j];
         }
     }
@@ -51,8 +53,8 @@ __global__ __launch_bounds__(256) void k_node_update(const float* __restrict__ t
             if (c < d) { const float dlt = y[j] - mean; v += dlt * dlt; }
         }
         const float rstd = rsqrtf(wave_sum(v) / (float)d + 1e-5f);
-        const float* __restrict__ w = lnw + t * d;
-        const float* __restrict__ b = lnb + t * d;
+        const float* __restrict__ w = lnw + (ln_shared ? 0 : t * d);
+        const float* __restrict__ b = lnb + (ln_shared ? 0 : t * d);
 #pragma unroll
         for (int j = 0; j < MAX_PER_LANE; ++j) {
             const int c = lane + 64 * j;
@@ -120,16 +122,23 @@ extern "C" int hgt_zero_rows(const int32_t* rows, const int32_t* range, int32_t 
     return HGT_OK;
 }
 
-extern "C" int hgt_node_update(const float* trans, const float* x, int64_t ldx, const int64_t* node_type, const float* skip,
-                               const float* ln_w, const float* ln_b, int32_t use_norm, int64_t n_nodes, int32_t d,
-                               int32_t n_types, float* out, void* stream) {
-    if (!trans || !x || !node_type || !skip || !out || d <= 0 || n_nodes < 0 || (use_norm && (!ln_w || !ln_b))) return HGT_ERR_INVALID_ARG;
+extern "C" int hgt_node_update_ex(const float* trans, const float* x, int64_t ldx, const int64_t* node_type, const float* skip,
+                                  const float* ln_w, const float* ln_b, int32_t use_norm, int32_t ln_shared, int64_t n_nodes,
+                                  int32_t d, int32_t n_types, float* out, void* stream) {
+    if (!trans || !x || !node_type || !out || d <= 0 || n_nodes < 0 || (use_norm && (!ln_w || !ln_b))) return HGT_ERR_INVALID_ARG;
     if (d > 64 * MAX_PER_LANE) return HGT_ERR_UNSUPPORTED;
     if (n_nodes == 0) return HGT_OK;
     k_node_update<<<(unsigned)((n_nodes + 3) / 4), 256, 0, (hipStream_t)stream>>>(trans, x, ldx, node_type, skip, ln_w, ln_b, use_norm,
-                                                                                 n_nodes, d, n_types, out);
+                                                                                 ln_shared, n_nodes, d, n_types, out);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
+}
+
+extern "C" int hgt_node_update(const float* trans, const float* x, int64_t ldx, const int64_t* node_type, const float* skip,
+                               const float* ln_w, const float* ln_b, int32_t use_norm, int64_t n_nodes, int32_t d,
+                               int32_t n_types, float* out, void* stream) {
+    if (!skip) return HGT_ERR_INVALID_ARG;
+    return hgt_node_update_ex(trans, x, ldx, node_type, skip, ln_w, ln_b, use_norm, 0, n_nodes, d, n_types, out, stream);
 }
 
 extern "C" int hgt_gather_rows(const float* x, int64_t ldx, const int32_t* idx, int64_t n, int32_t d, float* out, void* stream) {

@@ -24,13 +24,15 @@ def golden_names():
 def load_golden(name):
     """Fixture written by oracle/gen_golden.py from the verbatim reference."""
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
-    N, E, d, H, T, R, use_norm, use_RTE = [int(v) for v in z["meta"]]
+    meta = [int(v) for v in z["meta"]]
+    N, E, d, H, T, R, use_norm, use_RTE = meta[:8]
+    dense = bool(meta[8]) if len(meta) > 8 else False       # DenseHGTConv fixture (conv.py:143-280)
     sd = {k[len("param::"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param::")}
     ei = torch.from_numpy(z["edge_index"].astype(np.int64))
     if int(z["strided"][0]):
         ei = ei.t().contiguous().t()      # the (1,2)-strided view data.py:254 delivers
     return dict(
-        name=name, N=N, E=E, d=d, H=H, T=T, R=R, use_norm=bool(use_norm), use_RTE=bool(use_RTE), sd=sd,
+        name=name, N=N, E=E, d=d, H=H, T=T, R=R, use_norm=bool(use_norm), use_RTE=bool(use_RTE), dense=dense, sd=sd,
         x=torch.from_numpy(z["node_feature"]), node_type=torch.from_numpy(z["node_type"].astype(np.int64)),
         edge_index=ei, edge_type=torch.from_numpy(z["edge_type"].astype(np.int64)),
         edge_time=torch.from_numpy(z["edge_time"].astype(np.int64)),

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_strings():
     lib = _lib.load()
-    assert lib.hgt_abi_version() == 1
+    assert lib.hgt_abi_version() == 2
     assert lib.hgt_strerror(0) == b"ok"
     assert b"invalid" in lib.hgt_strerror(-1)
 
@@ -109,10 +109,35 @@ def test_cpu_input_fails_loudly():
 
 
 def test_general_conv_rejects_out_of_scope_layers():
-    from pyhgt_amd import GeneralConv
+    from pyhgt_amd import GeneralConv, DenseHGTConv
     GeneralConv('hgt', 16, 16, 2, 2, 2, 0.2)
+    assert isinstance(GeneralConv('dense_hgt', 16, 16, 2, 2, 2, 0.2).base_conv, DenseHGTConv)
     with pytest.raises(NotImplementedError):
         GeneralConv('gcn', 16, 16, 2, 2, 2, 0.2)
+
+
+def test_dense_module_keeps_reference_state_dict_names():
+    from pyhgt_amd import DenseHGTConv
+    T, R, H, d = 3, 4, 4, 64
+    layer = DenseHGTConv(d, d, T, R, H, 0.2, True, True)
+    sd = O.make_state_dict(d, d, T, R, H, True, True, seed=0, dense=True)
+    assert set(layer.state_dict().keys()) == set(sd.keys())       # no `skip`; mid_linear / out_linear / out_norm
+    for k, v in layer.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    layer.load_state_dict(sd)
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+def test_dense_state_dict_names_equal_the_live_reference():
+    from pyhgt_amd import DenseHGTConv
+    conv = load_reference_conv()
+    ref = conv.DenseHGTConv(32, 32, 2, 3, 4, 0.2, True, True)
+    ours = DenseHGTConv(32, 32, 2, 3, 4, 0.2, True, True)
+    rs, os_ = ref.state_dict(), ours.state_dict()
+    assert set(rs.keys()) == set(os_.keys())
+    assert all(rs[k].shape == os_[k].shape for k in rs)
+    ours.load_state_dict(rs)
+    assert repr(ours) == repr(ref)
 
 
 def test_gnn_wrapper_matches_reference_parameter_count():

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import hgt_oracle as O
-from pyhgt_amd import HGTConv, GeneralConv, GraphPlan, _lib
+from pyhgt_amd import HGTConv, DenseHGTConv, GeneralConv, GraphPlan, _lib
 from pyhgt_amd.synth import synthetic_typed_graph
 
 pytestmark = pytest.mark.gpu
@@ -17,8 +17,9 @@ TOL = 1e-4
 DEV = "cuda:0"
 
 
-def _layer_from(sd, d, T, R, H, use_norm, use_RTE, keep_att=True, precision="fp32"):
-    layer = HGTConv(d, d, T, R, H, 0.2, use_norm, use_RTE, keep_att=keep_att, precision=precision).eval()
+def _layer_from(sd, d, T, R, H, use_norm, use_RTE, keep_att=True, precision="fp32", dense=False):
+    cls = DenseHGTConv if dense else HGTConv
+    layer = cls(d, d, T, R, H, 0.2, use_norm, use_RTE, keep_att=keep_att, precision=precision).eval()
     layer.load_state_dict(sd)
     return layer.to(DEV)
 
@@ -38,7 +39,7 @@ def _run(layer, x, nt, ei, et, tm):
 # ------------------------------------------------------------------ (a) the reference's own outputs
 def test_matches_reference_golden(golden):
     g = golden
-    layer = _layer_from(g["sd"], g["d"], g["T"], g["R"], g["H"], g["use_norm"], g["use_RTE"])
+    layer = _layer_from(g["sd"], g["d"], g["T"], g["R"], g["H"], g["use_norm"], g["use_RTE"], dense=g["dense"])
     out, att = _run(layer, g["x"], g["node_type"], g["edge_index"], g["edge_type"], g["edge_time"])
     assert out.shape == g["out"].shape
     assert (out - g["out"]).abs().max().item() < TOL
@@ -48,7 +49,7 @@ def test_matches_reference_golden(golden):
 def test_split_bf16_precision_matches_reference_golden(golden):
     """precision="bf16x3" (3-term split-bf16 MFMA for the typed linears) must meet the same 1e-4 bound."""
     g = golden
-    layer = _layer_from(g["sd"], g["d"], g["T"], g["R"], g["H"], g["use_norm"], g["use_RTE"], precision="bf16x3")
+    layer = _layer_from(g["sd"], g["d"], g["T"], g["R"], g["H"], g["use_norm"], g["use_RTE"], precision="bf16x3", dense=g["dense"])
     out, att = _run(layer, g["x"], g["node_type"], g["edge_index"], g["edge_type"], g["edge_time"])
     assert (out - g["out"]).abs().max().item() < TOL
     assert (att - g["att"]).abs().max().item() < 1e-5
@@ -83,6 +84,36 @@ def test_matches_oracle(case, precision):
     print("case N=%d E=%d d=%d H=%d %s: max|out| err %.2e, att err %.2e" % (N, E, d, H, precision, err, err_att))
     assert err < TOL
     assert err_att < 1e-5
+
+
+DENSE_CASES = [
+    # N, E, d, H, T, R, use_norm, use_RTE
+    (2500, 25000, 256, 8, 4, 8, True, False),      # c2 shape
+    (900, 7000, 400, 8, 5, 12, True, True),        # d_k = 50 padded to 64; out_linear has K = 800 (multi-panel GEMM)
+    (1200, 9000, 64, 4, 3, 4, False, True),        # no per-type LayerNorm
+]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("case", DENSE_CASES, ids=[str(i) for i in range(len(DENSE_CASES))])
+def test_dense_hgt_conv_matches_oracle(case, precision):
+    """DenseHGTConv (conv.py:143-280): HGTConv's message() + the dense update; unknown node types and unclaimed
+    relations included (rows of unknown type are 0, conv.py:255)."""
+    N, E, d, H, T, R, use_norm, use_RTE = case
+    sd = O.make_state_dict(d, d, T, R, H, use_norm, use_RTE, seed=7 * N + E, dense=True)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=E + 3)
+    nt = nt.clone(); et = et.clone()
+    nt[::97] = T + 1                                  # unknown node types
+    et[::53] = R                                      # relation ids no meta relation claims
+    ref, att_ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, use_norm=use_norm, use_RTE=use_RTE,
+                                         dtype=torch.float64, return_att=True, dense=True)
+    layer = _layer_from(sd, d, T, R, H, use_norm, use_RTE, precision=precision, dense=True)
+    out, att = _run(layer, x, nt, ei, et, tm if use_RTE else None)
+    err = (out.double() - ref).abs().max().item()
+    print("dense case N=%d E=%d d=%d H=%d %s: max|out| err %.2e" % (N, E, d, H, precision, err))
+    assert err < TOL
+    assert (att.double() - att_ref).abs().max().item() < 1e-5
+    assert out[nt == T + 1].abs().max().item() == 0.0
 
 
 def test_large_logit_spread_forces_softmax_rereference():
