@@ -207,6 +207,10 @@ def main():
         import torch.distributed as dist
         pg = PartitionedGraph(node_type_own, src_global, dst_local, edge_type, edge_time, T, R, Nl, rank, world)
         plan_ms = None
+        # own features live at the front of the [own ; halo] buffer, so a step does not copy them (pyhgt_amd/dist.py)
+        pg.x_local = torch.empty(pg.n_local, d, dtype=torch.float32, device=dev)
+        pg.x_local[:Nl].copy_(x_own)
+        x_own = pg.x_local[:Nl]
 
         def step(events=None):
             return pg.forward(layer, x_own, phase_events=events)
@@ -227,6 +231,13 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     assert torch.isfinite(out).all()
+    if hasattr(_lib.load(), "hgt_debug_fu_trace"):   # development builds (-DHGT_FU_TRACE=1) only
+        buf = (C.c_uint64 * 8)()
+        _lib.load().hgt_debug_fu_trace(buf, 1)
+        v = list(buf)
+        n = max(1, v[7])
+        sys.stderr.write("fused trace, cycles per workgroup (wave 0): aggregate=%d wait=%d slab=%d mfma=%d epilogue=%d\n" % (
+            v[0] // n, v[4] // n, v[1] // n, v[2] // n, v[3] // n))
 
     if world > 1:
         import torch.distributed as dist
@@ -246,6 +257,10 @@ def main():
     phase_ms = {p: v / args.steps for p, v in phase_ms.items()}
     n_local_nodes = Nl if world == 1 else pg.n_local
     alg = algorithmic_bytes(Nl, El, d, use_rte)
+    fused_update = (phase_ms["a_linear"] + phase_ms["node_update"]) < 0.05 * phase_ms["edge_aggregate"]
+    if fused_update:   # hgt_edge_aggregate_update: the node update runs as the epilogue of the aggregation kernel
+        alg["edge_aggregate"] += alg["node_update"]
+        alg["node_update"] = 0
     dom = max(("edge_logits", "edge_aggregate", "project_qkv"), key=lambda p: phase_ms[p])
     ach = alg[dom] / (phase_ms[dom] * 1e-3) / 1e9
     traffic = None
@@ -255,7 +270,7 @@ def main():
             traffic = json.load(open(tpath)).get(dom)
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": dom + ("+node_update (fused)" if fused_update and dom == "edge_aggregate" else ""), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": round(phase_ms[dom], 4),
                 "layer_achieved_GBs": round(alg["layer"] / (ms_per_step * 1e-3) / 1e9, 1),

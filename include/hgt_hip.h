@@ -216,6 +216,21 @@ int hgt_tanh_inplace(float* x, int64_t n, void* stream);
 /* row gather used to pack halo rows for the multi-GPU exchange: out[i] = x[idx[i]] */
 int hgt_gather_rows(const float* x, int64_t ldx, const int32_t* idx, int64_t n, int32_t d, float* out, void* stream);
 
+/* hgt_edge_aggregate with HGTConv's node update (conv.py:119-133) fused in: the workgroup that aggregated 64 targets
+ * multiplies their gelu'd rows with W_a on the matrix cores (split-bf16 x3, w_a_split = hgt_split_weights(W_a,
+ * k = H*dk_pad, n_out)) and writes
+ *     out[i] = LN_t( (gelu(agg_i) W_a[t]^T + b_a[t]) * sigmoid(skip[t]) + x_skip[i] * (1 - sigmoid(skip[t])) ),
+ * rows of unknown type = 0, so agg never goes through HBM.  Needs H*dk_pad <= 256, n_out % 4 == 0 and a layout without
+ * head-group split (HGT_ERR_UNSUPPORTED otherwise -> hgt_edge_aggregate + hgt_linear_update_bf16x3).
+ * `agg` [n_q_rows][H*dk_pad] and `pending` [(n_q_rows+63)/64] int32 are scratch: workgroups that contain a hub target
+ * (hub_ws != NULL) finish through agg and the hub kernels, exactly like hgt_edge_aggregate, and are updated last. */
+int hgt_edge_aggregate_update(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                              int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
+                              const float* msg_p, float* agg, int64_t n_q_rows, void* hub_ws, int32_t* pending,
+                              const int64_t* node_type, const void* w_a_split, const float* b_a, const float* x_skip,
+                              int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm,
+                              int32_t n_out, float* out, void* stream);
+
 /* ----------------------------------------------------------------------------------------------
  * One whole HGTConv.forward (conv.py:56-134, eval mode) as a single enqueue of the kernels above.
  * ---------------------------------------------------------------------------------------------- */

@@ -73,6 +73,8 @@ SIGNATURES = {
     "hgt_edge_aggregate": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "hgt_hub_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_u64)]),
     "hgt_att_export": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "hgt_edge_aggregate_update": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+                                            _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "hgt_node_update": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "hgt_node_update_ex": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp]),
     "hgt_tanh_inplace": (C.c_int, [_vp, _i64, _vp]),

@@ -8,7 +8,7 @@ namespace {
 
 struct ConvWorkspace {
     uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p, off_hub;
-    uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, off_ws_qkv, off_ws_a, off_ws_rte, off_off2, total;
+    uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, off_ws_qkv, off_ws_a, off_ws_rte, off_off2, off_pending, total;
 };
 
 static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim, int out_dim, int T, int R, int H, int use_rte,
@@ -47,6 +47,7 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
     hgt_split_weights_bytes(1, in_dim, in_dim, &b);
     w.off_ws_rte = take(use_rte ? b : 0);
     w.off_off2 = take(256);
+    w.off_pending = take((uint64_t)(NQ / 64 + 1) * 4);
     w.total = o;
     return w;
 }
@@ -201,8 +202,31 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     }
     mark(2);
     mark(3);
-    // runs for E == 0 too: it writes the zero rows of isolated targets; stores gelu(agg) (conv.py:119)
-    rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ, dense ? 0 : 1, getenv("HGT_NO_HUB") ? nullptr : (void*)(wb + w.off_hub), stream);
+    // (5) aggregation + update.  Preferred form: one kernel that never writes agg (hgt_edge_aggregate_update).
+    const bool fuse_all = split && !dense && dp <= 256 && dout <= dp && (dout & 3) == 0 && (din & 3) == 0 && !getenv("HGT_NO_FUSE_AGG");
+    if (fuse_all) {
+        rc = hgt_split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_a, stream);
+        if (rc != HGT_OK) return rc;
+        rc = hgt_edge_aggregate_update(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ,
+                                       getenv("HGT_NO_HUB") ? nullptr : (void*)(wb + w.off_hub), (int32_t*)(wb + w.off_pending), a->node_type,
+                                       ws_a, a->b_a, a->x, din, a->skip, a->ln_w, a->ln_b, a->use_norm, dout, a->out, stream);
+        if (rc == HGT_OK) {
+            if (a->want_att && E > 0) {
+                rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);
+                if (rc != HGT_OK) return rc;
+                rc = hgt_att_export(a->plan, N, E, T, R, H, logits, a->att_out, stream);
+                if (rc != HGT_OK) return rc;
+            }
+            mark(4);
+            mark(5);
+            mark(6);
+            return HGT_OK;
+        }
+        if (rc != HGT_ERR_UNSUPPORTED) return rc;   // unsupported layout (head-group split): the unfused kernels below
+    }
+    // runs for E == 0 too: it writes the zero rows of isolated targets; HGTConv stores gelu(agg) (conv.py:119), DenseHGTConv agg
+    rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ, dense ? 0 : 1,
+                            getenv("HGT_NO_HUB") ? nullptr : (void*)(wb + w.off_hub), stream);
     if (rc != HGT_OK) return rc;
     if (a->want_att && E > 0) {   // self.att (conv.py:108): normalise the logits in place and un-sort them
         rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);
@@ -211,7 +235,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
         if (rc != HGT_OK) return rc;
     }
     mark(4);
-    // (5) update: a_linear(gelu(agg)) -> gated skip -> LayerNorm (conv.py:119-133)
+    // (6) update: a_linear(gelu(agg)) -> gated skip -> LayerNorm (conv.py:119-133)
     const bool fuse_update = !dense && split && dout <= 256 && (dout & 3) == 0 && (din & 3) == 0;
     if (dense) {
         // DenseHGTConv.update (conv.py:250-274): no gelu on the aggregate, plain residual, then the shared dense layer

@@ -16,6 +16,10 @@
 // wavefront instruction); head h = l / LPH; per-head dot products are reduced over LPH adjacent
 // lanes with DPP.  Rows for the next UN edges are requested before the current ones are consumed.
 #include "hgt_common.h"
+#include "hgt_split_common.h"
+#ifndef HGT_FU_TRACE
+#define HGT_FU_TRACE 0
+#endif
 
 namespace {
 
@@ -260,12 +264,15 @@ __global__ __launch_bounds__(256) void k_edge_softmax(const int32_t* __restrict_
 constexpr int HGT_SUB = 16;       // targets per wavefront
 constexpr float HGT_NEG = -1.0e30f;
 
-template <int VEC, int LPH, bool RTE, bool HUBS>
+// FUSE: instead of writing agg rows, the 16 finished rows (normalised, through gelu) stay in registers (`rowvals`) for
+// the fused a_linear + node-update epilogue of k_edge_aggregate_update.
+template <int VEC, int LPH, bool RTE, bool HUBS, bool FUSE = false>
 __device__ __forceinline__ void aggregate_subtile(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
     const float* __restrict__ rteV, const float* __restrict__ msgP, float* __restrict__ agg, int R, int64_t NQ, int apply_gelu,
-    int HT, unsigned hub_mask, float (&s_acc)[4][16 * 64 * VEC], float (&s_bounce)[4][64 * VEC + 4 * (64 / LPH)], float (&s_ml)[4][2][16 * 16]) {
+    int HT, unsigned hub_mask, float (&s_acc)[4][16 * 64 * VEC], float (&s_bounce)[4][64 * VEC + 4 * (64 / LPH)], float (&s_ml)[4][2][16 * 16],
+    float (&rowvals)[FUSE ? 16 : 1][VEC]) {
     constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = RTE ? unroll_for<VEC>() / 2 : unroll_for<VEC>();
     const int hg = blockIdx.y;              // head group (see k_edge_logits)
     const int64_t ld = (int64_t)HT * DKP;
@@ -276,7 +283,15 @@ __device__ __forceinline__ void aggregate_subtile(
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // a workgroup covers 64 consecutive targets (4 waves x 16); the plan's destination tile may be larger
     const int64_t row0 = (int64_t)blockIdx.x * 64 + wib * HGT_SUB;
-    if (row0 >= NQ) return;
+    if (row0 >= NQ) {
+        if constexpr (FUSE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) rowvals[r][i] = 0.0f;
+        }
+        return;
+    }
     const int tile = (int)(row0 / HGT_TD);
     const int within = (int)(row0 % HGT_TD);
     const int h = lane / LPH, p = lane % LPH;
@@ -411,6 +426,19 @@ __device__ __forceinline__ void aggregate_subtile(
       }
     }
 
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int r = 0; r < HGT_SUB; ++r) {
+            // rows beyond NQ (last tile only) have an all-zero accumulator: gelu(0) = 0, no branch needed
+            const float inv = 1.0f / (s_l[r * 16 + h] + 1e-16f);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float o = acc[r * DP + i * 64 + lane] * inv;
+                rowvals[r][i] = 0.5f * o * (1.0f + erff(o * 0.70710678118654752440f));   // conv.py:119
+            }
+        }
+        return;
+    }
     // write-out: normalise, un-permute the planar layout, one coalesced row store per wave instruction
     for (int r = 0; r < HGT_SUB; ++r) {
         const int64_t row = row0 + r;
@@ -454,12 +482,343 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
         const bool is_hub = (lane < 16) && (rr < NQ) && (hub_slot[rr] >= 0);
         hub_mask = (unsigned)(__builtin_amdgcn_ballot_w64(is_hub) & 0xFFFFull);
     }
+    float no_rowvals[1][VEC];
     if (hub_mask == 0)
         aggregate_subtile<VEC, LPH, RTE, false>(segptr, esrc, edst, ertei, logits, V, rteV, msgP, agg, R, NQ, apply_gelu, HT, 0u, s_acc,
-                                                s_bounce, s_ml);
+                                                s_bounce, s_ml, no_rowvals);
     else
         aggregate_subtile<VEC, LPH, RTE, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgP, agg, R, NQ, apply_gelu, HT, hub_mask,
-                                               s_acc, s_bounce, s_ml);
+                                               s_acc, s_bounce, s_ml, no_rowvals);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pass 2 with the node update fused in (HGTConv, split-bf16 precision, d_pad <= 256, plan without hubs):
+//     out[i] = LN_t( (gelu(agg_i) W_a[t]^T + b_a[t]) * sigmoid(skip[t]) + x_i * (1 - sigmoid(skip[t])) )   conv.py:119-133
+// The workgroup that aggregated 64 targets already holds their finished rows; writing them to HBM only for a second
+// kernel to read them back costs 2 x 4d bytes per node and a kernel that is latency bound on its own (1.2 ms at c2).
+// Here the rows go registers -> LDS as the bf16 hi/mid A operand (the 66 KB slab overlays the accumulator, which is
+// dead by then), the four wavefronts run the 64 x d x d split-bf16 MFMA product against the L2-resident fragment-ordered
+// W_a (hgt_split_weights), and the gated skip + LayerNorm epilogue writes `out` directly.  agg never touches HBM --
+// which is what the minimal-traffic model of SURVEY.md 8(d) assumes.
+// A tile whose rows have several node types (only at the T-1 type boundaries of a type-sorted graph) repeats the
+// product per type present; rows of unknown type are written as 0 (conv.py:120).
+// ---------------------------------------------------------------------------------------------
+#if HGT_FU_TRACE
+__device__ unsigned long long fu_trace[8];   // development aid: shader-clock totals of wave 0 of every workgroup
+#define FU_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define FU_TADD(slot, a, b) if (threadIdx.x == 0) atomicAdd(&fu_trace[slot], (b) - (a))
+#else
+#define FU_T(v)
+#define FU_TADD(slot, a, b)
+#endif
+
+struct FusedUpdate {
+    const int64_t* node_type;
+    const unsigned short* w_split;   // hgt_split_weights(W_a): [T][1][n_kc][2][8][64][8] bf16
+    const float* bias;               // [T][n_out]
+    const float* xs;                 // skip input rows [*][ldxs]
+    int64_t ldxs;
+    const float* skip;               // [T]
+    const float* lnw;                // [T][n_out] or nullptr
+    const float* lnb;
+    int use_norm, n_types, n_out;
+    float* out;                      // [NQ][n_out]
+};
+
+// The epilogue proper: `vals` = this wavefront's 16 finished rows (gelu applied), `slab` = >= 2*A_PLANE bytes of LDS
+// every wavefront is done with, `tables` = 2.5 KB of LDS for the row types and the LayerNorm partial sums.
+template <int VEC>
+__device__ __forceinline__ void fused_update_epilogue(const float (&vals)[16][VEC], unsigned char* slab, unsigned char* tables,
+                                                      int64_t row0, int64_t NQ, const FusedUpdate& fu) {
+    constexpr int DP = 64 * VEC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    FU_T(t0);
+    // ---- A operand: hi/mid bf16 planes of the 64 finished rows, [plane][row][k], 528 B row stride
+    int* s_type = reinterpret_cast<int*>(tables);                // [64]
+    float* s_sum = reinterpret_cast<float*>(tables + 256);         // [64][4]
+    float* s_var = s_sum + 256;                                    // [64][4]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        unsigned char* prow = slab + (wave * 16 + r) * A_STRIDE + lane * VEC * 2;
+        unsigned short hi[VEC], mid[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            hi[i] = bf16_rne(vals[r][i]);
+            mid[i] = bf16_rne(vals[r][i] - bf16_to_f32(hi[i]));
+        }
+        if constexpr (VEC == 1) {
+            *reinterpret_cast<unsigned short*>(prow) = hi[0];
+            *reinterpret_cast<unsigned short*>(prow + A_PLANE) = mid[0];
+        } else if constexpr (VEC == 2) {
+            *reinterpret_cast<unsigned*>(prow) = (unsigned)hi[0] | ((unsigned)hi[1] << 16);
+            *reinterpret_cast<unsigned*>(prow + A_PLANE) = (unsigned)mid[0] | ((unsigned)mid[1] << 16);
+        } else {
+            *reinterpret_cast<uint2*>(prow) = make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
+            *reinterpret_cast<uint2*>(prow + A_PLANE) =
+                make_uint2((unsigned)mid[0] | ((unsigned)mid[1] << 16), (unsigned)mid[2] | ((unsigned)mid[3] << 16));
+        }
+    }
+    if (tid < 64) {
+        const int64_t row = row0 + tid;
+        int64_t t = (row < NQ) ? fu.node_type[row] : -1;
+        s_type[tid] = (t >= 0 && t < fu.n_types) ? (int)t : -1;
+    }
+    __syncthreads();
+
+    const int my_t = s_type[lane];
+    int tmin = my_t < 0 ? 0x7fffffff : my_t, tmax = my_t;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        tmin = min(tmin, __shfl_xor(tmin, sft));
+        tmax = max(tmax, __shfl_xor(tmax, sft));
+    }
+    tmin = __builtin_amdgcn_readfirstlane(tmin);
+    tmax = __builtin_amdgcn_readfirstlane(tmax);
+
+    constexpr int NKC = DP / KC;                       // k-chunks (a multiple of 4, like split_dims)
+    const int n_out = fu.n_out;
+    const int frow = lane & 31, khalf = lane >> 5;
+    const unsigned char* abase = slab + frow * A_STRIDE + khalf * 16;
+    const bool o1 = lane & 1, o2 = lane & 2;
+    const float inv_n = 1.0f / (float)n_out;
+    const int rt0 = (lane & 3) + 4 * (lane >> 5);      // row of register group (j, q): rt0 + 32 j + 8 q
+
+    FU_T(t1);
+    FU_TADD(1, t0, t1);                                // slab write + types
+    for (int g = tmin; g <= tmax; ++g) {               // empty range when no row has a valid type
+        if (__builtin_amdgcn_ballot_w64(my_t == g) == 0) continue;
+        FU_T(t2);
+        // ---- 64 x n_out x DP product; this wavefront owns columns [64 wave, 64 wave + 64) = column tiles 2 wave, 2 wave + 1
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.0f;
+        if (wave * 64 < n_out) {
+            const unsigned short* __restrict__ wf = fu.w_split + (int64_t)g * NKC * 2 * W_PLANE_ELEMS + ((2 * wave) * 64 + lane) * 8;
+            // B fragments of two column tiles, NSTG k-chunks ahead in named register stages; A fragments one chunk ahead.
+            // The sched barriers pin "next A -> 12 MFMAs -> refill of the consumed stage" (see k_typed_linear_pc: left alone,
+            // hipcc sinks the loads next to their uses and every wait becomes a wait for a load that was just issued).
+            bf16x8 s0h0, s0h1, s0m0, s0m1, s1h0, s1h1, s1m0, s1m1, s2h0, s2h1, s2m0, s2m1, s3h0, s3h1, s3m0, s3m1;
+            bf16x8 e_h0, e_m0, e_h1, e_m1, o_h0, o_m0, o_h1, o_m1;
+#define FU_LOAD_B(S, KCI)                                                                            \
+    {                                                                                                \
+        const unsigned short* t_ = wf + (int64_t)min((KCI), NKC - 1) * 2 * W_PLANE_ELEMS;            \
+        s##S##h0 = *reinterpret_cast<const bf16x8*>(t_);                                             \
+        s##S##h1 = *reinterpret_cast<const bf16x8*>(t_ + 64 * 8);                                    \
+        s##S##m0 = *reinterpret_cast<const bf16x8*>(t_ + W_PLANE_ELEMS);                             \
+        s##S##m1 = *reinterpret_cast<const bf16x8*>(t_ + W_PLANE_ELEMS + 64 * 8);                    \
+    }
+#define FU_LOAD_A(P, KCI)                                                                            \
+    {                                                                                                \
+        const unsigned char* a_ = abase + min((KCI), NKC - 1) * (KC * 2);                            \
+        P##_h0 = *reinterpret_cast<const bf16x8*>(a_);                                               \
+        P##_m0 = *reinterpret_cast<const bf16x8*>(a_ + A_PLANE);                                     \
+        P##_h1 = *reinterpret_cast<const bf16x8*>(a_ + 32 * A_STRIDE);                               \
+        P##_m1 = *reinterpret_cast<const bf16x8*>(a_ + A_PLANE + 32 * A_STRIDE);                     \
+    }
+#define FU_STEP(S, KCI, P, PN)                                                                                     \
+    {                                                                                                              \
+        FU_LOAD_A(PN, (KCI) + 1)                                                                                   \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m0, s##S##h0, acc[0][0], 0, 0, 0);                 \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m1, s##S##h0, acc[0][1], 0, 0, 0);                 \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m0, s##S##h1, acc[1][0], 0, 0, 0);                 \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m1, s##S##h1, acc[1][1], 0, 0, 0);                 \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##m0, acc[0][0], 0, 0, 0);                 \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##m0, acc[0][1], 0, 0, 0);                 \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##m1, acc[1][0], 0, 0, 0);                 \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##m1, acc[1][1], 0, 0, 0);                 \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##h0, acc[0][0], 0, 0, 0);                 \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##h0, acc[0][1], 0, 0, 0);                 \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##h1, acc[1][0], 0, 0, 0);                 \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##h1, acc[1][1], 0, 0, 0);                 \
+        FU_LOAD_B(S, (KCI) + 4)                                                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  /* 4 DS reads   */                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0); /* 12 MFMAs     */                                     \
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);  /* 4 VMEM reads */                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    }
+            FU_LOAD_B(0, 0)
+            FU_LOAD_B(1, 1)
+            FU_LOAD_B(2, 2)
+            FU_LOAD_B(3, 3)
+            FU_LOAD_A(e, 0)
+            for (int kq = 0; kq < NKC; kq += 4) {
+                FU_STEP(0, kq, e, o)
+                FU_STEP(1, kq + 1, o, e)
+                FU_STEP(2, kq + 2, e, o)
+                FU_STEP(3, kq + 3, o, e)
+            }
+#undef FU_STEP
+#undef FU_LOAD_A
+#undef FU_LOAD_B
+        }
+        FU_T(t3);
+        FU_TADD(2, t2, t3);                            // MFMA product
+        // ---- epilogue for the rows of type g: bias, gated skip, LayerNorm, store
+        const float alpha = 1.0f / (1.0f + expf(-fu.skip[g]));
+        float y[16][4];                                // [c*8 + j*4 + q][4 consecutive columns]
+        int orow[8];                                   // row of group (j, q); -1 = not a row of this type
+#pragma unroll
+        for (int jq = 0; jq < 8; ++jq) {
+            const int rt = rt0 + 32 * (jq >> 2) + 8 * (jq & 3);
+            orow[jq] = (s_type[rt] == g) ? rt : -1;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = wave * 64 + c * 32 + ((lane & 31) >> 2) * 4;
+            const bool col_ok = col < n_out;
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col_ok) b4 = *reinterpret_cast<const float4*>(fu.bias + (int64_t)g * n_out + col);
+#pragma unroll
+            for (int jq = 0; jq < 8; ++jq) {
+                const int j = jq >> 2, q = jq & 3;
+                float v0 = acc[c][j][4 * q], v1 = acc[c][j][4 * q + 1], v2 = acc[c][j][4 * q + 2], v3 = acc[c][j][4 * q + 3];
+                quad_transpose(v0, v1, v2, v3, o1, o2);
+                // (requesting these rows before the workgroup barrier was measured slower: the loads only queue behind the
+                // gathers of the workgroup sharing the CU, and 64 more live registers spill)
+                float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (col_ok && orow[jq] >= 0) xv = *reinterpret_cast<const float4*>(fu.xs + (row0 + orow[jq]) * fu.ldxs + col);
+                y[c * 8 + jq][0] = col_ok ? (v0 + b4.x) * alpha + xv.x * (1.0f - alpha) : 0.0f;
+                y[c * 8 + jq][1] = col_ok ? (v1 + b4.y) * alpha + xv.y * (1.0f - alpha) : 0.0f;
+                y[c * 8 + jq][2] = col_ok ? (v2 + b4.z) * alpha + xv.z * (1.0f - alpha) : 0.0f;
+                y[c * 8 + jq][3] = col_ok ? (v3 + b4.w) * alpha + xv.w * (1.0f - alpha) : 0.0f;
+            }
+        }
+        if (fu.use_norm) {
+            // a row's columns live in 4 wavefronts x 2 column tiles x 8 lanes: lane-strided sums, one table entry per (row, wave)
+#pragma unroll
+            for (int jq = 0; jq < 8; ++jq) {
+                const int rt = rt0 + 32 * (jq >> 2) + 8 * (jq & 3);
+                float ps = y[jq][0] + y[jq][1] + y[jq][2] + y[jq][3] + y[8 + jq][0] + y[8 + jq][1] + y[8 + jq][2] + y[8 + jq][3];
+                ps = strided8_sum(ps);
+                if (((lane & 31) >> 2) == 0) s_sum[rt * 4 + wave] = ps;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int jq = 0; jq < 8; ++jq) {
+                const int rt = rt0 + 32 * (jq >> 2) + 8 * (jq & 3);
+                const float4 a4 = *reinterpret_cast<const float4*>(&s_sum[rt * 4]);
+                const float mean = (a4.x + a4.y + a4.z + a4.w) * inv_n;
+                float ps = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const bool col_ok = wave * 64 + c * 32 + ((lane & 31) >> 2) * 4 < n_out;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        y[c * 8 + jq][e] -= mean;                                  // centred from here on
+                        if (col_ok) ps += y[c * 8 + jq][e] * y[c * 8 + jq][e];
+                    }
+                }
+                ps = strided8_sum(ps);
+                if (((lane & 31) >> 2) == 0) s_var[rt * 4 + wave] = ps;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = wave * 64 + c * 32 + ((lane & 31) >> 2) * 4;
+            const bool col_ok = col < n_out;
+            float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f), c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (fu.use_norm && col_ok) {
+                w4 = *reinterpret_cast<const float4*>(fu.lnw + (int64_t)g * n_out + col);
+                c4 = *reinterpret_cast<const float4*>(fu.lnb + (int64_t)g * n_out + col);
+            }
+#pragma unroll
+            for (int jq = 0; jq < 8; ++jq) {
+                if (!col_ok || orow[jq] < 0) continue;
+                float rstd = 1.0f;
+                if (fu.use_norm) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(&s_var[orow[jq] * 4]);
+                    rstd = rsqrtf((a4.x + a4.y + a4.z + a4.w) * inv_n + 1e-5f);
+                }
+                const float* yy = y[c * 8 + jq];
+                *reinterpret_cast<float4*>(fu.out + (row0 + orow[jq]) * n_out + col) =
+                    make_float4(yy[0] * rstd * w4.x + c4.x, yy[1] * rstd * w4.y + c4.y, yy[2] * rstd * w4.z + c4.z, yy[3] * rstd * w4.w + c4.w);
+            }
+        }
+        if (fu.use_norm) __syncthreads();   // the tables are rewritten by the next type of a mixed tile
+        FU_T(t4);
+        FU_TADD(3, t3, t4);                            // gated skip + LayerNorm + store
+    }
+    // rows of unknown type -> 0 (conv.py:120)
+    for (int r = wave * 16; r < wave * 16 + 16; ++r) {
+        if (row0 + r < NQ && s_type[r] < 0) {
+            for (int cidx = lane; cidx < n_out; cidx += 64) fu.out[(row0 + r) * n_out + cidx] = 0.0f;
+        }
+    }
+}
+
+// Workgroups that contain a hub target cannot finish their rows here (the hub kernels write those rows of agg later):
+// they take the unfused path, raise pending[workgroup], and k_update_pending runs the same epilogue from agg afterwards.
+template <int VEC, int LPH, bool RTE>
+__global__ __launch_bounds__(256, 2) void k_edge_aggregate_update(
+    const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
+    const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
+    const float* __restrict__ rteV, const float* __restrict__ msgP, float* __restrict__ agg, int R, int64_t NQ, int HT,
+    const int32_t* __restrict__ hub_slot, int32_t* __restrict__ pending, FusedUpdate fu) {
+    constexpr int DP = 64 * VEC;
+    static_assert(DP <= KP, "the fused epilogue keeps the whole K extent in one LDS slab");
+    constexpr int AGG_PART = 4 * 16 * 64 * VEC * 4 + 4 * (64 * VEC + 4 * (64 / LPH)) * 4;
+    constexpr int FRONT = AGG_PART > 2 * A_PLANE ? AGG_PART : 2 * A_PLANE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[FRONT + 4 * 2 * 256 * 4];
+    auto& s_acc = *reinterpret_cast<float(*)[4][16 * 64 * VEC]>(smem);
+    auto& s_bounce = *reinterpret_cast<float(*)[4][64 * VEC + 4 * (64 / LPH)]>(smem + 4 * 16 * 64 * VEC * 4);
+    auto& s_ml = *reinterpret_cast<float(*)[4][2][16 * 16]>(smem + FRONT);
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+
+    unsigned hub_mask = 0;
+    if (hub_slot) {
+        const int lane = threadIdx.x & 63;
+        const int64_t rr = row0 + (threadIdx.x >> 6) * 16 + (lane & 15);
+        const bool is_hub = (lane < 16) && (rr < NQ) && (hub_slot[rr] >= 0);
+        hub_mask = (unsigned)(__builtin_amdgcn_ballot_w64(is_hub) & 0xFFFFull);
+    }
+    const bool any_hub = hub_slot ? (__syncthreads_or(hub_mask != 0) != 0) : false;
+    if (threadIdx.x == 0) pending[blockIdx.x] = any_hub ? 1 : 0;
+    if (any_hub) {
+        float no_rowvals[1][VEC];
+        if (hub_mask == 0)
+            aggregate_subtile<VEC, LPH, RTE, false>(segptr, esrc, edst, ertei, logits, V, rteV, msgP, agg, R, NQ, 1, HT, 0u, s_acc,
+                                                    s_bounce, s_ml, no_rowvals);
+        else
+            aggregate_subtile<VEC, LPH, RTE, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgP, agg, R, NQ, 1, HT, hub_mask, s_acc,
+                                                   s_bounce, s_ml, no_rowvals);
+        return;
+    }
+    float vals[16][VEC];
+    FU_T(ta);
+    aggregate_subtile<VEC, LPH, RTE, false, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgP, nullptr, R, NQ, 1, HT, 0u, s_acc,
+                                                  s_bounce, s_ml, vals);
+    FU_T(tb);
+    __syncthreads();   // every wavefront is done with the accumulators, bounce rows and softmax state
+    FU_T(tc);
+    FU_TADD(0, ta, tb);                                // aggregation (wave 0)
+    FU_TADD(4, tb, tc);                                // waiting for the other wavefronts
+    FU_TADD(7, ta - ta, ta - ta + 1);                  // workgroups
+    fused_update_epilogue<VEC>(vals, smem, smem + FRONT, row0, NQ, fu);
+}
+
+// the node update of the workgroups k_edge_aggregate_update left pending (their agg rows are complete by now)
+template <int VEC>
+__global__ __launch_bounds__(256, 2) void k_update_pending(const float* __restrict__ agg, int64_t ld_agg, int64_t NQ,
+                                                           const int32_t* __restrict__ pending, FusedUpdate fu) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_PLANE + 4096];
+    if (pending[blockIdx.x] == 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    float vals[16][VEC];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + wave * 16 + r;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) vals[r][i] = 0.0f;
+        if (row < NQ) load_vec<VEC>(agg + row * ld_agg + lane * VEC, vals[r]);
+    }
+    fused_update_epilogue<VEC>(vals, smem, smem + 2 * A_PLANE, row0, NQ, fu);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -721,6 +1080,43 @@ struct LaunchAggregate {
     }
 };
 
+template <int VEC, int LPH>
+struct LaunchAggregateUpdate {
+    static int run(const HgtPlanView& pv, const float* logits, const float* V, const float* rteV, const float* msgP, float* agg, int R,
+                   int64_t NQ, int HT, HubBuffers hb, int32_t* pending, FusedUpdate fu, hipStream_t stream) {
+        if constexpr (64 * VEC <= KP) {
+            if (HT != 64 / LPH) return HGT_ERR_UNSUPPORTED;   // a head-group split leaves a workgroup with part of the row
+            const int64_t tiles = (NQ + 63) / 64;
+            dim3 grid((unsigned)tiles, 1);
+            const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
+            if (rteV)
+                k_edge_aggregate_update<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgP,
+                                                                                 agg, R, NQ, HT, hub_slot, pending, fu);
+            else
+                k_edge_aggregate_update<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV,
+                                                                                  msgP, agg, R, NQ, HT, hub_slot, pending, fu);
+            if (hb.mx) {   // hub path (see LaunchAggregate) + the update of the workgroups that had to wait for it
+                const int dkp = VEC * LPH;
+                const int64_t cells = (int64_t)pv.L.max_hubs * (2 * HT + HT * dkp);
+                k_hub_init<<<(unsigned)((cells + 255) / 256), 256, 0, stream>>>(pv.hdr, hb, HT, HT * dkp);
+                k_hub_max<<<HUB_GRID_WAVES / 4, 256, 0, stream>>>(pv.hdr, pv.hub_list, pv.segptr, logits, R, HT, hb);
+                dim3 hgrid(HUB_GRID_WAVES / 4, 1);
+                if (rteV)
+                    k_hub_accumulate<VEC, LPH, true><<<hgrid, 256, 0, stream>>>(pv.hdr, pv.hub_list, pv.segptr, pv.esrc, pv.ertei, logits, V,
+                                                                                rteV, msgP, R, HT, hb);
+                else
+                    k_hub_accumulate<VEC, LPH, false><<<hgrid, 256, 0, stream>>>(pv.hdr, pv.hub_list, pv.segptr, pv.esrc, pv.ertei, logits, V,
+                                                                                 rteV, msgP, R, HT, hb);
+                k_hub_finalize<<<256, 256, 0, stream>>>(pv.hdr, pv.hub_list, hb, agg, HT, dkp, NQ, 1);
+                k_update_pending<VEC><<<grid, 256, 0, stream>>>(agg, (int64_t)HT * dkp, NQ, pending, fu);
+            }
+            return HGT_OK;
+        } else {
+            return HGT_ERR_UNSUPPORTED;
+        }
+    }
+};
+
 // Head-group split: the smallest power of two that makes the per-lane relation fragment (dk_pad * vec / split floats)
 // fit in 128 registers; 1 for every layout up to d = 256 / 8 heads.  Measured at c2 (d=256): a split of 2 is slower
 // (logits 2.86 vs 2.75 ms, aggregate 4.19 vs 3.42 ms), so it is only used when the fragment cannot be hoisted
@@ -765,6 +1161,51 @@ extern "C" int hgt_edge_softmax(const void* plan, int64_t N, int64_t E, int32_t 
     HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
     const int64_t threads = N * H;
     k_edge_softmax<<<(unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream>>>(pv.segptr, logits_att, N, H, R);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+#if HGT_FU_TRACE
+extern "C" int hgt_debug_fu_trace(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(fu_trace), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(fu_trace), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+extern "C" int hgt_edge_aggregate_update(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                         const float* logits, const float* V, const float* rte_v, const float* msg_p, float* agg,
+                                         int64_t n_q_rows, void* hub_ws, int32_t* pending, const int64_t* node_type,
+                                         const void* w_a_split, const float* b_a, const float* x_skip, int64_t ld_skip,
+                                         const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm, int32_t n_out,
+                                         float* out, void* stream) {
+    if (!plan || !V || !msg_p || !agg || !pending || !node_type || !w_a_split || !b_a || !x_skip || !skip || !out || H <= 0 ||
+        64 % H != 0 || dk_pad <= 0 || n_out <= 0)
+        return HGT_ERR_INVALID_ARG;
+    if (E > 0 && !logits) return HGT_ERR_INVALID_ARG;
+    if (use_norm && (!ln_w || !ln_b)) return HGT_ERR_INVALID_ARG;
+    const int64_t NQ = (n_q_rows > 0 && n_q_rows <= N) ? n_q_rows : N;
+    if (NQ == 0) return HGT_OK;
+    const int lph = 64 / H;
+    if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
+    const int dp = H * dk_pad;
+    if (dp > KP || n_out > dp || (n_out & 3) != 0 || (ld_skip & 3) != 0 || ((uintptr_t)x_skip & 15) != 0) return HGT_ERR_UNSUPPORTED;
+    if (head_split_for(dk_pad / lph, lph, dk_pad) != 1) return HGT_ERR_UNSUPPORTED;
+    HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
+    HubBuffers hb = {nullptr, nullptr, nullptr};
+    if (hub_ws && E > 0) {   // same carving as hgt_edge_aggregate
+        const uint64_t per = hgt_align_up((uint64_t)pv.L.max_hubs * H * 4, 256);
+        hb.mx = (int*)hub_ws;
+        hb.l = (float*)((char*)hub_ws + per);
+        hb.acc = (float*)((char*)hub_ws + 2 * per);
+    }
+    FusedUpdate fu = {node_type, (const unsigned short*)w_a_split, b_a, x_skip, ld_skip, skip, ln_w, ln_b, use_norm, T, n_out, out};
+    int rc = dispatch_layout<LaunchAggregateUpdate>(dk_pad / lph, lph, pv, logits, V, rte_v, msg_p, agg, (int)R, NQ, (int)H, hb, pending, fu,
+                                                    (hipStream_t)stream);
+    if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }

@@ -23,6 +23,7 @@
 //     and -- because nothing is written to LDS in the main loop -- there is NO barrier in it.
 // The 528 B LDS row stride puts the 16 lanes of a ds_read_b128 group on 16 distinct 4-bank slots.
 #include "hgt_common.h"
+#include "hgt_split_common.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -31,39 +32,6 @@
 #endif
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int BM = 64;          // rows per workgroup
-constexpr int BNP = 256;        // output columns per pass (8 waves x 32)
-constexpr int KC = 16;          // k per MFMA (v_mfma_f32_32x32x16_bf16)
-constexpr int KP = 256;         // k panel kept in LDS
-constexpr int A_STRIDE = KP * 2 + 16;   // bytes
-constexpr int A_PLANE = BM * A_STRIDE;          // 33792
-constexpr int W_PLANE_ELEMS = BNP * KC;         // bf16 elements per plane of one (pass, k-chunk) tile = 8 x 64 x 8
-
-__device__ __forceinline__ float gelu_erf_(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
-
-// round-to-nearest-even fp32 -> bf16 (inputs are finite)
-__device__ __forceinline__ unsigned short bf16_rne(float f) {
-    unsigned u = __builtin_bit_cast(unsigned, f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
-
-__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid) {
-    const float f[4] = {v.x, v.y, v.z, v.w};
-    unsigned short h[4], m[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        h[i] = bf16_rne(f[i]);
-        m[i] = bf16_rne(f[i] - bf16_to_f32(h[i]));
-    }
-    hi = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-    mid = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
-}
 
 // W [n_groups][n_out][k] fp32 -> [g][pass][kchunk][plane][col tile 8][lane 64][8] bf16 (zero padded): the 8 bf16 of
 // (col tile ct, lane l) are W[pass*256 + ct*32 + (l&31)][kchunk*16 + (l>>5)*8 .. +8] = one lane's B fragment.
@@ -136,20 +104,6 @@ __device__ __forceinline__ void load_a_panel(int kp0, int tid, const int* s_rid,
     __syncthreads();   // panel visible
 }
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-
-// 4x4 transpose between the 4 lanes of a quad and 4 registers: lane j reg i <- lane i reg j
-__device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, bool o1, bool o2) {
-    float t;
-    t = dpp_mov_f<0xB1>(o1 ? v0 : v1); if (o1) v0 = t; else v1 = t;    // quad_perm [1,0,3,2]
-    t = dpp_mov_f<0xB1>(o1 ? v2 : v3); if (o1) v2 = t; else v3 = t;
-    t = dpp_mov_f<0x4E>(o2 ? v0 : v2); if (o2) v0 = t; else v2 = t;    // quad_perm [2,3,0,1]
-    t = dpp_mov_f<0x4E>(o2 ? v1 : v3); if (o2) v1 = t; else v3 = t;
-}
-
 // epilogue of one 256-column pass.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 // Narrow (4 B per lane) stores are issue-bound, so each group of 4 registers (4 consecutive rows, one column per lane)
 // is transposed inside the lane quad: afterwards a lane holds 4 consecutive COLUMNS of one row and writes one 16 B
@@ -199,13 +153,6 @@ struct UpdateArgs {
     const float* lnb;
     int use_norm;
 };
-
-__device__ __forceinline__ float strided8_sum(float v) {   // sum over the 8 lanes {j, j+4, ..., j+28} of a 32-lane half
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
-    return v;
-}
 
 // Fused node update (conv.py:129-133) as the epilogue of the a_linear GEMM, single 256-column pass:
 //   y = (acc + b) * sigmoid(skip[t]) + x * (1 - sigmoid(skip[t]));  out = LayerNorm_t(y)  (two-pass mean/variance)
