@@ -276,6 +276,17 @@ typedef struct hgt_conv_args {
     const float* out_b;          /* [out_dim]                                  */
     const float* out_ln_w;       /* [out_dim]                                  */
     const float* out_ln_b;       /* [out_dim]                                  */
+    /* Staged execution for the multi-GPU path (pyhgt_amd/dist.py), so that the halo exchange overlaps the projections.
+     * All stages of one forward use the same args (same workspace) on the same stream:
+     *   0  the whole layer (default)
+     *   1  parameter packing + Q|K|V projections of the rows [0, n_q_rows) only (+ temporal tables)
+     *   2  K|V projections of the rows listed in proj_rows (typed row list: group t = proj_rows[proj_off[t] ..
+     *      proj_off[t+1]), device arrays, n_types+1 offsets) -- call once per received chunk of halo rows
+     *   3  edge phase + update (needs K,V of every source row: stages 1 and 2 done)                              */
+    int32_t stage;
+    const int32_t* proj_rows;
+    const int32_t* proj_off;
+    int64_t proj_n;              /* number of rows in proj_rows (host value)   */
 } hgt_conv_args;
 
 /* phase boundaries at which hgt_conv_forward records phase_events[i]:

@@ -44,6 +44,7 @@ class HgtConvArgs(C.Structure):
         ("update_mode", C.c_int32),
         ("mid_w", C.c_void_p), ("mid_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p),
         ("out_ln_w", C.c_void_p), ("out_ln_b", C.c_void_p),
+        ("stage", C.c_int32), ("proj_rows", C.c_void_p), ("proj_off", C.c_void_p), ("proj_n", C.c_int64),
     ]
 
 

@@ -249,10 +249,14 @@ class HGTConv(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def forward(self, node_inp, node_type, edge_index, edge_type, edge_time=None, plan=None, n_q_rows=None,
-                phase_events=None):
+                phase_events=None, stage=0, proj=None):
         """node_inp f32[N,in_dim], node_type i64[N], edge_index i64[2,E] (row 0 = source, row 1 =
         target; any strides), edge_type i64[E], edge_time i64[E] (needed iff use_RTE).
-        Returns f32[N,out_dim] (or [n_q_rows,out_dim] when only the first n_q_rows nodes are targets)."""
+        Returns f32[N,out_dim] (or [n_q_rows,out_dim] when only the first n_q_rows nodes are targets).
+
+        stage / proj: staged execution for pyhgt_amd.dist (hgt_conv_args.stage): 1 = projections of the own rows,
+        2 = K|V of the rows in proj = (rows int32[n], offsets int32[T+1]) (one call per received halo chunk),
+        3 = edge phase + update (returns the output); stages 1 and 2 return None."""
         lib = _lib.load()
         if not node_inp.is_cuda:
             raise RuntimeError("pyhgt_amd.HGTConv runs only on a ROCm GPU tensor; there is no CPU fallback "
@@ -283,8 +287,9 @@ class HGTConv(nn.Module):
         _lib.check(lib.hgt_conv_workspace_bytes(N, E, self.in_dim, self.out_dim, self.num_types, self.num_relations,
                                                 self.n_heads, int(self.use_RTE), C.byref(nbytes)), "hgt_conv_workspace_bytes")
         ws = _Workspace.get(x.device, nbytes.value)
-        out = torch.empty(NQ, self.out_dim, dtype=torch.float32, device=x.device)
-        att = torch.empty(E, self.n_heads, dtype=torch.float32, device=x.device) if self.keep_att else None
+        final = stage in (0, 3)
+        out = torch.empty(NQ, self.out_dim, dtype=torch.float32, device=x.device) if final else None
+        att = torch.empty(E, self.n_heads, dtype=torch.float32, device=x.device) if (self.keep_att and final) else None
         ntype = node_type.contiguous()
 
         a = _lib.HgtConvArgs()
@@ -302,11 +307,19 @@ class HGTConv(nn.Module):
         self._set_update_args(a, pk)
         a.rte_emb, a.rte_w, a.rte_b = _ptr(pk.get("rte_emb")), _ptr(pk.get("rte_w")), _ptr(pk.get("rte_b"))
         a.workspace, a.workspace_bytes = _ptr(ws), ws.numel()
-        a.out, a.att_out = _ptr(out), _ptr(att)
+        a.out, a.att_out = _ptr(out) if final else _ptr(ws), _ptr(att)   # stages 1/2 write no output (non-NULL placeholder)
+        a.want_att = int(self.keep_att and final)
+        a.stage = int(stage)
+        if stage == 2:
+            rows, off = proj
+            if rows.dtype != torch.int32 or off.dtype != torch.int32 or off.numel() != self.num_types + 1:
+                raise TypeError("proj must be (int32 rows, int32 offsets[T+1])")
+            a.proj_rows, a.proj_off, a.proj_n = _ptr(rows), _ptr(off), int(rows.numel())
         if phase_events is not None:      # ctypes array of HGT_N_PHASE_EVENTS hipEvent_t (bench.py instrumentation)
             a.phase_events = C.cast(phase_events, C.c_void_p)
         _lib.check(lib.hgt_conv_forward(C.byref(a), _stream()), "hgt_conv_forward")
-        self.att = att
+        if final:
+            self.att = att
         return out
 
     def __repr__(self):

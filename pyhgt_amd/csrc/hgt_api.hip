@@ -136,14 +136,19 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     auto mark = [&](int i) {
         if (a->phase_events && a->phase_events[i]) (void)hipEventRecord((hipEvent_t)a->phase_events[i], stream);
     };
-    mark(0);
+    const int stage = a->stage;
+    if (stage < 0 || stage > 3) return HGT_ERR_INVALID_ARG;
+    if (stage == 2 && (a->proj_n < 0 || (a->proj_n > 0 && (!a->proj_rows || !a->proj_off)))) return HGT_ERR_INVALID_ARG;
+    if (stage == 0 || stage == 1) mark(0);
     hgt_plan_rows pr;
     rc = hgt_plan_row_lists(a->plan, N, E, T, R, &pr);
     if (rc != HGT_OK) return rc;
 
     // (1) relation matrices: fold pri/sqrt(dk), transpose att, zero-pad heads (conv.py:98-99,104)
-    rc = hgt_relation_pack(a->relation_att, a->relation_msg, a->relation_pri, R, H, lay.d_k, lay.dk_pad, att_t, msg_p, stream);
-    if (rc != HGT_OK) return rc;
+    if (stage == 0 || stage == 1) {
+        rc = hgt_relation_pack(a->relation_att, a->relation_msg, a->relation_pri, R, H, lay.d_k, lay.dk_pad, att_t, msg_p, stream);
+        if (rc != HGT_OK) return rc;
+    }
 
     // typed linear dispatch: exact fp32 MFMA, or split-bf16 x3 with weights split+tiled into the workspace
     const bool split = (a->precision == 1);
@@ -163,7 +168,16 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
 
     // (2) typed projections once per NODE (conv.py:96-97,103 did them per edge)
     const int64_t wstride = (int64_t)3 * dp * din;
-    if (NQ == N) {
+    if (stage == 2) {   // K|V of one received chunk of halo rows (the K|V split tiles are re-made each time: tiny)
+        if (a->proj_n == 0) return HGT_OK;
+        return linear(a->x, din, a->proj_rows, a->proj_off, T, a->proj_n, din, 2 * dp, a->w_qkv + (int64_t)dp * din, wstride, a->b_qkv + dp,
+                      3 * dp, K, V, nullptr, dp, 0, ws_a);
+    }
+    if (stage == 3) goto edge_phase;
+    if (stage == 1) {   // own rows only: one fused Q|K|V launch, exactly like the single-GPU layer
+        rc = linear(a->x, din, pr.rows_q, pr.off_q, T, NQ, din, 3 * dp, a->w_qkv, wstride, a->b_qkv, 3 * dp, Q, K, V, dp, 0, ws_qkv);
+        if (rc != HGT_OK) return rc;
+    } else if (NQ == N) {
         rc = linear(a->x, din, pr.rows_all, pr.off_all, T, N, din, 3 * dp, a->w_qkv, wstride, a->b_qkv, 3 * dp, Q, K, V, dp, 0, ws_qkv);
         if (rc != HGT_OK) return rc;
     } else {
@@ -194,6 +208,12 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
         if (rc != HGT_OK) return rc;
     }
 
+    if (stage == 1) return HGT_OK;
+edge_phase:
+    if (a->use_rte) {   // (stage 3 re-derives the pointers stage 1 filled)
+        rte_k = (float*)(wb + w.off_rte_k);
+        rte_v = (float*)(wb + w.off_rte_v);
+    }
     mark(1);
     // (4) edge phase: logits, then softmax fused into the aggregation (online, per target sub-tile)
     if (E > 0) {

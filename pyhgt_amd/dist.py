@@ -13,6 +13,16 @@ whose source lives on another rank (halo).  Per layer there is exactly one excha
 Halo ids are deduplicated per rank, so a source referenced by many local edges crosses the link
 once.  Everything that depends only on the graph (halo id lists, split sizes, halo node types,
 local edge ids, the GraphPlan) is built once in __init__.
+
+Overlap (n_chunks > 1, the default on GPUs): every peer's rows are cut into n_chunks slices and the
+halo part of the local buffer is ordered (chunk, peer, row).  A step then runs
+
+    pack(c0), all-to-all(c0, async) | Q|K|V of the own rows | pack(c1), all-to-all(c1, async) |
+    wait(c0), K|V of chunk 0 | pack(c2), ... | wait(c_last), K|V of the last chunk | edge phase + update
+
+through hgt_conv_forward's stages 1/2/3, so the exchange (RCCL's own stream) overlaps the own-row
+projections, the packing and the halo projections of the earlier chunks; only the edge phase needs
+every source row.
 """
 import torch
 import torch.distributed as dist
@@ -31,9 +41,10 @@ class HaloPlan:
     receive go.  Pure index arithmetic + three small all-to-alls; backend-agnostic (the CPU tests
     run it over gloo)."""
 
-    def __init__(self, node_type_own, src_global, node_offsets, rank, world, group=None):
+    def __init__(self, node_type_own, src_global, node_offsets, rank, world, group=None, n_chunks=1):
         dev = src_global.device
         self.rank, self.world, self.group = rank, world, group
+        self.n_chunks = C = max(1, int(n_chunks))
         self.offsets = torch.as_tensor(node_offsets, dtype=torch.int64, device=dev)       # [world+1]
         lo, hi = int(self.offsets[rank]), int(self.offsets[rank + 1])
         self.n_own = hi - lo
@@ -48,31 +59,89 @@ class HaloPlan:
         self.send_splits = got.tolist()
         # tell every owner which of its rows I need; receive which of my rows the peers need
         asked = _all_to_all_int64(need, self.recv_splits, self.send_splits, group)
-        self.send_rows = (asked - lo).to(torch.int32)                                      # local row ids, grouped by peer
+        send_rows = (asked - lo).to(torch.int32)                                           # local row ids, grouped by peer
         # node types of my halo rows (owners answer in the order I asked)
         types_for_peers = node_type_own[(asked - lo)]
-        self.halo_types = _all_to_all_int64(types_for_peers.contiguous(), self.send_splits, self.recv_splits, group)
-        # local id of every edge source: own rows first, then halo rows in `need` order
+        halo_types = _all_to_all_int64(types_for_peers.contiguous(), self.send_splits, self.recv_splits, group)
+        # Chunk-major order of the halo rows / of the rows I send: slice c of a peer's list of length L is
+        # [c*L//C, (c+1)*L//C) -- both sides derive the same slices from the same per-peer lengths.
+        def chunk_major(splits):
+            starts = [0]
+            for n in splits:
+                starts.append(starts[-1] + n)
+            pieces, per_chunk = [], []
+            for c in range(C):
+                sizes = []
+                for p, n in enumerate(splits):
+                    a, b = starts[p] + (c * n) // C, starts[p] + ((c + 1) * n) // C
+                    pieces.append(torch.arange(a, b, device=dev))
+                    sizes.append(b - a)
+                per_chunk.append(sizes)
+            order = torch.cat(pieces) if pieces else torch.zeros(0, dtype=torch.int64, device=dev)
+            return order, per_chunk
+        recv_order, self.recv_chunk_splits = chunk_major(self.recv_splits)     # new halo position -> position in `need`
+        send_order, self.send_chunk_splits = chunk_major(self.send_splits)
+        self.send_rows = send_rows[send_order].contiguous()
+        self.halo_types = halo_types[recv_order].contiguous()
+        inv = torch.empty_like(recv_order)
+        inv[recv_order] = torch.arange(recv_order.numel(), device=dev)                     # position in `need` -> new halo position
+        # local id of every edge source: own rows first, then halo rows (chunk, peer, id order)
         pos = torch.searchsorted(need, src_global.clamp(min=0)) if self.n_halo > 0 else torch.zeros_like(src_global)
+        pos = inv[pos.clamp(max=max(self.n_halo - 1, 0))] if self.n_halo > 0 else pos
         self.src_local = torch.where(remote_mask, self.n_own + pos, src_global - lo)
         self.node_type_local = torch.cat([node_type_own, self.halo_types])
         self.n_local = self.n_own + self.n_halo
+        self.halo_order = recv_order      # halo row i holds global node need[halo_order[i]]
+        self.need = need
+        # per chunk: offsets into the send list / the halo rows
+        self.send_chunk_off = [0]
+        self.recv_chunk_off = [0]
+        for c in range(C):
+            self.send_chunk_off.append(self.send_chunk_off[-1] + sum(self.send_chunk_splits[c]))
+            self.recv_chunk_off.append(self.recv_chunk_off[-1] + sum(self.recv_chunk_splits[c]))
 
-    def exchange(self, x_own, x_local, pack=None):
-        """Fill x_local[n_own:] with the halo rows (x_local[:n_own] must already hold x_own).
-        `pack(x_own, rows_int32) -> [len(rows), d]`; defaults to the HIP gather kernel on GPU."""
+    def chunk_row_lists(self, num_types):
+        """Typed row lists (int32 rows grouped by node type, int32 offsets[T+1]) of the halo rows of every chunk,
+        in the form hgt_conv_forward stage 2 takes.  Rows of a type outside [0, T) get no projection (their edges are
+        unclaimed, conv.py:68-69)."""
+        lists = []
+        for c in range(self.n_chunks):
+            a, b = self.recv_chunk_off[c], self.recv_chunk_off[c + 1]
+            t = self.halo_types[a:b]
+            valid = (t >= 0) & (t < num_types)
+            key = torch.where(valid, t, torch.full_like(t, num_types))
+            order = torch.argsort(key, stable=True)
+            counts = torch.bincount(key, minlength=num_types + 1)[:num_types]
+            off = torch.zeros(num_types + 1, dtype=torch.int64, device=t.device)
+            off[1:] = torch.cumsum(counts, 0)
+            n_valid = int(valid.sum())
+            rows = (self.n_own + a + order[:n_valid]).to(torch.int32).contiguous()
+            lists.append((rows, off.to(torch.int32).contiguous()))
+        return lists
+
+    def exchange_chunk(self, c, x_own, x_local, pack=None, async_op=False):
+        """One slice of the exchange: pack the rows of chunk c the peers need, all-to-all them into the halo rows of
+        chunk c.  Returns the work handle when async_op (wait() makes the current stream wait for the rows)."""
         d = x_own.size(1)
+        rows = self.send_rows[self.send_chunk_off[c]:self.send_chunk_off[c + 1]]
         if pack is None:
             if not x_own.is_cuda:
                 raise RuntimeError("pyhgt_amd.dist: halo packing runs the HIP gather kernel; CPU tensors need an explicit pack fn")
-            send = torch.empty(self.send_rows.numel(), d, dtype=x_own.dtype, device=x_own.device)
-            _lib.check(_lib.load().hgt_gather_rows(x_own.data_ptr(), x_own.stride(0), self.send_rows.data_ptr(),
-                                                   self.send_rows.numel(), d, send.data_ptr(),
-                                                   torch.cuda.current_stream().cuda_stream), "hgt_gather_rows")
+            send = torch.empty(rows.numel(), d, dtype=x_own.dtype, device=x_own.device)
+            _lib.check(_lib.load().hgt_gather_rows(x_own.data_ptr(), x_own.stride(0), rows.data_ptr(), rows.numel(), d,
+                                                   send.data_ptr(), torch.cuda.current_stream().cuda_stream), "hgt_gather_rows")
         else:
-            send = pack(x_own, self.send_rows)
-        recv = x_local[self.n_own:]
-        dist.all_to_all_single(recv, send, [s for s in self.recv_splits], [s for s in self.send_splits], group=self.group)
+            send = pack(x_own, rows)
+        recv = x_local[self.n_own + self.recv_chunk_off[c]:self.n_own + self.recv_chunk_off[c + 1]]
+        work = dist.all_to_all_single(recv, send, list(self.recv_chunk_splits[c]), list(self.send_chunk_splits[c]),
+                                      group=self.group, async_op=async_op)
+        return (work, send) if async_op else None
+
+    def exchange(self, x_own, x_local, pack=None):
+        """Fill x_local[n_own:] with the halo rows (x_local[:n_own] must already hold x_own), one slice after the other.
+        `pack(x_own, rows_int32) -> [len(rows), d]`; defaults to the HIP gather kernel on GPU."""
+        for c in range(self.n_chunks):
+            self.exchange_chunk(c, x_own, x_local, pack=pack)
         return x_local
 
 
@@ -80,11 +149,12 @@ class PartitionedGraph:
     """One rank's share of a destination-partitioned typed graph + the per-layer forward."""
 
     def __init__(self, node_type_own, src_global, dst_local, edge_type, edge_time, num_types, num_relations,
-                 nodes_per_rank, rank, world, group=None, node_offsets=None):
+                 nodes_per_rank, rank, world, group=None, node_offsets=None, n_chunks=4):
         from .conv import GraphPlan
         if node_offsets is None:
             node_offsets = [nodes_per_rank * r for r in range(world + 1)]
-        self.halo = HaloPlan(node_type_own, src_global, node_offsets, rank, world, group)
+        self.halo = HaloPlan(node_type_own, src_global, node_offsets, rank, world, group, n_chunks=n_chunks)
+        self.chunk_lists = self.halo.chunk_row_lists(num_types) if self.halo.n_chunks > 1 else None
         self.n_own, self.n_local = self.halo.n_own, self.halo.n_local
         self.edge_index = torch.stack([self.halo.src_local, dst_local], dim=0).contiguous()
         self.edge_type, self.edge_time = edge_type, edge_time
@@ -99,6 +169,22 @@ class PartitionedGraph:
             self.x_local = torch.empty(self.n_local, d, dtype=x_own.dtype, device=x_own.device)
         if x_own.data_ptr() != self.x_local.data_ptr():
             self.x_local[:self.n_own].copy_(x_own)
-        self.halo.exchange(self.x_local[:self.n_own], self.x_local)
-        return layer(self.x_local, self.node_type_local, self.edge_index, self.edge_type, self.edge_time,
-                     plan=self.plan, n_q_rows=self.n_own, phase_events=phase_events)
+        x_own_v = self.x_local[:self.n_own]
+        if self.chunk_lists is None:
+            self.halo.exchange(x_own_v, self.x_local)
+            return layer(self.x_local, self.node_type_local, self.edge_index, self.edge_type, self.edge_time,
+                         plan=self.plan, n_q_rows=self.n_own, phase_events=phase_events)
+        # pipelined: chunk c+1 is packed and put on the links while chunk c's halo rows are projected
+        args = (self.x_local, self.node_type_local, self.edge_index, self.edge_type, self.edge_time)
+        kw = dict(plan=self.plan, n_q_rows=self.n_own)
+        C = self.halo.n_chunks
+        pending = [self.halo.exchange_chunk(0, x_own_v, self.x_local, async_op=True)]
+        layer(*args, stage=1, phase_events=phase_events, **kw)            # Q|K|V of the own rows
+        for c in range(C):
+            if c + 1 < C:
+                pending.append(self.halo.exchange_chunk(c + 1, x_own_v, self.x_local, async_op=True))
+            work, send = pending[c]
+            work.wait()                                                   # current stream waits for chunk c
+            send.record_stream(torch.cuda.current_stream())
+            layer(*args, stage=2, proj=self.chunk_lists[c], **kw)         # K|V of the halo rows of chunk c
+        return layer(*args, stage=3, phase_events=phase_events, **kw)

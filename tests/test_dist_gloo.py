@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, N, E, d, T, R, H, offsets, tmpdir):
+def _worker(rank, world, port, N, E, d, T, R, H, offsets, tmpdir, n_chunks=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -33,7 +33,7 @@ def _worker(rank, world, port, N, E, d, T, R, H, offsets, tmpdir):
         lo, hi = offsets[rank], offsets[rank + 1]
         mine = (ei[1] >= lo) & (ei[1] < hi)                       # a rank owns ALL in-edges of its targets
         src_g, dst_l = ei[0][mine], ei[1][mine] - lo
-        hp = HaloPlan(nt[lo:hi], src_g, offsets, rank, world)
+        hp = HaloPlan(nt[lo:hi], src_g, offsets, rank, world, n_chunks=n_chunks)
         # structural checks
         assert hp.n_own == hi - lo and hp.n_local == hp.n_own + hp.n_halo
         assert sum(hp.recv_splits) == hp.n_halo and sum(hp.send_splits) == hp.send_rows.numel()
@@ -42,9 +42,25 @@ def _worker(rank, world, port, N, E, d, T, R, H, offsets, tmpdir):
         hp.exchange(x[lo:hi], x_local, pack=lambda xo, rows: xo.index_select(0, rows.long()))
         # halo rows are exactly the remote sources, deduplicated, with their features and types
         remote = torch.unique(src_g[(src_g < lo) | (src_g >= hi)])
+        assert torch.equal(hp.need, remote)
+        assert torch.equal(torch.sort(hp.halo_order).values, torch.arange(remote.numel()))     # a permutation
+        if n_chunks == 1:
+            assert torch.equal(hp.halo_order, torch.arange(remote.numel()))
+        remote = remote[hp.halo_order]                            # (chunk, peer, id) order of the halo rows
         assert torch.equal(x_local[hp.n_own:], x[remote])
         assert torch.equal(hp.node_type_local[hp.n_own:], nt[remote])
         assert torch.equal(x_local[hp.src_local], x[src_g])
+        # stage-2 row lists: every halo row of a valid type exactly once, grouped by type, chunk by chunk
+        seen = []
+        for c, (rows, off) in enumerate(hp.chunk_row_lists(T)):
+            a, b = hp.n_own + hp.recv_chunk_off[c], hp.n_own + hp.recv_chunk_off[c + 1]
+            assert off[0] == 0 and off[-1] == rows.numel() and ((rows >= a) & (rows < b)).all()
+            for t in range(T):
+                assert (hp.node_type_local[rows[off[t]:off[t + 1]].long()] == t).all()
+            seen.append(rows.long())
+        seen = torch.cat(seen)
+        valid = (hp.node_type_local[hp.n_own:] >= 0) & (hp.node_type_local[hp.n_own:] < T)
+        assert torch.equal(torch.sort(seen).values, hp.n_own + valid.nonzero(as_tuple=True)[0])
         # local layer (oracle) on [own; halo] == rows [lo,hi) of the global layer
         ei_local = torch.stack([hp.src_local, dst_l])
         out_local = O.forward_closed_form(sd, T, R, H, x_local, hp.node_type_local, ei_local, et[mine], tm[mine])
@@ -56,10 +72,11 @@ def _worker(rank, world, port, N, E, d, T, R, H, offsets, tmpdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,offsets", [(2, [0, 300, 600]), (3, [0, 150, 380, 600])])
-def test_partitioned_forward_equals_global(world, offsets, tmp_path):
+@pytest.mark.parametrize("world,offsets,n_chunks", [(2, [0, 300, 600], 1), (3, [0, 150, 380, 600], 1), (3, [0, 150, 380, 600], 4),
+                                                    (2, [0, 300, 600], 7)])
+def test_partitioned_forward_equals_global(world, offsets, n_chunks, tmp_path):
     N, E, d, T, R, H = 600, 5000, 32, 3, 4, 4
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, N, E, d, T, R, H, offsets, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, N, E, d, T, R, H, offsets, str(tmp_path), n_chunks), nprocs=world, join=True)
     for r in range(world):
         assert os.path.isfile(os.path.join(str(tmp_path), "ok%d.pt" % r))

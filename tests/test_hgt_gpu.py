@@ -248,6 +248,42 @@ def test_source_only_halo_rows(precision):
     assert (out.cpu().double() - ref[:NQ]).abs().max().item() < TOL
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("use_RTE", [False, True])
+def test_staged_forward_equals_whole_layer(precision, use_RTE):
+    """hgt_conv_forward stages 1 / 2 / 3 (the pipelined multi-GPU step of pyhgt_amd/dist.py): own-row projections, K|V
+    of the halo rows chunk by chunk (typed row lists, some halo rows of unknown type), then the edge phase -- must give
+    bit-identical output to the one-call layer on the same [own ; halo] buffer."""
+    T, R, H, d, N, NQ, E = 3, 4, 4, 64, 3000, 1100, 20000
+    sd = O.make_state_dict(d, d, T, R, H, True, use_RTE, seed=41)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=42, sorted_types=False)
+    ei = ei.clone(); nt = nt.clone()
+    ei[1] = ei[1] % NQ
+    nt[NQ + 5::37] = T + 2                                # halo rows of unknown type get no projection
+    layer = _layer_from(sd, d, T, R, H, True, use_RTE, keep_att=False, precision=precision)
+    xd, ntd, eid, etd, tmd = _to_dev(x, nt, ei, et, tm if use_RTE else None)
+    GraphPlan.clear_cache()
+    with torch.no_grad():
+        whole = layer(xd, ntd, eid, etd, tmd, n_q_rows=NQ).clone()
+        # three chunks of the halo rows [NQ, N), each as a typed row list
+        bounds = [NQ, NQ + 500, NQ + 1300, N]
+        layer(xd, ntd, eid, etd, tmd, n_q_rows=NQ, stage=1)
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            tt = ntd[a:b]
+            valid = (tt >= 0) & (tt < T)
+            key = torch.where(valid, tt, torch.full_like(tt, T))
+            order = torch.argsort(key, stable=True)
+            rows = (a + order[:int(valid.sum())]).to(torch.int32).contiguous()
+            off = torch.zeros(T + 1, dtype=torch.int64, device=DEV)
+            off[1:] = torch.cumsum(torch.bincount(key, minlength=T + 1)[:T], 0)
+            layer(xd, ntd, eid, etd, tmd, n_q_rows=NQ, stage=2, proj=(rows, off.to(torch.int32)))
+        staged = layer(xd, ntd, eid, etd, tmd, n_q_rows=NQ, stage=3)
+    torch.cuda.synchronize()
+    assert torch.equal(whole, staged)
+    ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, use_RTE=use_RTE, dtype=torch.float64)
+    assert (staged.cpu().double() - ref[:NQ]).abs().max().item() < TOL
+
+
 def test_partitioned_graph_on_gpu_single_rank():
     """pyhgt_amd.dist on the real device path (RCCL all_to_all_single, HIP halo pack) with world_size 1;
     world_size 2/3 index logic is covered on CPU over gloo (tests/test_dist_gloo.py)."""
@@ -269,11 +305,12 @@ def test_partitioned_graph_on_gpu_single_rank():
         ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, dtype=torch.float64)
         layer = _layer_from(sd, d, T, R, H, True, True, keep_att=False)
         xs, nts, eis, ets, tms = _to_dev(x, nt, ei, et, tm)
-        pg = PartitionedGraph(nts, eis[0].contiguous(), eis[1].contiguous(), ets, tms, T, R, N, 0, 1)
-        assert pg.n_own == N and pg.n_local == N
-        with torch.no_grad():
-            out = pg.forward(layer, xs)
-        assert (out.cpu().double() - ref).abs().max().item() < TOL
+        for n_chunks in (1, 3):      # 3: the pipelined step (async all-to-all per chunk + stages 1/2/3), chunks empty here
+            pg = PartitionedGraph(nts, eis[0].contiguous(), eis[1].contiguous(), ets, tms, T, R, N, 0, 1, n_chunks=n_chunks)
+            assert pg.n_own == N and pg.n_local == N
+            with torch.no_grad():
+                out = pg.forward(layer, xs)
+            assert (out.cpu().double() - ref).abs().max().item() < TOL
     finally:
         dist.destroy_process_group()
 
