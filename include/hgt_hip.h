@@ -287,6 +287,14 @@ typedef struct hgt_conv_args {
     const int32_t* proj_rows;
     const int32_t* proj_off;
     int64_t proj_n;              /* number of rows in proj_rows (host value)   */
+    /* Weight-only preprocessing kept across calls (inference with fixed parameters: the reference re-derives nothing
+     * per call either): packed relation matrices, split-bf16 tiles of W_qkv and W_a, temporal tables RTE_K / RTE_V.
+     * `prepared` = caller-owned device buffer of hgt_conv_prepared_bytes() bytes that belongs to ONE parameter set;
+     * prepared_valid = 0 -> this call fills it, 1 -> this call trusts it (the caller resets it to 0 whenever a
+     * parameter, the precision or the buffer changed).  NULL = recompute into the workspace every call. */
+    void* prepared;
+    uint64_t prepared_bytes;
+    int32_t prepared_valid;
 } hgt_conv_args;
 
 /* phase boundaries at which hgt_conv_forward records phase_events[i]:
@@ -297,6 +305,8 @@ typedef struct hgt_conv_args {
 int hgt_conv_workspace_bytes(int64_t n_nodes, int64_t n_edges, int32_t in_dim, int32_t out_dim,
                              int32_t n_types, int32_t n_relations, int32_t n_heads, int32_t use_rte,
                              uint64_t* out_host);
+int hgt_conv_prepared_bytes(int32_t in_dim, int32_t out_dim, int32_t n_types, int32_t n_relations, int32_t n_heads,
+                            int32_t use_rte, uint64_t* out_host);
 int hgt_conv_forward(const hgt_conv_args* args_host, void* stream);
 
 #ifdef __cplusplus

@@ -45,6 +45,7 @@ class HgtConvArgs(C.Structure):
         ("mid_w", C.c_void_p), ("mid_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p),
         ("out_ln_w", C.c_void_p), ("out_ln_b", C.c_void_p),
         ("stage", C.c_int32), ("proj_rows", C.c_void_p), ("proj_off", C.c_void_p), ("proj_n", C.c_int64),
+        ("prepared", C.c_void_p), ("prepared_bytes", C.c_uint64), ("prepared_valid", C.c_int32),
     ]
 
 
@@ -81,6 +82,7 @@ SIGNATURES = {
     "hgt_tanh_inplace": (C.c_int, [_vp, _i64, _vp]),
     "hgt_gather_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "hgt_conv_workspace_bytes": (C.c_int, [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_u64)]),
+    "hgt_conv_prepared_bytes": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_u64)]),
     "hgt_conv_forward": (C.c_int, [C.POINTER(HgtConvArgs), _vp]),
 }
 

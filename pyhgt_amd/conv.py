@@ -190,6 +190,9 @@ class HGTConv(nn.Module):
             self.emb = RelTemporalEncoding(in_dim)
         self._packed = None
         self._packed_key = None
+        self._prepared = None
+        self._prepared_tag = None
+        self._prepared_valid = False
 
     _UPDATE_MODE = 0     # hgt_conv_args.update_mode
 
@@ -245,7 +248,21 @@ class HGTConv(nn.Module):
                               rte_b=self.emb.lin.bias.detach().float().contiguous())
         assert w_qkv.shape == (T, 3 * dp, din) and w_a.shape == (T, dout, dp)
         self._packed, self._packed_key = packed, key
+        self._prepared_valid = False      # the device-side weight images (hgt_conv_args.prepared) are stale now
         return packed
+
+    def _prepared_buffer(self, device):
+        """Per-layer device buffer for the weight-only preprocessing hgt_conv_forward keeps across calls (packed relation
+        matrices, split-bf16 weight tiles, temporal tables): valid until a parameter, the precision or the device changes."""
+        key = (str(device), self.precision)
+        if getattr(self, "_prepared", None) is None or self._prepared_tag != key:
+            n = C.c_uint64()
+            _lib.check(_lib.load().hgt_conv_prepared_bytes(self.in_dim, self.out_dim, self.num_types, self.num_relations,
+                                                          self.n_heads, int(self.use_RTE), C.byref(n)), "hgt_conv_prepared_bytes")
+            self._prepared = torch.empty(max(int(n.value), 256), dtype=torch.uint8, device=device)
+            self._prepared_tag = key
+            self._prepared_valid = False
+        return self._prepared
 
     # ------------------------------------------------------------------------------------------
     def forward(self, node_inp, node_type, edge_index, edge_type, edge_time=None, plan=None, n_q_rows=None,
@@ -310,6 +327,8 @@ class HGTConv(nn.Module):
         a.out, a.att_out = _ptr(out) if final else _ptr(ws), _ptr(att)   # stages 1/2 write no output (non-NULL placeholder)
         a.want_att = int(self.keep_att and final)
         a.stage = int(stage)
+        prep = self._prepared_buffer(x.device)          # after _pack_parameters: a re-pack has invalidated it
+        a.prepared, a.prepared_bytes, a.prepared_valid = _ptr(prep), prep.numel(), int(self._prepared_valid)
         if stage == 2:
             rows, off = proj
             if rows.dtype != torch.int32 or off.dtype != torch.int32 or off.numel() != self.num_types + 1:
@@ -320,6 +339,7 @@ class HGTConv(nn.Module):
         _lib.check(lib.hgt_conv_forward(C.byref(a), _stream()), "hgt_conv_forward")
         if final:
             self.att = att
+            self._prepared_valid = True                 # every image was written by this forward (or an earlier one)
         return out
 
     def __repr__(self):

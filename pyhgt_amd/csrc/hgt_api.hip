@@ -52,6 +52,26 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
     return w;
 }
 
+struct PreparedLayout {
+    uint64_t off_att_t, off_msg_p, off_ws_qkv, off_ws_upd, off_rte_k, off_rte_v, total;
+};
+
+static PreparedLayout prepared_layout(int in_dim, int out_dim, int T, int R, int H, int use_rte, const hgt_layout& lay) {
+    PreparedLayout p;
+    uint64_t o = 0, b = 0;
+    auto take = [&](uint64_t bytes) { uint64_t r = o; o = hgt_align_up(o + bytes, 256); return r; };
+    p.off_att_t = take((uint64_t)R * H * lay.dk_pad * lay.dk_pad * 4);
+    p.off_msg_p = take((uint64_t)R * H * lay.dk_pad * lay.dk_pad * 4);
+    hgt_split_weights_bytes(T, in_dim, 3 * lay.d_pad, &b);
+    p.off_ws_qkv = take(b);
+    hgt_split_weights_bytes(T, lay.d_pad, out_dim, &b);
+    p.off_ws_upd = take(b);
+    p.off_rte_k = take(use_rte ? (uint64_t)T * HGT_RTE_LEN * lay.d_pad * 4 : 0);
+    p.off_rte_v = take(use_rte ? (uint64_t)T * HGT_RTE_LEN * lay.d_pad * 4 : 0);
+    p.total = o;
+    return p;
+}
+
 // off2 = {0, off_q[T]}: all rows of a valid type as ONE group (the shared dense layer of DenseHGTConv)
 __global__ void k_single_group(const int32_t* __restrict__ off_q, int T, int32_t* __restrict__ off2) {
     if (threadIdx.x == 0) { off2[0] = 0; off2[1] = off_q[T]; }
@@ -98,6 +118,16 @@ extern "C" int hgt_conv_workspace_bytes(int64_t n_nodes, int64_t n_edges, int32_
     return HGT_OK;
 }
 
+extern "C" int hgt_conv_prepared_bytes(int32_t in_dim, int32_t out_dim, int32_t n_types, int32_t n_relations, int32_t n_heads,
+                                       int32_t use_rte, uint64_t* out) {
+    if (!out || in_dim <= 0 || n_types <= 0 || n_relations <= 0) return HGT_ERR_INVALID_ARG;
+    hgt_layout lay;
+    int rc = hgt_layout_for(out_dim, n_heads, &lay);
+    if (rc != HGT_OK) return rc;
+    *out = prepared_layout(in_dim, out_dim, n_types, n_relations, n_heads, use_rte, lay).total;
+    return HGT_OK;
+}
+
 extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     if (!a) return HGT_ERR_INVALID_ARG;
     hipStream_t stream = (hipStream_t)stream_;
@@ -132,6 +162,15 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     float* msg_p = (float*)(wb + w.off_msg_p);
     float* rte_k = nullptr;
     float* rte_v = nullptr;
+    // weight-only preprocessing: in the caller's `prepared` buffer (kept across calls) or in the workspace (every call)
+    char* pb = (char*)a->prepared;
+    PreparedLayout pl = prepared_layout(din, dout, T, R, H, a->use_rte, lay);
+    if (pb && a->prepared_bytes < pl.total) return HGT_ERR_WORKSPACE;
+    const bool fresh = !(pb && a->prepared_valid);          // derive the weight images in this call
+    if (pb) {
+        att_t = (float*)(pb + pl.off_att_t);
+        msg_p = (float*)(pb + pl.off_msg_p);
+    }
 
     auto mark = [&](int i) {
         if (a->phase_events && a->phase_events[i]) (void)hipEventRecord((hipEvent_t)a->phase_events[i], stream);
@@ -145,7 +184,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     if (rc != HGT_OK) return rc;
 
     // (1) relation matrices: fold pri/sqrt(dk), transpose att, zero-pad heads (conv.py:98-99,104)
-    if (stage == 0 || stage == 1) {
+    if ((stage == 0 || stage == 1) && fresh) {
         rc = hgt_relation_pack(a->relation_att, a->relation_msg, a->relation_pri, R, H, lay.d_k, lay.dk_pad, att_t, msg_p, stream);
         if (rc != HGT_OK) return rc;
     }
@@ -154,17 +193,21 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     const bool split = (a->precision == 1);
     auto linear = [&](const float* xin, int64_t ldx, const int32_t* rws, const int32_t* goff, int ng, int64_t nrows, int kk, int nout,
                       const float* Wp, int64_t wgs, const float* bp, int64_t bgs, float* o0, float* o1, float* o2, int bcols,
-                      int by_pos, void* wsplit, int prologue = 0) -> int {
+                      int by_pos, void* wsplit, int prologue = 0, bool tiles_ready = false) -> int {
         if (!split)
             return hgt_typed_linear(xin, ldx, rws, goff, ng, nrows, kk, nout, Wp, wgs, bp, bgs, o0, o1, o2, bcols, by_pos, prologue, 0, stream);
         if (((nout | bcols) & 3) != 0)   // the split kernel stores 16 B per lane: odd widths take the exact fp32 kernel
             return hgt_typed_linear(xin, ldx, rws, goff, ng, nrows, kk, nout, Wp, wgs, bp, bgs, o0, o1, o2, bcols, by_pos, prologue, 0, stream);
-        int r2 = hgt_split_weights(Wp, wgs, ng, kk, nout, wsplit, stream);
-        if (r2 != HGT_OK) return r2;
+        if (!tiles_ready) {
+            int r2 = hgt_split_weights(Wp, wgs, ng, kk, nout, wsplit, stream);
+            if (r2 != HGT_OK) return r2;
+        }
         return hgt_typed_linear_bf16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos, prologue, stream);
     };
-    void* ws_qkv = wb + w.off_ws_qkv;
-    void* ws_a = wb + w.off_ws_a;
+    void* ws_qkv_scratch = wb + w.off_ws_qkv;                       // K|V-only tiles of the halo branch
+    void* ws_qkv = pb ? (void*)(pb + pl.off_ws_qkv) : ws_qkv_scratch; // tiles of the full [Q|K|V] weight
+    void* ws_a = wb + w.off_ws_a;                                     // scratch tiles (Q-only, K|V, temporal, dense layer)
+    void* ws_upd = pb ? (void*)(pb + pl.off_ws_upd) : ws_a;           // tiles of W_a
 
     // (2) typed projections once per NODE (conv.py:96-97,103 did them per edge)
     const int64_t wstride = (int64_t)3 * dp * din;
@@ -175,10 +218,10 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     }
     if (stage == 3) goto edge_phase;
     if (stage == 1) {   // own rows only: one fused Q|K|V launch, exactly like the single-GPU layer
-        rc = linear(a->x, din, pr.rows_q, pr.off_q, T, NQ, din, 3 * dp, a->w_qkv, wstride, a->b_qkv, 3 * dp, Q, K, V, dp, 0, ws_qkv);
+        rc = linear(a->x, din, pr.rows_q, pr.off_q, T, NQ, din, 3 * dp, a->w_qkv, wstride, a->b_qkv, 3 * dp, Q, K, V, dp, 0, ws_qkv, 0, !fresh);
         if (rc != HGT_OK) return rc;
     } else if (NQ == N) {
-        rc = linear(a->x, din, pr.rows_all, pr.off_all, T, N, din, 3 * dp, a->w_qkv, wstride, a->b_qkv, 3 * dp, Q, K, V, dp, 0, ws_qkv);
+        rc = linear(a->x, din, pr.rows_all, pr.off_all, T, N, din, 3 * dp, a->w_qkv, wstride, a->b_qkv, 3 * dp, Q, K, V, dp, 0, ws_qkv, 0, !fresh);
         if (rc != HGT_OK) return rc;
     } else {
         // halo rows (>= NQ) only need K and V.  The split tiles of the full [Q|K|V] weight serve both launches:
@@ -186,15 +229,19 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
         rc = linear(a->x, din, pr.rows_q, pr.off_q, T, NQ, din, dp, a->w_qkv, wstride, a->b_qkv, 3 * dp, Q, nullptr, nullptr, dp, 0, ws_a);
         if (rc != HGT_OK) return rc;
         rc = linear(a->x, din, pr.rows_all, pr.off_all, T, N, din, 2 * dp, a->w_qkv + (int64_t)dp * din, wstride, a->b_qkv + dp, 3 * dp,
-                    K, V, nullptr, dp, 0, ws_qkv);
+                    K, V, nullptr, dp, 0, ws_qkv_scratch);
         if (rc != HGT_OK) return rc;
+        if (pb && fresh && split) {   // keep the prepared buffer complete: a later call may be a whole-graph or staged one
+            rc = hgt_split_weights(a->w_qkv, wstride, T, din, 3 * dp, ws_qkv, stream);
+            if (rc != HGT_OK) return rc;
+        }
     }
 
     // (3) temporal tables: rte_k[t][p] = (emb[p] W_rte^T + b_rte) W_k[t]^T  (conv.py:91-92,298-299 hoisted off the edges)
-    if (a->use_rte) {
+    if (a->use_rte && fresh) {
         float* rte_lin = (float*)(wb + w.off_rte_lin);
-        rte_k = (float*)(wb + w.off_rte_k);
-        rte_v = (float*)(wb + w.off_rte_v);
+        rte_k = pb ? (float*)(pb + pl.off_rte_k) : (float*)(wb + w.off_rte_k);
+        rte_v = pb ? (float*)(pb + pl.off_rte_v) : (float*)(wb + w.off_rte_v);
         int32_t* rrows = (int32_t*)(wb + w.off_rte_rows);
         int32_t* roff = (int32_t*)(wb + w.off_rte_off);
         const int nthr = T * HGT_RTE_LEN;
@@ -202,7 +249,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
         rc = linear(a->rte_emb, din, rrows, roff, 1, HGT_RTE_LEN, din, din, a->rte_w, 0, a->rte_b, 0, rte_lin, nullptr, nullptr, din, 1,
                     wb + w.off_ws_rte);
         if (rc != HGT_OK) return rc;
-        // the K|V split tiles are already in ws_qkv only when NQ == N used the full 3*dp weight; re-split the K|V part (tiny)
+        // K|V part of the weight, split again for this 2-output launch (tiny)
         rc = linear(rte_lin, din, rrows, roff, T, (int64_t)T * HGT_RTE_LEN, din, 2 * dp, a->w_qkv + (int64_t)dp * din, wstride, nullptr, 0,
                     rte_k, rte_v, nullptr, dp, 1, ws_a);
         if (rc != HGT_OK) return rc;
@@ -210,9 +257,9 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
 
     if (stage == 1) return HGT_OK;
 edge_phase:
-    if (a->use_rte) {   // (stage 3 re-derives the pointers stage 1 filled)
-        rte_k = (float*)(wb + w.off_rte_k);
-        rte_v = (float*)(wb + w.off_rte_v);
+    if (a->use_rte) {   // (also for stage 3 and for calls that trust the prepared tables)
+        rte_k = pb ? (float*)(pb + pl.off_rte_k) : (float*)(wb + w.off_rte_k);
+        rte_v = pb ? (float*)(pb + pl.off_rte_v) : (float*)(wb + w.off_rte_v);
     }
     mark(1);
     // (4) edge phase: logits, then softmax fused into the aggregation (online, per target sub-tile)
@@ -225,11 +272,13 @@ edge_phase:
     // (5) aggregation + update.  Preferred form: one kernel that never writes agg (hgt_edge_aggregate_update).
     const bool fuse_all = split && !dense && dp <= 256 && dout <= dp && (dout & 3) == 0 && (din & 3) == 0 && !getenv("HGT_NO_FUSE_AGG");
     if (fuse_all) {
-        rc = hgt_split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_a, stream);
-        if (rc != HGT_OK) return rc;
+        if (fresh || !pb) {
+            rc = hgt_split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
+            if (rc != HGT_OK) return rc;
+        }
         rc = hgt_edge_aggregate_update(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ,
                                        getenv("HGT_NO_HUB") ? nullptr : (void*)(wb + w.off_hub), (int32_t*)(wb + w.off_pending), a->node_type,
-                                       ws_a, a->b_a, a->x, din, a->skip, a->ln_w, a->ln_b, a->use_norm, dout, a->out, stream);
+                                       ws_upd, a->b_a, a->x, din, a->skip, a->ln_w, a->ln_b, a->use_norm, dout, a->out, stream);
         if (rc == HGT_OK) {
             if (a->want_att && E > 0) {
                 rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);
@@ -280,9 +329,11 @@ edge_phase:
         // out = out_norm(out_linear(...) + y1), in place over y1
         rc = hgt_node_update_ex(trans, a->out, dout, a->node_type, nullptr, a->out_ln_w, a->out_ln_b, 1, 1, NQ, dout, T, a->out, stream);
     } else if (fuse_update) {
-        rc = hgt_split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_a, stream);
-        if (rc != HGT_OK) return rc;
-        rc = hgt_linear_update_bf16x3(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, ws_a, a->b_a, dout, a->x, din, a->skip, a->ln_w,
+        if (fresh || !pb) {
+            rc = hgt_split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
+            if (rc != HGT_OK) return rc;
+        }
+        rc = hgt_linear_update_bf16x3(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, ws_upd, a->b_a, dout, a->x, din, a->skip, a->ln_w,
                                       a->ln_b, a->use_norm, a->out, stream);
         if (rc != HGT_OK) return rc;
         mark(5);

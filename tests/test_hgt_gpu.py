@@ -116,6 +116,32 @@ def test_dense_hgt_conv_matches_oracle(case, precision):
     assert out[nt == T + 1].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_prepared_weight_images_follow_parameter_updates(precision):
+    """hgt_conv_args.prepared keeps the weight-only preprocessing (packed relation matrices, split weight tiles, temporal
+    tables) across calls; it must be rebuilt when any parameter changes in place and reused (bit-identical output) when
+    nothing changed."""
+    T, R, H, d, N, E = 3, 4, 4, 64, 1500, 12000
+    sd = O.make_state_dict(d, d, T, R, H, True, True, seed=61)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=62)
+    layer = _layer_from(sd, d, T, R, H, True, True, keep_att=False, precision=precision)
+    out1, _ = _run(layer, x, nt, ei, et, tm)
+    out2, _ = _run(layer, x, nt, ei, et, tm)                    # second call trusts the prepared buffer
+    assert torch.equal(out1, out2)
+    assert (out1.double() - O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, dtype=torch.float64)).abs().max().item() < TOL
+    with torch.no_grad():                                        # in-place updates of every kind of cached parameter
+        layer.relation_pri.mul_(1.7)
+        layer.relation_msg.add_(0.05)
+        layer.k_linears[1].weight.mul_(0.8)
+        layer.a_linears[0].weight.add_(0.02)
+        layer.emb.lin.bias.add_(0.1)
+    sd2 = {k: v.detach().cpu().clone() for k, v in layer.state_dict().items()}
+    out3, _ = _run(layer, x, nt, ei, et, tm)
+    ref3 = O.forward_closed_form(sd2, T, R, H, x, nt, ei, et, tm, dtype=torch.float64)
+    assert (out3.double() - ref3).abs().max().item() < TOL
+    assert (out3 - out1).abs().max().item() > 1e-3             # the update really changed the result
+
+
 def test_large_logit_spread_forces_softmax_rereference():
     """The aggregation kernel re-references its running softmax only when a logit exceeds the segment's reference by
     more than 40 (deferred rescaling).  Blow the logits up (relation_pri x 60, multi-edge segments via few targets)
