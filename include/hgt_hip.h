@@ -82,6 +82,9 @@ int hgt_plan_sizes_for(int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_
                        hgt_plan_sizes* out_host);
 /* build-time constants of the plan: destination tile size and the edge cap of one work item */
 int hgt_plan_constants(int32_t* tile_nodes_host, int32_t* item_edges_host);
+/* edges per logits work item for a graph of n_edges edges (<= the maximum hgt_plan_constants reports; smaller for small
+ * graphs so that enough wavefronts exist) */
+int hgt_plan_item_edges(int64_t n_edges, int32_t* item_edges);
 
 /* Row lists exported by a built plan (device pointers INTO the plan buffer), for hgt_typed_linear:
  *   rows_all / off_all : all n_nodes nodes stably sorted by type, int32[n_nodes] / int32[T+2]

@@ -58,6 +58,7 @@ SIGNATURES = {
     "hgt_layout_for": (C.c_int, [_i32, _i32, C.POINTER(HgtLayout)]),
     "hgt_plan_sizes_for": (C.c_int, [_i64, _i64, _i32, _i32, C.POINTER(HgtPlanSizes)]),
     "hgt_plan_constants": (C.c_int, [C.POINTER(_i32), C.POINTER(_i32)]),
+    "hgt_plan_item_edges": (C.c_int, [_i64, C.POINTER(_i32)]),
     "hgt_plan_row_lists": (C.c_int, [_vp, _i64, _i64, _i32, _i32, C.POINTER(HgtPlanRows)]),
     "hgt_plan_build": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _u64, _vp, _u64, _vp]),
     "hgt_typed_linear": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp,

@@ -270,7 +270,10 @@ edge_phase:
     mark(2);
     mark(3);
     // (5) aggregation + update.  Preferred form: one kernel that never writes agg (hgt_edge_aggregate_update).
-    const bool fuse_all = split && !dense && dp <= 256 && dout <= dp && (dout & 3) == 0 && (din & 3) == 0 && !getenv("HGT_NO_FUSE_AGG");
+    // (graphs below 64k targets take the unfused kernels: hgt_edge_aggregate then runs 4 targets per wavefront, which
+    //  matters more in the latency regime than the saved agg round trip)
+    const bool fuse_all = split && !dense && dp <= 256 && dout <= dp && (dout & 3) == 0 && (din & 3) == 0 && NQ >= 65536 &&
+                          !getenv("HGT_NO_FUSE_AGG");
     if (fuse_all) {
         if (fresh || !pb) {
             rc = hgt_split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);

@@ -38,6 +38,14 @@ struct __attribute__((aligned(16))) HgtItem {
     int32_t beg, end, rel, tile;
 };
 
+// Edges per logits work item.  HGT_CH for large graphs; small graphs (the sampled subgraphs of the reference: E ~ 30k)
+// get shorter items so that there are a few thousand wavefronts instead of ~100 walking 512 edges each one after the other.
+static inline int hgt_item_edges(int64_t E) {
+    int ch = HGT_CH;
+    while (ch > 64 && E / ch < 4096) ch >>= 1;
+    return ch;
+}
+
 // Byte offsets of the arrays inside the plan buffer; a pure function of (N, E, T, R).
 struct HgtPlanLayout {
     uint64_t off_hdr, off_esrc, off_edst, off_ertei, off_eid, off_segptr, off_items, off_tile_items;
@@ -50,7 +58,7 @@ static inline HgtPlanLayout hgt_plan_layout(int64_t N, int64_t E, int32_t T, int
     L.n_tiles = (N + HGT_TD - 1) / HGT_TD;
     L.n_pairs = L.n_tiles * (R + 1);
     L.n_bins = L.n_pairs * HGT_TD;
-    L.max_items = L.n_pairs + E / HGT_CH + 1;
+    L.max_items = L.n_pairs + E / hgt_item_edges(E) + 1;
     uint64_t o = 0;
     auto take = [&](uint64_t bytes) { uint64_t r = o; o = hgt_align_up(o + bytes, 256); return r; };
     L.off_hdr = take(sizeof(HgtPlanHeader));

@@ -272,7 +272,9 @@ __device__ __forceinline__ void aggregate_subtile(
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
     const float* __restrict__ rteV, const float* __restrict__ msgP, float* __restrict__ agg, int R, int64_t NQ, int apply_gelu,
     int HT, unsigned hub_mask, float (&s_acc)[4][16 * 64 * VEC], float (&s_bounce)[4][64 * VEC + 4 * (64 / LPH)], float (&s_ml)[4][2][16 * 16],
-    float (&rowvals)[FUSE ? 16 : 1][VEC]) {
+    float (&rowvals)[FUSE ? 16 : 1][VEC], int sub_rt = HGT_SUB) {
+    // targets per wavefront: HGT_SUB, or fewer (a divisor of it) on small graphs so that more wavefronts exist
+    const int SUBR = FUSE ? HGT_SUB : sub_rt;
     constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = RTE ? unroll_for<VEC>() / 2 : unroll_for<VEC>();
     const int hg = blockIdx.y;              // head group (see k_edge_logits)
     const int64_t ld = (int64_t)HT * DKP;
@@ -282,7 +284,7 @@ __device__ __forceinline__ void aggregate_subtile(
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // a workgroup covers 64 consecutive targets (4 waves x 16); the plan's destination tile may be larger
-    const int64_t row0 = (int64_t)blockIdx.x * 64 + wib * HGT_SUB;
+    const int64_t row0 = (int64_t)blockIdx.x * (4 * SUBR) + wib * SUBR;
     if (row0 >= NQ) {
         if constexpr (FUSE) {
 #pragma unroll
@@ -308,12 +310,12 @@ __device__ __forceinline__ void aggregate_subtile(
     for (int rel = 0; rel <= R; ++rel) {
       const int64_t b0 = ((int64_t)tile * (R + 1) + rel) * HGT_TD + within;
       // maximal runs [dl0, dl1) of non-hub targets: one run covering the whole sub-tile unless it contains a hub
-      for (int dl0 = 0; dl0 < HGT_SUB;) {
-        int dl1 = HGT_SUB;
+      for (int dl0 = 0; dl0 < SUBR;) {
+        int dl1 = SUBR;
         if constexpr (HUBS) {
             if ((hub_mask >> dl0) & 1u) { ++dl0; continue; }
             dl1 = dl0 + 1;
-            while (dl1 < HGT_SUB && !((hub_mask >> dl1) & 1u)) ++dl1;
+            while (dl1 < SUBR && !((hub_mask >> dl1) & 1u)) ++dl1;
         }
         const int beg = __builtin_amdgcn_readfirstlane(segptr[b0 + dl0]);
         const int end = __builtin_amdgcn_readfirstlane(segptr[b0 + dl1]);
@@ -440,7 +442,7 @@ __device__ __forceinline__ void aggregate_subtile(
         return;
     }
     // write-out: normalise, un-permute the planar layout, one coalesced row store per wave instruction
-    for (int r = 0; r < HGT_SUB; ++r) {
+    for (int r = 0; r < SUBR; ++r) {
         const int64_t row = row0 + r;
         if (row >= NQ) break;
         if (HUBS && ((hub_mask >> r) & 1u)) continue;   // written by k_hub_finalize
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
     const float* __restrict__ rteV, const float* __restrict__ msgP, float* __restrict__ agg, int R, int64_t NQ, int apply_gelu,
-    int HT, const int32_t* __restrict__ hub_slot) {
+    int HT, const int32_t* __restrict__ hub_slot, int sub) {
     __shared__ __attribute__((aligned(16))) float s_acc[4][16 * 64 * VEC];
     __shared__ __attribute__((aligned(16))) float s_bounce[4][64 * VEC + 4 * (64 / LPH)];
     __shared__ float s_ml[4][2][16 * 16];   // running max / sum per (target, head); H <= 16
@@ -478,17 +480,17 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(
     unsigned hub_mask = 0;
     if (hub_slot) {
         const int lane = threadIdx.x & 63;
-        const int64_t rr = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 6) * 16 + (lane & 15);
-        const bool is_hub = (lane < 16) && (rr < NQ) && (hub_slot[rr] >= 0);
+        const int64_t rr = (int64_t)blockIdx.x * (4 * sub) + (threadIdx.x >> 6) * sub + (lane & 15);
+        const bool is_hub = (lane < sub) && (rr < NQ) && (hub_slot[rr] >= 0);
         hub_mask = (unsigned)(__builtin_amdgcn_ballot_w64(is_hub) & 0xFFFFull);
     }
     float no_rowvals[1][VEC];
     if (hub_mask == 0)
         aggregate_subtile<VEC, LPH, RTE, false>(segptr, esrc, edst, ertei, logits, V, rteV, msgP, agg, R, NQ, apply_gelu, HT, 0u, s_acc,
-                                                s_bounce, s_ml, no_rowvals);
+                                                s_bounce, s_ml, no_rowvals, sub);
     else
         aggregate_subtile<VEC, LPH, RTE, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgP, agg, R, NQ, apply_gelu, HT, hub_mask,
-                                               s_acc, s_bounce, s_ml, no_rowvals);
+                                               s_acc, s_bounce, s_ml, no_rowvals, sub);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1052,16 +1054,19 @@ template <int VEC, int LPH>
 struct LaunchAggregate {
     static int run(const HgtPlanView& pv, const float* logits, const float* V, const float* rteV, const float* msgP, float* agg,
                    int R, int64_t NQ, int apply_gelu, int HT, HubBuffers hb, hipStream_t stream) {
-        const int64_t tiles = (NQ + 63) / 64;
+        // small graphs (the reference's sampled subgraphs): 4 instead of 16 targets per wavefront -> 4x the wavefronts, each
+        // with a quarter of the serial edge walk (c3 surrogate, N = 2.5k: 150 -> 60 us)
+        const int sub = (NQ < 65536) ? 4 : HGT_SUB;
+        const int64_t tiles = (NQ + 4 * sub - 1) / (4 * sub);
         const unsigned ny = (unsigned)(HT / (64 / LPH));
         dim3 grid((unsigned)tiles, ny);
         const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
         if (rteV)
             k_edge_aggregate<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgP, agg, R,
-                                                                       NQ, apply_gelu, HT, hub_slot);
+                                                                       NQ, apply_gelu, HT, hub_slot, sub);
         else
             k_edge_aggregate<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgP, agg, R,
-                                                                        NQ, apply_gelu, HT, hub_slot);
+                                                                        NQ, apply_gelu, HT, hub_slot, sub);
         if (hb.mx) {   // hub path: a fixed grid, every wave returns at once when the plan has no hub
             const int dkp = VEC * LPH;
             const int64_t cells = (int64_t)pv.L.max_hubs * (2 * HT + HT * dkp);

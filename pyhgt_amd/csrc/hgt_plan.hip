@@ -121,15 +121,15 @@ __global__ void k_segptr(const uint32_t* __restrict__ keys_sorted, int64_t E, in
     segptr[b] = (int32_t)lo;
 }
 
-__global__ void k_pair_counts(const int32_t* __restrict__ segptr, int64_t n_pairs, int32_t* __restrict__ cnt) {
+__global__ void k_pair_counts(const int32_t* __restrict__ segptr, int64_t n_pairs, int ch, int32_t* __restrict__ cnt) {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j > n_pairs) return;
     if (j == n_pairs) { cnt[j] = 0; return; }
     int32_t len = segptr[(j + 1) * HGT_TD] - segptr[j * HGT_TD];
-    cnt[j] = (len + HGT_CH - 1) / HGT_CH;
+    cnt[j] = (len + ch - 1) / ch;
 }
 
-__global__ void k_items(const int32_t* __restrict__ segptr, const int32_t* __restrict__ pair_off, int64_t n_pairs, int R,
+__global__ void k_items(const int32_t* __restrict__ segptr, const int32_t* __restrict__ pair_off, int64_t n_pairs, int R, int ch,
                         HgtItem* __restrict__ items, int32_t* __restrict__ tile_items, HgtPlanHeader* hdr) {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j > n_pairs) return;
@@ -138,10 +138,10 @@ __global__ void k_items(const int32_t* __restrict__ segptr, const int32_t* __res
     int32_t beg = segptr[j * HGT_TD], end = segptr[(j + 1) * HGT_TD];
     int32_t o = pair_off[j];
     int32_t rel = (int32_t)(j % (R + 1)), tile = (int32_t)(j / (R + 1));
-    for (int32_t b = beg; b < end; b += HGT_CH) {
+    for (int32_t b = beg; b < end; b += ch) {
         HgtItem it;
         it.beg = b;
-        it.end = (b + HGT_CH < end) ? b + HGT_CH : end;
+        it.end = (b + ch < end) ? b + ch : end;
         it.rel = rel;
         it.tile = tile;
         items[o++] = it;
@@ -217,6 +217,12 @@ extern "C" int hgt_plan_constants(int32_t* tile_nodes, int32_t* item_edges) {
     return HGT_OK;
 }
 
+extern "C" int hgt_plan_item_edges(int64_t n_edges, int32_t* item_edges) {
+    if (!item_edges || n_edges < 0) return HGT_ERR_INVALID_ARG;
+    *item_edges = hgt_item_edges(n_edges);
+    return HGT_OK;
+}
+
 extern "C" int hgt_plan_row_lists(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types,
                                   int32_t n_relations, hgt_plan_rows* out) {
     if (!plan || !out) return HGT_ERR_INVALID_ARG;
@@ -282,11 +288,11 @@ extern "C" int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int
                                                    eid, esrc, edst, ertei);
     }
     k_segptr<<<nblk(L.n_bins + 1, BS), BS, 0, stream>>>(keys_out, E, L.n_bins, segptr);
-    k_pair_counts<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(segptr, L.n_pairs, pair_cnt);
+    k_pair_counts<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(segptr, L.n_pairs, hgt_item_edges(E), pair_cnt);
     sort_bytes = (size_t)tl.sort_tmp_bytes;
     if (rocprim::exclusive_scan(sort_tmp, sort_bytes, pair_cnt, pair_off, 0, (size_t)(L.n_pairs + 1),
                                 rocprim::plus<int32_t>(), stream) != hipSuccess) return HGT_ERR_LAUNCH;
-    k_items<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(segptr, pair_off, L.n_pairs, R, items, tile_items, hdr);
+    k_items<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(segptr, pair_off, L.n_pairs, R, hgt_item_edges(E), items, tile_items, hdr);
     if (N > 0) k_hub_detect<<<nblk(N, BS), BS, 0, stream>>>(segptr, N, R, hub_slot, hub_list, hdr);
 
     // typed row lists: all nodes, and target nodes [0, NQ)

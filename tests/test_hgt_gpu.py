@@ -371,16 +371,18 @@ def test_gnn_wrapper_matches_oracle():
 
 
 # ------------------------------------------------------------------ integer work: bit exact
-def _plan_constants():
+def _plan_constants(E):
     td, ch = C.c_int32(), C.c_int32()
     assert _lib.load().hgt_plan_constants(C.byref(td), C.byref(ch)) == 0
-    return td.value, ch.value
+    ce = C.c_int32()
+    assert _lib.load().hgt_plan_item_edges(E, C.byref(ce)) == 0 and 64 <= ce.value <= ch.value
+    return td.value, ce.value
 
 
 def _plan_arrays(plan):
     """Mirror of hgt_plan_layout() in pyhgt_amd/csrc/hgt_common.h (256-byte aligned arrays)."""
     N, E, T, R = plan.N, plan.E, plan.T, plan.R
-    TD, CH = _plan_constants()
+    TD, CH = _plan_constants(E)
     n_tiles = (N + TD - 1) // TD
     n_pairs = n_tiles * (R + 1)
     n_bins = n_pairs * TD
@@ -420,7 +422,7 @@ def test_plan_is_bit_exact(sorted_types, skew):
     p = _plan_arrays(plan)
     src, dst = ei[0].numpy(), ei[1].numpy()
     rel = np.where(et.numpy() < R, et.numpy(), R)
-    TD, CH = _plan_constants()
+    TD, CH = _plan_constants(plan.E)
     key = ((dst // TD) * (R + 1) + rel) * TD + dst % TD
     order = np.argsort(key, kind="stable")
     assert p["bad"] == 0
