@@ -298,6 +298,10 @@ typedef struct hgt_conv_args {
     void* prepared;
     uint64_t prepared_bytes;
     int32_t prepared_valid;
+    /* != 0: the caller KNOWS (from the plan header, read back asynchronously -- pyhgt_amd.GraphPlan.no_hubs) that the plan
+     * found no hub target, so the hub kernels of the aggregation (4-5 launches that would exit at once) are not enqueued.
+     * 0 = unknown: they are enqueued. */
+    int32_t plan_no_hubs;
 } hgt_conv_args;
 
 /* phase boundaries at which hgt_conv_forward records phase_events[i]:

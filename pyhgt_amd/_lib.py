@@ -46,6 +46,7 @@ class HgtConvArgs(C.Structure):
         ("out_ln_w", C.c_void_p), ("out_ln_b", C.c_void_p),
         ("stage", C.c_int32), ("proj_rows", C.c_void_p), ("proj_off", C.c_void_p), ("proj_n", C.c_int64),
         ("prepared", C.c_void_p), ("prepared_bytes", C.c_uint64), ("prepared_valid", C.c_int32),
+        ("plan_no_hubs", C.c_int32),
     ]
 
 

@@ -10,6 +10,7 @@ CPU / eager fallback: a non-GPU input or a missing library raises.
 """
 import ctypes as C
 import math
+import weakref
 from collections import OrderedDict
 
 import torch
@@ -47,6 +48,33 @@ class _Workspace:
     @classmethod
     def clear(cls):
         cls._bufs.clear()
+
+
+class _HeaderSlots:
+    """A small ring of pinned host slots for the asynchronous read-back of plan headers (allocating pinned memory per plan
+    costs ~20 us).  A plan whose slot is taken over before it looked at it simply never learns its hub count (safe)."""
+    N = 64
+    buf = None
+    owners = [None] * 64
+    nxt = 0
+
+    @classmethod
+    def acquire(cls, plan):
+        if cls.buf is None:
+            cls.buf = torch.zeros(cls.N, 4, dtype=torch.int32).pin_memory()
+        i = cls.nxt
+        cls.nxt = (i + 1) % cls.N
+        old = cls.owners[i]() if cls.owners[i] is not None else None
+        if old is not None and old._hdr_slot == i:
+            old._hdr_slot = None
+        cls.owners[i] = weakref.ref(plan)
+        return i
+
+    @classmethod
+    def release(cls, plan):
+        if plan._hdr_slot is not None:
+            cls.owners[plan._hdr_slot] = None
+            plan._hdr_slot = None
 
 
 class GraphPlan:
@@ -93,6 +121,22 @@ class GraphPlan:
         # tmp is released by the caching allocator only after the stream ran past this point
         tmp.record_stream(torch.cuda.current_stream())
         self.device = dev
+        # plan header (n_items, bad_index, n_hubs) copied to pinned host memory WITHOUT synchronising; `no_hubs` reads it once
+        # the copy has completed (from the second layer on, in practice)
+        self._no_hubs = None
+        self._hdr_slot = _HeaderSlots.acquire(self)
+        _HeaderSlots.buf[self._hdr_slot].copy_(self.buf[:16].view(torch.int32), non_blocking=True)
+        self._hdr_event = torch.cuda.Event()
+        self._hdr_event.record()
+
+    @property
+    def no_hubs(self):
+        """True once it is known (no synchronisation) that no target exceeds the hub in-degree threshold; False = unknown
+        or hubs exist.  Lets hgt_conv_forward skip enqueueing the hub kernels (they would exit immediately)."""
+        if self._no_hubs is None and self._hdr_slot is not None and self._hdr_event.query():
+            self._no_hubs = int(_HeaderSlots.buf[self._hdr_slot][2]) == 0
+            _HeaderSlots.release(self)
+        return bool(self._no_hubs)
 
     @property
     def ptr(self):
@@ -327,6 +371,7 @@ class HGTConv(nn.Module):
         a.out, a.att_out = _ptr(out) if final else _ptr(ws), _ptr(att)   # stages 1/2 write no output (non-NULL placeholder)
         a.want_att = int(self.keep_att and final)
         a.stage = int(stage)
+        a.plan_no_hubs = int(plan.no_hubs)
         prep = self._prepared_buffer(x.device)          # after _pack_parameters: a re-pack has invalidated it
         a.prepared, a.prepared_bytes, a.prepared_valid = _ptr(prep), prep.numel(), int(self._prepared_valid)
         if stage == 2:

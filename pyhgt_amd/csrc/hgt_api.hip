@@ -167,6 +167,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     PreparedLayout pl = prepared_layout(din, dout, T, R, H, a->use_rte, lay);
     if (pb && a->prepared_bytes < pl.total) return HGT_ERR_WORKSPACE;
     const bool fresh = !(pb && a->prepared_valid);          // derive the weight images in this call
+    void* hub_ws = (a->plan_no_hubs || getenv("HGT_NO_HUB")) ? nullptr : (void*)(wb + w.off_hub);
     if (pb) {
         att_t = (float*)(pb + pl.off_att_t);
         msg_p = (float*)(pb + pl.off_msg_p);
@@ -280,7 +281,7 @@ edge_phase:
             if (rc != HGT_OK) return rc;
         }
         rc = hgt_edge_aggregate_update(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ,
-                                       getenv("HGT_NO_HUB") ? nullptr : (void*)(wb + w.off_hub), (int32_t*)(wb + w.off_pending), a->node_type,
+                                       hub_ws, (int32_t*)(wb + w.off_pending), a->node_type,
                                        ws_upd, a->b_a, a->x, din, a->skip, a->ln_w, a->ln_b, a->use_norm, dout, a->out, stream);
         if (rc == HGT_OK) {
             if (a->want_att && E > 0) {
@@ -298,7 +299,7 @@ edge_phase:
     }
     // runs for E == 0 too: it writes the zero rows of isolated targets; HGTConv stores gelu(agg) (conv.py:119), DenseHGTConv agg
     rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ, dense ? 0 : 1,
-                            getenv("HGT_NO_HUB") ? nullptr : (void*)(wb + w.off_hub), stream);
+                            hub_ws, stream);
     if (rc != HGT_OK) return rc;
     if (a->want_att && E > 0) {   // self.att (conv.py:108): normalise the logits in place and un-sort them
         rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);
