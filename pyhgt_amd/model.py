@@ -46,6 +46,19 @@ class GNN(nn.Module):
             self._packed, self._packed_key = (w, b), key
         return self._packed
 
+    def _adapter_tiles(self, w, in_dim, n_hid, st):
+        """Split-bf16 MFMA tiles of the adapter weights (hgt_split_weights), kept until the weights change."""
+        key = (w.data_ptr(), self._packed_key)
+        if getattr(self, "_tiles_key", None) != key:
+            lib = _lib.load()
+            nb = C.c_uint64()
+            _lib.check(lib.hgt_split_weights_bytes(self.num_types, in_dim, n_hid, C.byref(nb)), "hgt_split_weights_bytes")
+            self._tiles = torch.empty(int(nb.value), dtype=torch.uint8, device=w.device)
+            _lib.check(lib.hgt_split_weights(_ptr(w), n_hid * in_dim, self.num_types, in_dim, n_hid, _ptr(self._tiles), st),
+                       "hgt_split_weights(adapter)")
+            self._tiles_key = key
+        return self._tiles
+
     def forward(self, node_feature, node_type, edge_time, edge_index, edge_type):
         """Same argument order as the reference (model.py:69): note edge_time comes third."""
         lib = _lib.load()
@@ -63,9 +76,15 @@ class GNN(nn.Module):
         T, n_hid, in_dim = self.num_types, self.n_hid, self.in_dim
         h = torch.empty(N, n_hid, dtype=torch.float32, device=x.device)
         st = _stream()
-        # typed adapter: exact fp32 MFMA kernel (in_dim is arbitrary, e.g. 129 or 1169: not a multiple of 4)
-        _lib.check(lib.hgt_typed_linear(_ptr(x), in_dim, rows.rows_all, rows.off_all, T, N, in_dim, n_hid, _ptr(w), n_hid * in_dim,
-                                        _ptr(b), n_hid, _ptr(h), 0, 0, n_hid, 0, 0, 0, st), "hgt_typed_linear(adapter)")
+        # typed adapter (in_dim is arbitrary, e.g. 129 or 1169): the precision of the layers -- split-bf16 x3 MFMA (its row loader
+        # takes any K) or the exact fp32 MFMA kernel
+        if conv0.precision == "bf16x3" and n_hid % 4 == 0:
+            tiles = self._adapter_tiles(w, in_dim, n_hid, st)
+            _lib.check(lib.hgt_typed_linear_bf16x3(_ptr(x), in_dim, rows.rows_all, rows.off_all, T, N, in_dim, n_hid, _ptr(tiles),
+                                                   _ptr(b), n_hid, _ptr(h), 0, 0, n_hid, 0, 0, st), "hgt_typed_linear_bf16x3(adapter)")
+        else:
+            _lib.check(lib.hgt_typed_linear(_ptr(x), in_dim, rows.rows_all, rows.off_all, T, N, in_dim, n_hid, _ptr(w), n_hid * in_dim,
+                                            _ptr(b), n_hid, _ptr(h), 0, 0, n_hid, 0, 0, 0, st), "hgt_typed_linear(adapter)")
         # nodes whose type no adapter claims stay zero like the reference's zero-initialised `res` (model.py:70);
         # rows_all[off_all[T] .. off_all[T+1]) are exactly those nodes
         _lib.check(lib.hgt_zero_rows(rows.rows_all, rows.off_all + 4 * T, n_hid, _ptr(h), st), "hgt_zero_rows")

@@ -341,8 +341,10 @@ def test_partitioned_graph_on_gpu_single_rank():
         dist.destroy_process_group()
 
 
-def test_gnn_wrapper_matches_oracle():
-    """typed input adapter (Linear + tanh, model.py:70-76) + 2 stacked layers sharing one plan."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_gnn_wrapper_matches_oracle(precision):
+    """typed input adapter (Linear + tanh, model.py:70-76) + 2 stacked layers sharing one plan
+    (in_dim = 37: the adapter GEMM has an odd K in both precisions)."""
     from pyhgt_amd import GNN
     T, R, H, in_dim, d, N, E = 3, 4, 4, 37, 64, 1500, 12000
     x, nt, ei, et, tm = synthetic_typed_graph(N, E, in_dim, T, R, seed=71)
@@ -362,6 +364,8 @@ def test_gnn_wrapper_matches_oracle():
         sd = {k: v.detach().clone() for k, v in gc.base_conv.state_dict().items()}
         h = O.forward_closed_form(sd, T, R, H, h, nt, ei, et, tm, use_norm=(li == 0), use_RTE=True, dtype=torch.float64)
     gnn = gnn.to(DEV)
+    for gc in gnn.gcs:
+        gc.base_conv.precision = precision
     GraphPlan.clear_cache()
     with torch.no_grad():
         out = gnn(*_to_dev(x, nt, tm, ei, et))          # reference argument order: edge_time third (model.py:69)
