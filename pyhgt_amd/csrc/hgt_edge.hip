@@ -307,6 +307,15 @@ __device__ __forceinline__ void aggregate_subtile(
 #pragma unroll
     for (int j = 0; j < HGT_SUB * 16 / 64; ++j) { s_m[j * 64 + lane] = HGT_NEG; s_l[j * 64 + lane] = 0.0f; }
 
+    // hub-free sub-tiles: the edge range of every relation bucket is read up front (lane r = bucket r), so that empty
+    // relations cost a v_readlane instead of a dependent load (c5: 33 relations, most of them empty for a given target type)
+    const bool ranges_ready = !HUBS && R < 64;
+    int my_beg = 0, my_end = 0;
+    if (ranges_ready) {
+        const int64_t bb = ((int64_t)tile * (R + 1) + min(lane, R)) * HGT_TD + within;
+        my_beg = segptr[bb];
+        my_end = segptr[bb + SUBR];
+    }
     for (int rel = 0; rel <= R; ++rel) {
       const int64_t b0 = ((int64_t)tile * (R + 1) + rel) * HGT_TD + within;
       // maximal runs [dl0, dl1) of non-hub targets: one run covering the whole sub-tile unless it contains a hub
@@ -317,8 +326,8 @@ __device__ __forceinline__ void aggregate_subtile(
             dl1 = dl0 + 1;
             while (dl1 < SUBR && !((hub_mask >> dl1) & 1u)) ++dl1;
         }
-        const int beg = __builtin_amdgcn_readfirstlane(segptr[b0 + dl0]);
-        const int end = __builtin_amdgcn_readfirstlane(segptr[b0 + dl1]);
+        const int beg = ranges_ready ? __builtin_amdgcn_readlane(my_beg, rel) : __builtin_amdgcn_readfirstlane(segptr[b0 + dl0]);
+        const int end = ranges_ready ? __builtin_amdgcn_readlane(my_end, rel) : __builtin_amdgcn_readfirstlane(segptr[b0 + dl1]);
         dl0 = dl1;
         if (beg == end) continue;
         const bool claimed = rel < R;   // bucket R: logit 0, no message
