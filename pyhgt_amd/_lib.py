@@ -50,6 +50,8 @@ class HgtConvArgs(C.Structure):
     ]
 
 
+ABI_VERSION = 2          # HGT_ABI_VERSION of include/hgt_hip.h this binding was written against
+
 _i32, _i64, _u64, _vp = C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
 
 # name -> (restype, argtypes); every symbol include/hgt_hip.h declares
@@ -104,7 +106,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.hgt_abi_version() != 2:
+        if lib.hgt_abi_version() != ABI_VERSION:
             raise RuntimeError("pyhgt_amd: ABI version mismatch in %s" % LIB_PATH)
         _lib = lib
     return _lib

@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_strings():
     lib = _lib.load()
-    assert lib.hgt_abi_version() == 2
+    text = open(os.path.join(ROOT, "include", "hgt_hip.h")).read()
+    assert lib.hgt_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define HGT_ABI_VERSION (\d+)", text).group(1))
     assert lib.hgt_strerror(0) == b"ok"
     assert b"invalid" in lib.hgt_strerror(-1)
 
