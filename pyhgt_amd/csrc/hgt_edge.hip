@@ -100,6 +100,11 @@ __device__ __forceinline__ void head_matvec(const float (&xv)[VEC], float* bounc
                 for (int i = 0; i < VEC; ++i) y[i] = fmaf(xs[jj], f[i], y[i]);
             }
         }
+        // d_k = 64 (16 bounce reads): without a fence hipcc issues all of them up front -- 64 live registers on top of the
+        // 128-register fragment push the aggregation kernel past 256 and to one wave per SIMD
+        if constexpr (DKP > 32) {
+            if ((j4 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
     }
     __builtin_amdgcn_wave_barrier();   // the bounce row may be rewritten only after every lane has read it
 }
@@ -477,7 +482,7 @@ __device__ __forceinline__ void aggregate_subtile(
 // Sub-tiles without a hub target (all of them on c2) take the HUBS = false instantiation: its loop nest is the plain
 // "one range per relation" walk (the run logic costs ~4 % when it is compiled into the hot path).
 template <int VEC, int LPH, bool RTE>
-__global__ __launch_bounds__(256) void k_edge_aggregate(
+__global__ __launch_bounds__(256, 2) void k_edge_aggregate(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
     const float* __restrict__ rteV, const float* __restrict__ msgP, float* __restrict__ agg, int R, int64_t NQ, int apply_gelu,
