@@ -216,6 +216,12 @@ int hgt_node_update_ex(const float* trans, const float* x, int64_t ldx, const in
 /* x[i] = tanh(x[i]) in place: the activation of the typed input adapter of model.GNN (model.py:70-76) */
 int hgt_tanh_inplace(float* x, int64_t n, void* stream);
 
+/* Task heads of model.py, used by pyhgt_amd.Classifier / Matcher on the seed rows:
+ *   hgt_log_softmax_rows: out[r] = log_softmax(x[r])   (torch.log_softmax(..., dim=-1), model.py:11)
+ *   hgt_row_dot:          out[r] = scale * <x[r], y[r]> (Matcher pair=True, model.py:41,44) */
+int hgt_log_softmax_rows(const float* x, int64_t n_rows, int32_t n_cols, float* out, void* stream);
+int hgt_row_dot(const float* x, const float* y, int64_t n_rows, int32_t d, float scale, float* out, void* stream);
+
 /* row gather used to pack halo rows for the multi-GPU exchange: out[i] = x[idx[i]] */
 int hgt_gather_rows(const float* x, int64_t ldx, const int32_t* idx, int64_t n, int32_t d, float* out, void* stream);
 

@@ -4,6 +4,6 @@ Drop-in for the reference layers pyHGT/conv.py::HGTConv / DenseHGTConv (same con
 names, forward signature) backed by hand-written HIP kernels behind a C ABI (include/hgt_hip.h).
 """
 from .conv import HGTConv, DenseHGTConv, GeneralConv, RelTemporalEncoding, GraphPlan, install_into  # noqa: F401
-from .model import GNN  # noqa: F401
+from .model import GNN, Classifier, Matcher  # noqa: F401
 
-__all__ = ["HGTConv", "DenseHGTConv", "GeneralConv", "RelTemporalEncoding", "GraphPlan", "install_into", "GNN"]
+__all__ = ["HGTConv", "DenseHGTConv", "GeneralConv", "RelTemporalEncoding", "GraphPlan", "install_into", "GNN", "Classifier", "Matcher"]

@@ -81,6 +81,8 @@ SIGNATURES = {
     "hgt_att_export": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "hgt_edge_aggregate_update": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
                                             _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "hgt_log_softmax_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "hgt_row_dot": (C.c_int, [_vp, _vp, _i64, _i32, C.c_float, _vp, _vp]),
     "hgt_node_update": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "hgt_node_update_ex": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp]),
     "hgt_tanh_inplace": (C.c_int, [_vp, _i64, _vp]),

@@ -105,7 +105,57 @@ __global__ void k_tanh_inplace(float* __restrict__ x, int64_t n) {
     }
 }
 
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) v = fmaxf(v, __shfl_xor(v, sft));
+    return v;
+}
+
+// out[r][c] = x[r][c] - max_r - log(sum_c exp(x[r][c] - max_r)); one wavefront per row, any width
+__global__ __launch_bounds__(256) void k_log_softmax_rows(const float* __restrict__ x, int64_t n, int c, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float* __restrict__ xr = x + r * c;
+    float m = -3.0e38f;
+    for (int j = lane; j < c; j += 64) m = fmaxf(m, xr[j]);
+    m = wave_max(m);
+    float s = 0.0f;
+    for (int j = lane; j < c; j += 64) s += expf(xr[j] - m);
+    const float lse = m + logf(wave_sum(s));
+    float* __restrict__ o = out + r * c;
+    for (int j = lane; j < c; j += 64) o[j] = xr[j] - lse;
+}
+
+// out[r] = scale * <x[r], y[r]>
+__global__ __launch_bounds__(256) void k_row_dot(const float* __restrict__ x, const float* __restrict__ y, int64_t n, int d, float scale,
+                                                 float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float s = 0.0f;
+    for (int j = lane; j < d; j += 64) s = fmaf(x[r * d + j], y[r * d + j], s);
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s * scale;
+}
+
 }  // namespace
+
+extern "C" int hgt_log_softmax_rows(const float* x, int64_t n_rows, int32_t n_cols, float* out, void* stream) {
+    if (n_rows == 0) return HGT_OK;
+    if (!x || !out || n_rows < 0 || n_cols <= 0) return HGT_ERR_INVALID_ARG;
+    k_log_softmax_rows<<<(unsigned)((n_rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(x, n_rows, n_cols, out);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_row_dot(const float* x, const float* y, int64_t n_rows, int32_t d, float scale, float* out, void* stream) {
+    if (n_rows == 0) return HGT_OK;
+    if (!x || !y || !out || n_rows < 0 || d <= 0) return HGT_ERR_INVALID_ARG;
+    k_row_dot<<<(unsigned)((n_rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(x, y, n_rows, d, scale, out);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
 
 extern "C" int hgt_tanh_inplace(float* x, int64_t n, void* stream) {
     if (n == 0) return HGT_OK;

@@ -5,9 +5,10 @@
 followed by `n_layers` GeneralConv('hgt') layers that all receive the same graph tensors (model.py:78-79).
 The adapter runs on the same typed-linear kernels as the layers (no per-type boolean masks, no host sync --
 the reference syncs once per type at model.py:73), and one GraphPlan is built for the whole stack.
-Forward only (eval mode: both dropouts are the identity).  Classifier / Matcher heads stay the reference's.
+Forward only (eval mode: both dropouts are the identity).  Classifier / Matcher (model.py:3-49) run on the same kernels.
 """
 import ctypes as C
+import math
 
 import torch
 import torch.nn as nn
@@ -15,7 +16,7 @@ import torch.nn as nn
 from . import _lib
 from .conv import GeneralConv, GraphPlan, _ptr, _stream
 
-__all__ = ["GNN"]
+__all__ = ["GNN", "Classifier", "Matcher"]
 
 
 class GNN(nn.Module):
@@ -92,3 +93,71 @@ class GNN(nn.Module):
         for gc in self.gcs:
             h = gc.base_conv(h, node_type, edge_index, edge_type, edge_time, plan=plan)
         return h
+
+
+def _dense_linear(x, weight, bias, scale=1.0):
+    """y = (x @ weight^T + bias) * scale on the exact fp32 MFMA typed-linear kernel (one group = every row)."""
+    lib = _lib.load()
+    if not x.is_cuda:
+        raise RuntimeError("pyhgt_amd heads run only on a ROCm GPU tensor; there is no CPU fallback")
+    x = x.detach().float().contiguous()
+    n, k = x.shape
+    n_out = weight.size(0)
+    w = (weight.detach().float() * scale).contiguous()
+    b = (bias.detach().float() * scale).contiguous() if bias is not None else None
+    rows = torch.arange(n, dtype=torch.int32, device=x.device)
+    off = torch.tensor([0, n], dtype=torch.int32, device=x.device)
+    y = torch.empty(n, n_out, dtype=torch.float32, device=x.device)
+    _lib.check(lib.hgt_typed_linear(_ptr(x), k, _ptr(rows), _ptr(off), 1, n, k, n_out, _ptr(w), 0, _ptr(b), 0, _ptr(y), 0, 0, n_out,
+                                    0, 0, 0, _stream()), "hgt_typed_linear(head)")
+    return y
+
+
+class Classifier(nn.Module):
+    """model.py:3-14: log_softmax(linear(x).squeeze(), dim=-1) on the seed rows."""
+
+    def __init__(self, n_hid, n_out):
+        super().__init__()
+        self.n_hid, self.n_out = n_hid, n_out
+        self.linear = nn.Linear(n_hid, n_out)
+
+    def forward(self, x):
+        tx = _dense_linear(x.reshape(-1, self.n_hid), self.linear.weight, self.linear.bias)
+        out = torch.empty_like(tx)
+        _lib.check(_lib.load().hgt_log_softmax_rows(_ptr(tx), tx.size(0), tx.size(1), _ptr(out), _stream()), "hgt_log_softmax_rows")
+        return out.reshape(*x.shape[:-1], self.n_out).squeeze()
+
+    def __repr__(self):
+        return '{}(n_hid={}, n_out={})'.format(self.__class__.__name__, self.n_hid, self.n_out)
+
+
+class Matcher(nn.Module):
+    """model.py:16-49: scaled dot product between projected node pairs (link prediction), with the reference's
+    inference-time cache of the projected candidates."""
+
+    def __init__(self, n_hid):
+        super().__init__()
+        self.left_linear = nn.Linear(n_hid, n_hid)
+        self.right_linear = nn.Linear(n_hid, n_hid)
+        self.sqrt_hd = math.sqrt(n_hid)
+        self.n_hid = n_hid
+        self.cache = None
+
+    def forward(self, x, y, infer=False, pair=False):
+        ty = _dense_linear(y, self.right_linear.weight, self.right_linear.bias)
+        if infer and self.cache is not None:
+            tx = self.cache
+        else:
+            tx = _dense_linear(x, self.left_linear.weight, self.left_linear.bias)
+            if infer:
+                self.cache = tx
+        if pair:
+            out = torch.empty(tx.size(0), dtype=torch.float32, device=tx.device)
+            _lib.check(_lib.load().hgt_row_dot(_ptr(tx), _ptr(ty), tx.size(0), self.n_hid, 1.0 / self.sqrt_hd, _ptr(out), _stream()),
+                       "hgt_row_dot")
+            return out
+        # tx @ ty^T / sqrt(n_hid): the typed-linear kernel with ty as the "weight" and no bias
+        return _dense_linear(tx, ty / self.sqrt_hd, None)
+
+    def __repr__(self):
+        return '{}(n_hid={})'.format(self.__class__.__name__, self.n_hid)

@@ -543,3 +543,29 @@ def test_properties_at_scale():
     ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, None, use_RTE=False, dtype=torch.float32)
     out, _ = _run(layer, x, nt, ei, et, None)
     assert (out - ref).abs().max().item() < TOL
+
+
+def test_classifier_and_matcher_heads():
+    """model.py:3-49 on the native kernels: log_softmax(linear(x)), and the scaled (pairwise / all-pairs) dot product of
+    projected node pairs incl. the inference cache -- against the same formulas in fp64 torch."""
+    from pyhgt_amd import Classifier, Matcher
+    g = torch.Generator().manual_seed(5)
+    n_hid, n_out, n, m = 96, 37, 300, 45
+    x, y = torch.randn(n, n_hid, generator=g), torch.randn(m, n_hid, generator=g)
+    clf = Classifier(n_hid, n_out).eval()
+    ref = torch.log_softmax(x.double() @ clf.linear.weight.double().T + clf.linear.bias.double(), dim=-1)
+    with torch.no_grad():
+        out = clf.to(DEV)(x.to(DEV))
+    assert out.shape == ref.shape and (out.cpu().double() - ref).abs().max().item() < 1e-5
+    mt = Matcher(n_hid).eval()
+    tx = x.double() @ mt.left_linear.weight.double().T + mt.left_linear.bias.double()
+    ty = y.double() @ mt.right_linear.weight.double().T + mt.right_linear.bias.double()
+    mt = mt.to(DEV)
+    with torch.no_grad():
+        full = mt(x.to(DEV), y.to(DEV))
+        pair = mt(x[:m].to(DEV), y.to(DEV), pair=True)
+        cached = mt(x.to(DEV), y.to(DEV), infer=True)
+        cached2 = mt(torch.zeros_like(x).to(DEV), y.to(DEV), infer=True)        # second call must use the cache, not x
+    assert (full.cpu().double() - tx @ ty.T / n_hid ** 0.5).abs().max().item() < 1e-5
+    assert (pair.cpu().double() - (tx[:m] * ty).sum(-1) / n_hid ** 0.5).abs().max().item() < 1e-5
+    assert torch.equal(cached, full) and torch.equal(cached2, full)
