@@ -100,6 +100,13 @@ class HaloPlan:
             self.send_chunk_off.append(self.send_chunk_off[-1] + sum(self.send_chunk_splits[c]))
             self.recv_chunk_off.append(self.recv_chunk_off[-1] + sum(self.recv_chunk_splits[c]))
 
+    def to(self, device):
+        """Move the index tensors of the plan to `device` (the plan itself can be built on any backend)."""
+        for k, v in list(vars(self).items()):
+            if torch.is_tensor(v):
+                setattr(self, k, v.to(device))
+        return self
+
     def chunk_row_lists(self, num_types):
         """Typed row lists (int32 rows grouped by node type, int32 offsets[T+1]) of the halo rows of every chunk,
         in the form hgt_conv_forward stage 2 takes.  Rows of a type outside [0, T) get no projection (their edges are
@@ -149,11 +156,14 @@ class PartitionedGraph:
     """One rank's share of a destination-partitioned typed graph + the per-layer forward."""
 
     def __init__(self, node_type_own, src_global, dst_local, edge_type, edge_time, num_types, num_relations,
-                 nodes_per_rank, rank, world, group=None, node_offsets=None, n_chunks=4):
+                 nodes_per_rank, rank, world, group=None, node_offsets=None, n_chunks=4, halo=None):
+        """halo: a prebuilt HaloPlan for this rank (tests build it on CPU over gloo and move it to the device with
+        HaloPlan.to); otherwise it is negotiated here with three small all-to-alls."""
         from .conv import GraphPlan
         if node_offsets is None:
             node_offsets = [nodes_per_rank * r for r in range(world + 1)]
-        self.halo = HaloPlan(node_type_own, src_global, node_offsets, rank, world, group, n_chunks=n_chunks)
+        self.halo = halo if halo is not None else HaloPlan(node_type_own, src_global, node_offsets, rank, world, group,
+                                                            n_chunks=n_chunks)
         self.chunk_lists = self.halo.chunk_row_lists(num_types) if self.halo.n_chunks > 1 else None
         self.n_own, self.n_local = self.halo.n_own, self.halo.n_local
         self.edge_index = torch.stack([self.halo.src_local, dst_local], dim=0).contiguous()
