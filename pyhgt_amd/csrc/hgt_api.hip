@@ -43,6 +43,14 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
     w.off_ws_qkv = take(b);
     // shared by the a_linear / Q-only / temporal K|V splits (used one after the other on the stream)
     hgt_split_weights_bytes(T, in_dim > lay.d_pad ? in_dim : lay.d_pad, 2 * lay.d_pad > out_dim ? 2 * lay.d_pad : out_dim, &b);
+    {   // ... and by the shared dense layer of DenseHGTConv (one group; its out_linear has K = 2*out_dim, which the typed
+        // shapes above do not cover when T == 1 and d_pad <= 128 -- found by tools/fuzz_parity.py)
+        uint64_t b2 = 0;
+        hgt_split_weights_bytes(1, 2 * out_dim, out_dim, &b2);
+        if (b2 > b) b = b2;
+        hgt_split_weights_bytes(1, out_dim, 2 * out_dim, &b2);
+        if (b2 > b) b = b2;
+    }
     w.off_ws_a = take(b);
     hgt_split_weights_bytes(1, in_dim, in_dim, &b);
     w.off_ws_rte = take(use_rte ? b : 0);

@@ -92,6 +92,7 @@ DENSE_CASES = [
     (2500, 25000, 256, 8, 4, 8, True, False),      # c2 shape
     (900, 7000, 400, 8, 5, 12, True, True),        # d_k = 50 padded to 64; out_linear has K = 800 (multi-panel GEMM)
     (1200, 9000, 64, 4, 3, 4, False, True),        # no per-type LayerNorm
+    (1419, 6268, 128, 16, 1, 9, True, False),      # one node type, d_pad = 128: the shared dense layer sizes the weight-tile scratch
 ]
 
 

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Randomised parity sweep (development aid): many small random shapes / options, HIP path vs the fp64 oracle."""
+import os
+import random
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import hgt_oracle as O  # noqa: E402
+from pyhgt_amd import HGTConv, DenseHGTConv, GraphPlan  # noqa: E402
+from pyhgt_amd.synth import synthetic_typed_graph  # noqa: E402
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = random.Random(1234)
+    worst = 0.0
+    for case in range(n_cases):
+        H = rng.choice([1, 2, 4, 8, 16])
+        dk = rng.choice([4, 8, 16, 25, 32, 50, 64]) if H <= 8 else rng.choice([4, 8, 16])
+        d = H * dk
+        if d > 512 or d < 8:
+            continue
+        T, R = rng.randint(1, 5), rng.randint(1, 12)
+        N, E = rng.randint(1, 3000), rng.randint(0, 20000)
+        use_norm, use_rte, dense = rng.random() < 0.7, rng.random() < 0.5, rng.random() < 0.3
+        if d % 2:
+            use_rte = False          # the reference's sinusoid table needs an even width (conv.py:289-294)
+        prec = rng.choice(["fp32", "bf16x3"])
+        gk = dict(sorted_types=rng.random() < 0.5)
+        if gk["sorted_types"] and rng.random() < 0.4:
+            gk["schema"] = True
+        if rng.random() < 0.3:
+            gk["dst_skew"] = 1.1
+        x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=1000 + case, **gk)
+        nt, et = nt.clone(), et.clone()
+        if rng.random() < 0.3 and N > 10:
+            nt[::7] = T + 1
+        if rng.random() < 0.3 and E > 10:
+            et[::5] = R
+        nq = N if rng.random() < 0.7 else max(1, N // 2)
+        if nq < N:
+            ei = ei.clone()
+            ei[1] = ei[1] % nq
+        sd = O.make_state_dict(d, d, T, R, H, use_norm, use_rte, seed=case, dense=dense)
+        ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, use_norm=use_norm, use_RTE=use_rte, dtype=torch.float64, dense=dense)
+        cls = DenseHGTConv if dense else HGTConv
+        layer = cls(d, d, T, R, H, 0.2, use_norm, use_rte, precision=prec).eval()
+        layer.load_state_dict(sd)
+        layer = layer.to("cuda:0")
+        GraphPlan.clear_cache()
+        with torch.no_grad():
+            out = layer(x.cuda(), nt.cuda(), ei.cuda(), et.cuda(), tm.cuda() if use_rte else None, n_q_rows=nq if nq < N else None)
+        torch.cuda.synchronize()
+        err = (out.cpu().double() - ref[:nq]).abs().max().item() if out.numel() else 0.0
+        worst = max(worst, err)
+        flag = "" if err < 1e-4 else "   <<<<<< FAIL"
+        print("case %3d N=%5d NQ=%5d E=%6d d=%3d H=%2d T=%d R=%2d norm=%d rte=%d dense=%d %-6s %s err=%.2e%s" % (
+            case, N, nq, E, d, H, T, R, use_norm, use_rte, dense, prec, sorted(gk.items()), err, flag), flush=True)
+    print("worst error %.3e" % worst)
+
+
+if __name__ == "__main__":
+    main()
