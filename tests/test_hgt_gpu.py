@@ -547,6 +547,38 @@ def test_properties_at_scale():
     assert (out - ref).abs().max().item() < TOL
 
 
+FUSED_CASES = [
+    # N (>= 65536: the fused aggregate + update kernel), E, d, H, T, R, use_norm, use_RTE, graph kwargs
+    (70_000, 350_000, 64, 4, 3, 4, True, True, dict(sorted_types=False)),              # mixed-type tiles everywhere
+    (66_000, 300_000, 256, 8, 4, 8, True, False, {}),                                   # c2 layout, type-sorted
+    (80_000, 400_000, 128, 8, 2, 5, False, False, dict(dst_skew=1.05)),                 # hubs -> pending workgroups
+    (65_536 + 70, 200_000, 200, 4, 3, 3, True, True, dict(sorted_types=False)),         # d_k = 50 padded, ragged last tile
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES, ids=[str(i) for i in range(len(FUSED_CASES))])
+def test_fused_aggregate_update_matches_oracle(case):
+    """hgt_edge_aggregate_update only runs for >= 65536 targets with the split-bf16 precision: the small oracle cases do
+    not reach it.  Unknown node types (rows must be 0) and unclaimed relations included."""
+    N, E, d, H, T, R, use_norm, use_RTE, gk = case
+    sd = O.make_state_dict(d, d, T, R, H, use_norm, use_RTE, seed=N % 1000 + E % 77)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=E % 1000 + 5, **gk)
+    nt, et = nt.clone(), et.clone()
+    nt[::211] = T + 3
+    et[::97] = R
+    if "dst_skew" in gk:                 # two certain hub targets (> 1024 in-edges): their workgroups finish through `pending`
+        ei = ei.clone()
+        ei[1, :3000] = 12_345
+        ei[1, 3000:5000] = 70_001
+    ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, use_norm=use_norm, use_RTE=use_RTE, dtype=torch.float64)
+    layer = _layer_from(sd, d, T, R, H, use_norm, use_RTE, keep_att=False, precision="bf16x3")
+    out, _ = _run(layer, x, nt, ei, et, tm if use_RTE else None)
+    err = (out.double() - ref).abs().max().item()
+    print("fused case N=%d E=%d d=%d H=%d: max|out| err %.2e" % (N, E, d, H, err))
+    assert err < TOL
+    assert out[nt == T + 3].abs().max().item() == 0.0
+
+
 def test_classifier_and_matcher_heads():
     """model.py:3-49 on the native kernels: log_softmax(linear(x)), and the scaled (pairwise / all-pairs) dot product of
     projected node pairs incl. the inference cache -- against the same formulas in fp64 torch."""
