@@ -14,7 +14,8 @@ from pyhgt_amd.synth import synthetic_typed_graph  # noqa: E402
 
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    rng = random.Random(1234)
+    big = len(sys.argv) > 2 and sys.argv[2] == "big"      # around the 65536-target switch to the fused kernel
+    rng = random.Random(4321 if big else 1234)
     worst = 0.0
     for case in range(n_cases):
         H = rng.choice([1, 2, 4, 8, 16])
@@ -24,6 +25,10 @@ def main():
             continue
         T, R = rng.randint(1, 5), rng.randint(1, 12)
         N, E = rng.randint(1, 3000), rng.randint(0, 20000)
+        if big:
+            N, E = rng.randint(60000, 80000), rng.randint(0, 300000)
+            if d > 128:
+                continue
         use_norm, use_rte, dense = rng.random() < 0.7, rng.random() < 0.5, rng.random() < 0.3
         if d % 2:
             use_rte = False          # the reference's sinusoid table needs an even width (conv.py:289-294)
@@ -46,7 +51,8 @@ def main():
         sd = O.make_state_dict(d, d, T, R, H, use_norm, use_rte, seed=case, dense=dense)
         ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, use_norm=use_norm, use_RTE=use_rte, dtype=torch.float64, dense=dense)
         cls = DenseHGTConv if dense else HGTConv
-        layer = cls(d, d, T, R, H, 0.2, use_norm, use_rte, precision=prec).eval()
+        keep_att = rng.random() < 0.3
+        layer = cls(d, d, T, R, H, 0.2, use_norm, use_rte, precision=prec, keep_att=keep_att).eval()
         layer.load_state_dict(sd)
         layer = layer.to("cuda:0")
         GraphPlan.clear_cache()
