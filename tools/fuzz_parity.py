@@ -60,6 +60,28 @@ def main():
             out = layer(x.cuda(), nt.cuda(), ei.cuda(), et.cuda(), tm.cuda() if use_rte else None, n_q_rows=nq if nq < N else None)
         torch.cuda.synchronize()
         err = (out.cpu().double() - ref[:nq]).abs().max().item() if out.numel() else 0.0
+        if nq < N and rng.random() < 0.7:
+            # staged execution (the pipelined multi-GPU step): own rows, then the source-only rows in 1-3 typed chunks
+            xd, ntd, eid, etd = x.cuda(), nt.cuda(), ei.cuda(), et.cuda()
+            tmd = tm.cuda() if use_rte else None
+            cuts = sorted(set([nq, N] + [rng.randint(nq, N) for _ in range(rng.randint(0, 2))]))
+            with torch.no_grad():
+                layer(xd, ntd, eid, etd, tmd, n_q_rows=nq, stage=1)
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    tt = ntd[a:b]
+                    valid = (tt >= 0) & (tt < T)
+                    key = torch.where(valid, tt, torch.full_like(tt, T))
+                    order = torch.argsort(key, stable=True)
+                    rows = (a + order[:int(valid.sum())]).to(torch.int32).contiguous()
+                    off = torch.zeros(T + 1, dtype=torch.int64, device="cuda:0")
+                    off[1:] = torch.cumsum(torch.bincount(key, minlength=T + 1)[:T], 0)
+                    layer(xd, ntd, eid, etd, tmd, n_q_rows=nq, stage=2, proj=(rows, off.to(torch.int32)))
+                staged = layer(xd, ntd, eid, etd, tmd, n_q_rows=nq, stage=3)
+            torch.cuda.synchronize()
+            # bit-identical, except that hub targets are accumulated with fp32 atomics (order varies from run to run)
+            if not (torch.equal(staged, out) or ("dst_skew" in gk and (staged - out).abs().max().item() < 1e-6)):
+                err = max(err, 1.0)
+                print("   staged forward differs from the one-call layer: max diff %.3e" % (staged - out).abs().max().item())
         worst = max(worst, err)
         flag = "" if err < 1e-4 else "   <<<<<< FAIL"
         print("case %3d N=%5d NQ=%5d E=%6d d=%3d H=%2d T=%d R=%2d norm=%d rte=%d dense=%d %-6s %s err=%.2e%s" % (
