@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256) void k_edge_logits(
     // A wave covers DP = 64*VEC consecutive floats of a row = H = 64/LPH heads.  When the row has more heads (HT > H),
     // blockIdx.y selects the head group: used when the full-width relation fragment (dk_pad*vec floats per lane) would
     // not fit in registers (d = 512: 512 floats) -- narrower slices keep it register-resident.
-    // With temporal encoding the table rows get their own slots (added at use), so the batch is half as deep.
-    constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = RTE ? unroll_for<VEC>() / 2 : unroll_for<VEC>();
+    // With temporal encoding the table rows get their own slots (added at use), so the batch is 3/4 as deep (full depth needs 270 registers).
+    constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = RTE ? (unroll_for<VEC>() * 3) / 4 : unroll_for<VEC>();
     const int hg = blockIdx.y;
     const int64_t ld = (int64_t)HT * DKP;   // row stride of Q/K/V/rte tables in floats
     const int co = hg * DP;                 // first column of this head group
