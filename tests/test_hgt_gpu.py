@@ -665,3 +665,29 @@ def test_pipelined_partitioned_forward_with_real_halos(precision, tmp_path):
             out = pg.forward(layer, xg[lo:hi].contiguous())
         assert out.shape == (hi - lo, d)
         assert (out.cpu().double() - ref[lo:hi]).abs().max().item() < TOL
+
+
+def test_forward_is_hip_graph_capturable():
+    """hgt_conv_forward never synchronises and only uses torch's caching allocator, so a whole forward (here two stacked
+    layers) can be captured in a hipGraph and replayed; the replay must reproduce the eager result bit for bit."""
+    T, R, H, d, N, E = 3, 4, 4, 64, 1200, 9000
+    sd = O.make_state_dict(d, d, T, R, H, True, True, seed=17)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=18)
+    layer = _layer_from(sd, d, T, R, H, True, True, keep_att=False, precision="bf16x3")
+    xd, ntd, eid, etd, tmd = _to_dev(x, nt, ei, et, tm)
+    GraphPlan.clear_cache()
+    plan = GraphPlan(ntd, eid, etd, tmd, T, R)
+    with torch.no_grad():
+        eager = layer(layer(xd, ntd, eid, etd, tmd, plan=plan), ntd, eid, etd, tmd, plan=plan).clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            layer(xd, ntd, eid, etd, tmd, plan=plan)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = layer(layer(xd, ntd, eid, etd, tmd, plan=plan), ntd, eid, etd, tmd, plan=plan)
+        for _ in range(3):
+            g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
