@@ -15,7 +15,8 @@ from pyhgt_amd.synth import synthetic_typed_graph  # noqa: E402
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     big = len(sys.argv) > 2 and sys.argv[2] == "big"      # around the 65536-target switch to the fused kernel
-    rng = random.Random(4321 if big else 1234)
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else (4321 if big else 1234)
+    rng = random.Random(seed)
     worst = 0.0
     for case in range(n_cases):
         H = rng.choice([1, 2, 4, 8, 16])
@@ -79,7 +80,7 @@ def main():
                 staged = layer(xd, ntd, eid, etd, tmd, n_q_rows=nq, stage=3)
             torch.cuda.synchronize()
             # bit-identical, except that hub targets are accumulated with fp32 atomics (order varies from run to run)
-            if not (torch.equal(staged, out) or ("dst_skew" in gk and (staged - out).abs().max().item() < 1e-6)):
+            if not (torch.equal(staged, out) or ("dst_skew" in gk and (staged - out).abs().max().item() < 1e-5)):
                 err = max(err, 1.0)
                 print("   staged forward differs from the one-call layer: max diff %.3e" % (staged - out).abs().max().item())
         worst = max(worst, err)
