@@ -316,3 +316,23 @@ def forward_meta_relation_port(sd, num_types, num_relations, n_heads, x, node_ty
     agg = torch.zeros(N, d, dtype=dtype).index_add_(0, dst, res)
     out = _update(sd, agg, x, node_type.long(), T, use_norm, dtype, library_ops=True)
     return (out, att) if return_att else out
+
+
+# --------------------------------------------------------------------------
+# entry point 3: gradients (oracle for the backward pass, SURVEY.md section 8f-2 -- not built on the GPU yet)
+# --------------------------------------------------------------------------
+def backward_reference(sd, num_types, num_relations, n_heads, x, node_type, edge_index, edge_type, edge_time, grad_out,
+                       use_norm=True, use_RTE=True, dtype=torch.float64, dense=False):
+    """d<out, grad_out> / d(x) and / d(every floating parameter of sd), by reverse-mode differentiation of
+    forward_closed_form (every step of it is a differentiable torch op, so this is the exact backward of the math of
+    conv.py:60-134 in eval mode).  Pinned against autograd through the verbatim reference in tests/test_oracle.py."""
+    leaf = {k: v.detach().to(dtype).requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    xg = x.detach().to(dtype).requires_grad_(True)
+    out = forward_closed_form(leaf, num_types, num_relations, n_heads, xg, node_type, edge_index, edge_type, edge_time,
+                              use_norm=use_norm, use_RTE=use_RTE, dtype=dtype, dense=dense)
+    names = list(leaf.keys())
+    grads = torch.autograd.grad((out * grad_out.to(dtype)).sum(), [xg] + [leaf[k] for k in names], allow_unused=True)
+    res = {"x": grads[0]}
+    for k, g in zip(names, grads[1:]):
+        res[k] = g if g is not None else torch.zeros_like(leaf[k])
+    return res

@@ -88,3 +88,29 @@ def test_live_reference_agrees_with_oracle_and_param_count():
     net = torch.nn.Sequential(model.GNN(129, 512, 4, 9, 8, 4, prev_norm=True, last_norm=True, use_RTE=True),
                               model.Classifier(512, 349))
     assert sum(p.numel() for p in net.parameters()) == 21173389
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+@pytest.mark.parametrize("dense", [False, True])
+def test_backward_oracle_matches_autograd_through_the_live_reference(dense):
+    """Oracle for the (not yet built) backward pass, SURVEY 8f-2: gradients of <out, g> with respect to the input features
+    and every parameter, from oracle.backward_reference, against torch.autograd through the verbatim reference layer
+    (eval mode, fp64 vs the reference's fp32 -> 2e-4 relative)."""
+    conv = load_reference_conv()
+    T, R, H, d, N, E = 3, 4, 4, 32, 300, 2500
+    sd = O.make_state_dict(d, d, T, R, H, True, True, seed=21, dense=dense)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=22)
+    g = torch.randn(N, d, generator=torch.Generator().manual_seed(23))
+    layer = (conv.DenseHGTConv if dense else conv.HGTConv)(d, d, T, R, H, 0.2, True, True).eval()
+    layer.load_state_dict(sd)
+    xr = x.clone().requires_grad_(True)
+    (layer(xr, nt, ei, et, tm) * g).sum().backward()
+    got = O.backward_reference(sd, T, R, H, x, nt, ei, et, tm, g, dense=dense)
+
+    def close(a, b):
+        return (a.double() - b.double()).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
+    assert close(xr.grad, got["x"])
+    for name, p in layer.named_parameters():
+        if p.grad is None:                      # the sinusoid table is detached by nn.Embedding? (it is not: it has a grad)
+            continue
+        assert close(p.grad, got[name]), name
