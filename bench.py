@@ -290,6 +290,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: synthetic %d-type/%d-relation graph, %d nodes / %d edges per GPU, "
                                    "d=%d, n_heads=%d, use_RTE=%s, use_norm=True, plan cached" % (T, R, Nl, El, d, H, use_rte),
                        "nodes_per_gpu": Nl, "edges_per_gpu": El, "local_nodes_incl_halo": int(n_local_nodes),
+                       "halo_exchange_bytes_per_gpu_per_step": 0 if world == 1 else int(pg.halo.n_halo) * d * 4,
+                       "halo_chunks": 0 if world == 1 else int(pg.halo.n_chunks),
                        "parallelism": "single" if world == 1 else "dst-partition x%d + RCCL all-to-all halo" % world,
                        "plan_build_ms": plan_ms, "precision": args.precision},
             "roofline": roofline, "cpu_baseline": cpu,
