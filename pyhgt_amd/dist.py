@@ -30,9 +30,34 @@ import torch.distributed as dist
 from . import _lib
 
 
+def _host_staged(t, group):
+    """gloo has no device all-to-all: device tensors are staged through the host (only used to run the multi-GPU code path
+    on a box without several GPUs; RCCL takes the device tensors as they are)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_to_all(recv, send, recv_splits, send_splits, group, async_op=False):
+    """dist.all_to_all_single, host-staged under gloo.  Returns an object with wait() when async_op."""
+    if not _host_staged(send, group):
+        return dist.all_to_all_single(recv, send, recv_splits, send_splits, group=group, async_op=async_op)
+    recv_h = torch.empty(recv.shape, dtype=recv.dtype)
+    work = dist.all_to_all_single(recv_h, send.cpu(), recv_splits, send_splits, group=group, async_op=async_op)
+
+    class _Staged:
+        def wait(self):
+            if work is not None:
+                work.wait()
+            recv.copy_(recv_h)
+            return True
+    if async_op:
+        return _Staged()
+    recv.copy_(recv_h)
+    return None
+
+
 def _all_to_all_int64(send, send_splits, recv_splits, group):
     recv = send.new_empty(int(sum(recv_splits)))
-    dist.all_to_all_single(recv, send, recv_splits, send_splits, group=group)
+    _all_to_all(recv, send, recv_splits, send_splits, group)
     return recv
 
 
@@ -55,7 +80,7 @@ class HaloPlan:
         self.recv_splits = (owner_bounds[1:] - owner_bounds[:-1]).tolist()
         counts = torch.tensor(self.recv_splits, dtype=torch.int64, device=dev)
         got = torch.empty_like(counts)
-        dist.all_to_all_single(got, counts, group=group)
+        _all_to_all(got, counts, None, None, group)
         self.send_splits = got.tolist()
         # tell every owner which of its rows I need; receive which of my rows the peers need
         asked = _all_to_all_int64(need, self.recv_splits, self.send_splits, group)
@@ -140,8 +165,8 @@ class HaloPlan:
         else:
             send = pack(x_own, rows)
         recv = x_local[self.n_own + self.recv_chunk_off[c]:self.n_own + self.recv_chunk_off[c + 1]]
-        work = dist.all_to_all_single(recv, send, list(self.recv_chunk_splits[c]), list(self.send_chunk_splits[c]),
-                                      group=self.group, async_op=async_op)
+        work = _all_to_all(recv, send, list(self.recv_chunk_splits[c]), list(self.send_chunk_splits[c]), self.group,
+                           async_op=async_op)
         return (work, send) if async_op else None
 
     def exchange(self, x_own, x_local, pack=None):
