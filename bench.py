@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--rte", action="store_true", help="5-argument form with temporal encoding")
     ap.add_argument("--dst-skew", type=float, default=0.0, help="secondary variant: Zipf exponent a in (0,1) of the target in-degree distribution (hubs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--halo-fp32", action="store_true", help="multi-GPU: ship halo rows as exact fp32 instead of the 24-bit transport format")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
                     help="typed linears: 3-term split-bf16 MFMA with fp32 accumulation (default; parity-tested at 1e-4) "
                          "or exact fp32 MFMA")
@@ -213,7 +214,8 @@ def main():
     else:
         from pyhgt_amd.dist import PartitionedGraph
         import torch.distributed as dist
-        pg = PartitionedGraph(node_type_own, src_global, dst_local, edge_type, edge_time, T, R, Nl, rank, world)
+        pg = PartitionedGraph(node_type_own, src_global, dst_local, edge_type, edge_time, T, R, Nl, rank, world,
+                              compress=not args.halo_fp32)
         plan_ms = None
         # own features live at the front of the [own ; halo] buffer, so a step does not copy them (pyhgt_amd/dist.py)
         pg.x_local = torch.empty(pg.n_local, d, dtype=torch.float32, device=dev)
@@ -301,7 +303,8 @@ def main():
                                        "BASELINE.json configs[3] recipe (configs[1] per GPU, sources uniform over all ranks)",
                                        T, R, Nl, El, d, H, use_rte),
                        "nodes_per_gpu": Nl, "edges_per_gpu": El, "local_nodes_incl_halo": int(n_local_nodes),
-                       "halo_exchange_bytes_per_gpu_per_step": 0 if world == 1 else int(pg.halo.n_halo) * d * 4,
+                       "halo_exchange_bytes_per_gpu_per_step": 0 if world == 1 else int(pg.halo.n_halo) * d * (3 if pg.compress else 4),
+                       "halo_format": None if world == 1 else ("24-bit (sign, 8 exp, 15 mantissa; fp32 arithmetic)" if pg.compress else "fp32"),
                        "halo_chunks": 0 if world == 1 else int(pg.halo.n_chunks),
                        "parallelism": "single" if world == 1 else "dst-partition x%d + RCCL all-to-all halo" % world,
                        "plan_build_ms": plan_ms, "precision": args.precision},

@@ -224,6 +224,11 @@ int hgt_row_dot(const float* x, const float* y, int64_t n_rows, int32_t d, float
 
 /* row gather used to pack halo rows for the multi-GPU exchange: out[i] = x[idx[i]] */
 int hgt_gather_rows(const float* x, int64_t ldx, const int32_t* idx, int64_t n, int32_t d, float* out, void* stream);
+/* The same rows in a 24-bit transport format (sign, 8 exponent, 15 mantissa bits, round to nearest: relative error <= 2^-16;
+ * 3*d bytes per row, d % 4 == 0) and its inverse: the multi-GPU exchange is bound by the links, and halo rows only feed the
+ * K/V projections. */
+int hgt_gather_rows_c24(const float* x, int64_t ldx, const int32_t* idx, int64_t n, int32_t d, void* out, void* stream);
+int hgt_unpack_rows_c24(const void* in, int64_t n, int32_t d, float* out, int64_t ld_out, void* stream);
 
 /* hgt_edge_aggregate with HGTConv's node update (conv.py:119-133) fused in: the workgroup that aggregated 64 targets
  * multiplies their gelu'd rows with W_a on the matrix cores (split-bf16 x3, w_a_split = hgt_split_weights(W_a,

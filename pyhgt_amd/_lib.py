@@ -86,6 +86,8 @@ SIGNATURES = {
     "hgt_node_update": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "hgt_node_update_ex": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp]),
     "hgt_tanh_inplace": (C.c_int, [_vp, _i64, _vp]),
+    "hgt_gather_rows_c24": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
+    "hgt_unpack_rows_c24": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp]),
     "hgt_gather_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "hgt_conv_workspace_bytes": (C.c_int, [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_u64)]),
     "hgt_conv_prepared_bytes": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_u64)]),

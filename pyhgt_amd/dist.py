@@ -151,23 +151,50 @@ class HaloPlan:
             lists.append((rows, off.to(torch.int32).contiguous()))
         return lists
 
-    def exchange_chunk(self, c, x_own, x_local, pack=None, async_op=False):
+    def exchange_chunk(self, c, x_own, x_local, pack=None, async_op=False, compress=False):
         """One slice of the exchange: pack the rows of chunk c the peers need, all-to-all them into the halo rows of
-        chunk c.  Returns the work handle when async_op (wait() makes the current stream wait for the rows)."""
+        chunk c.  Returns (work, buffers) when async_op: work.wait() makes the current stream wait for the rows (and, with
+        compress, expands them).  compress: rows travel in the 24-bit format of hgt_gather_rows_c24 (3/4 of the bytes;
+        relative error <= 2^-16 on halo features, which only feed the K/V projections)."""
         d = x_own.size(1)
         rows = self.send_rows[self.send_chunk_off[c]:self.send_chunk_off[c + 1]]
+        recv = x_local[self.n_own + self.recv_chunk_off[c]:self.n_own + self.recv_chunk_off[c + 1]]
+        lib = _lib.load() if x_own.is_cuda else None
+        st = torch.cuda.current_stream().cuda_stream if x_own.is_cuda else None
+        if compress and pack is None and x_own.is_cuda and d % 4 == 0:
+            send = torch.empty(rows.numel(), 3 * d, dtype=torch.uint8, device=x_own.device)
+            _lib.check(lib.hgt_gather_rows_c24(x_own.data_ptr(), x_own.stride(0), rows.data_ptr(), rows.numel(), d,
+                                               send.data_ptr(), st), "hgt_gather_rows_c24")
+            wire = torch.empty(recv.size(0), 3 * d, dtype=torch.uint8, device=x_own.device)
+            work = _all_to_all(wire, send, list(self.recv_chunk_splits[c]), list(self.send_chunk_splits[c]), self.group,
+                               async_op=async_op)
+            n_recv, ld = recv.size(0), x_local.stride(0)
+
+            def expand():
+                _lib.check(lib.hgt_unpack_rows_c24(wire.data_ptr(), n_recv, d, recv.data_ptr(), ld,
+                                                   torch.cuda.current_stream().cuda_stream), "hgt_unpack_rows_c24")
+
+            class _Expanding:
+                def wait(self):
+                    if work is not None:
+                        work.wait()
+                    expand()
+                    return True
+            if async_op:
+                return _Expanding(), (send, wire)
+            expand()
+            return None
         if pack is None:
             if not x_own.is_cuda:
                 raise RuntimeError("pyhgt_amd.dist: halo packing runs the HIP gather kernel; CPU tensors need an explicit pack fn")
             send = torch.empty(rows.numel(), d, dtype=x_own.dtype, device=x_own.device)
-            _lib.check(_lib.load().hgt_gather_rows(x_own.data_ptr(), x_own.stride(0), rows.data_ptr(), rows.numel(), d,
-                                                   send.data_ptr(), torch.cuda.current_stream().cuda_stream), "hgt_gather_rows")
+            _lib.check(lib.hgt_gather_rows(x_own.data_ptr(), x_own.stride(0), rows.data_ptr(), rows.numel(), d,
+                                           send.data_ptr(), st), "hgt_gather_rows")
         else:
             send = pack(x_own, rows)
-        recv = x_local[self.n_own + self.recv_chunk_off[c]:self.n_own + self.recv_chunk_off[c + 1]]
         work = _all_to_all(recv, send, list(self.recv_chunk_splits[c]), list(self.send_chunk_splits[c]), self.group,
                            async_op=async_op)
-        return (work, send) if async_op else None
+        return (work, (send,)) if async_op else None
 
     def exchange(self, x_own, x_local, pack=None):
         """Fill x_local[n_own:] with the halo rows (x_local[:n_own] must already hold x_own), one slice after the other.
@@ -181,7 +208,7 @@ class PartitionedGraph:
     """One rank's share of a destination-partitioned typed graph + the per-layer forward."""
 
     def __init__(self, node_type_own, src_global, dst_local, edge_type, edge_time, num_types, num_relations,
-                 nodes_per_rank, rank, world, group=None, node_offsets=None, n_chunks=4, halo=None):
+                 nodes_per_rank, rank, world, group=None, node_offsets=None, n_chunks=4, halo=None, compress=False):
         """halo: a prebuilt HaloPlan for this rank (tests build it on CPU over gloo and move it to the device with
         HaloPlan.to); otherwise it is negotiated here with three small all-to-alls."""
         from .conv import GraphPlan
@@ -189,6 +216,7 @@ class PartitionedGraph:
             node_offsets = [nodes_per_rank * r for r in range(world + 1)]
         self.halo = halo if halo is not None else HaloPlan(node_type_own, src_global, node_offsets, rank, world, group,
                                                             n_chunks=n_chunks)
+        self.compress = bool(compress)     # 24-bit halo rows on the links (exchange_chunk); off: exact fp32 rows
         self.chunk_lists = self.halo.chunk_row_lists(num_types) if self.halo.n_chunks > 1 else None
         self.n_own, self.n_local = self.halo.n_own, self.halo.n_local
         self.edge_index = torch.stack([self.halo.src_local, dst_local], dim=0).contiguous()
@@ -206,20 +234,22 @@ class PartitionedGraph:
             self.x_local[:self.n_own].copy_(x_own)
         x_own_v = self.x_local[:self.n_own]
         if self.chunk_lists is None:
-            self.halo.exchange(x_own_v, self.x_local)
+            for c in range(self.halo.n_chunks):
+                self.halo.exchange_chunk(c, x_own_v, self.x_local, compress=self.compress)
             return layer(self.x_local, self.node_type_local, self.edge_index, self.edge_type, self.edge_time,
                          plan=self.plan, n_q_rows=self.n_own, phase_events=phase_events)
         # pipelined: chunk c+1 is packed and put on the links while chunk c's halo rows are projected
         args = (self.x_local, self.node_type_local, self.edge_index, self.edge_type, self.edge_time)
         kw = dict(plan=self.plan, n_q_rows=self.n_own)
         C = self.halo.n_chunks
-        pending = [self.halo.exchange_chunk(0, x_own_v, self.x_local, async_op=True)]
+        pending = [self.halo.exchange_chunk(0, x_own_v, self.x_local, async_op=True, compress=self.compress)]
         layer(*args, stage=1, phase_events=phase_events, **kw)            # Q|K|V of the own rows
         for c in range(C):
             if c + 1 < C:
-                pending.append(self.halo.exchange_chunk(c + 1, x_own_v, self.x_local, async_op=True))
-            work, send = pending[c]
-            work.wait()                                                   # current stream waits for chunk c
-            send.record_stream(torch.cuda.current_stream())
+                pending.append(self.halo.exchange_chunk(c + 1, x_own_v, self.x_local, async_op=True, compress=self.compress))
+            work, bufs = pending[c]
+            work.wait()                                                   # current stream waits for chunk c (and expands it)
+            for b in bufs:
+                b.record_stream(torch.cuda.current_stream())
             layer(*args, stage=2, proj=self.chunk_lists[c], **kw)         # K|V of the halo rows of chunk c
         return layer(*args, stage=3, phase_events=phase_events, **kw)
