@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HGT_ABI_VERSION 2
+#define HGT_ABI_VERSION 3
 
 /* error codes */
 #define HGT_OK 0
@@ -313,7 +313,13 @@ typedef struct hgt_conv_args {
      * found no hub target, so the hub kernels of the aggregation (4-5 launches that would exit at once) are not enqueued.
      * 0 = unknown: they are enqueued. */
     int32_t plan_no_hubs;
+    /* ABI 3: bit set of HGT_FLAG_* (0 = the default kernel selection) */
+    int32_t flags;
 } hgt_conv_args;
+
+/* hgt_conv_args.flags: explicit kernel-selection switches (A/B measurements, tests); never read from the environment */
+#define HGT_FLAG_NO_FUSED_UPDATE 1   /* aggregation writes agg, the node update runs as its own kernel(s) */
+#define HGT_FLAG_VALU_AGGREGATE  2   /* relation transforms of the aggregation on the vector ALU (round-1 kernel) instead of MFMA */
 
 /* phase boundaries at which hgt_conv_forward records phase_events[i]:
  *   0 start | 1 relation pack + Q/K/V (+ temporal tables) done | 2 logits done | 3 softmax done |

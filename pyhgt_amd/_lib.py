@@ -12,6 +12,8 @@ LIB_PATH = os.environ.get("HGT_LIB_PATH", os.path.join(_HERE, "lib", "libhgt_hip
 
 HGT_RTE_LEN = 240
 HGT_N_PHASE_EVENTS = 7
+HGT_FLAG_NO_FUSED_UPDATE = 1
+HGT_FLAG_VALU_AGGREGATE = 2
 
 
 class HgtLayout(C.Structure):
@@ -47,10 +49,11 @@ class HgtConvArgs(C.Structure):
         ("stage", C.c_int32), ("proj_rows", C.c_void_p), ("proj_off", C.c_void_p), ("proj_n", C.c_int64),
         ("prepared", C.c_void_p), ("prepared_bytes", C.c_uint64), ("prepared_valid", C.c_int32),
         ("plan_no_hubs", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 
-ABI_VERSION = 2          # HGT_ABI_VERSION of include/hgt_hip.h this binding was written against
+ABI_VERSION = 3          # HGT_ABI_VERSION of include/hgt_hip.h this binding was written against
 
 _i32, _i64, _u64, _vp = C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
 

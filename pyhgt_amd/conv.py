@@ -10,6 +10,7 @@ CPU / eager fallback: a non-GPU input or a missing library raises.
 """
 import ctypes as C
 import math
+import threading
 import weakref
 from collections import OrderedDict
 
@@ -31,23 +32,30 @@ def _stream():
 
 
 class _Workspace:
-    """One growing device scratch buffer per device, shared by all layers (layers run back to
-    back on one stream; the C ABI never allocates)."""
+    """Growing device scratch buffers, one per (device, stream): layers that run back to back on one stream share a
+    buffer, layers enqueued on different streams (or from different threads on their own streams) never do -- the
+    C ABI is re-entrant given distinct workspaces and never allocates (include/hgt_hip.h).
+    Staged multi-GPU execution keeps Q/K/V in the workspace between calls and therefore passes its OWN buffer
+    (`forward(..., workspace=...)`, pyhgt_amd.dist.PartitionedGraph), which nothing else can grow or overwrite."""
     _bufs = {}
+    _lock = threading.Lock()
 
     @classmethod
-    def get(cls, device, nbytes):
-        buf = cls._bufs.get(device)
-        if buf is None or buf.numel() < nbytes:
-            buf = None
-            cls._bufs.pop(device, None)
-            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-            cls._bufs[device] = buf
-        return buf
+    def get(cls, device, nbytes, stream=None):
+        key = (str(device), int(stream if stream is not None else _stream()))
+        with cls._lock:
+            buf = cls._bufs.get(key)
+            if buf is None or buf.numel() < nbytes:
+                cls._bufs.pop(key, None)
+                buf = None
+                buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+                cls._bufs[key] = buf
+            return buf
 
     @classmethod
     def clear(cls):
-        cls._bufs.clear()
+        with cls._lock:
+            cls._bufs.clear()
 
 
 class _HeaderSlots:
@@ -84,7 +92,8 @@ class GraphPlan:
     gathers and the T*T*R mask loop, conv.py:57,71-84)."""
 
     _cache = OrderedDict()
-    CACHE_SIZE = 4
+    _cache_lock = threading.Lock()
+    CACHE_SIZE = 4          # plans (and the graph tensors they were built from) kept alive; set to 0 to disable caching
 
     def __init__(self, node_type, edge_index, edge_type, edge_time, num_types, num_relations, n_q_rows=None):
         lib = _lib.load()
@@ -121,9 +130,10 @@ class GraphPlan:
         # tmp is released by the caching allocator only after the stream ran past this point
         tmp.record_stream(torch.cuda.current_stream())
         self.device = dev
-        # plan header (n_items, bad_index, n_hubs) copied to pinned host memory WITHOUT synchronising; `no_hubs` reads it once
-        # the copy has completed (from the second layer on, in practice)
+        # plan header (n_items, bad_index, n_hubs) copied to pinned host memory WITHOUT synchronising; `no_hubs` /
+        # `raise_if_bad` read it once the copy has completed (from the second layer on, in practice)
         self._no_hubs = None
+        self._bad = None
         self._hdr_slot = _HeaderSlots.acquire(self)
         _HeaderSlots.buf[self._hdr_slot].copy_(self.buf[:16].view(torch.int32), non_blocking=True)
         self._hdr_event = torch.cuda.Event()
@@ -133,10 +143,33 @@ class GraphPlan:
     def no_hubs(self):
         """True once it is known (no synchronisation) that no target exceeds the hub in-degree threshold; False = unknown
         or hubs exist.  Lets hgt_conv_forward skip enqueueing the hub kernels (they would exit immediately)."""
-        if self._no_hubs is None and self._hdr_slot is not None and self._hdr_event.query():
-            self._no_hubs = int(_HeaderSlots.buf[self._hdr_slot][2]) == 0
-            _HeaderSlots.release(self)
+        self._poll_header()
         return bool(self._no_hubs)
+
+    def _poll_header(self, wait=False):
+        if self._no_hubs is None and self._hdr_slot is not None and (wait or self._hdr_event.query()):
+            if wait:
+                self._hdr_event.synchronize()
+            row = _HeaderSlots.buf[self._hdr_slot]
+            self._no_hubs = int(row[2]) == 0
+            self._bad = int(row[1])
+            _HeaderSlots.release(self)
+
+    def raise_if_bad(self, wait=False):
+        """The reference fails with an IndexError (index_select / nn.Embedding) when edge_index holds a node id outside
+        [0, N) or edge_time a value outside [0, 240).  The plan build flags both on the device; the flag reaches the host
+        asynchronously, so -- without a synchronisation -- the error surfaces on the first forward AFTER the header copy
+        has landed (the second layer of a GNN, in practice); wait=True synchronises and checks now."""
+        self._poll_header(wait)
+        if self._bad is None and wait and self._hdr_slot is None:      # slot was recycled before we looked: read the device copy
+            self._bad = int(self.buf[:16].view(torch.int32)[1].item())
+        if self._bad:
+            what = []
+            if self._bad & 1:
+                what.append("edge_index contains node ids outside [0, num_nodes) (or targets beyond n_q_rows)")
+            if self._bad & 2:
+                what.append("edge_time contains values outside [0, %d)" % _lib.HGT_RTE_LEN)
+            raise IndexError("pyhgt_amd: " + "; ".join(what))
 
     @property
     def ptr(self):
@@ -150,10 +183,8 @@ class GraphPlan:
     def check_indices(self):
         """Debug aid (synchronises): raise if an edge endpoint was outside [0, N) (the reference
         would have raised an IndexError inside index_select)."""
-        hdr = self.buf[:8].view(torch.int32).cpu()
-        if int(hdr[1]) != 0:
-            raise IndexError("pyhgt_amd: edge_index contains node ids outside [0, num_nodes)")
-        return int(hdr[0])
+        self.raise_if_bad(wait=True)
+        return int(self.buf[:8].view(torch.int32)[0].item())
 
     # -- cache: the reference passes the SAME tensors to every layer (model.py:78-79) ------------
     @classmethod
@@ -161,20 +192,23 @@ class GraphPlan:
         tensors = (node_type, edge_index, edge_type, edge_time)
         key = tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride())) if t is not None else None for t in tensors)
         key = key + (int(num_types), int(num_relations), n_q_rows, str(node_type.device))
-        hit = cls._cache.get(key)
-        if hit is not None:
-            cls._cache.move_to_end(key)
-            return hit[0]
+        with cls._cache_lock:
+            hit = cls._cache.get(key)
+            if hit is not None:
+                cls._cache.move_to_end(key)
+                return hit[0]
         plan = cls(node_type, edge_index, edge_type, edge_time, num_types, num_relations, n_q_rows)
-        # keep the key tensors alive so their addresses cannot be recycled while the entry lives
-        cls._cache[key] = (plan, tensors)
-        while len(cls._cache) > cls.CACHE_SIZE:
-            cls._cache.popitem(last=False)
+        with cls._cache_lock:
+            # keep the key tensors alive so their addresses cannot be recycled while the entry lives
+            cls._cache[key] = (plan, tensors)
+            while len(cls._cache) > max(int(cls.CACHE_SIZE), 0):
+                cls._cache.popitem(last=False)
         return plan
 
     @classmethod
     def clear_cache(cls):
-        cls._cache.clear()
+        with cls._cache_lock:
+            cls._cache.clear()
 
 
 class RelTemporalEncoding(nn.Module):
@@ -221,6 +255,7 @@ class HGTConv(nn.Module):
         if precision not in ("fp32", "bf16x3"):
             raise ValueError("precision must be 'fp32' or 'bf16x3'")
         self.precision = precision
+        self.kernel_flags = 0          # hgt_conv_args.flags (HGT_FLAG_*): explicit kernel selection for A/B runs and tests
         self.att = None
 
         self.k_linears = nn.ModuleList(nn.Linear(in_dim, out_dim) for _ in range(num_types))
@@ -236,13 +271,53 @@ class HGTConv(nn.Module):
         self.drop = nn.Dropout(dropout)
         if use_RTE:
             self.emb = RelTemporalEncoding(in_dim)
-        self._packed = None
-        self._packed_key = None
-        self._prepared = None
-        self._prepared_tag = None
-        self._prepared_valid = False
+        self._init_runtime_state()
 
     _UPDATE_MODE = 0     # hgt_conv_args.update_mode
+
+    # -- state that is not part of the reference module: caches of packed parameters / device-side weight images ------
+    _RUNTIME_DEFAULTS = dict(keep_att=False, precision="bf16x3", kernel_flags=0, att=None, _packed=None, _packed_key=None,
+                             _prepared=None, _prepared_tag=None, _prepared_valid=False)
+
+    def _init_runtime_state(self):
+        for k, v in self._RUNTIME_DEFAULTS.items():
+            if k not in self.__dict__:
+                self.__dict__[k] = v
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for k in ("_packed", "_packed_key", "_prepared", "_prepared_tag"):     # derived device buffers: rebuilt on demand
+            st[k] = None
+        st["_prepared_valid"] = False
+        st["att"] = None
+        return st
+
+    def __setstate__(self, state):
+        """Whole-module pickles (torch.save(model), OAG/train_paper_field.py:279) written by the REFERENCE class carry none of
+        this implementation's runtime attributes: fill in the defaults so that such a module loads and runs
+        (pyHGT.conv.HGTConv must resolve to this class at load time: install_into)."""
+        super().__setstate__(state)
+        self._init_runtime_state()
+        if "d_k" not in self.__dict__:
+            self.d_k = self.out_dim // self.n_heads
+        if "sqrt_dk" not in self.__dict__:
+            self.sqrt_dk = math.sqrt(self.d_k)
+
+    def invalidate(self):
+        """Drop the packed-parameter cache and the device-side weight images.  They are keyed on every parameter's
+        (data_ptr, _version), which optimizer steps, load_state_dict, .to()/.float() and in-place torch ops all change --
+        but writes through `.data` (`p.data.copy_()`, `p.data[...] = x`; EMA / manual initialisation code) do NOT bump
+        `_version`: call invalidate() after such an update (training mode re-packs on every forward anyway)."""
+        self._packed = self._packed_key = None
+        self._prepared_valid = False
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate()
+        return super()._apply(fn, *args, **kwargs)
 
     def _init_update_parameters(self, num_types, out_dim):
         self.skip = nn.Parameter(torch.ones(num_types))                 # conv.py:47
@@ -260,7 +335,7 @@ class HGTConv(nn.Module):
         hgt_conv_forward takes (pure data movement; cached until a parameter changes)."""
         params = list(self.parameters())
         key = tuple((p.data_ptr(), p._version) for p in params)
-        if self._packed is not None and self._packed_key == key:
+        if self._packed is not None and self._packed_key == key and not self.training:
             return self._packed
         lay = _lib.layout_for(self.out_dim, self.n_heads)
         H, dk, dkp, dp = self.n_heads, lay.d_k, lay.dk_pad, lay.d_pad
@@ -314,14 +389,16 @@ class HGTConv(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def forward(self, node_inp, node_type, edge_index, edge_type, edge_time=None, plan=None, n_q_rows=None,
-                phase_events=None, stage=0, proj=None):
+                phase_events=None, stage=0, proj=None, workspace=None):
         """node_inp f32[N,in_dim], node_type i64[N], edge_index i64[2,E] (row 0 = source, row 1 =
         target; any strides), edge_type i64[E], edge_time i64[E] (needed iff use_RTE).
         Returns f32[N,out_dim] (or [n_q_rows,out_dim] when only the first n_q_rows nodes are targets).
 
         stage / proj: staged execution for pyhgt_amd.dist (hgt_conv_args.stage): 1 = projections of the own rows,
         2 = K|V of the rows in proj = (rows int32[n], offsets int32[T+1]) (one call per received halo chunk),
-        3 = edge phase + update (returns the output); stages 1 and 2 return None."""
+        3 = edge phase + update (returns the output); stages 1 and 2 return None.
+        workspace: caller-owned uint8 device buffer (>= workspace_bytes(N, E)) instead of the per-(device, stream) scratch;
+        staged callers MUST pass one (Q/K/V live in it between the stages)."""
         lib = _lib.load()
         if not node_inp.is_cuda:
             raise RuntimeError("pyhgt_amd.HGTConv runs only on a ROCm GPU tensor; there is no CPU fallback "
@@ -344,6 +421,7 @@ class HGTConv(nn.Module):
                                     self.num_types, self.num_relations, n_q_rows)
         if plan.N != N or plan.T != self.num_types or plan.R != self.num_relations:
             raise ValueError("plan was built for a different graph / schema")
+        plan.raise_if_bad()
         NQ, E = plan.NQ, plan.E
         pk = self._pack_parameters()
         if pk["w_qkv"].device != x.device:
@@ -351,7 +429,14 @@ class HGTConv(nn.Module):
         nbytes = C.c_uint64()
         _lib.check(lib.hgt_conv_workspace_bytes(N, E, self.in_dim, self.out_dim, self.num_types, self.num_relations,
                                                 self.n_heads, int(self.use_RTE), C.byref(nbytes)), "hgt_conv_workspace_bytes")
-        ws = _Workspace.get(x.device, nbytes.value)
+        if workspace is not None:
+            if workspace.dtype != torch.uint8 or workspace.device != x.device or workspace.numel() < nbytes.value:
+                raise ValueError("workspace must be a uint8 tensor of >= %d bytes on %s" % (nbytes.value, x.device))
+            ws = workspace
+        else:
+            if stage != 0:
+                raise ValueError("staged execution keeps Q/K/V in the workspace between calls: pass workspace=")
+            ws = _Workspace.get(x.device, nbytes.value)
         final = stage in (0, 3)
         out = torch.empty(NQ, self.out_dim, dtype=torch.float32, device=x.device) if final else None
         att = torch.empty(E, self.n_heads, dtype=torch.float32, device=x.device) if (self.keep_att and final) else None
@@ -376,6 +461,7 @@ class HGTConv(nn.Module):
         a.want_att = int(self.keep_att and final)
         a.stage = int(stage)
         a.plan_no_hubs = int(plan.no_hubs)
+        a.flags = int(self.kernel_flags)
         prep = self._prepared_buffer(x.device)          # after _pack_parameters: a re-pack has invalidated it
         a.prepared, a.prepared_bytes, a.prepared_valid = _ptr(prep), prep.numel(), int(self._prepared_valid)
         if stage == 2:
@@ -390,6 +476,13 @@ class HGTConv(nn.Module):
             self.att = att
             self._prepared_valid = True                 # every image was written by this forward (or an earlier one)
         return out
+
+    def workspace_bytes(self, n_nodes, n_edges):
+        n = C.c_uint64()
+        _lib.check(_lib.load().hgt_conv_workspace_bytes(int(n_nodes), int(n_edges), self.in_dim, self.out_dim, self.num_types,
+                                                        self.num_relations, self.n_heads, int(self.use_RTE), C.byref(n)),
+                   "hgt_conv_workspace_bytes")
+        return int(n.value)
 
     def __repr__(self):
         return '{}(in_dim={}, out_dim={}, num_types={}, num_types={})'.format(

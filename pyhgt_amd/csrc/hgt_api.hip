@@ -1,7 +1,5 @@
 // C-ABI glue: error strings, layout helper and the whole-layer entry point that enqueues every
 // kernel of one HGTConv.forward (conv.py:56-134, eval mode) on the caller's stream.
-#include <cstdlib>
-
 #include "hgt_common.h"
 
 namespace {
@@ -175,7 +173,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     PreparedLayout pl = prepared_layout(din, dout, T, R, H, a->use_rte, lay);
     if (pb && a->prepared_bytes < pl.total) return HGT_ERR_WORKSPACE;
     const bool fresh = !(pb && a->prepared_valid);          // derive the weight images in this call
-    void* hub_ws = (a->plan_no_hubs || getenv("HGT_NO_HUB")) ? nullptr : (void*)(wb + w.off_hub);
+    void* hub_ws = a->plan_no_hubs ? nullptr : (void*)(wb + w.off_hub);
     if (pb) {
         att_t = (float*)(pb + pl.off_att_t);
         msg_p = (float*)(pb + pl.off_msg_p);
@@ -282,7 +280,7 @@ edge_phase:
     // (graphs below 64k targets take the unfused kernels: hgt_edge_aggregate then runs 4 targets per wavefront, which
     //  matters more in the latency regime than the saved agg round trip)
     const bool fuse_all = split && !dense && dp <= 256 && dout <= dp && (dout & 3) == 0 && (din & 3) == 0 && NQ >= 65536 &&
-                          !getenv("HGT_NO_FUSE_AGG");
+                          !(a->flags & HGT_FLAG_NO_FUSED_UPDATE);
     if (fuse_all) {
         if (fresh || !pb) {
             rc = hgt_split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);

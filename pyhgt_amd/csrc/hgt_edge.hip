@@ -17,9 +17,6 @@
 // lanes with DPP.  Rows for the next UN edges are requested before the current ones are consumed.
 #include "hgt_common.h"
 #include "hgt_split_common.h"
-#ifndef HGT_FU_TRACE
-#define HGT_FU_TRACE 0
-#endif
 
 namespace {
 
@@ -519,14 +516,6 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate(
 // A tile whose rows have several node types (only at the T-1 type boundaries of a type-sorted graph) repeats the
 // product per type present; rows of unknown type are written as 0 (conv.py:120).
 // ---------------------------------------------------------------------------------------------
-#if HGT_FU_TRACE
-__device__ unsigned long long fu_trace[8];   // development aid: shader-clock totals of wave 0 of every workgroup
-#define FU_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
-#define FU_TADD(slot, a, b) if (threadIdx.x == 0) atomicAdd(&fu_trace[slot], (b) - (a))
-#else
-#define FU_T(v)
-#define FU_TADD(slot, a, b)
-#endif
 
 struct FusedUpdate {
     const int64_t* node_type;
@@ -549,7 +538,6 @@ __device__ __forceinline__ void fused_update_epilogue(const float (&vals)[16][VE
     constexpr int DP = 64 * VEC;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    FU_T(t0);
     // ---- A operand: hi/mid bf16 planes of the 64 finished rows, [plane][row][k], 528 B row stride
     int* s_type = reinterpret_cast<int*>(tables);                // [64]
     float* s_sum = reinterpret_cast<float*>(tables + 256);         // [64][4]
@@ -600,11 +588,8 @@ __device__ __forceinline__ void fused_update_epilogue(const float (&vals)[16][VE
     const float inv_n = 1.0f / (float)n_out;
     const int rt0 = (lane & 3) + 4 * (lane >> 5);      // row of register group (j, q): rt0 + 32 j + 8 q
 
-    FU_T(t1);
-    FU_TADD(1, t0, t1);                                // slab write + types
     for (int g = tmin; g <= tmax; ++g) {               // empty range when no row has a valid type
         if (__builtin_amdgcn_ballot_w64(my_t == g) == 0) continue;
-        FU_T(t2);
         // ---- 64 x n_out x DP product; this wavefront owns columns [64 wave, 64 wave + 64) = column tiles 2 wave, 2 wave + 1
         f32x16 acc[2][2];
 #pragma unroll
@@ -672,8 +657,6 @@ __device__ __forceinline__ void fused_update_epilogue(const float (&vals)[16][VE
 #undef FU_LOAD_A
 #undef FU_LOAD_B
         }
-        FU_T(t3);
-        FU_TADD(2, t2, t3);                            // MFMA product
         // ---- epilogue for the rows of type g: bias, gated skip, LayerNorm, store
         const float alpha = 1.0f / (1.0f + expf(-fu.skip[g]));
         float y[16][4];                                // [c*8 + j*4 + q][4 consecutive columns]
@@ -757,8 +740,6 @@ __device__ __forceinline__ void fused_update_epilogue(const float (&vals)[16][VE
             }
         }
         if (fu.use_norm) __syncthreads();   // the tables are rewritten by the next type of a mixed tile
-        FU_T(t4);
-        FU_TADD(3, t3, t4);                            // gated skip + LayerNorm + store
     }
     // rows of unknown type -> 0 (conv.py:120)
     for (int r = wave * 16; r < wave * 16 + 16; ++r) {
@@ -806,15 +787,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update(
         return;
     }
     float vals[16][VEC];
-    FU_T(ta);
     aggregate_subtile<VEC, LPH, RTE, false, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgP, nullptr, R, NQ, 1, HT, 0u, s_acc,
                                                   s_bounce, s_ml, vals);
-    FU_T(tb);
     __syncthreads();   // every wavefront is done with the accumulators, bounce rows and softmax state
-    FU_T(tc);
-    FU_TADD(0, ta, tb);                                // aggregation (wave 0)
-    FU_TADD(4, tb, tc);                                // waiting for the other wavefronts
-    FU_TADD(7, ta - ta, ta - ta + 1);                  // workgroups
     fused_update_epilogue<VEC>(vals, smem, smem + FRONT, row0, NQ, fu);
 }
 
@@ -843,8 +818,7 @@ __global__ __launch_bounds__(256, 2) void k_update_pending(const float* __restri
 // handled by a fixed grid of wavefronts that split every (hub, relation) edge range into HUB_CHUNKS pieces:
 //   k_hub_max        max logit per (hub, head)  (wave reduce + one atomicMax per head and piece)
 //   k_hub_accumulate sum exp(s - m) and (sum exp(s - m) V[src]) M[rel] per piece, atomically added to the hub's
-//                    fp32 accumulators (any reference m gives the same softmax; m = max(max logit, 0) covers the
-//                    unclaimed bucket, whose logits are 0)
+//                    fp32 accumulators, m = the hub's true max logit per head (unclaimed edges count with logit 0)
 //   k_hub_finalize   agg[hub] = gelu(acc / (l + 1e-16))
 // All three exit immediately when the plan found no hub (hdr->n_hubs == 0).
 // ---------------------------------------------------------------------------------------------
@@ -937,7 +911,8 @@ __global__ __launch_bounds__(256) void k_hub_accumulate(
         rel = __builtin_amdgcn_readfirstlane(rel);
         pb = __builtin_amdgcn_readfirstlane(pb);
         pe = __builtin_amdgcn_readfirstlane(pe);
-        const float mref = fmaxf(ord2f(hb.mx[slot * HT + hg * H + h]), 0.0f);
+        // true max over ALL in-edges of the hub (k_hub_max folds a 0 in for a non-empty unclaimed bucket), like PyG's softmax
+        const float mref = ord2f(hb.mx[slot * HT + hg * H + h]);
         float l_part = 0.0f;
         if (rel >= R) {                            // unclaimed: logit 0, no message
             l_part = (float)(pe - pb) * __expf(0.0f - mref);
@@ -1184,16 +1159,6 @@ extern "C" int hgt_edge_softmax(const void* plan, int64_t N, int64_t E, int32_t 
     return HGT_OK;
 }
 
-#if HGT_FU_TRACE
-extern "C" int hgt_debug_fu_trace(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(fu_trace), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[8] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(fu_trace), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 extern "C" int hgt_edge_aggregate_update(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
                                          const float* logits, const float* V, const float* rte_v, const float* msg_p, float* agg,

@@ -25,11 +25,7 @@
 #include "hgt_common.h"
 #include "hgt_split_common.h"
 #include <algorithm>
-#include <cstdlib>
 
-#ifndef PC_DBG
-#define PC_DBG 0   // development switches for timing experiments; 0 in the product build
-#endif
 
 namespace {
 
@@ -111,11 +107,7 @@ __device__ __forceinline__ void load_a_panel(int kp0, int tid, const int* s_rid,
 __device__ __forceinline__ void store_pass(f32x16 (&acc)[2], int pass, int wave, int lane, int g, int n_out, int nrows, int row0,
                                            const int* s_rid, const float* __restrict__ bias, int64_t bgs, float* __restrict__ out0,
                                            float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos) {
-#if PC_DBG & 16
-    const int col = pass * BNP + wave * 32 + (lane & 7) * 4;   // timing experiment only: WRONG placement, coalesced pattern
-#else
     const int col = pass * BNP + wave * 32 + ((lane & 31) >> 2) * 4;      // first of this lane's 4 columns after the transpose
-#endif
     const bool col_ok = col < n_out;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col_ok && bias) b4 = *reinterpret_cast<const float4*>(bias + (int64_t)g * bgs + col);
@@ -128,11 +120,7 @@ __device__ __forceinline__ void store_pass(f32x16 (&acc)[2], int pass, int wave,
         for (int q = 0; q < 4; ++q) {
             float v0 = acc[j][4 * q], v1 = acc[j][4 * q + 1], v2 = acc[j][4 * q + 2], v3 = acc[j][4 * q + 3];
             quad_transpose(v0, v1, v2, v3, o1, o2);
-#if PC_DBG & 16
-            const int rt = j * 32 + 8 * q + (lane >> 3);
-#else
             const int rt = j * 32 + (lane & 3) + 8 * q + 4 * (lane >> 5);
-#endif
             if (col_ok && rt < nrows) {
                 const int64_t orow = by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
                 *reinterpret_cast<float4*>(ob + orow * block_cols + cc) = make_float4(v0 + b4.x, v1 + b4.y, v2 + b4.z, v3 + b4.w);
@@ -367,21 +355,6 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
 //     epilogue of the fused update; the producers simply arrive at those as well).
 // LDS: 2 x 66 KB slabs + row ids + the LayerNorm tables = 137 KB.  VGPR budget 168 (3 waves/SIMD).
 // =============================================================================================
-#ifndef PC_PRIO
-#define PC_PRIO 0
-#endif
-#ifndef PC_TRACE
-#define PC_TRACE 0
-#endif
-#if PC_TRACE
-// development aid: per-phase shader-clock totals of consumer wave 0 / producer wave 8 of every workgroup
-__device__ unsigned long long pc_trace[16];
-#define PC_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define PC_TADD(slot, from, to) if (trace_me) atomicAdd(&pc_trace[slot], (to) - (from))
-#else
-#define PC_T(var)
-#define PC_TADD(slot, from, to)
-#endif
 constexpr int PC_CONS = 8, PC_PROD = 4, PC_THREADS = 64 * (PC_CONS + PC_PROD);
 constexpr int PC_AREGS = BM * (KP / 4) / (64 * PC_PROD);   // float4 per producer lane per tile = 16
 
@@ -409,7 +382,7 @@ __device__ __forceinline__ void pc_issue(float4 (&a)[PC_AREGS], int& v_rid, int 
     v_rid = (lane < PC_AREGS && myrow < nrows) ? rows[row0 + myrow] : -1;
     const int kk = lane * 4;
     if (vec_ok) {   // k % 4 == 0: a lane is entirely inside or entirely outside the row
-        if (kk < k && !(PC_DBG & 2)) {
+        if (kk < k) {
 #pragma unroll
             for (int j = 0; j < PC_AREGS; ++j) {
                 const int rid = max(__builtin_amdgcn_readlane(v_rid, j), 0);
@@ -615,12 +588,6 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
     const int first = blockIdx.x, stride = gridDim.x;
     const int n_mine = (total_tiles > first) ? (total_tiles - first + stride - 1) / stride : 0;
     if (n_mine == 0) return;
-#if PC_PRIO
-    // producers first (short bursts that keep HBM busy); consumer waves 0..3 ahead of 4..7 so that the two consumer waves
-    // of a SIMD drift half a pass apart: one drains its stores (vmcnt(0)) while the other owns the matrix core
-    if (wave >= PC_CONS) __builtin_amdgcn_s_setprio(3);
-    else if (wave < 4) __builtin_amdgcn_s_setprio(2);
-#endif
 
     if (wave >= PC_CONS) {
         // ------------------------------------------------ producers
@@ -637,35 +604,19 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
             pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
         }
         pc_barrier();                                   // B_0
-#if PC_TRACE
-        const bool trace_me = (pw == 0 && lane == 0);
-#endif
         for (int i = 0; i < n_mine; ++i) {
-            PC_T(p0);
             if (i + 1 < n_mine) {
-#if PC_TRACE
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
-                PC_T(p1);
                 pc_commit<PROLOGUE>(a, v_rid, pw, lane, sA[(i + 1) & 1], s_rid[(i + 1) % 3]);
-                PC_T(p2);
                 if (i + 2 < n_mine) {
                     tile_lookup(first + (i + 2) * stride, group_off, n_groups, g, row0, nrows);
                     pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
                 }
-                PC_T(p3);
-                PC_TADD(8, p0, p1);    // producer: wait for the loads
-                PC_TADD(9, p1, p2);    // producer: split + LDS store
-                PC_TADD(10, p2, p3);   // producer: issue next
             }
-            PC_T(p4);
             if constexpr (UPD) {
                 pc_barrier();
                 pc_barrier();
             }
             if (i + 1 < n_mine) pc_barrier();           // B_{i+1}
-            PC_T(p5);
-            PC_TADD(11, p4, p5);       // producer: barriers
         }
         return;
     }
@@ -690,13 +641,10 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
     pr.rid = s_rid[0];
     pr.row0 = pr.nrows = pr.by_pos = 0;
 #define PC_STORE(U)                                                                                   \
-    if (have_pend && !(PC_DBG & 4)) {                                                                 \
+    if (have_pend) {                                                                 \
         const int r_ = pr.row(U, lane);                                                               \
         if (r_ >= 0) hidden_store16(pr.base + (int64_t)r_ * pr.ld, pr.v[U]);                          \
     }
-#if PC_TRACE
-    const bool trace_me = (wave == 0 && lane == 0);
-#endif
 
     for (int i = 0; i < n_mine; ++i) {
         int g, row0, nrows;
@@ -711,7 +659,6 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
     }
         // B fragments are prefetched NST k-chunks ahead (the fused-update variant has fewer registers to spare)
         constexpr int NST = UPD ? 2 : 4;
-        PC_T(c0);
         PC_LOAD_STAGE(0, 0)
         PC_LOAD_STAGE(1, 1)
         if constexpr (NST == 4) {
@@ -719,9 +666,6 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
             PC_LOAD_STAGE(3, 3)
         }
         pc_barrier();                                      // B_i: slab[i&1] holds tile i
-        PC_T(c1);
-        PC_TADD(0, c0, c1);            // consumer: tile barrier
-        PC_TADD(7, c0 - c0, c0 - c0 + 1);   // tiles
         const unsigned char* slab = sA[i & 1] + frow * A_STRIDE + khalf * 16;
         // A fragments (2 row tiles x hi/mid) are read one k-chunk ahead, into alternating register sets
         bf16x8 e_h0, e_m0, e_h1, e_m1, o_h0, o_m0, o_h1, o_m1;
@@ -746,7 +690,7 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##m, acc[1], 0, 0, 0);                        \
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##h, acc[0], 0, 0, 0);                        \
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##h, acc[1], 0, 0, 0);                        \
-        if (!(PC_DBG & 1)) PC_LOAD_STAGE(S, (T) + NST)                                                             \
+        PC_LOAD_STAGE(S, (T) + NST)                                                             \
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); /* 4 DS reads    */                                     \
         __builtin_amdgcn_sched_group_barrier(0x008, 6, 0); /* 6 MFMAs       */                                     \
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0); /* 2 VMEM reads  */                                     \
@@ -780,7 +724,6 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
         PC_LOAD_A(e, 0)
         for (int pass = 0; pass < n_pass; ++pass) {
             const int tbase = pass * n_kc;
-            PC_T(c3);
             PC_BODY(0)
             if (n_kc > 4) PC_BODY(1)
             if (n_kc > 8) PC_BODY(2)
@@ -789,8 +732,6 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
             if (n_kc <= 12) { PC_STORE(6) PC_STORE(7) }
             if (n_kc <= 8) { PC_STORE(4) PC_STORE(5) }
             if (n_kc <= 4) { PC_STORE(2) PC_STORE(3) }
-            PC_T(c4);
-            PC_TADD(2, c3, c4);        // consumer: MFMA loop (+ the parked stores of the previous pass)
             if constexpr (UPD) {
                 pc_store_update(acc, wave, lane, g, n_out, nrows, s_rid[i % 3], bias, bgs, out0, upd, s_red[i & 1][0], s_red[i & 1][1], pr);
 #pragma unroll
@@ -805,8 +746,6 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
             pr.row0 = row0;
             pr.nrows = nrows;
             pr.by_pos = UPD ? 0 : by_pos;
-            PC_T(c5);
-            PC_TADD(3, c4, c5);        // consumer: epilogue arithmetic
         }
 #undef PC_LOAD_A
 #undef PC_STEP
@@ -824,9 +763,6 @@ static int pc_grid() {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         n_cu = v;
-#if PC_TRACE
-        if (const char* e = getenv("HGT_PC_GRID")) n_cu = atoi(e);   // development aid
-#endif
     }
     return n_cu;
 }
@@ -838,16 +774,6 @@ static inline void split_dims(int k, int n_out, int* n_pass, int* n_kc) {
 
 }  // namespace
 
-#if PC_TRACE
-extern "C" int hgt_debug_pc_trace(unsigned long long* out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pc_trace), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(pc_trace), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 extern "C" int hgt_split_weights_bytes(int32_t n_groups, int32_t k, int32_t n_out, uint64_t* out) {
     if (!out || n_groups <= 0 || k <= 0 || n_out <= 0) return HGT_ERR_INVALID_ARG;

@@ -79,7 +79,7 @@ __global__ void k_edge_keys(const int64_t* __restrict__ ei, int64_t sr, int64_t 
     bool bad = false;
     if (src < 0 || src >= N) { src = 0; bad = true; }
     if (dst < 0 || dst >= NQ) { dst = 0; bad = true; }
-    if (bad) hdr->bad_index = 1;
+    if (bad) atomicOr(&hdr->bad_index, 1);
     int64_t ts = ntype[src], td = ntype[dst], r = etype[e];
     bool claimed = !bad && ts >= 0 && ts < T && td >= 0 && td < T && r >= 0 && r < R;
     uint32_t rr = claimed ? (uint32_t)r : (uint32_t)R;
@@ -91,7 +91,7 @@ __global__ void k_edge_keys(const int64_t* __restrict__ ei, int64_t sr, int64_t 
 __global__ void k_edge_fill(const int64_t* __restrict__ ei, int64_t sr, int64_t sc, const int64_t* __restrict__ etime,
                             const int64_t* __restrict__ ntype, int64_t N, int64_t NQ, int64_t E, int T,
                             const int32_t* __restrict__ order, int32_t* __restrict__ esrc, int32_t* __restrict__ edst,
-                            uint16_t* __restrict__ ertei) {
+                            uint16_t* __restrict__ ertei, HgtPlanHeader* hdr) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= E) return;
     int32_t e = order[p];
@@ -102,8 +102,10 @@ __global__ void k_edge_fill(const int64_t* __restrict__ ei, int64_t sr, int64_t 
     int64_t ts = ntype[src];
     if (ts < 0 || ts >= T) ts = 0;
     int64_t tm = etime ? etime[e] : 0;
-    if (tm < 0) tm = 0;
-    if (tm >= HGT_RTE_LEN) tm = HGT_RTE_LEN - 1;
+    if (tm < 0 || tm >= HGT_RTE_LEN) {   // the reference's nn.Embedding lookup (conv.py:299) raises; here: flagged + clamped
+        atomicOr(&hdr->bad_index, 2);
+        tm = tm < 0 ? 0 : HGT_RTE_LEN - 1;
+    }
     esrc[p] = (int32_t)src;
     edst[p] = (int32_t)dst;
     ertei[p] = (uint16_t)(ts * HGT_RTE_LEN + tm);
@@ -285,7 +287,7 @@ extern "C" int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int
         if (rocprim::radix_sort_pairs(sort_tmp, sort_bytes, keys_in, keys_out, vals_in, eid, (size_t)E, 0,
                                       key_bits((uint64_t)L.n_bins), stream) != hipSuccess) return HGT_ERR_LAUNCH;
         k_edge_fill<<<nblk(E, BS), BS, 0, stream>>>(edge_index, stride_row, stride_col, edge_time, node_type, N, NQ, E, T,
-                                                   eid, esrc, edst, ertei);
+                                                   eid, esrc, edst, ertei, hdr);
     }
     k_segptr<<<nblk(L.n_bins + 1, BS), BS, 0, stream>>>(keys_out, E, L.n_bins, segptr);
     k_pair_counts<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(segptr, L.n_pairs, hgt_item_edges(E), pair_cnt);

@@ -225,9 +225,13 @@ class PartitionedGraph:
         self.plan = GraphPlan(self.node_type_local, self.edge_index, edge_type, edge_time, num_types, num_relations,
                               n_q_rows=self.n_own)
         self.x_local = None
+        self.workspace = None      # owned here: Q/K/V stay in it between the stages of one step
 
     def forward(self, layer, x_own, phase_events=None):
         d = x_own.size(1)
+        need = layer.workspace_bytes(self.n_local, self.plan.E)
+        if self.workspace is None or self.workspace.numel() < need or self.workspace.device != x_own.device:
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=x_own.device)
         if self.x_local is None or self.x_local.size(1) != d:
             self.x_local = torch.empty(self.n_local, d, dtype=x_own.dtype, device=x_own.device)
         if x_own.data_ptr() != self.x_local.data_ptr():
@@ -237,10 +241,10 @@ class PartitionedGraph:
             for c in range(self.halo.n_chunks):
                 self.halo.exchange_chunk(c, x_own_v, self.x_local, compress=self.compress)
             return layer(self.x_local, self.node_type_local, self.edge_index, self.edge_type, self.edge_time,
-                         plan=self.plan, n_q_rows=self.n_own, phase_events=phase_events)
+                         plan=self.plan, n_q_rows=self.n_own, phase_events=phase_events, workspace=self.workspace)
         # pipelined: chunk c+1 is packed and put on the links while chunk c's halo rows are projected
         args = (self.x_local, self.node_type_local, self.edge_index, self.edge_type, self.edge_time)
-        kw = dict(plan=self.plan, n_q_rows=self.n_own)
+        kw = dict(plan=self.plan, n_q_rows=self.n_own, workspace=self.workspace)
         C = self.halo.n_chunks
         pending = [self.halo.exchange_chunk(0, x_own_v, self.x_local, async_op=True, compress=self.compress)]
         layer(*args, stage=1, phase_events=phase_events, **kw)            # Q|K|V of the own rows

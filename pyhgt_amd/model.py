@@ -37,10 +37,40 @@ class GNN(nn.Module):
         self._packed = None
         self._packed_key = None
 
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_packed"] = st["_packed_key"] = None
+        st.pop("_tiles", None)
+        st.pop("_tiles_key", None)
+        return st
+
+    def __setstate__(self, state):
+        """Modules pickled by the reference class (torch.save(model), train_paper_field.py:279) lack the cache attributes."""
+        super().__setstate__(state)
+        self.__dict__.setdefault("_packed", None)
+        self.__dict__.setdefault("_packed_key", None)
+
+    def invalidate(self):
+        """Forget the packed adapter weights and every layer's packed / prepared images (needed after writes through
+        `.data`, which do not bump the parameter versions the caches are keyed on; see HGTConv.invalidate)."""
+        self._packed = self._packed_key = None
+        self.__dict__.pop("_tiles_key", None)
+        for gc in self.gcs:
+            if hasattr(gc.base_conv, "invalidate"):
+                gc.base_conv.invalidate()
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._packed = self._packed_key = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._packed = self._packed_key = None
+        return super()._apply(fn, *args, **kwargs)
+
     def _pack_adapter(self):
         params = [p for lin in self.adapt_ws for p in lin.parameters()]
         key = tuple((p.data_ptr(), p._version) for p in params)
-        if self._packed is None or self._packed_key != key:
+        if self._packed is None or self._packed_key != key or self.training:
             with torch.no_grad():
                 w = torch.stack([lin.weight for lin in self.adapt_ws]).float().contiguous()   # [T, n_hid, in_dim]
                 b = torch.stack([lin.bias for lin in self.adapt_ws]).float().contiguous()     # [T, n_hid]

@@ -188,6 +188,33 @@ def test_hub_targets_take_the_split_path(use_RTE):
     assert (att.double() - att_ref).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("scale", [-60.0, 60.0, -400.0, 400.0])
+def test_hub_targets_with_extreme_logits(scale):
+    """Hub path numerics (round-1 review): the per-(hub, head) reference of the exp-sums must be the TRUE max logit.
+    relation_pri x (+-60) spreads a hub's logits over hundreds of units; x (+-400) plus a multi-edge hub (2000 copies of ONE
+    edge, so all its logits are equal) yields, for one of the two signs, a hub whose logits are ALL far below -87: with a
+    reference of max(max, 0) every exp underflows and the hub's aggregate collapses to 0."""
+    T, R, H, d, N, E = 2, 3, 4, 64, 2500, 30000
+    sd = O.make_state_dict(d, d, T, R, H, True, False, seed=71)
+    sd["relation_pri"] = sd["relation_pri"] * scale
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=72)
+    ei, et = ei.clone(), et.clone()
+    ei[1, :6000] = 11                   # hub with random sources / relations: logits of both signs
+    ei[1, 6000:8000] = 1200             # multi-edge hub: 2000 x the same (source, relation) -> identical logits
+    ei[0, 6000:8000] = 77
+    et[6000:8000] = 1
+    ref, att_ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, None, use_RTE=False, dtype=torch.float64, return_att=True)
+    assert (att_ref[6000:8000] - 1.0 / 2000).abs().max().item() < 1e-12
+    layer = _layer_from(sd, d, T, R, H, True, False)
+    out, att = _run(layer, x, nt, ei, et, None)
+    assert torch.isfinite(out).all()
+    # logits of magnitude ~1e3 carry ~1e-4 of fp32 rounding into the exponent: the 1e-4 bar holds for the x60 cases, the x400
+    # cases test against a collapse to 0 (an O(1) error)
+    assert (out.double() - ref).abs().max().item() < (TOL if abs(scale) <= 60 else 2e-3)
+    assert (att[6000:8000].double() - 1.0 / 2000).abs().max().item() < 1e-7
+    assert (att.double() - att_ref).abs().max().item() < (1e-4 if abs(scale) <= 60 else 2e-3)   # logits ~ 1e2..1e3 in fp32
+
+
 def test_no_edges_and_isolated_targets():
     T, R, H, d = 3, 2, 4, 64
     sd = O.make_state_dict(d, d, T, R, H, True, False, seed=1)
@@ -295,7 +322,8 @@ def test_staged_forward_equals_whole_layer(precision, use_RTE):
         whole = layer(xd, ntd, eid, etd, tmd, n_q_rows=NQ).clone()
         # three chunks of the halo rows [NQ, N), each as a typed row list
         bounds = [NQ, NQ + 500, NQ + 1300, N]
-        layer(xd, ntd, eid, etd, tmd, n_q_rows=NQ, stage=1)
+        ws = torch.empty(layer.workspace_bytes(N, E), dtype=torch.uint8, device=DEV)   # staged runs own their workspace
+        layer(xd, ntd, eid, etd, tmd, n_q_rows=NQ, stage=1, workspace=ws)
         for a, b in zip(bounds[:-1], bounds[1:]):
             tt = ntd[a:b]
             valid = (tt >= 0) & (tt < T)
@@ -304,8 +332,8 @@ def test_staged_forward_equals_whole_layer(precision, use_RTE):
             rows = (a + order[:int(valid.sum())]).to(torch.int32).contiguous()
             off = torch.zeros(T + 1, dtype=torch.int64, device=DEV)
             off[1:] = torch.cumsum(torch.bincount(key, minlength=T + 1)[:T], 0)
-            layer(xd, ntd, eid, etd, tmd, n_q_rows=NQ, stage=2, proj=(rows, off.to(torch.int32)))
-        staged = layer(xd, ntd, eid, etd, tmd, n_q_rows=NQ, stage=3)
+            layer(xd, ntd, eid, etd, tmd, n_q_rows=NQ, stage=2, proj=(rows, off.to(torch.int32)), workspace=ws)
+        staged = layer(xd, ntd, eid, etd, tmd, n_q_rows=NQ, stage=3, workspace=ws)
     torch.cuda.synchronize()
     assert torch.equal(whole, staged)
     ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, use_RTE=use_RTE, dtype=torch.float64)
@@ -417,9 +445,12 @@ def _plan_arrays(plan):
                 items=items, tile_items=tile_items, rows_all=rows_all, off_all=off_all, rows_q=rows_q, off_q=off_q, n_bins=n_bins)
 
 
-@pytest.mark.parametrize("sorted_types,skew", [(True, 0.0), (False, 1.2)])
-def test_plan_is_bit_exact(sorted_types, skew):
-    N, E, T, R = 5000, 70000, 4, 8
+@pytest.mark.parametrize("N,E,sorted_types,skew", [(5000, 70000, True, 0.0), (5000, 70000, False, 1.2),
+                                                   # E >= 2^21: 512-edge work items and the radix-sort sizes the benchmarked
+                                                   # configuration runs with (hgt_item_edges); 131k-edge hub included
+                                                   (150_000, 2_300_000, True, 0.0), (120_001, 2_150_000, False, 1.5)])
+def test_plan_is_bit_exact(N, E, sorted_types, skew):
+    T, R = 4, 8
     x, nt, ei, et, tm = synthetic_typed_graph(N, E, 8, T, R, seed=11, sorted_types=sorted_types, dst_skew=skew)
     et = et.clone()
     et[::11] = R          # unclaimed bucket
@@ -429,6 +460,8 @@ def test_plan_is_bit_exact(sorted_types, skew):
     src, dst = ei[0].numpy(), ei[1].numpy()
     rel = np.where(et.numpy() < R, et.numpy(), R)
     TD, CH = _plan_constants(plan.E)
+    if E >= (1 << 21):
+        assert CH == 512
     key = ((dst // TD) * (R + 1) + rel) * TD + dst % TD
     order = np.argsort(key, kind="stable")
     assert p["bad"] == 0
@@ -458,6 +491,30 @@ def test_plan_flags_out_of_range_node_ids():
     plan = GraphPlan(*_to_dev(nt, ei, et, tm), 2, 2)
     with pytest.raises(IndexError):
         plan.check_indices()
+
+
+def test_malformed_input_raises_like_the_reference():
+    """The reference fails with an IndexError for node ids outside [0, N) (index_select) and for edge_time outside [0, 240)
+    (nn.Embedding, conv.py:299).  Here the plan build flags both; the flag reaches the host asynchronously, so forward()
+    raises once the header copy has landed -- at the latest on the forward after a synchronisation."""
+    T, R, H, d = 2, 2, 2, 32
+    sd = O.make_state_dict(d, d, T, R, H, True, True, seed=3)
+    layer = _layer_from(sd, d, T, R, H, True, True)
+    x, nt, ei, et, tm = synthetic_typed_graph(300, 2000, d, T, R, seed=4, strided_edge_index=False)
+    for what in ("time", "node"):
+        ei2, tm2 = ei.clone(), tm.clone()
+        if what == "time":
+            tm2[17] = 240
+        else:
+            ei2[1, 5] = -1
+        GraphPlan.clear_cache()
+        args = _to_dev(x, nt, ei2, et, tm2)
+        with torch.no_grad():
+            with pytest.raises(IndexError):
+                layer(*args)                 # may or may not know yet ...
+                torch.cuda.synchronize()
+                layer(*args)                 # ... but does now (same cached plan, header copy complete)
+    GraphPlan.clear_cache()
 
 
 # ------------------------------------------------------------------ kernels in isolation

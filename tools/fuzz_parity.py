@@ -67,7 +67,8 @@ def main():
             tmd = tm.cuda() if use_rte else None
             cuts = sorted(set([nq, N] + [rng.randint(nq, N) for _ in range(rng.randint(0, 2))]))
             with torch.no_grad():
-                layer(xd, ntd, eid, etd, tmd, n_q_rows=nq, stage=1)
+                ws = torch.empty(layer.workspace_bytes(N, ei.size(1)), dtype=torch.uint8, device="cuda:0")
+                layer(xd, ntd, eid, etd, tmd, n_q_rows=nq, stage=1, workspace=ws)
                 for a, b in zip(cuts[:-1], cuts[1:]):
                     tt = ntd[a:b]
                     valid = (tt >= 0) & (tt < T)
@@ -76,8 +77,8 @@ def main():
                     rows = (a + order[:int(valid.sum())]).to(torch.int32).contiguous()
                     off = torch.zeros(T + 1, dtype=torch.int64, device="cuda:0")
                     off[1:] = torch.cumsum(torch.bincount(key, minlength=T + 1)[:T], 0)
-                    layer(xd, ntd, eid, etd, tmd, n_q_rows=nq, stage=2, proj=(rows, off.to(torch.int32)))
-                staged = layer(xd, ntd, eid, etd, tmd, n_q_rows=nq, stage=3)
+                    layer(xd, ntd, eid, etd, tmd, n_q_rows=nq, stage=2, proj=(rows, off.to(torch.int32)), workspace=ws)
+                staged = layer(xd, ntd, eid, etd, tmd, n_q_rows=nq, stage=3, workspace=ws)
             torch.cuda.synchronize()
             # bit-identical, except that hub targets are accumulated with fp32 atomics (order varies from run to run)
             if not (torch.equal(staged, out) or ("dst_skew" in gk and (staged - out).abs().max().item() < 1e-5)):
