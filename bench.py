@@ -7,12 +7,15 @@
 
 One step = one HGTConv.forward (eval mode, fp32, plan cached -- the reference reuses one sampled
 graph for all layers and `repeat` optimisation steps, model.py:78-79 / train_paper_field.py:240)
-over a synthetic typed graph that is already resident in HBM.
+over a synthetic typed graph that is already resident in HBM.  After the timed region the output
+of the benchmarked configuration itself is checked against the fp64 CPU oracle on ~2000 sampled
+target rows (`parity_max_abs_err`; the run fails above 1e-4), and secondary figures are taken:
+the other precision, the plan-included rate, the median next to the mean.
   N = 1 : BASELINE.json configs[1]: T=4 R=8, 1M nodes / 10M edges, d=256, H=8, 4-argument form
           (use_RTE=False), LayerNorm on.
   N > 1 : weak scaling -- every rank owns 1M target nodes and their 10M in-edges; sources are
-          uniform over all N*1M nodes; halo source rows come over one RCCL all-to-all per step
-          (pyhgt_amd/dist.py); value = total edges of all ranks / max-over-ranks time.
+          uniform over all N*1M nodes; halo source rows (exact fp32) come over one RCCL all-to-all per
+          step (pyhgt_amd/dist.py); value = total edges of all ranks / max-over-ranks time.
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant kernel,
 timed with HIP events on the launch stream during the timed steps) and `cpu_baseline` (the CPU
 port of the reference algorithm, oracle/hgt_oracle.py, on a bounded sample).
@@ -75,25 +78,29 @@ class HipEvents:
 
 
 def cpu_baseline_measure(d, H, T, R):
-    """The reference-cost CPU port (oracle.forward_meta_relation_port) on a bounded sample of the c2
-    recipe (1/20 scale).  Threads are capped at 32: the port is a chain of small eager torch ops and
-    over-subscribing a 256-core host makes it slower, not faster."""
+    """The reference-cost CPU port (oracle.forward_meta_relation_port: per-meta-relation masks, per-EDGE projections, like
+    conv.py:64-111) on the SURVEY.md section 8(d) fallback sample of the c2 recipe: E = 1M / N = 100k (the verbatim reference
+    cannot travel to the GPU box; c2 itself needs 44 GB RSS and 75 s per forward).  Timed with os.cpu_count() threads AND with
+    32 threads -- the port is a chain of eager torch ops, and over-subscribing a 256-core host can make it slower -- the
+    faster of the two is the reported value, both are stated."""
     from oracle import hgt_oracle as O
     from pyhgt_amd.synth import synthetic_typed_graph
-    N, E = 50_000, 500_000
+    N, E = 100_000, 1_000_000
     cores = os.cpu_count() or 1
-    threads = min(32, cores)
-    torch.set_num_threads(threads)
     sd = O.make_state_dict(d, d, T, R, H, True, False, seed=0)
     x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=0)
-    with torch.no_grad():
-        O.forward_meta_relation_port(sd, T, R, H, x[:2000], nt[:2000], ei[:, :0], et[:0], None, use_RTE=False)  # warm
-        t0 = time.time()
-        reps = 0
-        while reps < 1 or (time.time() - t0 < 12.0 and reps < 5):
-            O.forward_meta_relation_port(sd, T, R, H, x, nt, ei, et, None, use_RTE=False)
-            reps += 1
-        dt = (time.time() - t0) / reps
+    runs = {}
+    for threads in sorted({cores, min(32, cores)}, reverse=True):
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            O.forward_meta_relation_port(sd, T, R, H, x[:2000], nt[:2000], ei[:, :0], et[:0], None, use_RTE=False)  # warm
+            t0 = time.time()
+            reps = 0
+            while reps < 1 or (time.time() - t0 < 10.0 and reps < 4):
+                O.forward_meta_relation_port(sd, T, R, H, x, nt, ei, et, None, use_RTE=False)
+                reps += 1
+            runs[threads] = ((time.time() - t0) / reps, reps)
+    best = min(runs, key=lambda t: runs[t][0])
     cpu_model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -102,13 +109,16 @@ def cpu_baseline_measure(d, H, T, R):
                 break
     except OSError:
         pass
-    return {"value": E / dt, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": "c2 recipe at 1/20 scale (T%d R%d N=50k E=500k d=%d H=%d, use_RTE=False), %d forwards of "
-                      "oracle.forward_meta_relation_port, %.2f s each" % (T, R, d, H, reps, dt),
+    return {"value": E / runs[best][0], "unit": "edges/s", "cores": best, "kind": "port",
+            "sample": "c2 recipe at E=1M / N=100k (SURVEY 8d fallback; T%d R%d d=%d H=%d, use_RTE=False), "
+                      "oracle.forward_meta_relation_port, %s; fastest: %d threads" % (
+                          T, R, d, H, ", ".join("%d threads: %d forwards of %.2f s" % (t, runs[t][1], runs[t][0])
+                                                for t in sorted(runs, reverse=True)), best),
+            "by_threads": {str(t): E / runs[t][0] for t in runs},
             "cpu_model": cpu_model, "host_cores": cores}
 
 
-def cpu_baseline(d, H, T, R, limit_s=150):
+def cpu_baseline(d, H, T, R, limit_s=240):
     """Run the CPU leg in a child process with a hard time limit so it can never stall the bench line."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--dim", str(d), "--heads", str(H),
@@ -121,6 +131,22 @@ def cpu_baseline(d, H, T, R, limit_s=150):
         return {"value": None, "unit": "edges/s", "cores": None, "kind": "port", "sample": "failed: " + res.stderr[-200:]}
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "edges/s", "cores": None, "kind": "port", "sample": "timed out after %d s" % limit_s}
+
+
+def parity_check(layer_sd, out, x, node_type, edge_index, edge_type, edge_time, T, R, H, use_rte, n_q_rows=None):
+    """After the timed region: compare the rows of `out` for ~2000 sampled targets (type-boundary tiles, first / last ragged
+    tile, max in-degree rows, random rows) with the fp64 CPU oracle run on the sub-graph induced by ALL their in-edges
+    (pyhgt_amd.synth.induced_in_neighbourhood: exact for those rows).  The oracle is the checker, never the thing measured."""
+    from oracle import hgt_oracle as O
+    from pyhgt_amd.synth import pick_check_targets, induced_in_neighbourhood
+    nq = int(out.size(0)) if n_q_rows is None else int(n_q_rows)
+    tg = pick_check_targets(node_type[:nq], edge_index[1])
+    xs, nts, eis, ets, tms, pos = induced_in_neighbourhood(x, node_type, edge_index, edge_type, edge_time, tg)
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    ref = O.forward_closed_form(layer_sd, T, R, H, xs, nts, eis, ets, tms, use_norm=True, use_RTE=use_rte, dtype=torch.float64)
+    err = (out[tg].cpu().double() - ref[pos]).abs().max().item()
+    return {"max_abs_err": err, "rows": int(tg.numel()), "edges": int(eis.size(1)), "sub_nodes": int(xs.size(0)),
+            "max_in_degree": int(torch.bincount(eis[1]).max()) if eis.numel() else 0}
 
 
 def main():
@@ -137,10 +163,15 @@ def main():
     ap.add_argument("--rte", action="store_true", help="5-argument form with temporal encoding")
     ap.add_argument("--dst-skew", type=float, default=0.0, help="secondary variant: Zipf exponent a in (0,1) of the target in-degree distribution (hubs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--halo-fp32", action="store_true", help="multi-GPU: ship halo rows as exact fp32 instead of the 24-bit transport format")
+    ap.add_argument("--no-parity", action="store_true", help="skip the sampled-target oracle check after the timed region")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (other precision / other halo format)")
+    ap.add_argument("--halo-c24", action="store_true", help="multi-GPU: ship halo rows in the 24-bit transport format in the JUDGED run "
+                    "(default: exact fp32 rows; the 24-bit variant is then reported as a secondary figure)")
+    ap.add_argument("--halo-fp32", action="store_true", help=argparse.SUPPRESS)   # the default now; kept for old command lines
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
-                    help="typed linears: 3-term split-bf16 MFMA with fp32 accumulation (default; parity-tested at 1e-4) "
-                         "or exact fp32 MFMA")
+                    help="typed linears / relation transforms: 3-term split-bf16 MFMA with fp32 accumulation (default; parity-tested "
+                         "at 1e-4) or exact fp32")
+    ap.add_argument("--kernel-flags", type=int, default=0, help="hgt_conv_args.flags (HGT_FLAG_*), A/B runs")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -189,82 +220,104 @@ def main():
     edge_type = torch.randint(0, R, (El,), generator=g, device=dev)
     edge_time = torch.randint(0, 240, (El,), generator=g, device=dev) if use_rte else None
 
-    torch.manual_seed(0)
-    layer = HGTConv(d, d, T, R, H, 0.2, True, use_rte, precision=args.precision).eval()
-    with torch.no_grad():
-        layer.relation_pri.uniform_(0.5, 1.5)
-        layer.skip.normal_()
-    layer = layer.to(dev)
+    def make_layer(precision):
+        torch.manual_seed(0)
+        layer = HGTConv(d, d, T, R, H, 0.2, True, use_rte, precision=precision).eval()
+        with torch.no_grad():
+            layer.relation_pri.uniform_(0.5, 1.5)
+            layer.skip.normal_()
+        layer.kernel_flags = args.kernel_flags
+        return layer.to(dev)
+
+    layer = make_layer(args.precision)
+    layer_sd = {k: v.detach().cpu() for k, v in layer.state_dict().items()}
 
     ev = HipEvents()
+    pg = None
     if world == 1:
         edge_index = torch.stack([src_global, dst_local], dim=1).t()       # (1,2)-strided view like data.py:254
-        t0 = time.time()
-        plan = GraphPlan(node_type_own, edge_index, edge_type, edge_time, T, R)
-        torch.cuda.synchronize()
-        plan_ms = (time.time() - t0) * 1e3
-        t0 = time.time()
-        plan = GraphPlan(node_type_own, edge_index, edge_type, edge_time, T, R)
-        torch.cuda.synchronize()
-        plan_ms = min(plan_ms, (time.time() - t0) * 1e3)
+        plan_times = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            plan = GraphPlan(node_type_own, edge_index, edge_type, edge_time, T, R)
+            torch.cuda.synchronize()
+            plan_times.append((time.perf_counter() - t0) * 1e3)
+        plan_ms = min(plan_times)
 
-        def step(events=None):
-            return layer(x_own, node_type_own, edge_index, edge_type, edge_time, plan=plan, phase_events=events)
+        def make_step(lay, compress=None):
+            return lambda events=None: lay(x_own, node_type_own, edge_index, edge_type, edge_time, plan=plan, phase_events=events)
         barrier = lambda: None
     else:
         from pyhgt_amd.dist import PartitionedGraph
         import torch.distributed as dist
         pg = PartitionedGraph(node_type_own, src_global, dst_local, edge_type, edge_time, T, R, Nl, rank, world,
-                              compress=not args.halo_fp32)
+                              compress=bool(args.halo_c24))
         plan_ms = None
         # own features live at the front of the [own ; halo] buffer, so a step does not copy them (pyhgt_amd/dist.py)
         pg.x_local = torch.empty(pg.n_local, d, dtype=torch.float32, device=dev)
         pg.x_local[:Nl].copy_(x_own)
         x_own = pg.x_local[:Nl]
 
-        def step(events=None):
-            return pg.forward(layer, x_own, phase_events=events)
+        def make_step(lay, compress=None):
+            def step(events=None):
+                if compress is not None:
+                    pg.compress = compress
+                return pg.forward(lay, x_own, phase_events=events)
+            return step
         barrier = dist.barrier
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            out = step()
-        event_sets = [ev.make_set(_lib.HGT_N_PHASE_EVENTS) for _ in range(args.steps)]
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = step(event_sets[i])
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    assert torch.isfinite(out).all()
-    if hasattr(_lib.load(), "hgt_debug_fu_trace"):   # development builds (-DHGT_FU_TRACE=1) only
-        buf = (C.c_uint64 * 8)()
-        _lib.load().hgt_debug_fu_trace(buf, 1)
-        v = list(buf)
-        n = max(1, v[7])
-        sys.stderr.write("fused trace, cycles per workgroup (wave 0): aggregate=%d wait=%d slab=%d mfma=%d epilogue=%d\n" % (
-            v[0] // n, v[4] // n, v[1] // n, v[2] // n, v[3] // n))
+    def timed(step, steps, warmup):
+        """W untimed steps, then EXACTLY K steps between barrier + synchronize pairs; max over ranks."""
+        with torch.no_grad():
+            for _ in range(warmup):
+                out = step()
+            event_sets = [ev.make_set(_lib.HGT_N_PHASE_EVENTS) for _ in range(steps)]
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                out = step(event_sets[i])
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        phase_ms = {p: 0.0 for p in PHASES}
+        per_step = []
+        for es in event_sets:
+            for i, p in enumerate(PHASES):
+                phase_ms[p] += ev.elapsed_ms(es[i], es[i + 1])
+            per_step.append(ev.elapsed_ms(es[0], es[len(PHASES)]))
+        phase_ms = {p: v / steps for p, v in phase_ms.items()}
+        per_step.sort()
+        median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
+        return out, elapsed, phase_ms, median
 
-    if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    out, elapsed, phase_ms, median_ms = timed(make_step(layer), args.steps, args.warmup)
+    assert torch.isfinite(out).all()
 
     ms_per_step = elapsed / args.steps * 1e3
     total_edges = El * world
     value = total_edges / (elapsed / args.steps)
 
-    # per-kernel time from the HIP events recorded inside the timed steps (this rank)
-    phase_ms = {p: 0.0 for p in PHASES}
-    for es in event_sets:
-        for i, p in enumerate(PHASES):
-            phase_ms[p] += ev.elapsed_ms(es[i], es[i + 1])
-    phase_ms = {p: v / args.steps for p, v in phase_ms.items()}
+    # ---------------- parity of the benchmarked configuration itself (after the timed region) ----------------
+    def check(o, sd):
+        if args.no_parity:
+            return None
+        if world == 1:
+            return parity_check(sd, o, x_own, node_type_own, edge_index, edge_type, edge_time, T, R, H, use_rte)
+        # a rank's local graph [own ; halo]: exact for its own targets only if the exchanged halo rows are right
+        return parity_check(sd, o, pg.x_local, pg.node_type_local, pg.edge_index, pg.edge_type, pg.edge_time, T, R, H, use_rte,
+                            n_q_rows=Nl)
+    parity = check(out, layer_sd) if rank == 0 else None
+    del out
+
     n_local_nodes = Nl if world == 1 else pg.n_local
     alg = algorithmic_bytes(Nl, El, d, use_rte)
     fused_update = (phase_ms["a_linear"] + phase_ms["node_update"]) < 0.05 * phase_ms["edge_aggregate"]
@@ -273,44 +326,95 @@ def main():
         alg["node_update"] = 0
     dom = max(("edge_logits", "edge_aggregate", "project_qkv"), key=lambda p: phase_ms[p])
     ach = alg[dom] / (phase_ms[dom] * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    # counter-derived figures come from the committed rocprofv3 passes of this same command (profiles/pmc_summary.json names
+    # the commit they were taken at); they are not re-measured inside the run
+    pmc = {}
+    tpath = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.isfile(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom)
+            pmc = json.load(open(tpath))
         except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "kernel": dom + ("+node_update (fused)" if fused_update and dom == "edge_aggregate" else ""), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            pmc = {}
+    traffic = (pmc.get("traffic_bytes") or {}).get(dom) if (world == 1 and not use_rte and args.dst_skew == 0.0) else None
+    roofline = {"bound": "hbm", "kernel": dom + ("+node_update (fused)" if fused_update and dom == "edge_aggregate" else ""),
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": round(phase_ms[dom], 4),
                 "layer_achieved_GBs": round(alg["layer"] / (ms_per_step * 1e-3) / 1e9, 1),
                 "layer_frac": round(alg["layer"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "phase_ms": {p: round(v, 4) for p, v in phase_ms.items()}}
+                "phase_ms": {p: round(v, 4) for p, v in phase_ms.items()},
+                "per_kernel_frac": {p: round(alg[p] / (phase_ms[p] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                    for p in ("project_qkv", "edge_logits", "edge_aggregate") if phase_ms[p] > 0},
+                "mfma_busy_pct": pmc.get("mfma_busy_pct"), "pmc_commit": pmc.get("commit")}
+
+    # ---------------- secondary measurements (never `value`) ----------------
+    secondary = {}
+    if not args.no_secondary:
+        if world == 1:
+            other = "fp32" if args.precision == "bf16x3" else "bf16x3"
+            lay2 = make_layer(other)
+            sd2 = {k: v.detach().cpu() for k, v in lay2.state_dict().items()}
+            out2, el2, ph2, med2 = timed(make_step(lay2), args.steps, 2)
+            ms2 = el2 / args.steps * 1e3
+            par2 = check(out2, sd2)
+            secondary["precision_" + other] = {
+                "ms_per_step": ms2, "median_ms_per_step": med2, "edges_per_s": El / (ms2 * 1e-3),
+                "layer_frac": round(alg["layer"] / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "phase_ms": {p: round(v, 4) for p, v in ph2.items()},
+                "parity_max_abs_err": None if par2 is None else par2["max_abs_err"]}
+            del out2, lay2
+        else:
+            out2, el2, ph2, med2 = timed(make_step(layer, compress=not args.halo_c24), args.steps, 2)
+            ms2 = el2 / args.steps * 1e3
+            par2 = check(out2, layer_sd) if rank == 0 else None
+            secondary["halo_" + ("fp32" if args.halo_c24 else "c24")] = {
+                "ms_per_step": ms2, "median_ms_per_step": med2, "edges_per_s": total_edges / (ms2 * 1e-3),
+                "parity_max_abs_err": None if par2 is None else par2["max_abs_err"],
+                "note": "24-bit transport format (sign, 8 exponent, 15 mantissa bits): narrower than the reference on the wire, "
+                        "reported for information only" if not args.halo_c24 else "exact fp32 halo rows"}
+            pg.compress = bool(args.halo_c24)
+            del out2
 
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(d, H, T, R)
+        prec_note = {"fp32": "f32", "bf16x3": "f32 (typed linears and relation transforms as 3-term split-bf16 MFMA, fp32 accumulate)"}
         line = {
             "metric": "HGTConv forward edges/sec", "value": value, "unit": "edges/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "median_ms_per_step": median_ms,
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f32 (typed linears as 3-term split-bf16 MFMA, fp32 accumulate)",
+            "dtype": prec_note[args.precision],
             "data": "synthetic",
             "config": {"workload": "%s: synthetic %d-type/%d-relation graph, %d nodes / %d edges per GPU, "
-                                   "d=%d, n_heads=%d, use_RTE=%s, use_norm=True, plan cached" % (
+                                   "d=%d, n_heads=%d, use_RTE=%s, use_norm=True, plan cached%s" % (
                                        "BASELINE.json configs[1]" if world == 1 else
                                        "BASELINE.json configs[3] recipe (configs[1] per GPU, sources uniform over all ranks)",
-                                       T, R, Nl, El, d, H, use_rte),
+                                       T, R, Nl, El, d, H, use_rte, (", Zipf(%.2f) targets" % args.dst_skew) if args.dst_skew > 0 else ""),
                        "nodes_per_gpu": Nl, "edges_per_gpu": El, "local_nodes_incl_halo": int(n_local_nodes),
                        "halo_exchange_bytes_per_gpu_per_step": 0 if world == 1 else int(pg.halo.n_halo) * d * (3 if pg.compress else 4),
                        "halo_format": None if world == 1 else ("24-bit (sign, 8 exp, 15 mantissa; fp32 arithmetic)" if pg.compress else "fp32"),
                        "halo_chunks": 0 if world == 1 else int(pg.halo.n_chunks),
                        "parallelism": "single" if world == 1 else "dst-partition x%d + RCCL all-to-all halo" % world,
-                       "plan_build_ms": plan_ms, "precision": args.precision},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "plan_build_ms": plan_ms, "precision": args.precision, "kernel_flags": args.kernel_flags},
+            "parity_max_abs_err": None if parity is None else parity["max_abs_err"],
+            "parity": parity,
+            "plan_included": None if plan_ms is None else {
+                "ms_per_step": ms_per_step + plan_ms, "edges_per_s": El / ((ms_per_step + plan_ms) * 1e-3),
+                "layer_frac": round(alg["layer"] / ((ms_per_step + plan_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(line))
+        bad = [k for k, v in [("headline", line["parity_max_abs_err"])] +
+               [(k, v.get("parity_max_abs_err")) for k, v in secondary.items() if k.startswith("precision_")]
+               if v is not None and not (v <= 1e-4)]
+        if bad:
+            sys.stderr.write("PARITY FAILURE (> 1e-4 against the fp64 oracle): %s\n" % bad)
+            if world > 1:
+                import torch.distributed as dist
+                dist.destroy_process_group()
+            sys.exit(3)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

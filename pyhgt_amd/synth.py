@@ -59,3 +59,43 @@ def synthetic_typed_graph(num_nodes, num_edges, dim, num_types, num_relations, s
         # .to() keeps the strides of edge_index
         out = tuple(t.to(device) for t in out)
     return out
+
+
+def pick_check_targets(node_type, dst, n_random=1600, tile=64, seed=0):
+    """Target rows for a sampled parity check of a LARGE graph: rows around every node-type boundary (mixed-type tiles of the
+    fused update), the first and the last (ragged) tile, the rows of maximum / minimum in-degree, and `n_random` random rows.
+    node_type / dst may live on any device; returns a sorted unique int64 tensor on that device."""
+    N = int(node_type.numel())
+    dev = node_type.device
+    picks = [torch.arange(0, min(N, tile), device=dev), torch.arange(max(0, N - tile - 7), N, device=dev)]
+    change = (node_type[1:] != node_type[:-1]).nonzero().flatten()[:16]          # type-sorted graphs: T-1 boundaries
+    for b in change.tolist():
+        picks.append(torch.arange(max(0, b - tile // 2), min(N, b + tile // 2), device=dev))
+    deg = torch.bincount(dst, minlength=N)
+    picks.append(deg.argmax().reshape(1))
+    picks.append(deg.argmin().reshape(1))
+    picks.append(torch.topk(deg, min(4, N)).indices)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    picks.append(torch.randint(0, N, (n_random,), generator=g).to(dev))
+    return torch.unique(torch.cat([p.to(torch.int64) for p in picks]))
+
+
+def induced_in_neighbourhood(node_feature, node_type, edge_index, edge_type, edge_time, targets):
+    """The sub-graph that determines HGTConv's output rows `targets` exactly: ALL in-edges of those targets (original order)
+    and the source nodes they reference, ids remapped to [0, n_sub).  A target's output depends on nothing else (softmax and
+    aggregation are per target, conv.py:108-111; update is per node, conv.py:114-134), so an oracle run on this graph is
+    exact for those rows -- the other nodes of the sub-graph lose in-edges and their outputs are meaningless.
+    Returns CPU tensors (x_sub, node_type_sub, edge_index_sub [2,E_sub], edge_type_sub, edge_time_sub or None,
+    pos) where pos[i] is the row of targets[i] in the sub-graph."""
+    N = int(node_type.numel())
+    dev = node_type.device
+    src, dst = edge_index[0], edge_index[1]
+    flag = torch.zeros(N, dtype=torch.bool, device=dev)
+    flag[targets] = True
+    eids = flag[dst].nonzero().flatten()
+    s, t = src[eids], dst[eids]
+    nodes = torch.unique(torch.cat([targets, s]))
+    ei_sub = torch.stack([torch.searchsorted(nodes, s), torch.searchsorted(nodes, t)], dim=0)
+    pos = torch.searchsorted(nodes, targets)
+    tm = edge_time[eids].cpu() if edge_time is not None else None
+    return (node_feature[nodes].cpu(), node_type[nodes].cpu(), ei_sub.cpu(), edge_type[eids].cpu(), tm, pos.cpu())
