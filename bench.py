@@ -77,30 +77,35 @@ class HipEvents:
         return float(ms.value)
 
 
-def cpu_baseline_measure(d, H, T, R):
-    """The reference-cost CPU port (oracle.forward_meta_relation_port: per-meta-relation masks, per-EDGE projections, like
-    conv.py:64-111) on the SURVEY.md section 8(d) fallback sample of the c2 recipe: E = 1M / N = 100k (the verbatim reference
-    cannot travel to the GPU box; c2 itself needs 44 GB RSS and 75 s per forward).  Timed with os.cpu_count() threads AND with
-    32 threads -- the port is a chain of eager torch ops, and over-subscribing a 256-core host can make it slower -- the
-    faster of the two is the reported value, both are stated."""
+def cpu_baseline_measure(d, H, T, R, threads):
+    """One thread setting of the CPU leg (child process): the reference-cost CPU port (oracle.forward_meta_relation_port:
+    per-meta-relation masks, per-EDGE projections, like conv.py:64-111) on the SURVEY.md section 8(d) fallback sample of the
+    c2 recipe, E = 1M / N = 100k (the verbatim reference cannot travel to the GPU box; c2 itself needs 44 GB RSS and 75 s per
+    forward)."""
     from oracle import hgt_oracle as O
     from pyhgt_amd.synth import synthetic_typed_graph
     N, E = 100_000, 1_000_000
-    cores = os.cpu_count() or 1
+    torch.set_num_threads(threads)
     sd = O.make_state_dict(d, d, T, R, H, True, False, seed=0)
     x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=0)
-    runs = {}
-    for threads in sorted({cores, min(32, cores)}, reverse=True):
-        torch.set_num_threads(threads)
-        with torch.no_grad():
-            O.forward_meta_relation_port(sd, T, R, H, x[:2000], nt[:2000], ei[:, :0], et[:0], None, use_RTE=False)  # warm
-            t0 = time.time()
-            reps = 0
-            while reps < 1 or (time.time() - t0 < 10.0 and reps < 4):
-                O.forward_meta_relation_port(sd, T, R, H, x, nt, ei, et, None, use_RTE=False)
-                reps += 1
-            runs[threads] = ((time.time() - t0) / reps, reps)
-    best = min(runs, key=lambda t: runs[t][0])
+    with torch.no_grad():
+        O.forward_meta_relation_port(sd, T, R, H, x[:2000], nt[:2000], ei[:, :0], et[:0], None, use_RTE=False)  # warm
+        t0 = time.time()
+        reps = 0
+        while reps < 1 or (time.time() - t0 < 10.0 and reps < 4):
+            O.forward_meta_relation_port(sd, T, R, H, x, nt, ei, et, None, use_RTE=False)
+            reps += 1
+        dt = (time.time() - t0) / reps
+    return {"threads": threads, "seconds_per_forward": dt, "forwards": reps, "edges": E, "nodes": N}
+
+
+def cpu_baseline(d, H, T, R, limit_s=75):
+    """The CPU leg, each thread setting in a child process with a hard time limit so that it can never stall the bench line:
+    32 threads AND os.cpu_count() threads (the port is a chain of eager torch ops; over-subscribing a 256-core host can make it
+    much slower -- a setting that does not finish one forward within the limit is reported as such).  The faster setting is
+    the reported value; both are stated."""
+    import subprocess
+    cores = os.cpu_count() or 1
     cpu_model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -109,28 +114,33 @@ def cpu_baseline_measure(d, H, T, R):
                 break
     except OSError:
         pass
-    return {"value": E / runs[best][0], "unit": "edges/s", "cores": best, "kind": "port",
+    runs, notes = {}, []
+    for threads in sorted({min(32, cores), cores}):
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-threads", str(threads), "--dim", str(d),
+               "--heads", str(H), "--types", str(T), "--relations", str(R)]
+        try:
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s)
+            got = None
+            for line in reversed(res.stdout.strip().splitlines()):
+                if line.startswith("{"):
+                    got = json.loads(line)
+                    break
+            if got is None:
+                notes.append("%d threads: failed (%s)" % (threads, res.stderr[-120:].replace("\n", " ")))
+            else:
+                runs[threads] = got
+                notes.append("%d threads: %d forwards of %.2f s" % (threads, got["forwards"], got["seconds_per_forward"]))
+        except subprocess.TimeoutExpired:
+            notes.append("%d threads: no forward finished within %d s" % (threads, limit_s))
+    if not runs:
+        return {"value": None, "unit": "edges/s", "cores": None, "kind": "port", "sample": "; ".join(notes), "host_cores": cores}
+    best = min(runs, key=lambda t: runs[t]["seconds_per_forward"])
+    E = runs[best]["edges"]
+    return {"value": E / runs[best]["seconds_per_forward"], "unit": "edges/s", "cores": best, "kind": "port",
             "sample": "c2 recipe at E=1M / N=100k (SURVEY 8d fallback; T%d R%d d=%d H=%d, use_RTE=False), "
-                      "oracle.forward_meta_relation_port, %s; fastest: %d threads" % (
-                          T, R, d, H, ", ".join("%d threads: %d forwards of %.2f s" % (t, runs[t][1], runs[t][0])
-                                                for t in sorted(runs, reverse=True)), best),
-            "by_threads": {str(t): E / runs[t][0] for t in runs},
+                      "oracle.forward_meta_relation_port; %s; fastest: %d threads" % (T, R, d, H, "; ".join(notes), best),
+            "by_threads": {str(t): r["edges"] / r["seconds_per_forward"] for t, r in runs.items()},
             "cpu_model": cpu_model, "host_cores": cores}
-
-
-def cpu_baseline(d, H, T, R, limit_s=240):
-    """Run the CPU leg in a child process with a hard time limit so it can never stall the bench line."""
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--dim", str(d), "--heads", str(H),
-           "--types", str(T), "--relations", str(R)]
-    try:
-        res = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s)
-        for line in reversed(res.stdout.strip().splitlines()):
-            if line.startswith("{"):
-                return json.loads(line)
-        return {"value": None, "unit": "edges/s", "cores": None, "kind": "port", "sample": "failed: " + res.stderr[-200:]}
-    except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "edges/s", "cores": None, "kind": "port", "sample": "timed out after %d s" % limit_s}
 
 
 def parity_check(layer_sd, out, x, node_type, edge_index, edge_type, edge_time, T, R, H, use_rte, n_q_rows=None):
@@ -173,9 +183,10 @@ def main():
                          "at 1e-4) or exact fp32")
     ap.add_argument("--kernel-flags", type=int, default=0, help="hgt_conv_args.flags (HGT_FLAG_*), A/B runs")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=32, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline_measure(args.dim, args.heads, args.types, args.relations)))
+        print(json.dumps(cpu_baseline_measure(args.dim, args.heads, args.types, args.relations, args.cpu_threads)))
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -46,13 +46,17 @@ int hgt_abi_version(void);
  * (dk_pad >= d_k = d_out / n_heads, extra columns are zero) so that one 64-lane wavefront covers
  * a row with `vec` contiguous floats per lane and every head maps to dk_pad / vec adjacent lanes.
  * Replaces the .view(-1, n_heads, d_k) of conv.py:96-97,103.
- * Requires: d_out % n_heads == 0 and 64 % n_heads == 0 (n_heads a power of two <= 64).
+ * Requires: d_out % n_heads == 0, n_heads <= 16.  A head count that does not divide 64 (3, 5, 6, 12: legal in the reference,
+ * conv.py:21) runs in the layout of the next power of two `heads`: the extra heads are all-zero and never reach an output.
+ * Every kernel-level entry point below takes the LAYOUT head count (`heads`) as its n_heads; hgt_conv_forward, the workspace
+ * helpers, hgt_relation_pack and hgt_att_export take the model's real head count as well.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct hgt_layout {
     int32_t d_k;     /* d_out / n_heads                         */
     int32_t dk_pad;  /* padded head width                       */
-    int32_t d_pad;   /* n_heads * dk_pad = 64 * vec             */
+    int32_t d_pad;   /* heads * dk_pad = 64 * vec               */
     int32_t vec;     /* floats per lane (1,2,4,8,16)            */
+    int32_t heads;   /* head count of the layout: n_heads rounded up to a power of two (ABI 3) */
 } hgt_layout;
 int hgt_layout_for(int32_t d_out, int32_t n_heads, hgt_layout* out_host);
 
@@ -108,6 +112,17 @@ int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride
                    int64_t n_nodes, int64_t n_q_rows, int64_t n_edges, int32_t n_types, int32_t n_relations,
                    void* plan, uint64_t plan_bytes, void* tmp, uint64_t tmp_bytes, void* stream);
 
+/* Plan from a graph that is ALREADY in the order the reference's sampler produces (data.py:183-209,
+ * 227-246): nodes type-contiguous with ascending types (type t = ids [type_off[t], type_off[t+1])), edges grouped by relation
+ * (relation r = positions [rel_ptr[r], rel_ptr[r+1]) of src / dst / edge_time) with NON-DECREASING target ids inside a
+ * relation, ids already int32.  Builds the same plan as hgt_plan_build (bit-identical arrays; eid = position in the given
+ * order) without its radix sorts: seven small launches, no 64-bit index traffic.  pyhgt_amd.sampled.to_device_graph is the
+ * sibling of to_torch (data.py:212-256) that emits this form.  Same buffer sizes as hgt_plan_build (hgt_plan_sizes_for).
+ * edge_time may be NULL.  All arrays are DEVICE arrays. */
+int hgt_plan_from_sorted(const int32_t* src, const int32_t* dst, const int32_t* edge_time, const int32_t* rel_ptr,
+                         const int32_t* type_off, int64_t n_nodes, int64_t n_q_rows, int64_t n_edges, int32_t n_types,
+                         int32_t n_relations, void* plan, uint64_t plan_bytes, void* tmp, uint64_t tmp_bytes, void* stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Typed (grouped) linear layer on MFMA: for every node type t and every row n of that type
  *     y[n, :] = prologue(x[n, :]) @ W[t]^T + b[t]
@@ -156,14 +171,15 @@ int hgt_zero_rows(const int32_t* rows, const int32_t* range, int32_t d, float* o
 
 /* ----------------------------------------------------------------------------------------------
  * Relation parameter packing (per forward, R*H*dk*dk elements):
- *   att_t[r][h][c][k] = relation_att[r][h][k][c] * relation_pri[r][h] / sqrt(d_k)   (zero padded)
+ *   att_t[r][h][c][k] = relation_att[r][h][k][c] * relation_pri[r][h] / sqrt(d_k)   (zero padded; heads >= n_heads: zero)
  *   msg_p[r][h][k][c] = relation_msg[r][h][k][c]                                     (zero padded)
  * both [R][H][dk_pad][dk_pad].  Folds conv.py:99's "* relation_pri / sqrt_dk" into the matrix and
  * transposes relation_att so that  q . (k A) = (A q) . k  can be evaluated on the target side.
  * ---------------------------------------------------------------------------------------------- */
 int hgt_relation_pack(const float* relation_att, const float* relation_msg, const float* relation_pri,
-                      int32_t n_relations, int32_t n_heads, int32_t d_k, int32_t dk_pad,
+                      int32_t n_relations, int32_t n_heads, int32_t n_heads_layout, int32_t d_k, int32_t dk_pad,
                       float* att_t, float* msg_p, void* stream);
+/* n_heads = heads of the parameter tensors, n_heads_layout >= n_heads = heads of att_t / msg_p (extra heads: zero matrices) */
 
 /* ----------------------------------------------------------------------------------------------
  * Edge phase (replaces conv.py:98-99,104,108-111 and PyG's scatter-add, conv.py:13 aggr='add').
@@ -188,13 +204,21 @@ int hgt_edge_softmax(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t
                      int32_t n_heads, float* logits_att, void* stream);
 int hgt_edge_aggregate(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                        int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
-                       const float* msg_p, float* agg, int64_t n_q_rows, int32_t apply_gelu, void* hub_ws, void* stream);
+                       const float* msg_p, const void* msg_frag, float* agg, int64_t n_q_rows, int32_t apply_gelu,
+                       void* hub_ws, void* stream);
+/* msg_frag (ABI 3): hgt_relation_frag_pack(msg_p) = the relation message matrices as bf16 hi/mid MFMA fragments.  Non-NULL:
+ * the per-(target, relation) transforms  (sum att_e v_e) M[rel]  run on the matrix cores, 16 targets x one relation at a time,
+ * as 3-term split-bf16 products with fp32 accumulation (relative error of a product <= ~3*2^-18, like the split-bf16 typed
+ * linears).  NULL: exact fp32 mat-vecs on the vector ALU (the round-1 kernel; also taken for a head wider than 256 columns). */
+int hgt_relation_frag_bytes(int32_t n_relations, int32_t n_heads, int32_t dk_pad, uint64_t* out_host);
+int hgt_relation_frag_pack(const float* msg_p, int32_t n_relations, int32_t n_heads, int32_t dk_pad, void* msg_frag, void* stream);
 /* hub_ws: scratch of hgt_hub_workspace_bytes() bytes for targets with more than 1024 in-edges ("hubs"): their edge
  * ranges are split over many wavefronts (max / sum-exp / weighted sum accumulated with atomics) instead of being
  * walked by the one wavefront that owns their 16-target sub-tile.  NULL = no hub path (correct, slow on hubs). */
 int hgt_hub_workspace_bytes(int64_t n_edges, int32_t n_heads, int32_t dk_pad, uint64_t* out_host);
 int hgt_att_export(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
-                   int32_t n_heads, const float* att_sorted, float* att_out, void* stream);
+                   int32_t n_heads, const float* att_sorted, float* att_out, int32_t n_heads_out, void* stream);
+/* att_sorted [E][n_heads] (layout heads) -> att_out [E][n_heads_out] (the first n_heads_out heads; the model's real heads) */
 
 /* ----------------------------------------------------------------------------------------------
  * Node update epilogue (conv.py:129-133): per node n of type t (rows with a type outside [0,T)
@@ -240,10 +264,53 @@ int hgt_unpack_rows_c24(const void* in, int64_t n, int32_t d, float* out, int64_
  * (hub_ws != NULL) finish through agg and the hub kernels, exactly like hgt_edge_aggregate, and are updated last. */
 int hgt_edge_aggregate_update(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                               int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
-                              const float* msg_p, float* agg, int64_t n_q_rows, void* hub_ws, int32_t* pending,
+                              const float* msg_p, const void* msg_frag, float* agg, int64_t n_q_rows, void* hub_ws, int32_t* pending,
                               const int64_t* node_type, const void* w_a_split, const float* b_a, const float* x_skip,
                               int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm,
                               int32_t n_out, float* out, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Backward pass (the reference gets it from autograd: OAG/train_paper_field.py:249,
+ * ogbn-mag/train_ogbn_mag.py:172).  The chain rule on the node-level algebra of the forward needs three more edge
+ * primitives, all of them "forward kernels in disguise" (pyhgt_amd/autograd.py strings them together):
+ *   hgt_edge_spmm        out[i] = sum_rel ( sum_{e in (i,rel)} w_e (rows[src_e] + rte_rows[..]) ) F[rel]   -- the aggregation
+ *                        kernel with GIVEN edge weights (sorted edge order of `plan`) instead of the softmax; F = f_p
+ *                        (hgt_relation_pack layout, [R][H][dk_pad][dk_pad], out = in . F) and its MFMA image f_frag
+ *                        (hgt_relation_frag_pack).  dQ = spmm(plan, ds, K, A'), dK = spmm(plan^T, ds, Q, A'^T),
+ *                        dV = spmm(plan^T, att, dagg, M^T) where plan^T is the plan of the reversed edges.
+ *   hgt_edge_logits      (existing) with (Q, K, att_t) := (dagg, V, M^T) yields d att_e = <dagg_i M^T, v_e>
+ *   hgt_edge_softmax_bwd d s_e = att_e (d att_e - rho[dst_e]),  rho = hgt_head_dot(dagg, agg)
+ *   hgt_relation_outer   out[r][h][k][c] += sum_{e of relation r} w_e a[src_e][h][k] b[dst_e][h][c]  (d relation_msg, d A')
+ *   hgt_edge_gather_sorted  values given per ORIGINAL edge id -> sorted edge order of a plan (inverse of hgt_att_export)
+ * and the dense pieces:
+ *   hgt_node_update_bwd  reverse of hgt_node_update (+ the dropout mask of conv.py:125): d_trans, dx (skip path, overwritten),
+ *                        d_alpha[t] += sum dy (o - x) (d skip = d_alpha * a (1 - a)), d_ln_w / d_ln_b [T][d] += ...
+ *   hgt_gelu_bwd         out = dg * gelu'(agg)           hgt_mul_inplace   x *= m (dropout mask)
+ *   hgt_typed_wgrad      out[g][m][n] += sum_{rows p of group g} A[rows[p]][m] B[rows[p]][n]   (exact fp32 MFMA; fp32 atomics)
+ *   hgt_typed_colsum     out[g][c]    += sum_{rows p of group g} A[rows[p]][c]                  (bias gradients)
+ * Accumulating outputs (+=) must be zeroed by the caller.
+ * ---------------------------------------------------------------------------------------------- */
+int hgt_edge_spmm(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations, int32_t n_heads,
+                  int32_t dk_pad, const float* weights, const float* rows, const float* rte_rows, const float* f_p,
+                  const void* f_frag, float* out, int64_t ld_out, int64_t n_q_rows, void* hub_ws, void* stream);
+int hgt_edge_softmax_bwd(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations, int32_t n_heads,
+                         const float* att, const float* d_att, const float* rho, int64_t ld_rho, float* d_logits, void* stream);
+int hgt_edge_gather_sorted(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations, int32_t n_heads,
+                           const float* by_edge_id, float* sorted, void* stream);
+int hgt_head_dot(const float* a, const float* b, int64_t n_rows, int32_t n_heads, int32_t dk_pad, float* out, void* stream);
+int hgt_relation_outer(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations, int32_t n_heads,
+                       int32_t dk_pad, const float* weights, const float* a_src, const float* rte_a, const float* b_dst, float* out,
+                       void* stream);
+int hgt_node_update_bwd(const float* grad_out, const float* trans, const float* x, int64_t ldx, const int64_t* node_type,
+                        const float* skip, const float* ln_w, int32_t use_norm, const float* drop_mask, int64_t n_rows, int32_t d,
+                        int32_t n_types, float* d_trans, float* dx, int64_t ld_dx, float* d_alpha, float* d_ln_w, float* d_ln_b,
+                        void* stream);
+int hgt_gelu_bwd(const float* dg, const float* agg, float* out, int64_t n, void* stream);
+int hgt_mul_inplace(float* x, const float* m, int64_t n, void* stream);
+int hgt_typed_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, const int32_t* rows, const int32_t* group_off,
+                    int32_t n_groups, int64_t n_rows, int32_t m, int32_t n_cols, float* out, int64_t out_group_stride, void* stream);
+int hgt_typed_colsum(const float* A, int64_t lda, const int32_t* rows, const int32_t* group_off, int32_t n_groups, int64_t n_rows,
+                     int32_t m, float* out, int64_t out_group_stride, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * One whole HGTConv.forward (conv.py:56-134, eval mode) as a single enqueue of the kernels above.

@@ -33,3 +33,23 @@ def load_reference_model():
     """Returns the reference module `pyHGT.model` (GNN, Classifier, Matcher)."""
     load_reference_conv()
     return importlib.import_module("pyHGT.model")
+
+
+def load_reference_data():
+    """Returns the reference module `pyHGT.data` (Graph, sample_subgraph, to_torch).  Its plotting imports (seaborn,
+    matplotlib) are absent from this image and irrelevant to the sampler: empty stand-in modules are registered for them."""
+    import types
+    load_reference_conv()
+    for name in ("seaborn", "matplotlib", "matplotlib.pyplot", "matplotlib.cm"):
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+    import numpy as np
+    for alias, typ in (("int", int), ("float", float), ("str", str), ("bool", bool)):      # removed in numpy >= 1.24 (utils.py:59,69)
+        if not hasattr(np, alias):
+            setattr(np, alias, typ)
+    if not hasattr(np, "asfarray"):
+        np.asfarray = lambda a, dtype=float: np.asarray(a, dtype=dtype)
+    return importlib.import_module("pyHGT.data")

@@ -17,7 +17,7 @@ HGT_FLAG_VALU_AGGREGATE = 2
 
 
 class HgtLayout(C.Structure):
-    _fields_ = [("d_k", C.c_int32), ("dk_pad", C.c_int32), ("d_pad", C.c_int32), ("vec", C.c_int32)]
+    _fields_ = [("d_k", C.c_int32), ("dk_pad", C.c_int32), ("d_pad", C.c_int32), ("vec", C.c_int32), ("heads", C.c_int32)]
 
 
 class HgtPlanSizes(C.Structure):
@@ -67,6 +67,7 @@ SIGNATURES = {
     "hgt_plan_item_edges": (C.c_int, [_i64, C.POINTER(_i32)]),
     "hgt_plan_row_lists": (C.c_int, [_vp, _i64, _i64, _i32, _i32, C.POINTER(HgtPlanRows)]),
     "hgt_plan_build": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _u64, _vp, _u64, _vp]),
+    "hgt_plan_from_sorted": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _u64, _vp, _u64, _vp]),
     "hgt_typed_linear": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                                    _i32, _i32, _i32, _i32, _vp]),
     "hgt_split_weights_bytes": (C.c_int, [_i32, _i32, _i32, C.POINTER(_u64)]),
@@ -76,14 +77,26 @@ SIGNATURES = {
     "hgt_linear_update_bf16x3": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                                            _i32, _vp, _vp]),
     "hgt_zero_rows": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
-    "hgt_relation_pack": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "hgt_relation_pack": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "hgt_edge_logits": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hgt_edge_softmax": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
-    "hgt_edge_aggregate": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "hgt_edge_aggregate": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "hgt_relation_frag_bytes": (C.c_int, [_i32, _i32, _i32, C.POINTER(_u64)]),
+    "hgt_relation_frag_pack": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "hgt_hub_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_u64)]),
-    "hgt_att_export": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "hgt_edge_aggregate_update": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+    "hgt_att_export": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "hgt_edge_aggregate_update": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
                                             _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "hgt_edge_spmm": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "hgt_edge_softmax_bwd": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "hgt_edge_gather_sorted": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "hgt_head_dot": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "hgt_relation_outer": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hgt_node_update_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "hgt_gelu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "hgt_mul_inplace": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "hgt_typed_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i64, _vp]),
+    "hgt_typed_colsum": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _vp, _i64, _vp]),
     "hgt_log_softmax_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "hgt_row_dot": (C.c_int, [_vp, _vp, _i64, _i32, C.c_float, _vp, _vp]),
     "hgt_node_update": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),

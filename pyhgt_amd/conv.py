@@ -95,7 +95,9 @@ class GraphPlan:
     _cache_lock = threading.Lock()
     CACHE_SIZE = 4          # plans (and the graph tensors they were built from) kept alive; set to 0 to disable caching
 
-    def __init__(self, node_type, edge_index, edge_type, edge_time, num_types, num_relations, n_q_rows=None):
+    def __init__(self, node_type, edge_index, edge_type, edge_time, num_types, num_relations, n_q_rows=None, reverse=False):
+        """reverse=True builds the plan of the TRANSPOSED graph (every edge j -> i taken as i -> j; used by the backward pass,
+        pyhgt_amd/autograd.py) straight from the same edge_index tensor: the two rows are swapped through the row stride."""
         lib = _lib.load()
         if not node_type.is_cuda:
             raise RuntimeError("pyhgt_amd: graph tensors must live on the GPU (no CPU fallback)")
@@ -124,12 +126,22 @@ class GraphPlan:
         self.max_items = int(sz.max_items)
         # edge_index arrives as a (1,2)-strided view (data.py:254): hand the strides over, no copy
         sr, sc = (edge_index.stride(0), edge_index.stride(1)) if self.E > 0 else (0, 1)
-        _lib.check(lib.hgt_plan_build(_ptr(edge_index), sr, sc, _ptr(edge_type), _ptr(edge_time), _ptr(node_type),
+        ei_ptr = _ptr(edge_index)
+        if reverse and self.E > 0:
+            ei_ptr, sr = ei_ptr + 8 * sr, -sr                  # row 0 := targets, row 1 := sources
+        self.node_type = node_type
+        self._graph = (node_type, edge_index, edge_type, edge_time)   # kept for transposed() / rte_plan()
+        self._transposed = None
+        self._rte_plan = None
+        _lib.check(lib.hgt_plan_build(ei_ptr, sr, sc, _ptr(edge_type), _ptr(edge_time), _ptr(node_type),
                                       self.N, self.NQ, self.E, self.T, self.R, _ptr(self.buf), self.buf.numel(),
                                       _ptr(tmp), tmp.numel(), _stream()), "hgt_plan_build")
         # tmp is released by the caching allocator only after the stream ran past this point
         tmp.record_stream(torch.cuda.current_stream())
         self.device = dev
+        self._start_header_readback()
+
+    def _start_header_readback(self):
         # plan header (n_items, bad_index, n_hubs) copied to pinned host memory WITHOUT synchronising; `no_hubs` /
         # `raise_if_bad` read it once the copy has completed (from the second layer on, in practice)
         self._no_hubs = None
@@ -138,6 +150,42 @@ class GraphPlan:
         _HeaderSlots.buf[self._hdr_slot].copy_(self.buf[:16].view(torch.int32), non_blocking=True)
         self._hdr_event = torch.cuda.Event()
         self._hdr_event.record()
+
+    @classmethod
+    def from_sorted(cls, node_type, edge_index, edge_type, edge_time, src32, dst32, time32, rel_ptr, type_off, num_types,
+                    num_relations):
+        """Plan of a graph that is already in the sampler's order: type-contiguous nodes
+        (type_off int32[T+1]), edges grouped by relation (rel_ptr int32[R+1]) with non-decreasing targets inside a relation,
+        ids as int32 device arrays -- hgt_plan_from_sorted: no radix sort, no int64 index traffic.  The int64 tensors of
+        the reference's wire format (same edge order) are kept for the calls that still take them (forward() signature,
+        transposed()/rte_plan() of the backward pass)."""
+        lib = _lib.load()
+        self = cls.__new__(cls)
+        self.N, self.E = int(node_type.numel()), int(src32.numel())
+        self.T, self.R = int(num_types), int(num_relations)
+        self.NQ = self.N
+        for t in (src32, dst32, rel_ptr, type_off) + ((time32,) if time32 is not None else ()):
+            if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
+                raise TypeError("from_sorted takes contiguous int32 device arrays")
+        if rel_ptr.numel() != self.R + 1 or type_off.numel() != self.T + 1:
+            raise ValueError("rel_ptr must have R+1 and type_off T+1 entries")
+        sz = _lib.HgtPlanSizes()
+        _lib.check(lib.hgt_plan_sizes_for(self.N, self.E, self.T, self.R, C.byref(sz)), "hgt_plan_sizes_for")
+        dev = node_type.device
+        self.buf = torch.empty(int(sz.plan_bytes), dtype=torch.uint8, device=dev)
+        tmp = torch.empty(int(sz.tmp_bytes), dtype=torch.uint8, device=dev)
+        self.max_items = int(sz.max_items)
+        self.node_type = node_type
+        self._graph = (node_type, edge_index, edge_type, edge_time)
+        self._transposed = None
+        self._rte_plan = None
+        _lib.check(lib.hgt_plan_from_sorted(_ptr(src32), _ptr(dst32), _ptr(time32), _ptr(rel_ptr), _ptr(type_off), self.N, self.NQ,
+                                            self.E, self.T, self.R, _ptr(self.buf), self.buf.numel(), _ptr(tmp), tmp.numel(),
+                                            _stream()), "hgt_plan_from_sorted")
+        tmp.record_stream(torch.cuda.current_stream())
+        self.device = dev
+        self._start_header_readback()
+        return self
 
     @property
     def no_hubs(self):
@@ -186,12 +234,55 @@ class GraphPlan:
         self.raise_if_bad(wait=True)
         return int(self.buf[:8].view(torch.int32)[0].item())
 
+    # -- derived plans of the backward pass (built on first use, kept with the plan) -----------------
+    def transposed(self):
+        """Plan of the reversed edges over the same nodes (every node is a target): dK / dV of the backward pass are
+        aggregations over the OUT-edges of a node."""
+        if self._transposed is None:
+            nt, ei, et, _ = self._graph
+            self._transposed = GraphPlan(nt, ei, et, None, self.T, self.R, reverse=True)
+        return self._transposed
+
+    def rte_plan(self, num_types, num_relations):
+        """Plan whose targets are the rows of the temporal tables: edge e = (i -> row type(j) * 240 + dt_e), relation kept
+        (relation id R = unclaimed for edges the forward did not claim).  Its aggregations are the table gradients.
+        Returns (plan, number of table rows); node ids of the original graph are shifted by that number."""
+        if self._rte_plan is None:
+            nt, ei, et, tm = self._graph
+            T, R, L = int(num_types), int(num_relations), _lib.HGT_RTE_LEN
+            tab = T * L
+            src, dst = ei[0], ei[1]
+            tj, ti = nt[src], nt[dst]
+            ok = (tj >= 0) & (tj < T) & (ti >= 0) & (ti < T) & (et >= 0) & (et < R)
+            row = tj.clamp(0, T - 1) * L + tm.clamp(0, L - 1)
+            ei_r = torch.stack([dst + tab, row], dim=0).contiguous()
+            et_r = torch.where(ok, et, torch.full_like(et, R))
+            nt_r = torch.cat([torch.arange(T, device=nt.device, dtype=nt.dtype).repeat_interleave(L), nt])
+            self._rte_plan = (GraphPlan(nt_r, ei_r, et_r, None, T, R, n_q_rows=tab), tab)
+        return self._rte_plan
+
     # -- cache: the reference passes the SAME tensors to every layer (model.py:78-79) ------------
+    @staticmethod
+    def _cache_key(node_type, edge_index, edge_type, edge_time, num_types, num_relations, n_q_rows):
+        tensors = (node_type, edge_index, edge_type, edge_time)
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride())) if t is not None else None for t in tensors)
+        return key + (int(num_types), int(num_relations), n_q_rows, str(node_type.device))
+
+    @classmethod
+    def register(cls, plan, node_type, edge_index, edge_type, edge_time, num_types, num_relations):
+        """Put a plan built elsewhere (from_sorted) into the cache under the tensors the model will be called with, so that
+        the reference's unchanged call `gnn(node_feature, node_type, edge_time, edge_index, edge_type)` finds it."""
+        tensors = (node_type, edge_index, edge_type, edge_time)
+        with cls._cache_lock:
+            for tm in ((edge_time, None) if edge_time is not None else (None,)):      # layers with and without use_RTE
+                cls._cache[cls._cache_key(node_type, edge_index, edge_type, tm, num_types, num_relations, None)] = (plan, tensors)
+            while len(cls._cache) > max(int(cls.CACHE_SIZE), 2):
+                cls._cache.popitem(last=False)
+
     @classmethod
     def cached(cls, node_type, edge_index, edge_type, edge_time, num_types, num_relations, n_q_rows=None):
         tensors = (node_type, edge_index, edge_type, edge_time)
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride())) if t is not None else None for t in tensors)
-        key = key + (int(num_types), int(num_relations), n_q_rows, str(node_type.device))
+        key = cls._cache_key(node_type, edge_index, edge_type, edge_time, num_types, num_relations, n_q_rows)
         with cls._cache_lock:
             hit = cls._cache.get(key)
             if hit is not None:
@@ -322,34 +413,40 @@ class HGTConv(nn.Module):
     def _init_update_parameters(self, num_types, out_dim):
         self.skip = nn.Parameter(torch.ones(num_types))                 # conv.py:47
 
-    def _pack_update_parameters(self):
-        return dict(skip=self.skip.detach().float().contiguous())
+    def _pack_update_parameters(self, grad=False):
+        return dict(skip=(self.skip if grad else self.skip.detach()).float().contiguous())
 
     def _set_update_args(self, a, pk):
         a.update_mode = self._UPDATE_MODE
         a.skip = _ptr(pk["skip"])
 
     # ------------------------------------------------------------------------------------------
-    def _pack_parameters(self):
+    def _pack_parameters(self, grad=False):
         """Stack the per-type Linear / LayerNorm parameters into the contiguous, head-padded arrays
-        hgt_conv_forward takes (pure data movement; cached until a parameter changes)."""
+        hgt_conv_forward takes (pure data movement; cached until a parameter changes).  grad=True: built with autograd
+        recording (never cached), so that gradients of the packed arrays flow back to the reference-named parameters."""
         params = list(self.parameters())
         key = tuple((p.data_ptr(), p._version) for p in params)
-        if self._packed is not None and self._packed_key == key and not self.training:
+        if not grad and self._packed is not None and self._packed_key == key and not self.training:
             return self._packed
         lay = _lib.layout_for(self.out_dim, self.n_heads)
         H, dk, dkp, dp = self.n_heads, lay.d_k, lay.dk_pad, lay.d_pad
+        HL = lay.heads            # heads of the layout: H rounded up to a power of two; the extra heads are all-zero
         T, din, dout = self.num_types, self.in_dim, self.out_dim
 
-        def pad_rows(w):          # [dout, *] -> [dp, *] (each head's dk rows followed by dkp-dk zero rows)
-            if dkp == dk:
+        def pad_rows(w):          # [dout, *] -> [dp, *] (each head's dk rows followed by dkp-dk zero rows, then HL-H zero heads)
+            if dkp == dk and HL == H:
                 return w
             tail = w.shape[1:]
             w = w.reshape(H, dk, *tail)
-            z = w.new_zeros(H, dkp - dk, *tail)
-            return torch.cat([w, z], dim=1).reshape(dp, *tail)
+            if dkp != dk:
+                w = torch.cat([w, w.new_zeros(H, dkp - dk, *tail)], dim=1)
+            if HL != H:
+                w = torch.cat([w, w.new_zeros(HL - H, dkp, *tail)], dim=0)
+            return w.reshape(dp, *tail)
 
-        with torch.no_grad():
+        det = (lambda t: t) if grad else (lambda t: t.detach())
+        with torch.set_grad_enabled(bool(grad)):
             w_qkv = torch.stack([torch.cat([pad_rows(self.q_linears[t].weight), pad_rows(self.k_linears[t].weight),
                                             pad_rows(self.v_linears[t].weight)], 0) for t in range(T)]).float().contiguous()
             b_qkv = torch.stack([torch.cat([pad_rows(self.q_linears[t].bias), pad_rows(self.k_linears[t].bias),
@@ -361,15 +458,17 @@ class HGTConv(nn.Module):
                 ln_w = torch.stack([self.norms[t].weight for t in range(T)]).float().contiguous()
                 ln_b = torch.stack([self.norms[t].bias for t in range(T)]).float().contiguous()
             packed = dict(lay=lay, w_qkv=w_qkv, b_qkv=b_qkv, w_a=w_a, b_a=b_a, ln_w=ln_w, ln_b=ln_b,
-                          ratt=self.relation_att.detach().float().contiguous(),
-                          rmsg=self.relation_msg.detach().float().contiguous(),
-                          rpri=self.relation_pri.detach().float().contiguous())
-            packed.update(self._pack_update_parameters())
+                          ratt=det(self.relation_att).float().contiguous(),
+                          rmsg=det(self.relation_msg).float().contiguous(),
+                          rpri=det(self.relation_pri).float().contiguous())
+            packed.update(self._pack_update_parameters(grad))
             if self.use_RTE:
-                packed.update(rte_emb=self.emb.emb.weight.detach().float().contiguous(),
-                              rte_w=self.emb.lin.weight.detach().float().contiguous(),
-                              rte_b=self.emb.lin.bias.detach().float().contiguous())
+                packed.update(rte_emb=det(self.emb.emb.weight).float().contiguous(),
+                              rte_w=det(self.emb.lin.weight).float().contiguous(),
+                              rte_b=det(self.emb.lin.bias).float().contiguous())
         assert w_qkv.shape == (T, 3 * dp, din) and w_a.shape == (T, dout, dp)
+        if grad:
+            return packed
         self._packed, self._packed_key = packed, key
         self._prepared_valid = False      # the device-side weight images (hgt_conv_args.prepared) are stale now
         return packed
@@ -403,9 +502,10 @@ class HGTConv(nn.Module):
         if not node_inp.is_cuda:
             raise RuntimeError("pyhgt_amd.HGTConv runs only on a ROCm GPU tensor; there is no CPU fallback "
                                "(the CPU oracle lives under oracle/ and is test infrastructure)")
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError("pyhgt_amd.HGTConv is forward-only (SURVEY.md section 8f-2): call it under "
-                               "torch.no_grad() or in eval() mode")
+        needs_grad = torch.is_grad_enabled() and (node_inp.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_grad and (self._UPDATE_MODE != 0 or stage != 0 or n_q_rows is not None):
+            raise RuntimeError("pyhgt_amd: the backward pass covers HGTConv on a single GPU (SURVEY.md section 8f-2); "
+                               "DenseHGTConv / staged multi-GPU forwards run under torch.no_grad() only")
         if node_inp.dtype != torch.float32:
             raise TypeError("node_inp must be float32 (the reference layer is fp32-only, conv.py:68-69)")
         if self.in_dim != self.out_dim:
@@ -423,6 +523,14 @@ class HGTConv(nn.Module):
             raise ValueError("plan was built for a different graph / schema")
         plan.raise_if_bad()
         NQ, E = plan.NQ, plan.E
+        if needs_grad:
+            # training / differentiable path (pyhgt_amd/autograd.py): same kernels, intermediates kept, hand-written backward;
+            # dropout on the a_linear output in training mode only (conv.py:125)
+            from .autograd import hgt_conv_train
+            out = hgt_conv_train(self, plan, node_inp.float(), self._pack_parameters(grad=True),
+                                 float(self.drop.p) if self.training else 0.0)
+            self.att = None
+            return out
         pk = self._pack_parameters()
         if pk["w_qkv"].device != x.device:
             raise RuntimeError("module parameters and node_inp are on different devices")
@@ -505,7 +613,7 @@ class DenseHGTConv(HGTConv):
         self.out_linear = nn.Linear(out_dim * 2, out_dim)               # conv.py:190
         self.out_norm = nn.LayerNorm(out_dim)                           # conv.py:191
 
-    def _pack_update_parameters(self):
+    def _pack_update_parameters(self, grad=False):
         f = lambda t: t.detach().float().contiguous()
         return dict(mid_w=f(self.mid_linear.weight), mid_b=f(self.mid_linear.bias), out_w=f(self.out_linear.weight),
                     out_b=f(self.out_linear.bias), out_ln_w=f(self.out_norm.weight), out_ln_b=f(self.out_norm.bias))

@@ -5,12 +5,13 @@
 namespace {
 
 struct ConvWorkspace {
-    uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p, off_hub;
+    uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p, off_msg_f, off_hub;
     uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, off_ws_qkv, off_ws_a, off_ws_rte, off_off2, off_pending, total;
 };
 
-static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim, int out_dim, int T, int R, int H, int use_rte,
+static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim, int out_dim, int T, int R, int /*n_heads*/, int use_rte,
                                     const hgt_layout& lay) {
+    const int H = lay.heads;     // layout heads (n_heads rounded up to a power of two)
     ConvWorkspace w;
     uint64_t o = 0;
     auto take = [&](uint64_t bytes) { uint64_t r = o; o = hgt_align_up(o + bytes, 256); return r; };
@@ -23,6 +24,9 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
     w.off_trans = take((uint64_t)NQ * out_dim * 4);
     w.off_att_t = take((uint64_t)R * H * lay.dk_pad * lay.dk_pad * 4);
     w.off_msg_p = take((uint64_t)R * H * lay.dk_pad * lay.dk_pad * 4);
+    uint64_t fb = 0;
+    hgt_relation_frag_bytes(R, H, lay.dk_pad, &fb);
+    w.off_msg_f = take(fb);
     uint64_t hb = 0;
     hgt_hub_workspace_bytes(E, H, lay.dk_pad, &hb);
     w.off_hub = take(hb);
@@ -59,15 +63,18 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
 }
 
 struct PreparedLayout {
-    uint64_t off_att_t, off_msg_p, off_ws_qkv, off_ws_upd, off_rte_k, off_rte_v, total;
+    uint64_t off_att_t, off_msg_p, off_msg_f, off_ws_qkv, off_ws_upd, off_rte_k, off_rte_v, total;
 };
 
-static PreparedLayout prepared_layout(int in_dim, int out_dim, int T, int R, int H, int use_rte, const hgt_layout& lay) {
+static PreparedLayout prepared_layout(int in_dim, int out_dim, int T, int R, int /*n_heads*/, int use_rte, const hgt_layout& lay) {
+    const int H = lay.heads;
     PreparedLayout p;
     uint64_t o = 0, b = 0;
     auto take = [&](uint64_t bytes) { uint64_t r = o; o = hgt_align_up(o + bytes, 256); return r; };
     p.off_att_t = take((uint64_t)R * H * lay.dk_pad * lay.dk_pad * 4);
     p.off_msg_p = take((uint64_t)R * H * lay.dk_pad * lay.dk_pad * 4);
+    hgt_relation_frag_bytes(R, H, lay.dk_pad, &b);
+    p.off_msg_f = take(b);
     hgt_split_weights_bytes(T, in_dim, 3 * lay.d_pad, &b);
     p.off_ws_qkv = take(b);
     hgt_split_weights_bytes(T, lay.d_pad, out_dim, &b);
@@ -96,7 +103,7 @@ extern "C" const char* hgt_strerror(int code) {
     switch (code) {
         case HGT_OK: return "ok";
         case HGT_ERR_INVALID_ARG: return "invalid argument";
-        case HGT_ERR_UNSUPPORTED: return "unsupported shape (need d % n_heads == 0, 64 % n_heads == 0, n_heads <= 16, d_pad <= 512)";
+        case HGT_ERR_UNSUPPORTED: return "unsupported shape (need d % n_heads == 0, n_heads <= 16, padded row width <= 512)";
         case HGT_ERR_WORKSPACE: return "workspace too small";
         case HGT_ERR_TOO_LARGE: return "problem exceeds 32-bit plan indices";
         case HGT_ERR_LAUNCH: return "HIP launch/runtime error";
@@ -110,7 +117,7 @@ extern "C" int hgt_layout_for(int32_t d_out, int32_t n_heads, hgt_layout* out) {
     if (!out) return HGT_ERR_INVALID_ARG;
     int rc = hgt_layout_compute(d_out, n_heads, out);
     if (rc != HGT_OK) return rc;
-    if (out->vec > 8 || 64 / n_heads < 4) return HGT_ERR_UNSUPPORTED;   // kernels instantiated for vec <= 8, >= 4 lanes per head
+    if (out->vec > 8 || 64 / out->heads < 4) return HGT_ERR_UNSUPPORTED;   // kernels instantiated for vec <= 8, >= 4 lanes per head
     return HGT_OK;
 }
 
@@ -139,7 +146,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t N = a->n_nodes, E = a->n_edges;
     const int64_t NQ = (a->n_q_rows > 0 && a->n_q_rows <= N) ? a->n_q_rows : N;
-    const int T = a->n_types, R = a->n_relations, H = a->n_heads, din = a->in_dim, dout = a->out_dim;
+    const int T = a->n_types, R = a->n_relations, Hreal = a->n_heads, din = a->in_dim, dout = a->out_dim;
     if (!a->x || !a->node_type || !a->plan || !a->w_qkv || !a->b_qkv || !a->w_a || !a->b_a || !a->relation_att ||
         !a->relation_msg || !a->relation_pri || (!a->skip && a->update_mode == 0) || !a->workspace || !a->out)
         return HGT_ERR_INVALID_ARG;
@@ -151,8 +158,9 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     if (a->update_mode != 0 && a->update_mode != 1) return HGT_ERR_INVALID_ARG;
     if (dense && (!a->mid_w || !a->mid_b || !a->out_w || !a->out_b || !a->out_ln_w || !a->out_ln_b)) return HGT_ERR_INVALID_ARG;
     hgt_layout lay;
-    int rc = hgt_layout_for(dout, H, &lay);
+    int rc = hgt_layout_for(dout, Hreal, &lay);
     if (rc != HGT_OK) return rc;
+    const int H = lay.heads;     // the kernels run with the layout's head count (extra heads are all-zero)
     const int dp = lay.d_pad;
     ConvWorkspace w = conv_workspace(N, N, E, din, dout, T, R, H, a->use_rte, lay);   // sized for NQ == N (upper bound)
     if (a->workspace_bytes < w.total) return HGT_ERR_WORKSPACE;
@@ -174,10 +182,17 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     if (pb && a->prepared_bytes < pl.total) return HGT_ERR_WORKSPACE;
     const bool fresh = !(pb && a->prepared_valid);          // derive the weight images in this call
     void* hub_ws = a->plan_no_hubs ? nullptr : (void*)(wb + w.off_hub);
+    void* msg_f = wb + w.off_msg_f;
     if (pb) {
         att_t = (float*)(pb + pl.off_att_t);
         msg_p = (float*)(pb + pl.off_msg_p);
+        msg_f = pb + pl.off_msg_f;
     }
+    // relation transforms of the aggregation: matrix cores (split-bf16 x3) with the split precision, exact fp32 mat-vecs otherwise
+    uint64_t frag_bytes = 0;
+    hgt_relation_frag_bytes(R, H, lay.dk_pad, &frag_bytes);
+    const bool mfma_agg = (a->precision == 1) && frag_bytes > 0 && !(a->flags & HGT_FLAG_VALU_AGGREGATE);
+    if (!mfma_agg) msg_f = nullptr;
 
     auto mark = [&](int i) {
         if (a->phase_events && a->phase_events[i]) (void)hipEventRecord((hipEvent_t)a->phase_events[i], stream);
@@ -192,8 +207,12 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
 
     // (1) relation matrices: fold pri/sqrt(dk), transpose att, zero-pad heads (conv.py:98-99,104)
     if ((stage == 0 || stage == 1) && fresh) {
-        rc = hgt_relation_pack(a->relation_att, a->relation_msg, a->relation_pri, R, H, lay.d_k, lay.dk_pad, att_t, msg_p, stream);
+        rc = hgt_relation_pack(a->relation_att, a->relation_msg, a->relation_pri, R, Hreal, H, lay.d_k, lay.dk_pad, att_t, msg_p, stream);
         if (rc != HGT_OK) return rc;
+        if (mfma_agg) {
+            rc = hgt_relation_frag_pack(msg_p, R, H, lay.dk_pad, msg_f, stream);
+            if (rc != HGT_OK) return rc;
+        }
     }
 
     // typed linear dispatch: exact fp32 MFMA, or split-bf16 x3 with weights split+tiled into the workspace
@@ -286,14 +305,14 @@ edge_phase:
             rc = hgt_split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
             if (rc != HGT_OK) return rc;
         }
-        rc = hgt_edge_aggregate_update(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ,
+        rc = hgt_edge_aggregate_update(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ,
                                        hub_ws, (int32_t*)(wb + w.off_pending), a->node_type,
                                        ws_upd, a->b_a, a->x, din, a->skip, a->ln_w, a->ln_b, a->use_norm, dout, a->out, stream);
         if (rc == HGT_OK) {
             if (a->want_att && E > 0) {
                 rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);
                 if (rc != HGT_OK) return rc;
-                rc = hgt_att_export(a->plan, N, E, T, R, H, logits, a->att_out, stream);
+                rc = hgt_att_export(a->plan, N, E, T, R, H, logits, a->att_out, Hreal, stream);
                 if (rc != HGT_OK) return rc;
             }
             mark(4);
@@ -304,13 +323,13 @@ edge_phase:
         if (rc != HGT_ERR_UNSUPPORTED) return rc;   // unsupported layout (head-group split): the unfused kernels below
     }
     // runs for E == 0 too: it writes the zero rows of isolated targets; HGTConv stores gelu(agg) (conv.py:119), DenseHGTConv agg
-    rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, agg, NQ, dense ? 0 : 1,
+    rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ, dense ? 0 : 1,
                             hub_ws, stream);
     if (rc != HGT_OK) return rc;
     if (a->want_att && E > 0) {   // self.att (conv.py:108): normalise the logits in place and un-sort them
         rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);
         if (rc != HGT_OK) return rc;
-        rc = hgt_att_export(a->plan, N, E, T, R, H, logits, a->att_out, stream);
+        rc = hgt_att_export(a->plan, N, E, T, R, H, logits, a->att_out, Hreal, stream);
         if (rc != HGT_OK) return rc;
     }
     mark(4);

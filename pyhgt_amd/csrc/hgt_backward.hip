@@ -1,0 +1,514 @@
+// Backward pass of HGTConv: the kernels that have no forward counterpart.  The reference gets its
+// gradients from autograd through conv.py:60-134 (OAG/train_paper_field.py:249 `loss.backward()`); here the chain rule is
+// written out on the node-level algebra of the forward so that the E x d tensors never exist either:
+//
+//   out = LN_t(y), y = o a + x (1 - a), a = sigmoid(skip_t), o = D * (gelu(agg) W_a^T + b_a)   (D = dropout mask / keep prob.)
+//       -> hgt_node_update_bwd: d o, d x (skip path), d skip, d LN weight / bias
+//       -> d gelu(agg) = d o W_a (typed linear with W_a^T), d agg = . * gelu'(agg) (hgt_gelu_bwd),
+//          d W_a / d b_a = typed weight gradient (hgt_typed_wgrad / hgt_typed_colsum)
+//   agg_i,h = sum_e att_e (v_e M_r):   d att_e = <dagg_i M_r^T, v_e>      = the LOGITS kernel with (Q, K, A') := (dagg, V, M^T)
+//                                      d s_e   = att_e (d att_e - <dagg_i, agg_i>_h)                 (hgt_edge_softmax_bwd)
+//   s_e = <A'_r q_i, k_e>:             d Q_i = sum_r (sum_e ds_e k_e) A'_r          = hgt_edge_spmm on the graph
+//                                      d K_j = sum_r A'_r (sum_e ds_e q_i)          = hgt_edge_spmm on the TRANSPOSED graph
+//                                      d V_j = sum_r (sum_e att_e dagg_i) M_r^T     = hgt_edge_spmm on the TRANSPOSED graph
+//                                      d M_r = sum_e att_e v_e^T dagg_i,  d A'_r = sum_e ds_e k_e^T q_i   (hgt_relation_outer)
+//   Q|K|V = x W_qkv^T + b:             d x += [dQ|dK|dV] W_qkv (typed linear), d W_qkv / d b_qkv = typed weight gradient.
+// Everything is enqueued on the caller's stream; small parameter gradients are accumulated with fp32 atomics into
+// caller-zeroed buffers (run-to-run differences of the summation order only).
+#include "hgt_edge_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// node update backward (conv.py:125-133 in reverse).  One wavefront per chunk of ROWS_PER_WAVE consecutive rows; the
+// per-type parameter gradients are summed in registers while the type does not change and flushed with atomics.
+// ---------------------------------------------------------------------------------------------
+constexpr int NUB_ROWS = 32;
+constexpr int NUB_MAXC = 8;     // columns per lane: d <= 512
+
+__global__ __launch_bounds__(256) void k_node_update_bwd(
+    const float* __restrict__ gout, const float* __restrict__ trans, const float* __restrict__ x, int64_t ldx,
+    const int64_t* __restrict__ node_type, const float* __restrict__ skip, const float* __restrict__ lnw, int use_norm,
+    const float* __restrict__ drop_mask, int64_t NQ, int d, int T, float* __restrict__ d_trans, float* __restrict__ dx, int64_t ld_dx,
+    float* __restrict__ d_alpha, float* __restrict__ d_lnw, float* __restrict__ d_lnb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t r0 = wave * NUB_ROWS;
+    if (r0 >= NQ) return;
+    const int nc = (d + 63) / 64;
+    float gw[NUB_MAXC], gb[NUB_MAXC], ga = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NUB_MAXC; ++c) gw[c] = gb[c] = 0.0f;
+    int cur_t = -1;
+    auto flush = [&]() {
+        if (cur_t >= 0) {
+            if (use_norm) {
+#pragma unroll
+                for (int c = 0; c < NUB_MAXC; ++c) {
+                    const int col = c * 64 + lane;
+                    if (c < nc && col < d) {
+                        unsafeAtomicAdd(&d_lnw[(int64_t)cur_t * d + col], gw[c]);
+                        unsafeAtomicAdd(&d_lnb[(int64_t)cur_t * d + col], gb[c]);
+                    }
+                    gw[c] = gb[c] = 0.0f;
+                }
+            }
+            ga = wave_sum(ga);
+            if (lane == 0) unsafeAtomicAdd(&d_alpha[cur_t], ga);
+            ga = 0.0f;
+        }
+    };
+    for (int64_t r = r0; r < min(r0 + NUB_ROWS, NQ); ++r) {
+        const int64_t t64 = node_type[r];
+        const int t = (t64 >= 0 && t64 < T) ? (int)t64 : -1;
+        if (t != cur_t) { flush(); cur_t = t; }
+        if (t < 0) {     // rows of unknown type: output 0, no gradient (conv.py:120)
+#pragma unroll
+            for (int c = 0; c < NUB_MAXC; ++c) {
+                const int col = c * 64 + lane;
+                if (c < nc && col < d) { d_trans[r * d + col] = 0.0f; dx[r * ld_dx + col] = 0.0f; }
+            }
+            continue;
+        }
+        const float alpha = 1.0f / (1.0f + expf(-skip[t]));
+        float o[NUB_MAXC], xv[NUB_MAXC], g[NUB_MAXC], y[NUB_MAXC];
+        float s1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NUB_MAXC; ++c) {
+            const int col = c * 64 + lane;
+            const bool ok = c < nc && col < d;
+            o[c] = ok ? trans[r * d + col] : 0.0f;
+            xv[c] = ok ? x[r * ldx + col] : 0.0f;
+            g[c] = ok ? gout[r * d + col] : 0.0f;
+            y[c] = o[c] * alpha + xv[c] * (1.0f - alpha);
+            s1 += y[c];
+        }
+        float dy[NUB_MAXC];
+        if (use_norm) {
+            const float mean = wave_sum(s1) / (float)d;
+            float s2 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NUB_MAXC; ++c) {
+                const int col = c * 64 + lane;
+                const bool ok = c < nc && col < d;
+                y[c] = ok ? y[c] - mean : 0.0f;
+                s2 += y[c] * y[c];
+            }
+            const float rstd = rsqrtf(wave_sum(s2) / (float)d + 1e-5f);
+            float a1 = 0.0f, a2 = 0.0f;
+            float gh[NUB_MAXC];
+#pragma unroll
+            for (int c = 0; c < NUB_MAXC; ++c) {
+                const int col = c * 64 + lane;
+                const bool ok = c < nc && col < d;
+                y[c] *= rstd;                                            // y = normalised row
+                const float w = ok ? lnw[(int64_t)t * d + col] : 0.0f;
+                gw[c] += g[c] * y[c];
+                gb[c] += g[c];
+                gh[c] = g[c] * w;
+                a1 += gh[c];
+                a2 += gh[c] * y[c];
+            }
+            a1 = wave_sum(a1) / (float)d;
+            a2 = wave_sum(a2) / (float)d;
+#pragma unroll
+            for (int c = 0; c < NUB_MAXC; ++c) dy[c] = rstd * (gh[c] - a1 - y[c] * a2);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NUB_MAXC; ++c) dy[c] = g[c];
+        }
+#pragma unroll
+        for (int c = 0; c < NUB_MAXC; ++c) {
+            const int col = c * 64 + lane;
+            if (c < nc && col < d) {
+                ga += dy[c] * (o[c] - xv[c]);
+                float dt = dy[c] * alpha;
+                if (drop_mask) dt *= drop_mask[r * d + col];            // o = mask * (a_linear output), conv.py:125
+                d_trans[r * d + col] = dt;
+                dx[r * ld_dx + col] = dy[c] * (1.0f - alpha);
+            }
+        }
+    }
+    flush();
+}
+
+// dagg = dg * gelu'(agg), gelu = exact erf form (conv.py:119)
+__global__ void k_gelu_bwd(const float* __restrict__ dg, const float* __restrict__ agg, float* __restrict__ out, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 a = *reinterpret_cast<const float4*>(agg + i);
+    const float4 g = *reinterpret_cast<const float4*>(dg + i);
+    auto f = [](float v, float gg) {
+        const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
+        return gg * (cdf + v * pdf);
+    };
+    *reinterpret_cast<float4*>(out + i) = make_float4(f(a.x, g.x), f(a.y, g.y), f(a.z, g.z), f(a.w, g.w));
+}
+
+// x[i] *= m[i]  (dropout of the a_linear output, conv.py:125; the mask holds 0 or 1/(1-p))
+__global__ void k_mul_inplace(float* __restrict__ x, const float* __restrict__ m, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= m[i];
+}
+
+// ds[p][h] = att[p][h] * (datt[p][h] - rho[dst[p]][h])   (softmax backward per target and head; sorted edge order)
+__global__ void k_edge_softmax_bwd(const int32_t* __restrict__ edst, const float* __restrict__ att, const float* __restrict__ datt,
+                                   const float* __restrict__ rho, int64_t ld_rho, float* __restrict__ ds, int64_t E, int H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E * H) return;
+    const int64_t p = i / H;
+    const int h = (int)(i % H);
+    ds[i] = att[i] * (datt[i] - rho[(int64_t)edst[p] * ld_rho + h]);
+}
+
+// out[p][h] = in[eid[p]][h]: values in ORIGINAL edge order -> the sorted order of a plan
+__global__ void k_gather_sorted(const int32_t* __restrict__ eid, const float* __restrict__ in, float* __restrict__ out, int64_t E, int H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E * H) return;
+    const int64_t p = i / H;
+    out[i] = in[(int64_t)eid[p] * H + (i % H)];
+}
+
+// rho[n][h] = <a[n][h*dkp .. +dkp], b[n][...]>
+__global__ void k_head_dot(const float* __restrict__ a, const float* __restrict__ b, int64_t n_rows, int H, int dkp, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * H) return;
+    const float* pa = a + i * dkp;
+    const float* pb = b + i * dkp;
+    float s = 0.0f;
+    for (int k = 0; k < dkp; k += 4) {
+        const float4 u = *reinterpret_cast<const float4*>(pa + k);
+        const float4 v = *reinterpret_cast<const float4*>(pb + k);
+        s += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+    }
+    out[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Typed weight gradient  dW[g][m][n] += sum_{rows p of group g} A[rows[p]][m] * B[rows[p]][n]   (= A_g^T B_g)
+// on v_mfma_f32_32x32x2_f32 (exact fp32 products).  A workgroup owns a 64 x 64 tile of (m, n) and a chunk of WG_ROWS rows of
+// one group: the 64-row slices of A and B go through LDS ([row][64] fp32), each wavefront owns a 32 x 32 quadrant, the
+// partial tile is added to dW with fp32 atomics (one pass over every row per (m, n) tile: A is re-read n_out/64 times, B
+// m/64 times -- fine for a one-off per step; the forward GEMMs are the optimised ones).
+// ---------------------------------------------------------------------------------------------
+constexpr int WG_ROWS = 2048;
+
+__global__ __launch_bounds__(256) void k_typed_wgrad(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                     const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off, int n_groups,
+                                                     int M, int Nc, float* __restrict__ out, int64_t out_group_stride, int vecA, int vecB) {
+    __shared__ float sA[64][68];
+    __shared__ float sB[64][68];
+    // which (group, row chunk) is this block?
+    int slot = blockIdx.x, g = 0, gbeg = 0, gend = 0, before = 0;
+    for (; g < n_groups; ++g) {
+        gbeg = group_off[g];
+        gend = group_off[g + 1];
+        const int nch = (gend - gbeg + WG_ROWS - 1) / WG_ROWS;
+        if (slot < before + nch) break;
+        before += nch;
+    }
+    if (g >= n_groups) return;
+    const int p0 = gbeg + (slot - before) * WG_ROWS, p1 = min(p0 + WG_ROWS, gend);
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.z * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int pb = p0; pb < p1; pb += 64) {
+        __syncthreads();
+        // 64 rows x 64 columns of A and of B: thread -> (row = tid / 4 .. , 16 columns)
+        {
+            const int r = tid >> 2, cq = (tid & 3) * 16;
+            const int p = pb + r;
+            const int64_t rid = (p < p1) ? (int64_t)rows[p] : -1;
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+                if (rid >= 0) {
+                    const int ma = m0 + cq + j, nb = n0 + cq + j;
+                    if (vecA && ma + 3 < M) a = *reinterpret_cast<const float4*>(A + rid * lda + ma);
+                    else { if (ma < M) a.x = A[rid * lda + ma]; if (ma + 1 < M) a.y = A[rid * lda + ma + 1]; if (ma + 2 < M) a.z = A[rid * lda + ma + 2]; if (ma + 3 < M) a.w = A[rid * lda + ma + 3]; }
+                    if (vecB && nb + 3 < Nc) b = *reinterpret_cast<const float4*>(B + rid * ldb + nb);
+                    else { if (nb < Nc) b.x = B[rid * ldb + nb]; if (nb + 1 < Nc) b.y = B[rid * ldb + nb + 1]; if (nb + 2 < Nc) b.z = B[rid * ldb + nb + 2]; if (nb + 3 < Nc) b.w = B[rid * ldb + nb + 3]; }
+                }
+                *reinterpret_cast<float4*>(&sA[r][cq + j]) = a;
+                *reinterpret_cast<float4*>(&sB[r][cq + j]) = b;
+            }
+        }
+        __syncthreads();
+        // D[m][n] += sum_row A[row][m] B[row][n]: MFMA operand a = A^T[m = lane&31][k = row], b = B[k = row][n = lane&31]
+#pragma unroll 8
+        for (int k = 0; k < 64; k += 2) {
+            const int kr = k + (lane >> 5);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[kr][wm + (lane & 31)], sB[kr][wn + (lane & 31)], acc, 0, 0, 0);
+        }
+    }
+    // C layout: col (n) = lane & 31, row (m) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float* o = out + (int64_t)g * out_group_stride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), n = n0 + wn + (lane & 31);
+        if (m < M && n < Nc) unsafeAtomicAdd(&o[(int64_t)m * Nc + n], acc[r]);
+    }
+}
+
+// out[g][c] += sum_{rows p of group g} A[rows[p]][c]    (bias gradients)
+__global__ __launch_bounds__(256) void k_typed_colsum(const float* __restrict__ A, int64_t lda, const int32_t* __restrict__ rows,
+                                                      const int32_t* __restrict__ group_off, int n_groups, int M, float* __restrict__ out,
+                                                      int64_t out_group_stride) {
+    constexpr int CH = 256;
+    int slot = blockIdx.x * 4 + (threadIdx.x >> 6), g = 0, gbeg = 0, gend = 0, before = 0;
+    for (; g < n_groups; ++g) {
+        gbeg = group_off[g];
+        gend = group_off[g + 1];
+        const int nch = (gend - gbeg + CH - 1) / CH;
+        if (slot < before + nch) break;
+        before += nch;
+    }
+    if (g >= n_groups) return;
+    const int lane = threadIdx.x & 63;
+    const int p0 = gbeg + (slot - before) * CH, p1 = min(p0 + CH, gend);
+    for (int c0 = 0; c0 < M; c0 += 64 * 4) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int p = p0; p < p1; ++p) {
+            const int64_t rid = rows[p];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j * 64 + lane;
+                if (c < M) s[j] += A[rid * lda + c];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j * 64 + lane;
+            if (c < M) unsafeAtomicAdd(&out[(int64_t)g * out_group_stride + c], s[j]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Relation outer products:  out[r][h][k][c] += sum_{e of relation r} w_e,h * a[src_e][h][k] * b[dst_e][h][c]
+// (d relation_msg with (w, a, b) = (att, V, dagg); d A' with (ds, K, Q)).  A wavefront takes the work items of ONE relation
+// (blockIdx.z) inside its slice of the plan's item list (runs of <= 512 sorted edges of one (tile, relation)); lane = (head,
+// VEC rows k of the head's block); the b row of the edge is broadcast inside the head's lanes through LDS; the dkp x dkp
+// blocks accumulate in registers over ~64 items and are flushed once with atomics.
+// ---------------------------------------------------------------------------------------------
+template <int VEC, int LPH, bool RTE>
+__global__ __launch_bounds__(256) void k_relation_outer(
+    const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
+    const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ w, const float* __restrict__ a,
+    const float* __restrict__ rte_a, const float* __restrict__ b, float* __restrict__ out, int R, int HT, int items_per_wave) {
+    constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH;
+    __shared__ __attribute__((aligned(16))) float s_b[4][DP + 4 * (64 / LPH)];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hg = blockIdx.y;
+    const int rel_sel = blockIdx.z;            // this wavefront only takes the items of ONE relation: one flush per wavefront
+    const int64_t ld = (int64_t)HT * DKP;
+    const int co = hg * DP;
+    const int h = lane / LPH, p = lane % LPH;
+    float* bounce = s_b[wib];
+    const int n_items = hdr->n_items;
+    const int first = (blockIdx.x * 4 + wib) * items_per_wave;
+    if (first >= n_items) return;
+    float acc[VEC][DKP];      // rows k = p*VEC + i of head h, all DKP columns
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+#pragma unroll
+        for (int c = 0; c < DKP; ++c) acc[i][c] = 0.0f;
+    bool any = false;
+    for (int ib = first; ib < min(first + items_per_wave, n_items); ib += 64) {
+        // 64 item headers at a time (lane i = item ib + i); the matching ones are walked one after the other
+        const int my_i = min(ib + lane, n_items - 1);
+        const HgtItem mine = items[my_i];
+        const bool take = (ib + lane < min(first + items_per_wave, n_items)) && mine.rel == rel_sel;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(take);
+        while (todo) {
+            const int li_ = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int beg = __builtin_amdgcn_readlane(mine.beg, li_), end = __builtin_amdgcn_readlane(mine.end, li_);
+            any = true;
+            for (int base = beg; base < end; base += 64) {
+                const int nb = min(64, end - base);
+                const int li = base + min(lane, nb - 1);
+                const int my_src = esrc[li], my_dst = edst[li];
+                const int my_rte = RTE ? (int)ertei[li] : 0;
+                for (int e = 0; e < nb; ++e) {
+                    const int s = __builtin_amdgcn_readlane(my_src, e), dd = __builtin_amdgcn_readlane(my_dst, e);
+                    float av[VEC], bv[VEC];
+                    load_vec<VEC>(a + (int64_t)s * ld + co + lane * VEC, av);
+                    if constexpr (RTE) {
+                        const int ri = __builtin_amdgcn_readlane(my_rte, e);
+                        float tv[VEC];
+                        load_vec<VEC>(rte_a + (int64_t)ri * ld + co + lane * VEC, tv);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) av[i] += tv[i];
+                    }
+                    load_vec<VEC>(b + (int64_t)dd * ld + co + lane * VEC, bv);
+                    const float we = w[(int64_t)(base + e) * HT + hg * H + h];
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) av[i] *= we;
+                    store_vec_lds<VEC>(bounce + lane * VEC + (lane / LPH) * 4, bv);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const float* xb = bounce + h * (DKP + 4);
+#pragma unroll
+                    for (int c4 = 0; c4 < DKP / 4; ++c4) {
+                        const float4 bb = *reinterpret_cast<const float4*>(xb + 4 * c4);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            acc[i][4 * c4 + 0] = fmaf(av[i], bb.x, acc[i][4 * c4 + 0]);
+                            acc[i][4 * c4 + 1] = fmaf(av[i], bb.y, acc[i][4 * c4 + 1]);
+                            acc[i][4 * c4 + 2] = fmaf(av[i], bb.z, acc[i][4 * c4 + 2]);
+                            acc[i][4 * c4 + 3] = fmaf(av[i], bb.w, acc[i][4 * c4 + 3]);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    }
+    if (any) {
+        float* o = out + (((int64_t)rel_sel * HT + hg * H + h) * DKP + p * VEC) * DKP;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+#pragma unroll
+            for (int c = 0; c < DKP; ++c) unsafeAtomicAdd(&o[i * DKP + c], acc[i][c]);
+    }
+}
+
+template <int VEC, int LPH>
+struct LaunchOuter {
+    static int run(const HgtPlanView& pv, const float* w, const float* a, const float* rte_a, const float* b, float* out, int R, int HT,
+                   hipStream_t stream) {
+        if constexpr (VEC * LPH * VEC <= 128 && VEC * LPH >= 4) {
+            // ~64 items of the selected relation per wavefront (items are ordered (tile, relation))
+            const int ipw = 64 * (R + 1);
+            const int64_t waves = (pv.L.max_items + ipw - 1) / ipw;
+            dim3 grid((unsigned)((waves + 3) / 4), (unsigned)(HT / (64 / LPH)), (unsigned)R);
+            if (rte_a)
+                k_relation_outer<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, w, a, rte_a, b, out, R,
+                                                                          HT, ipw);
+            else
+                k_relation_outer<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, w, a, rte_a, b, out, R,
+                                                                           HT, ipw);
+            return HGT_OK;
+        } else {
+            return HGT_ERR_UNSUPPORTED;
+        }
+    }
+};
+
+static inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace
+
+extern "C" int hgt_node_update_bwd(const float* grad_out, const float* trans, const float* x, int64_t ldx, const int64_t* node_type,
+                                   const float* skip, const float* ln_w, int32_t use_norm, const float* drop_mask, int64_t n_rows,
+                                   int32_t d, int32_t n_types, float* d_trans, float* dx, int64_t ld_dx, float* d_alpha, float* d_ln_w,
+                                   float* d_ln_b, void* stream) {
+    if (!grad_out || !trans || !x || !node_type || !skip || !d_trans || !dx || !d_alpha || n_rows < 0 || d <= 0 || d > 64 * NUB_MAXC)
+        return HGT_ERR_INVALID_ARG;
+    if (use_norm && (!ln_w || !d_ln_w || !d_ln_b)) return HGT_ERR_INVALID_ARG;
+    if (n_rows == 0) return HGT_OK;
+    const int64_t waves = (n_rows + NUB_ROWS - 1) / NUB_ROWS;
+    k_node_update_bwd<<<nblk(waves, 4), 256, 0, (hipStream_t)stream>>>(grad_out, trans, x, ldx, node_type, skip, ln_w, use_norm, drop_mask,
+                                                                       n_rows, d, n_types, d_trans, dx, ld_dx, d_alpha, d_ln_w, d_ln_b);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_gelu_bwd(const float* dg, const float* agg, float* out, int64_t n, void* stream) {
+    if (!dg || !agg || !out || n < 0 || (n & 3) != 0) return HGT_ERR_INVALID_ARG;
+    if (n == 0) return HGT_OK;
+    k_gelu_bwd<<<nblk(n / 4, 256), 256, 0, (hipStream_t)stream>>>(dg, agg, out, n);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_mul_inplace(float* x, const float* m, int64_t n, void* stream) {
+    if (!x || !m || n < 0) return HGT_ERR_INVALID_ARG;
+    if (n == 0) return HGT_OK;
+    k_mul_inplace<<<nblk(n, 256), 256, 0, (hipStream_t)stream>>>(x, m, n);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_edge_softmax_bwd(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, const float* att,
+                                    const float* d_att, const float* rho, int64_t ld_rho, float* d_logits, void* stream) {
+    if (!plan || !att || !d_att || !rho || !d_logits || H <= 0) return HGT_ERR_INVALID_ARG;
+    if (E == 0) return HGT_OK;
+    HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
+    k_edge_softmax_bwd<<<nblk(E * H, 256), 256, 0, (hipStream_t)stream>>>(pv.edst, att, d_att, rho, ld_rho, d_logits, E, H);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_edge_gather_sorted(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, const float* by_edge_id,
+                                      float* sorted, void* stream) {
+    if (!plan || !by_edge_id || !sorted || H <= 0) return HGT_ERR_INVALID_ARG;
+    if (E == 0) return HGT_OK;
+    HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
+    k_gather_sorted<<<nblk(E * H, 256), 256, 0, (hipStream_t)stream>>>(pv.eid, by_edge_id, sorted, E, H);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_head_dot(const float* a, const float* b, int64_t n_rows, int32_t n_heads, int32_t dk_pad, float* out, void* stream) {
+    if (!a || !b || !out || n_rows < 0 || n_heads <= 0 || dk_pad <= 0 || (dk_pad & 3) != 0) return HGT_ERR_INVALID_ARG;
+    if (n_rows == 0) return HGT_OK;
+    k_head_dot<<<nblk(n_rows * n_heads, 256), 256, 0, (hipStream_t)stream>>>(a, b, n_rows, n_heads, dk_pad, out);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_typed_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, const int32_t* rows, const int32_t* group_off,
+                               int32_t n_groups, int64_t n_rows, int32_t m, int32_t n_cols, float* out, int64_t out_group_stride,
+                               void* stream) {
+    if (!A || !B || !rows || !group_off || !out || n_groups <= 0 || n_rows < 0 || m <= 0 || n_cols <= 0) return HGT_ERR_INVALID_ARG;
+    const int vecA = ((lda & 3) == 0 && ((uintptr_t)A & 15) == 0), vecB = ((ldb & 3) == 0 && ((uintptr_t)B & 15) == 0);   // 16 B row loads
+    if (n_rows == 0) return HGT_OK;
+    const int64_t chunks = (n_rows + WG_ROWS - 1) / WG_ROWS + n_groups;   // device-side group sizes: launch the upper bound
+    dim3 grid((unsigned)chunks, (unsigned)((m + 63) / 64), (unsigned)((n_cols + 63) / 64));
+    k_typed_wgrad<<<grid, 256, 0, (hipStream_t)stream>>>(A, lda, B, ldb, rows, group_off, n_groups, m, n_cols, out, out_group_stride, vecA, vecB);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_typed_colsum(const float* A, int64_t lda, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
+                                int64_t n_rows, int32_t m, float* out, int64_t out_group_stride, void* stream) {
+    if (!A || !rows || !group_off || !out || n_groups <= 0 || n_rows < 0 || m <= 0) return HGT_ERR_INVALID_ARG;
+    if (n_rows == 0) return HGT_OK;
+    const int64_t waves = (n_rows + 255) / 256 + n_groups;
+    k_typed_colsum<<<nblk(waves, 4), 256, 0, (hipStream_t)stream>>>(A, lda, rows, group_off, n_groups, m, out, out_group_stride);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_relation_outer(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                  const float* weights, const float* a_src, const float* rte_a, const float* b_dst, float* out,
+                                  void* stream) {
+    if (!plan || !a_src || !b_dst || !out || (E > 0 && !weights) || H <= 0 || 64 % H != 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
+    if (E == 0) return HGT_OK;
+    const int lph = 64 / H;
+    if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
+    HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
+    // the per-lane accumulator block is VEC x DKP floats: split head groups until it fits 256 registers
+    int vec = dk_pad / lph, l2 = lph;
+    while (vec * dk_pad > 128 && vec > 1 && l2 * 2 <= 64) { vec /= 2; l2 *= 2; }
+    int rc = dispatch_layout<LaunchOuter>(vec, l2, pv, weights, a_src, rte_a, b_dst, out, (int)R, (int)H, (hipStream_t)stream);
+    if (rc != HGT_OK) return rc;
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}

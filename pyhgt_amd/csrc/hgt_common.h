@@ -121,9 +121,14 @@ static inline HgtPlanView hgt_plan_view(const void* plan, int64_t N, int64_t E, 
 
 static inline int hgt_layout_compute(int32_t d_out, int32_t n_heads, hgt_layout* o) {
     if (d_out <= 0 || n_heads <= 0 || d_out % n_heads != 0) return HGT_ERR_INVALID_ARG;
-    if (n_heads > 64 || (64 % n_heads) != 0) return HGT_ERR_UNSUPPORTED;
+    if (n_heads > 64) return HGT_ERR_UNSUPPORTED;
+    // head counts that do not divide 64 (the reference accepts any d % n_heads == 0, conv.py:21: 3, 5, 6, 12 ...) run in the
+    // layout of the next power of two: the extra heads are all-zero (zero weight rows / relation matrices), contribute
+    // nothing to any real column and are cut away again at the boundary (hgt_relation_pack, hgt_att_export)
+    int heads = 1;
+    while (heads < n_heads) heads *= 2;
     int dk = d_out / n_heads;
-    int lph = 64 / n_heads;                 // lanes per head
+    int lph = 64 / heads;                   // lanes per head
     int vec = 1;
     while (vec * lph < dk) vec *= 2;
     if (vec > 16) return HGT_ERR_UNSUPPORTED;
@@ -131,5 +136,6 @@ static inline int hgt_layout_compute(int32_t d_out, int32_t n_heads, hgt_layout*
     o->vec = vec;
     o->dk_pad = vec * lph;
     o->d_pad = 64 * vec;
+    o->heads = heads;
     return HGT_OK;
 }

@@ -1,0 +1,984 @@
+// Pass 2 of the edge phase (softmax + attention-weighted aggregation, conv.py:104,108-111 + PyG's scatter-add) with the
+// relation transforms on the MATRIX CORES.
+//
+//     agg_i,h = sum_r ( sum_{e in (i,r)} att_e v_j,h ) M[r,h]                                 
+//
+// The vector-ALU kernel (hgt_edge_agg_valu.hip) evaluates the d_k x d_k product once per (target, relation) SEGMENT as a
+// mat-vec out of a 128-register fragment: 5.9 M segments x 64 dependent v_pk_fma_f32 + an LDS bounce + an accumulator
+// read-modify-write at c2 -- it is bound by VALU issue at 2 waves per SIMD, not by HBM (round-1 review: 0.36 of the roofline).
+// Here a wavefront still owns 16 consecutive targets and walks their relations in ascending order, but
+//   * per relation r it only accumulates  U_r[t] = sum_e exp(s_e - m_t) v_j  per target (per edge: one gathered row, one exp,
+//     VEC fmas); a finished segment is split into bf16 hi/mid and parked as ONE ROW of a wave-private LDS tile U_r[16 x DP]
+//     (XOR-swizzled 16-byte slots: conflict-free ds_write_b64 on the way in, conflict-free ds_read_b128 on the way out);
+//   * after the relation's edges,  Z^T += blockdiag(M_r)^T . U_r^T  runs on v_mfma_f32_16x16x32_bf16 (3 products per tile:
+//     mid*hi + hi*mid + hi*hi, fp32 accumulate): first operand = fragment-ordered hi/mid image of M_r (L2-resident, written
+//     once per parameter set by hgt_relation_frag_pack), second operand = U_r rows straight out of the tile.  Computing the
+//     TRANSPOSE puts all of a lane's accumulators on ONE target (column = lane & 15), so
+//   * the accumulators Z stay in MFMA registers across ALL relations (64 VGPRs at d = 256) -- no per-segment accumulator
+//     traffic at all -- and the softmax can stay online: weights are taken relative to a per-(target, head) reference that is
+//     only moved when a logit exceeds it by more than 40 (rare); moving it rescales that target's column = a per-lane multiply.
+// No barriers, no atomics, fixed summation order.  The node update (a_linear + gated skip + LayerNorm, conv.py:119-133) is
+// fused behind it exactly as before (hgt_fused_update.h): the finished rows go from the accumulators through gelu into the
+// bf16 hi/mid A slab of the epilogue.
+#include "hgt_edge_common.h"
+#include "hgt_fused_update.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef HGT_AGG_HIDDEN
+#define HGT_AGG_HIDDEN 0     // experiment switch (see agg_mfma_stream): row gathers hidden from hipcc, hand-counted waits
+#endif
+__device__ __forceinline__ void hidden_load(f32x4& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p)); }
+__device__ __forceinline__ void hidden_load(f32x2& d, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p)); }
+__device__ __forceinline__ void hidden_load(float& d, const float* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p)); }
+__device__ __forceinline__ void hidden_load(int& d, const int32_t* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p)); }
+__device__ __forceinline__ void hidden_load_u16(int& d, const uint16_t* p) { asm volatile("global_load_ushort %0, %1, off" : "=v"(d) : "v"(p)); }
+template <int VEC> struct RowT;
+template <> struct RowT<4> { typedef f32x4 type; };
+template <> struct RowT<2> { typedef f32x2 type; };
+template <> struct RowT<1> { typedef float type; };
+__device__ __forceinline__ float row_elem(const f32x4& v, int i) { return v[i]; }
+__device__ __forceinline__ float row_elem(const f32x2& v, int i) { return v[i]; }
+__device__ __forceinline__ float row_elem(const float& v, int) { return v; }
+
+template <int VEC, int LPH>
+struct MG {   // geometry of one wavefront's slice: DP columns = 64 lanes x VEC floats
+    static constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH;
+    static constexpr int NCT = DP / 16;                 // 16-column output tiles
+    static constexpr int KW = DKP > 32 ? DKP : 32;      // k window of a column tile (a head, or 32 columns holding several heads)
+    static constexpr int NKS = KW / 32;                 // MFMA k-steps per column tile
+    static constexpr int ROWB = DP * 2;                 // bytes of one bf16 row of the U tile
+    static constexpr int NS = DP / 8;                   // 16-byte slots per row
+    static constexpr int PLANE = 16 * ROWB;             // one bf16 plane of the tile (16 targets)
+};
+
+// msg_p [R][HT][DKP][DKP] fp32 (hgt_relation_pack: msg_p[r][h][k][c] = relation_msg[r][h][k][c], zero padded) ->
+// fragments [R][head group][col tile c][k-step s][plane][lane 64][8] bf16 of blockdiag_h(M[r,h]) restricted to the k window
+// of the column tile:  frag[..][l][e] = split( Mfull[kbase(c) + 32 s + (l>>4)*8 + e][16 c + (l&15)] )
+// = the FIRST operand of v_mfma_f32_16x16x32_bf16 (row = output column l&15, k = (l>>4)*8 + e).
+__global__ void k_msg_frag_pack(const float* __restrict__ msgP, int R, int HT, int DKP, int DP, unsigned short* __restrict__ out) {
+    const int KW = DKP > 32 ? DKP : 32, NKS = KW / 32, NCT = DP / 16, NY = HT * DKP / DP;
+    const int64_t total = (int64_t)R * NY * NCT * NKS * 512;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int64_t r = i;
+    const int e = (int)(r % 8); r /= 8;
+    const int l = (int)(r % 64); r /= 64;
+    const int s = (int)(r % NKS); r /= NKS;
+    const int c = (int)(r % NCT); r /= NCT;
+    const int hg = (int)(r % NY);
+    const int rel = (int)(r / NY);
+    const int kbase = (16 * c / KW) * KW;
+    const int kf = hg * DP + kbase + 32 * s + (l >> 4) * 8 + e, nf = hg * DP + 16 * c + (l & 15);
+    const int hk = kf / DKP, hn = nf / DKP;
+    float v = 0.0f;
+    if (hk == hn) v = msgP[(((int64_t)rel * HT + hn) * DKP + kf % DKP) * DKP + nf % DKP];
+    const unsigned short hi = bf16_rne(v);
+    const unsigned short mid = bf16_rne(v - bf16_to_f32(hi));
+    const int64_t tile = ((((int64_t)rel * NY + hg) * NCT + c) * NKS + s) * 2;
+    out[(tile + 0) * 512 + l * 8 + e] = hi;
+    out[(tile + 1) * 512 + l * 8 + e] = mid;
+}
+
+template <int VEC>
+constexpr int agg_unroll(bool rte) { return rte ? 4 : 8; }
+
+// One wavefront: targets [row0, row0 + SUBR) of the destination tile, all relations.  On return acc[c] holds, for target
+// (lane & 15) and columns 16 c + 4 (lane >> 4) .. + 3, the UN-normalised aggregate sum_e exp(s_e - m) v'_e; s_l (LDS) holds
+// the matching exp-sums per (target, head).
+template <int VEC, int LPH, bool RTE, bool HUBS>
+__device__ __forceinline__ void agg_mfma_subtile(
+    const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
+    const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
+    const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, int R, int HT, unsigned hub_mask, int SUBR, int64_t row0,
+    unsigned char* utile, float* s_m, float* s_l, float* s_sc, int raw, f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
+    using G = MG<VEC, LPH>;
+    constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS;
+    constexpr int UN = agg_unroll<VEC>(RTE);
+    const int hg = blockIdx.y;              // head group (head-group split: the wave covers DP of the HT * DKP columns)
+    const int64_t ld = (int64_t)HT * DKP;
+    const int co = hg * DP;
+    const int NY = HT / H;
+
+    const int lane = threadIdx.x & 63;
+    const int h = lane / LPH, p = lane % LPH;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int tile = (int)(row0 / HGT_TD);
+    const int within = (int)(row0 % HGT_TD);
+
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s_m[j * 64 + lane] = HGT_NEG; s_l[j * 64 + lane] = 0.0f; }
+
+    // byte offset of this lane's VEC columns inside a tile row (gather layout), before the row swizzle
+    const int wb = lane * VEC * 2;
+    // read offset of the (row = fi, k block fg) fragment of column tile 0 / k-step 0, before the swizzle
+    const int rrow = fi * ROWB;
+
+    // hub-free sub-tiles: the edge range of every relation bucket is read up front (lane r = bucket r)
+    const bool ranges_ready = !HUBS && R < 64;
+    int my_beg = 0, my_end = 0;
+    if (ranges_ready) {
+        const int64_t bb = ((int64_t)tile * (R + 1) + min(lane, R)) * HGT_TD + within;
+        my_beg = segptr[bb];
+        my_end = segptr[bb + SUBR];
+    }
+    for (int rel = 0; rel <= R; ++rel) {
+        const int64_t b0 = ((int64_t)tile * (R + 1) + rel) * HGT_TD + within;
+        const bool claimed = rel < R;   // bucket R: logit 0, no message (conv.py:68-69)
+        unsigned rowmask = 0;           // rows of the U tile written for this relation (wave-uniform)
+        // maximal runs [dl0, dl1) of non-hub targets: one run covering the whole sub-tile unless it contains a hub
+        for (int dl0 = 0; dl0 < SUBR;) {
+            int dl1 = SUBR;
+            if constexpr (HUBS) {
+                if ((hub_mask >> dl0) & 1u) { ++dl0; continue; }
+                dl1 = dl0 + 1;
+                while (dl1 < SUBR && !((hub_mask >> dl1) & 1u)) ++dl1;
+            }
+            const int beg = ranges_ready ? __builtin_amdgcn_readlane(my_beg, rel) : __builtin_amdgcn_readfirstlane(segptr[b0 + dl0]);
+            const int end = ranges_ready ? __builtin_amdgcn_readlane(my_end, rel) : __builtin_amdgcn_readfirstlane(segptr[b0 + dl1]);
+            dl0 = dl1;
+            if (beg == end) continue;
+
+            int cur_dst = -1;
+            float U[VEC], m_ref = 0.0f, l_seg = 0.0f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
+
+            auto flush = [&]() {
+                if (cur_dst >= 0) {
+                    const int dl = cur_dst - (int)row0;
+                    if (p == 0) {
+                        s_l[dl * 16 + h] += l_seg;
+                        s_m[dl * 16 + h] = m_ref;
+                    }
+                    if (claimed) {
+                        unsigned char* w = utile + dl * ROWB + ((((wb >> 4) ^ (dl & (NS - 1)))) << 4) + (wb & 15);
+                        unsigned short hi[VEC], mid[VEC];
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            hi[i] = bf16_rne(U[i]);
+                            mid[i] = bf16_rne(U[i] - bf16_to_f32(hi[i]));
+                        }
+                        if constexpr (VEC == 1) {
+                            *reinterpret_cast<unsigned short*>(w) = hi[0];
+                            *reinterpret_cast<unsigned short*>(w + G::PLANE) = mid[0];
+                        } else if constexpr (VEC == 2) {
+                            *reinterpret_cast<unsigned*>(w) = (unsigned)hi[0] | ((unsigned)hi[1] << 16);
+                            *reinterpret_cast<unsigned*>(w + G::PLANE) = (unsigned)mid[0] | ((unsigned)mid[1] << 16);
+                        } else {
+                            *reinterpret_cast<uint2*>(w) =
+                                make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
+                            *reinterpret_cast<uint2*>(w + G::PLANE) =
+                                make_uint2((unsigned)mid[0] | ((unsigned)mid[1] << 16), (unsigned)mid[2] | ((unsigned)mid[3] << 16));
+                        }
+                        rowmask |= 1u << dl;
+                    }
+                }
+            };
+
+            for (int base = beg; base < end; base += 64) {
+                const int nb = min(64, end - base);
+                const int li = base + min(lane, nb - 1);
+                const int my_src = esrc[li], my_dst = edst[li];
+                const int my_rte = RTE ? (int)ertei[li] : 0;
+                for (int i0 = 0; i0 < nb; i0 += UN) {
+                    float vr[UN][VEC], sl[UN], tr[RTE ? UN : 1][VEC];
+                    int dsts[UN];
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        const int idx = min(i0 + u, nb - 1);
+                        const int s = __builtin_amdgcn_readlane(my_src, idx);
+                        dsts[u] = __builtin_amdgcn_readlane(my_dst, idx);
+                        if (claimed) {
+                            load_vec<VEC>(V + (int64_t)s * ld + co + lane * VEC, vr[u]);
+                            sl[u] = logits[(int64_t)(base + idx) * HT + hg * H + h];
+                            if constexpr (RTE) {
+                                const int ri = __builtin_amdgcn_readlane(my_rte, idx);
+                                load_vec<VEC>(rteV + (int64_t)ri * ld + co + lane * VEC, tr[u]);
+                            }
+                        } else {
+                            sl[u] = 0.0f;
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) vr[u][i] = 0.0f;
+                            if constexpr (RTE) {
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) tr[u][i] = 0.0f;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        if (i0 + u < nb) {
+                            if (dsts[u] != cur_dst) {
+                                flush();
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
+                                l_seg = 0.0f;
+                                cur_dst = dsts[u];
+                                // reference of the target's softmax weights: the first logit the target ever saw (any
+                                // relation); kept in LDS between the relations.  Any reference gives the same softmax.
+                                const float m_t = s_m[(cur_dst - (int)row0) * 16 + h];
+                                m_ref = (m_t == HGT_NEG) ? sl[u] : m_t;
+                            }
+                            float dlt = sl[u] - m_ref;
+                            if (!raw && __builtin_amdgcn_ballot_w64(dlt > 40.0f) != 0) {
+                                // Rare: move the reference of the heads that were exceeded; everything this target has
+                                // accumulated so far is rescaled: U / l of the running segment, its exp-sum in LDS and its
+                                // COLUMN of the MFMA accumulators (lanes with (lane & 15) == target: a per-lane multiply).
+                                const float m_new = (dlt > 40.0f) ? sl[u] : m_ref;
+                                const float sc = __expf(m_ref - m_new);
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) U[i] *= sc;
+                                l_seg *= sc;
+                                const int dl = cur_dst - (int)row0;
+                                if (p == 0) {
+                                    s_l[dl * 16 + h] *= sc;
+                                    s_sc[h] = sc;
+                                }
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                                for (int c = 0; c < NCT; ++c) {
+                                    const float f = (fi == dl) ? s_sc[(16 * c + 4 * fg) / DKP] : 1.0f;
+                                    acc[c] *= f;
+                                }
+                                __builtin_amdgcn_wave_barrier();
+                                m_ref = m_new;
+                                dlt = sl[u] - m_ref;
+                            }
+                            const float pe = raw ? sl[u] : __expf(dlt);
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) {
+                                float vv = vr[u][i];
+                                if constexpr (RTE) vv += tr[u][i];
+                                U[i] = fmaf(pe, vv, U[i]);
+                            }
+                            l_seg += pe;
+                        }
+                    }
+                }
+            }
+            flush();
+        }
+        if (rowmask == 0) continue;   // no claimed edge in this relation: nothing to transform
+
+        // rows without an edge in this relation contribute nothing: zero them (rows >= SUBR are never read back: every
+        // column of the transposed product depends on its own row only)
+        for (int r = 0; r < SUBR; ++r) {
+            if ((rowmask >> r) & 1u) continue;
+            unsigned char* w = utile + r * ROWB + ((((wb >> 4) ^ (r & (NS - 1)))) << 4) + (wb & 15);
+            if constexpr (VEC == 1) {
+                *reinterpret_cast<unsigned short*>(w) = 0;
+                *reinterpret_cast<unsigned short*>(w + G::PLANE) = 0;
+            } else if constexpr (VEC == 2) {
+                *reinterpret_cast<unsigned*>(w) = 0u;
+                *reinterpret_cast<unsigned*>(w + G::PLANE) = 0u;
+            } else {
+                *reinterpret_cast<uint2*>(w) = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(w + G::PLANE) = make_uint2(0u, 0u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // Z^T[16 c .. +16][target] += M_r^T[cols of tile c][k window] . U_r^T[k window][target]
+        const unsigned short* __restrict__ mf = msgF + (((int64_t)rel * NY + hg) * NCT) * NKS * 2 * 512 + lane * 8;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const int kbase = (16 * c / KW) * KW;
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                const int slot = (kbase + 32 * s) / 8 + fg;
+                const unsigned char* up = utile + rrow + ((slot ^ (fi & (NS - 1))) << 4);
+                const bf16x8 uh = *reinterpret_cast<const bf16x8*>(up);
+                const bf16x8 um = *reinterpret_cast<const bf16x8*>(up + G::PLANE);
+                const unsigned short* t = mf + (int64_t)((c * NKS + s) * 2) * 512;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(t);
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(t + 512);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, uh, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, um, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, uh, acc[c], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // the tile is rewritten by the next relation only after every lane has read it
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming form of the sub-tile walk (hub-free sub-tiles, R < 64): the kernel is bound by the LATENCY of its gathers, not
+// by arithmetic (rocprofv3, c2: VALU 27 % busy, 64 % of the wave cycles parked in s_waitcnt), so what matters is how many
+// rows a wavefront keeps in flight.  The walk above restarts its load pipeline for every (sub-tile, relation) range
+// (~20 edges: three dependent round trips -- edge ids, rows, fragments -- per range).  Here
+//   * the R + 1 ranges of the sub-tile are concatenated into ONE virtual edge stream; edge ids / relation / sorted position
+//     of 64 stream entries live in lane registers (`meta`), the next 64 are fetched one chunk ahead;
+//   * the stream is cut into BATCHES of <= UN edges that never straddle a relation; the rows of batch k + 1 are requested
+//     before batch k is consumed (two register buffers A / B), across relation boundaries -- every request is unconditional
+//     and of fixed size, so hipcc keeps counted s_waitcnt vmcnt(N);
+//   * the relation-end work (zero rows, fragment loads, 48 MFMAs) runs BETWEEN batches, with the next batch's rows already
+//     on their way.
+// ---------------------------------------------------------------------------------------------
+template <int VEC, int LPH, bool RTE>
+__device__ __forceinline__ void agg_mfma_stream(
+    const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
+    const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
+    const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, int R, int HT, int SUBR, int64_t row0,
+    unsigned char* utile, float* s_m, float* s_l, float* s_sc, int raw, f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
+    using G = MG<VEC, LPH>;
+    constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS;
+    constexpr int UN = RTE ? 4 : 8;    // rows per batch; two batches (register buffers A / B) are in flight
+    const int hg = blockIdx.y;
+    const int64_t ld = (int64_t)HT * DKP;
+    const int co = hg * DP;
+    const int NY = HT / H;
+
+    const int lane = threadIdx.x & 63;
+    const int h = lane / LPH, p = lane % LPH;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int tile = (int)(row0 / HGT_TD);
+    const int within = (int)(row0 % HGT_TD);
+
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s_m[j * 64 + lane] = HGT_NEG; s_l[j * 64 + lane] = 0.0f; }
+
+    const int wb = lane * VEC * 2;
+    const int rrow = fi * ROWB;
+
+    // ranges of the R + 1 relation buckets (lane r = bucket r) and their exclusive prefix = position in the virtual stream
+    int my_beg = 0, my_len = 0;
+    {
+        const int64_t bb = ((int64_t)tile * (R + 1) + min(lane, R)) * HGT_TD + within;
+        my_beg = segptr[bb];
+        my_len = (lane <= R) ? segptr[bb + SUBR] - my_beg : 0;
+    }
+    int incl = my_len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const int my_pre = incl - my_len;
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total == 0) return;
+
+    // stream entries [vbase, vbase + 64) -> lane registers; entries beyond the end replicate the last edge
+    auto load_meta = [&](int vbase, int& m_src, int& m_dst, int& m_rel, int& m_pos, int& m_rte) {
+        const int v = min(vbase + lane, total - 1);
+        int rsel = 0;
+        for (int r = 0; r <= R; ++r) {
+            const int pr = __builtin_amdgcn_readlane(my_pre, r), ln = __builtin_amdgcn_readlane(my_len, r);
+            if (ln > 0 && v >= pr) rsel = r;
+        }
+        m_rel = rsel;
+        m_pos = __shfl(my_beg, rsel) + (v - __shfl(my_pre, rsel));
+        m_src = esrc[m_pos];
+        m_dst = edst[m_pos];
+        m_rte = RTE ? (int)ertei[m_pos] : 0;
+    };
+
+#if HGT_AGG_HIDDEN
+    auto load_meta_next = [&](int vbase, int& m_src, int& m_dst, int& m_rel, int& m_pos, int& m_rte) {
+        const int v = min(vbase + lane, total - 1);
+        int rsel = 0;
+        for (int r = 0; r <= R; ++r) {
+            const int pr = __builtin_amdgcn_readlane(my_pre, r), ln = __builtin_amdgcn_readlane(my_len, r);
+            if (ln > 0 && v >= pr) rsel = r;
+        }
+        m_rel = rsel;
+        m_pos = __shfl(my_beg, rsel) + (v - __shfl(my_pre, rsel));
+        hidden_load(m_src, esrc + m_pos);
+        hidden_load(m_dst, edst + m_pos);
+        if constexpr (RTE) hidden_load_u16(m_rte, ertei + m_pos);
+        else m_rte = 0;
+    };
+#define AGG_META_WAIT asm volatile("s_waitcnt vmcnt(%3)" : "+v"(n_src), "+v"(n_dst), "+v"(n_rte) : "n"(HIDDEN_PER_BATCH));
+#else
+#define load_meta_next load_meta
+#define AGG_META_WAIT
+#endif
+    int c_src, c_dst, c_rel, c_pos, c_rte;          // current chunk
+    int n_src = 0, n_dst = 0, n_rel = 0, n_pos = 0, n_rte = 0;   // next chunk (prefetched)
+    int vbase = 0, nb = min(64, total);
+    load_meta(0, c_src, c_dst, c_rel, c_pos, c_rte);
+    if (total > 64) load_meta(64, n_src, n_dst, n_rel, n_pos, n_rte);
+
+    int cur_dst = -1, cur_rel = -1;
+    unsigned rowmask = 0;
+    float U[VEC], m_ref = 0.0f, l_seg = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
+    bool seg_claimed = false;      // relation of the running segment is a real one (its rows go into the U tile)
+
+    auto flush = [&]() {
+        if (cur_dst >= 0) {
+            const int dl = cur_dst - (int)row0;
+            if (p == 0) {
+                s_l[dl * 16 + h] += l_seg;
+                s_m[dl * 16 + h] = m_ref;
+            }
+            if (seg_claimed) {
+                unsigned char* w = utile + dl * ROWB + ((((wb >> 4) ^ (dl & (NS - 1)))) << 4) + (wb & 15);
+                if constexpr (VEC == 1) {
+                    const unsigned short hi = bf16_rne(U[0]);
+                    *reinterpret_cast<unsigned short*>(w) = hi;
+                    *reinterpret_cast<unsigned short*>(w + G::PLANE) = bf16_rne(U[0] - bf16_to_f32(hi));
+                } else if constexpr (VEC == 2) {
+                    unsigned hi, mid;
+                    split2(U[0], U[1], hi, mid);
+                    *reinterpret_cast<unsigned*>(w) = hi;
+                    *reinterpret_cast<unsigned*>(w + G::PLANE) = mid;
+                } else {
+                    uint2 hi, mid;
+                    split4(make_float4(U[0], U[1], U[2], U[3]), hi, mid);
+                    *reinterpret_cast<uint2*>(w) = hi;
+                    *reinterpret_cast<uint2*>(w + G::PLANE) = mid;
+                }
+                rowmask |= 1u << dl;
+            }
+        }
+        cur_dst = -1;
+    };
+
+    // end of a relation: Z^T += M_r^T . U_r^T for the rows parked in the tile.  The fragments of M_r come from L2 in groups
+    // of GS column-tile steps, eight 1 KB loads in flight at a time, pinned with sched_barrier: left alone, hipcc issued the 32
+    // fragment loads of a relation two at a time and waited for each pair with vmcnt(0) (ISA audit of the first version) --
+    // sixteen dependent L2 round trips per relation end, the largest single cost of that version.
+    constexpr int STEPS = NCT * NKS, GS = 4, NG = STEPS / GS;
+    static_assert(STEPS % GS == 0, "column-tile steps come in multiples of 4 (DP is a multiple of 64)");
+    auto relation_end = [&](int rel) {
+        if (rowmask == 0) return;
+        for (int r = 0; r < SUBR; ++r) {
+            if ((rowmask >> r) & 1u) continue;
+            unsigned char* w = utile + r * ROWB + ((((wb >> 4) ^ (r & (NS - 1)))) << 4) + (wb & 15);
+            if constexpr (VEC == 1) {
+                *reinterpret_cast<unsigned short*>(w) = 0;
+                *reinterpret_cast<unsigned short*>(w + G::PLANE) = 0;
+            } else if constexpr (VEC == 2) {
+                *reinterpret_cast<unsigned*>(w) = 0u;
+                *reinterpret_cast<unsigned*>(w + G::PLANE) = 0u;
+            } else {
+                *reinterpret_cast<uint2*>(w) = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(w + G::PLANE) = make_uint2(0u, 0u);
+            }
+        }
+        rowmask = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned short* __restrict__ mf = msgF + (((int64_t)rel * NY + hg) * NCT) * NKS * 2 * 512 + lane * 8;
+        bf16x8 f0h[GS], f0m[GS];     // one group in flight: a second register buffer would push the kernel over 256 VGPRs
+#define FRAG_ISSUE(FH, FM, G_)                                                                     \
+    _Pragma("unroll") for (int j = 0; j < GS; ++j) {                                               \
+        const unsigned short* t_ = mf + (int64_t)(((G_) * GS + j) * 2) * 512;                      \
+        FH[j] = *reinterpret_cast<const bf16x8*>(t_);                                              \
+        FM[j] = *reinterpret_cast<const bf16x8*>(t_ + 512);                                        \
+    }                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);   /* all 2 GS loads of the group are issued before the first MFMA waits */
+#define FRAG_MUL(FH, FM, G_)                                                                       \
+    _Pragma("unroll") for (int j = 0; j < GS; ++j) {                                               \
+        const int step = (G_) * GS + j, c = step / NKS, ks = step % NKS;                           \
+        const int kbase = (16 * c / KW) * KW;                                                      \
+        const int slot = (kbase + 32 * ks) / 8 + fg;                                               \
+        const unsigned char* up = utile + rrow + ((slot ^ (fi & (NS - 1))) << 4);                  \
+        const bf16x8 uh = *reinterpret_cast<const bf16x8*>(up);                                    \
+        const bf16x8 um = *reinterpret_cast<const bf16x8*>(up + G::PLANE);                         \
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FM[j], uh, acc[c], 0, 0, 0);              \
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FH[j], um, acc[c], 0, 0, 0);              \
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FH[j], uh, acc[c], 0, 0, 0);              \
+    }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            FRAG_ISSUE(f0h, f0m, g)
+            FRAG_MUL(f0h, f0m, g)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef FRAG_ISSUE
+#undef FRAG_MUL
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    typedef typename RowT<VEC>::type Row;
+    Row vrA[UN], trA[RTE ? UN : 1], vrB[UN], trB[RTE ? UN : 1];
+    float slA[UN], slB[UN];
+    int dstA[UN], dstB[UN], relA[UN], relB[UN];
+    constexpr int HIDDEN_PER_BATCH = UN * (RTE ? 3 : 2);     // rows + logits (+ temporal rows)
+
+    // A batch = the next UN entries of the stream (fewer only at a chunk end), whatever their relations.
+#define AGG_ISSUE(VR, SL, TR, DS, RL, I0, CNT)                                                     \
+    _Pragma("unroll") for (int u = 0; u < UN; ++u) {                                               \
+        /* slots beyond the batch re-request its last edge (same address: served by the L1) */     \
+        const int idx = min((I0) + u, (I0) + max((CNT), 1) - 1);                                   \
+        const int s_ = __builtin_amdgcn_readlane(c_src, idx);                                      \
+        const int p_ = __builtin_amdgcn_readlane(c_pos, idx);                                      \
+        DS[u] = __builtin_amdgcn_readlane(c_dst, idx);                                             \
+        RL[u] = __builtin_amdgcn_readlane(c_rel, idx);                                             \
+        AGG_LOAD(VR[u], V + (int64_t)s_ * ld + co + lane * VEC)                                    \
+        AGG_LOAD(SL[u], logits + (int64_t)p_ * HT + hg * H + h)                                    \
+        if constexpr (RTE) {                                                                       \
+            const int ri = __builtin_amdgcn_readlane(c_rte, idx);                                  \
+            AGG_LOAD(TR[u], rteV + (int64_t)ri * ld + co + lane * VEC)                             \
+        }                                                                                          \
+    }
+#if HGT_AGG_HIDDEN
+#define AGG_LOAD(D, P) hidden_load(D, P);
+    // the hidden loads of THIS batch have landed once at most HIDDEN_PER_BATCH (= the next batch's) loads are outstanding
+#define AGG_WAIT(VR, SL, TR)                                                                       \
+    if constexpr (!RTE) {                                                                          \
+        asm volatile("s_waitcnt vmcnt(%16)"                                                        \
+                     : "+v"(VR[0]), "+v"(VR[1]), "+v"(VR[2]), "+v"(VR[3]), "+v"(VR[4]), "+v"(VR[5]), "+v"(VR[6]), "+v"(VR[7]),      \
+                       "+v"(SL[0]), "+v"(SL[1]), "+v"(SL[2]), "+v"(SL[3]), "+v"(SL[4]), "+v"(SL[5]), "+v"(SL[6]), "+v"(SL[7])       \
+                     : "n"(HIDDEN_PER_BATCH));                                                     \
+    } else {                                                                                       \
+        asm volatile("s_waitcnt vmcnt(%12)"                                                        \
+                     : "+v"(VR[0]), "+v"(VR[1]), "+v"(VR[2]), "+v"(VR[3]), "+v"(SL[0]), "+v"(SL[1]), "+v"(SL[2]), "+v"(SL[3]),      \
+                       "+v"(TR[0]), "+v"(TR[1]), "+v"(TR[2]), "+v"(TR[3])                          \
+                     : "n"(HIDDEN_PER_BATCH));                                                     \
+    }
+#else
+#define AGG_LOAD(D, P) D = *reinterpret_cast<const __typeof__(D)*>(P);
+#define AGG_WAIT(VR, SL, TR)
+#endif
+    // Consume a batch: runs [lo, hi) of one relation; the relation-end work sits between the runs (one call site per buffer)
+#define AGG_PROCESS(VR, SL, TR, DS, RL, CNT)                                                       \
+    for (int lo = 0; lo < (CNT);) {                                                                \
+        int rel_run = RL[0], hi = (CNT);                                                           \
+        _Pragma("unroll") for (int u = 1; u < UN; ++u) if (u <= lo) rel_run = RL[u];               \
+        _Pragma("unroll") for (int u = UN - 1; u >= 1; --u) if (u > lo && u < (CNT) && RL[u] != rel_run) hi = u; \
+        if (rel_run != cur_rel) {                                                                  \
+            flush();                                                                               \
+            relation_end(cur_rel);                                                                 \
+            cur_rel = rel_run;                                                                     \
+        }                                                                                          \
+        const bool claimed_ = rel_run < R;                                                         \
+        _Pragma("unroll") for (int u = 0; u < UN; ++u) {                                           \
+            if (u >= lo && u < hi) {                                                               \
+                if (DS[u] != cur_dst) {                                                            \
+                    flush();                                                                       \
+                    _Pragma("unroll") for (int i = 0; i < VEC; ++i) U[i] = 0.0f;                   \
+                    l_seg = 0.0f;                                                                  \
+                    cur_dst = DS[u];                                                               \
+                    seg_claimed = claimed_;                                                        \
+                    const float m_t = s_m[(cur_dst - (int)row0) * 16 + h];                         \
+                    m_ref = (m_t == HGT_NEG) ? SL[u] : m_t;                                        \
+                }                                                                                  \
+                float dlt = SL[u] - m_ref;                                                         \
+                if (!raw && __builtin_amdgcn_ballot_w64(dlt > 40.0f) != 0) {                       \
+                    const float m_new = (dlt > 40.0f) ? SL[u] : m_ref;                             \
+                    const float sc = __expf(m_ref - m_new);                                        \
+                    _Pragma("unroll") for (int i = 0; i < VEC; ++i) U[i] *= sc;                    \
+                    l_seg *= sc;                                                                   \
+                    const int dl = cur_dst - (int)row0;                                            \
+                    if (p == 0) {                                                                  \
+                        s_l[dl * 16 + h] *= sc;                                                    \
+                        s_sc[h] = sc;                                                              \
+                    }                                                                              \
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                         \
+                    __builtin_amdgcn_wave_barrier();                                               \
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                         \
+                    _Pragma("unroll") for (int c = 0; c < NCT; ++c) {                              \
+                        const float f = (fi == dl) ? s_sc[(16 * c + 4 * fg) / DKP] : 1.0f;         \
+                        acc[c] *= f;                                                               \
+                    }                                                                              \
+                    __builtin_amdgcn_wave_barrier();                                               \
+                    m_ref = m_new;                                                                 \
+                    dlt = SL[u] - m_ref;                                                           \
+                }                                                                                  \
+                const float pe = raw ? SL[u] : __expf(dlt);   /* raw: the array holds the edge weights themselves */ \
+                if (claimed_) {                                                                    \
+                    _Pragma("unroll") for (int i = 0; i < VEC; ++i) {                              \
+                        float vv = row_elem(VR[u], i);                                             \
+                        if constexpr (RTE) vv += row_elem(TR[u], i);                               \
+                        U[i] = fmaf(pe, vv, U[i]);                                                 \
+                    }                                                                              \
+                }                                                                                  \
+                l_seg += pe;                                                                       \
+            }                                                                                      \
+        }                                                                                          \
+        lo = hi;                                                                                   \
+    }
+    // batch after (I0, CNT); rotates the chunk registers at a chunk end; CNTN = 0: the stream is over (the issue that
+    // follows then re-requests the last edge: unconditional, fixed size)
+#define AGG_NEXT(I0, CNT, I0N, CNTN)                                                               \
+    {                                                                                              \
+        I0N = (I0) + (CNT);                                                                        \
+        if (I0N >= nb) {                                                                           \
+            if (vbase + 64 >= total) {                                                             \
+                I0N = nb - 1;                                                                      \
+                CNTN = 0;                                                                          \
+            } else {                                                                               \
+                vbase += 64;                                                                       \
+                nb = min(64, total - vbase);                                                       \
+                AGG_META_WAIT                                                                      \
+                c_src = n_src; c_dst = n_dst; c_rel = n_rel; c_pos = n_pos; c_rte = n_rte;          \
+                if (vbase + 64 < total) load_meta_next(vbase + 64, n_src, n_dst, n_rel, n_pos, n_rte); \
+                I0N = 0;                                                                           \
+                CNTN = min(UN, nb);                                                                \
+            }                                                                                      \
+        } else {                                                                                   \
+            CNTN = min(UN, nb - I0N);                                                              \
+        }                                                                                          \
+    }
+
+    // Two register buffers: the rows of batch k + 1 are requested before batch k is consumed.
+    int i0A = 0, cntA = min(UN, nb), i0B, cntB;
+    AGG_ISSUE(vrA, slA, trA, dstA, relA, 0, cntA)
+    for (;;) {
+        AGG_NEXT(i0A, cntA, i0B, cntB)
+        AGG_ISSUE(vrB, slB, trB, dstB, relB, i0B, cntB)
+        AGG_WAIT(vrA, slA, trA)
+        AGG_PROCESS(vrA, slA, trA, dstA, relA, cntA)
+        if (cntB == 0) break;
+        AGG_NEXT(i0B, cntB, i0A, cntA)
+        AGG_ISSUE(vrA, slA, trA, dstA, relA, i0A, cntA)
+        AGG_WAIT(vrB, slB, trB)
+        AGG_PROCESS(vrB, slB, trB, dstB, relB, cntB)
+        if (cntA == 0) break;
+    }
+#if HGT_AGG_HIDDEN
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AGG_WAIT(vrA, slA, trA)
+    AGG_WAIT(vrB, slB, trB)
+#endif
+    flush();
+    relation_end(cur_rel);
+#undef AGG_ISSUE
+#undef AGG_LOAD
+#undef AGG_WAIT
+#undef AGG_META_WAIT
+#if !HGT_AGG_HIDDEN
+#undef load_meta_next
+#endif
+#undef AGG_PROCESS
+#undef AGG_NEXT
+}
+
+// normalise (PyG softmax denominator, conv.py:108) + optional exact-erf gelu (conv.py:119), in the accumulator layout;
+// apply_gelu: 0 = normalise, 1 = normalise + gelu, 2 = raw weighted sum (no softmax: hgt_edge_spmm)
+template <int VEC, int LPH>
+__device__ __forceinline__ void agg_mfma_finish(const float* s_l, int apply_gelu, f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
+    using G = MG<VEC, LPH>;
+    const int lane = threadIdx.x & 63;
+    const int fi = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < G::NCT; ++c) {
+        const float inv = (apply_gelu == 2) ? 1.0f : 1.0f / (s_l[fi * 16 + (16 * c + 4 * fg) / G::DKP] + 1e-16f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float o = acc[c][r] * inv;
+            if (apply_gelu == 1) o = 0.5f * o * (1.0f + erff(o * 0.70710678118654752440f));
+            acc[c][r] = o;
+        }
+    }
+}
+
+template <int VEC, int LPH>
+__device__ __forceinline__ void agg_mfma_store(float* __restrict__ agg, int64_t row0, int SUBR, int64_t NQ, int64_t ld, int co,
+                                               unsigned hub_mask, const f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
+    using G = MG<VEC, LPH>;
+    const int lane = threadIdx.x & 63;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int64_t row = row0 + fi;
+    if (fi >= SUBR || row >= NQ || ((hub_mask >> fi) & 1u)) return;   // hub rows are written by k_hub_finalize
+    float* g = agg + row * ld + co + 4 * fg;
+#pragma unroll
+    for (int c = 0; c < G::NCT; ++c)
+        *reinterpret_cast<float4*>(g + 16 * c) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+}
+
+template <int VEC, int LPH>
+constexpr int agg_mfma_lds_bytes() { return 4 * 2 * MG<VEC, LPH>::PLANE; }
+
+template <int VEC, int LPH, bool RTE>
+__global__ __launch_bounds__(256, 2) void k_edge_aggregate_mfma(
+    const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
+    const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
+    const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, float* __restrict__ agg, int R, int64_t NQ, int apply_gelu,
+    int HT, const int32_t* __restrict__ hub_slot, int sub, int64_t ld_out) {
+    using G = MG<VEC, LPH>;
+    const int raw = (apply_gelu == 2);
+    __shared__ __attribute__((aligned(16))) unsigned char s_u[4][2 * G::PLANE];
+    __shared__ float s_ml[4][2][16 * 16];   // reference / exp-sum per (target, head); H <= 16
+    __shared__ float s_scale[4][16];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t row0 = (int64_t)blockIdx.x * (4 * sub) + wib * sub;
+    if (row0 >= NQ) return;
+    unsigned hub_mask = 0;
+    if (hub_slot) {
+        const int64_t rr = row0 + (lane & 15);
+        const bool is_hub = (lane < sub) && (rr < NQ) && (hub_slot[rr] >= 0);
+        hub_mask = (unsigned)(__builtin_amdgcn_ballot_w64(is_hub) & 0xFFFFull);
+    }
+    f32x4 acc[G::NCT];
+    if (hub_mask == 0 && R < 64)
+        agg_mfma_stream<VEC, LPH, RTE>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, HT, sub, row0, s_u[wib], s_ml[wib][0],
+                                       s_ml[wib][1], s_scale[wib], raw, acc);
+    else if (hub_mask == 0)
+        agg_mfma_subtile<VEC, LPH, RTE, false>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, HT, 0u, sub, row0, s_u[wib],
+                                               s_ml[wib][0], s_ml[wib][1], s_scale[wib], raw, acc);
+    else
+        agg_mfma_subtile<VEC, LPH, RTE, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, HT, hub_mask, sub, row0, s_u[wib],
+                                              s_ml[wib][0], s_ml[wib][1], s_scale[wib], raw, acc);
+    agg_mfma_finish<VEC, LPH>(s_ml[wib][1], apply_gelu, acc);
+    agg_mfma_store<VEC, LPH>(agg, row0, sub, NQ, ld_out, (int)blockIdx.y * G::DP, hub_mask, acc);
+}
+
+// Aggregation + fused node update (see hgt_fused_update.h).  Workgroups that contain a hub target cannot finish their rows
+// here: they write agg, raise pending[workgroup], and k_update_pending runs the same epilogue from agg after the hub kernels.
+template <int VEC, int LPH, bool RTE>
+__global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
+    const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
+    const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
+    const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, float* __restrict__ agg, int R, int64_t NQ, int HT,
+    const int32_t* __restrict__ hub_slot, int32_t* __restrict__ pending, HgtFusedUpdate fu) {
+    using G = MG<VEC, LPH>;
+    static_assert(G::DP <= KP, "the fused epilogue keeps the whole K extent in one LDS slab");
+    constexpr int TILES = 4 * 2 * G::PLANE;
+    constexpr int FRONT = TILES > 2 * A_PLANE ? TILES : 2 * A_PLANE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[FRONT + 4 * 2 * 256 * 4 + 4 * 16 * 4];
+    float* s_ml = reinterpret_cast<float*>(smem + FRONT);                 // [4][2][256]; later: the epilogue's tables
+    float* s_scale = reinterpret_cast<float*>(smem + FRONT + 4 * 2 * 256 * 4);
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int64_t wrow0 = row0 + wib * 16;
+
+    unsigned hub_mask = 0;
+    if (hub_slot) {
+        const int64_t rr = wrow0 + (lane & 15);
+        const bool is_hub = (lane < 16) && (rr < NQ) && (hub_slot[rr] >= 0);
+        hub_mask = (unsigned)(__builtin_amdgcn_ballot_w64(is_hub) & 0xFFFFull);
+    }
+    const bool any_hub = hub_slot ? (__syncthreads_or(hub_mask != 0) != 0) : false;
+    if (threadIdx.x == 0) pending[blockIdx.x] = any_hub ? 1 : 0;
+
+    unsigned char* utile = smem + wib * 2 * G::PLANE;
+    float* s_m = s_ml + wib * 512;
+    float* s_l = s_m + 256;
+    f32x4 acc[G::NCT];
+    if (wrow0 < NQ) {
+        // (the launcher only takes this kernel for R < 64; workgroups with a hub take the run-based walk for all four
+        //  sub-tiles: one walk variant less in the kernel keeps the register allocation of the common path spill-free)
+        if (!any_hub)
+            agg_mfma_stream<VEC, LPH, RTE>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, HT, 16, wrow0, utile, s_m, s_l,
+                                           s_scale + wib * 16, 0, acc);
+        else
+            agg_mfma_subtile<VEC, LPH, RTE, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, HT, hub_mask, 16, wrow0, utile, s_m,
+                                                  s_l, s_scale + wib * 16, 0, acc);
+        agg_mfma_finish<VEC, LPH>(s_l, 1, acc);
+    } else {
+#pragma unroll
+        for (int c = 0; c < G::NCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};   // rows beyond NQ: gelu(0) = 0
+    }
+    if (any_hub) {
+        if (wrow0 < NQ) agg_mfma_store<VEC, LPH>(agg, wrow0, 16, NQ, (int64_t)HT * G::DKP, 0, hub_mask, acc);
+        return;
+    }
+    __syncthreads();   // every wavefront is done with its U tile and its softmax state: the A slab overlays them
+    {
+        // accumulator layout -> A slab: target (lane & 15) of this wavefront, columns 16 c + 4 (lane >> 4) .. + 3
+        const int fi = lane & 15, fg = lane >> 4;
+        unsigned char* prow = smem + (wib * 16 + fi) * A_STRIDE + fg * 8;
+#pragma unroll
+        for (int c = 0; c < G::NCT; ++c) {
+            uint2 hi, mid;
+            split4(make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]), hi, mid);
+            *reinterpret_cast<uint2*>(prow + c * 32) = hi;
+            *reinterpret_cast<uint2*>(prow + A_PLANE + c * 32) = mid;
+        }
+    }
+    fused_update_tail<VEC, 2>(smem, smem + FRONT, row0, NQ, fu);
+}
+
+template <int VEC, int LPH>
+struct LaunchAggMfma {
+    static int run(const HgtPlanView& pv, const float* logits, const float* V, const float* rteV, const float* msgP,
+                   const unsigned short* msgF, float* agg, int R, int64_t NQ, int apply_gelu, int HT, HgtHubBuffers hb, int64_t ld_out,
+                   hipStream_t stream) {
+        if constexpr (VEC <= 4) {
+            // small graphs (the reference's sampled subgraphs): 4 instead of 16 targets per wavefront -> 4x the wavefronts
+            const int sub = (NQ < 65536) ? 4 : HGT_SUB;
+            const int64_t tiles = (NQ + 4 * sub - 1) / (4 * sub);
+            const unsigned ny = (unsigned)(HT / (64 / LPH));
+            dim3 grid((unsigned)tiles, ny);
+            const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
+            if (rteV)
+                k_edge_aggregate_mfma<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
+                                                                               agg, R, NQ, apply_gelu, HT, hub_slot, sub, ld_out);
+            else
+                k_edge_aggregate_mfma<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
+                                                                                agg, R, NQ, apply_gelu, HT, hub_slot, sub, ld_out);
+            if (hb.mx) return hgt_launch_hub(VEC, LPH, pv, logits, V, rteV, msgP, agg, R, NQ, apply_gelu, HT, hb, ny, ld_out, stream);
+            return HGT_OK;
+        } else {
+            return HGT_ERR_UNSUPPORTED;
+        }
+    }
+};
+
+template <int VEC, int LPH>
+struct LaunchAggUpdateMfma {
+    static int run(const HgtPlanView& pv, const float* logits, const float* V, const float* rteV, const float* msgP,
+                   const unsigned short* msgF, float* agg, int R, int64_t NQ, int HT, HgtHubBuffers hb, int32_t* pending,
+                   HgtFusedUpdate fu, hipStream_t stream) {
+        if constexpr (VEC <= 4) {
+            if (HT != 64 / LPH) return HGT_ERR_UNSUPPORTED;   // a head-group split leaves a workgroup with part of the row
+            if (R >= 64) return HGT_ERR_UNSUPPORTED;          // the streaming walk keeps the R + 1 ranges in lane registers
+            const int64_t tiles = (NQ + 63) / 64;
+            dim3 grid((unsigned)tiles, 1);
+            const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
+            if (rteV)
+                k_edge_aggregate_update_mfma<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV,
+                                                                                      msgF, agg, R, NQ, HT, hub_slot, pending, fu);
+            else
+                k_edge_aggregate_update_mfma<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV,
+                                                                                       msgF, agg, R, NQ, HT, hub_slot, pending, fu);
+            if (hb.mx) {   // hub path + the update of the workgroups that had to wait for it
+                int rc = hgt_launch_hub(VEC, LPH, pv, logits, V, rteV, msgP, agg, R, NQ, 1, HT, hb, 1u, (int64_t)HT * (VEC * LPH), stream);
+                if (rc != HGT_OK) return rc;
+                k_update_pending<VEC><<<grid, 256, 0, stream>>>(agg, (int64_t)HT * (VEC * LPH), NQ, pending, fu);
+            }
+            return HGT_OK;
+        } else {
+            return HGT_ERR_UNSUPPORTED;
+        }
+    }
+};
+
+// head-group split of the matrix-core kernels: the wave's slice must be <= 256 columns (VEC <= 4): 16 KB of U tile per wave
+static int mfma_split_for(int vec_full, int lph_full) {
+    int s = 1;
+    while (vec_full / s > 4 && lph_full * s * 2 <= 64) s *= 2;
+    return (vec_full / s <= 4) ? s : 0;   // 0: not covered (one head wider than 256 columns)
+}
+
+static HgtHubBuffers carve_hub(void* hub_ws, const HgtPlanView& pv, int H, int64_t E) {
+    HgtHubBuffers hb = {nullptr, nullptr, nullptr};
+    if (hub_ws && E > 0) {
+        const uint64_t per = hgt_align_up((uint64_t)pv.L.max_hubs * H * 4, 256);
+        hb.mx = (int*)hub_ws;
+        hb.l = (float*)((char*)hub_ws + per);
+        hb.acc = (float*)((char*)hub_ws + 2 * per);
+    }
+    return hb;
+}
+
+}  // namespace
+
+extern "C" int hgt_relation_frag_bytes(int32_t R, int32_t H, int32_t dk_pad, uint64_t* out) {
+    if (!out || R <= 0 || H <= 0 || dk_pad <= 0 || 64 % H != 0) return HGT_ERR_INVALID_ARG;
+    const int lph = 64 / H;
+    if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
+    const int sp = mfma_split_for(dk_pad / lph, lph);
+    if (sp == 0) { *out = 0; return HGT_OK; }      // layout not covered by the matrix-core kernel: no image needed
+    const int vec = dk_pad / lph / sp, lphs = lph * sp, dkp = vec * lphs, dp = 64 * vec;
+    const int kw = dkp > 32 ? dkp : 32;
+    *out = (uint64_t)R * (H * dk_pad / dp) * (dp / 16) * (kw / 32) * 2 * 512 * 2;
+    return HGT_OK;
+}
+
+extern "C" int hgt_relation_frag_pack(const float* msg_p, int32_t R, int32_t H, int32_t dk_pad, void* msg_frag, void* stream) {
+    if (!msg_p || !msg_frag || R <= 0 || H <= 0 || dk_pad <= 0 || 64 % H != 0) return HGT_ERR_INVALID_ARG;
+    const int lph = 64 / H;
+    if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
+    const int sp = mfma_split_for(dk_pad / lph, lph);
+    if (sp == 0) return HGT_ERR_UNSUPPORTED;
+    const int vec = dk_pad / lph / sp;
+    const int dp = 64 * vec;
+    // after a head-group split a "head" of the kernel is still a real head (heads are never cut): the block structure of
+    // blockdiag(M) is described by the REAL head width dk_pad
+    const int kw = dk_pad > 32 ? dk_pad : 32;
+    const int64_t total = (int64_t)R * (H * dk_pad / dp) * (dp / 16) * (kw / 32) * 512;
+    k_msg_frag_pack<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(msg_p, R, H, dk_pad, dp, (unsigned short*)msg_frag);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_hub_workspace_bytes(int64_t n_edges, int32_t n_heads, int32_t dk_pad, uint64_t* out) {
+    if (!out || n_edges < 0 || n_heads <= 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
+    const uint64_t max_hubs = (uint64_t)(n_edges / HGT_HUB_DEG + 1);
+    *out = hgt_align_up(max_hubs * n_heads * 4, 256) * 2 + hgt_align_up(max_hubs * n_heads * dk_pad * 4, 256);
+    return HGT_OK;
+}
+
+extern "C" int hgt_edge_aggregate(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                  const float* logits, const float* V, const float* rte_v, const float* msg_p, const void* msg_frag,
+                                  float* agg, int64_t n_q_rows, int32_t apply_gelu, void* hub_ws, void* stream) {
+    if (!plan || !V || !msg_p || !agg || (E > 0 && !logits) || H <= 0 || 64 % H != 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
+    const int64_t NQ = (n_q_rows > 0 && n_q_rows <= N) ? n_q_rows : N;
+    if (NQ == 0) return HGT_OK;
+    const int lph = 64 / H;
+    if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
+    HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
+    HgtHubBuffers hb = carve_hub(hub_ws, pv, H, E);
+    int rc = HGT_ERR_UNSUPPORTED;
+    const int sp = msg_frag ? mfma_split_for(dk_pad / lph, lph) : 0;
+    if (sp != 0)
+        rc = dispatch_layout<LaunchAggMfma>(dk_pad / lph / sp, lph * sp, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
+                                            (int)R, NQ, (int)(apply_gelu ? 1 : 0), (int)H, hb, (int64_t)H * dk_pad, (hipStream_t)stream);
+    if (rc == HGT_ERR_UNSUPPORTED)   // exact-fp32 request (msg_frag == NULL) or a layout only the vector-ALU kernel covers
+        rc = hgt_valu_aggregate(pv, dk_pad, logits, V, rte_v, msg_p, agg, (int)R, NQ, (int)(apply_gelu ? 1 : 0), (int)H, hb, (hipStream_t)stream);
+    if (rc != HGT_OK) return rc;
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_edge_aggregate_update(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                         const float* logits, const float* V, const float* rte_v, const float* msg_p,
+                                         const void* msg_frag, float* agg, int64_t n_q_rows, void* hub_ws, int32_t* pending,
+                                         const int64_t* node_type, const void* w_a_split, const float* b_a, const float* x_skip,
+                                         int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm,
+                                         int32_t n_out, float* out, void* stream) {
+    if (!plan || !V || !msg_p || !agg || !pending || !node_type || !w_a_split || !b_a || !x_skip || !skip || !out || H <= 0 ||
+        64 % H != 0 || dk_pad <= 0 || n_out <= 0)
+        return HGT_ERR_INVALID_ARG;
+    if (E > 0 && !logits) return HGT_ERR_INVALID_ARG;
+    if (use_norm && (!ln_w || !ln_b)) return HGT_ERR_INVALID_ARG;
+    const int64_t NQ = (n_q_rows > 0 && n_q_rows <= N) ? n_q_rows : N;
+    if (NQ == 0) return HGT_OK;
+    const int lph = 64 / H;
+    if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
+    const int dp = H * dk_pad;
+    if (dp > KP || n_out > dp || (n_out & 3) != 0 || (ld_skip & 3) != 0 || ((uintptr_t)x_skip & 15) != 0) return HGT_ERR_UNSUPPORTED;
+    HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
+    HgtHubBuffers hb = carve_hub(hub_ws, pv, H, E);
+    HgtFusedUpdate fu = {node_type, (const unsigned short*)w_a_split, b_a, x_skip, ld_skip, skip, ln_w, ln_b, use_norm, T, n_out, out};
+    int rc = HGT_ERR_UNSUPPORTED;
+    if (msg_frag && mfma_split_for(dk_pad / lph, lph) == 1)
+        rc = dispatch_layout<LaunchAggUpdateMfma>(dk_pad / lph, lph, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
+                                                  (int)R, NQ, (int)H, hb, pending, fu, (hipStream_t)stream);
+    if (rc == HGT_ERR_UNSUPPORTED && !msg_frag)
+        rc = hgt_valu_aggregate_update(pv, dk_pad, logits, V, rte_v, msg_p, agg, (int)R, NQ, (int)H, hb, pending, fu, (hipStream_t)stream);
+    if (rc != HGT_OK) return rc;
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+// out[i][ld_out] = sum_rel ( sum_{e in (i,rel)} w_e rows[src_e] ) F[rel]  -- the aggregation kernel without the softmax: the edge
+// weights are given.  The backward pass is three of these (include/hgt_hip.h).
+extern "C" int hgt_edge_spmm(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                             const float* weights, const float* rows, const float* rte_rows, const float* f_p, const void* f_frag,
+                             float* out, int64_t ld_out, int64_t n_q_rows, void* hub_ws, void* stream) {
+    if (!plan || !rows || !f_p || !f_frag || !out || (E > 0 && !weights) || H <= 0 || 64 % H != 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
+    const int64_t NQ = (n_q_rows > 0 && n_q_rows <= N) ? n_q_rows : N;
+    if (NQ == 0) return HGT_OK;
+    const int lph = 64 / H;
+    if (dk_pad % lph != 0 || ld_out < (int64_t)H * dk_pad || (ld_out & 3) != 0) return HGT_ERR_INVALID_ARG;
+    HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
+    HgtHubBuffers hb = carve_hub(hub_ws, pv, H, E);
+    const int sp = mfma_split_for(dk_pad / lph, lph);
+    if (sp == 0) return HGT_ERR_UNSUPPORTED;
+    int rc = dispatch_layout<LaunchAggMfma>(dk_pad / lph / sp, lph * sp, pv, weights, rows, rte_rows, f_p, (const unsigned short*)f_frag, out,
+                                            (int)R, NQ, 2, (int)H, hb, ld_out, (hipStream_t)stream);
+    if (rc != HGT_OK) return rc;
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}

@@ -8,6 +8,7 @@
 // key/fill/segment/item kernels are hand-written.  Everything is enqueued on the caller's stream,
 // nothing synchronises; the number of work items stays on the device (HgtPlanHeader::n_items)
 // and consumers launch the host-side upper bound.
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -190,6 +191,114 @@ __global__ void k_type_offsets(const uint32_t* __restrict__ keys_sorted, int64_t
     off[g] = (int32_t)lo;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Plan from a PRE-SORTED graph (hgt_plan_from_sorted; SURVEY.md section 8f-3: the reference's sampler already emits
+// type-contiguous nodes and, per relation, target-sorted edge runs -- data.py:183-209,227-246 -- so the radix sorts of
+// hgt_plan_build are redundant for its batches).  Input: edges grouped by relation (rel_ptr[R+1]), target ids
+// non-decreasing inside a relation.  The plan order (tile, relation, target) is then a MERGE of R sorted lists by tile:
+//   lb[tile][r]  = first edge of relation r with target >= tile * TD              (binary search)
+//   base[tile][r] = exclusive scan of (lb[tile+1][r] - lb[tile][r]) over (tile, r)  -> sorted position of that run
+//   edge i of relation r in tile t lands at base[t][r] + (i - lb[t][r]);  segptr by one more binary search per bin.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lower_bound_i32(const int32_t* __restrict__ a, int lo, int hi, int key) {
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// pair j = tile * (R+1) + r (r == R: the unclaimed bucket, always empty here).  cnt[j] = edges of the pair; icnt[j] = its items.
+__global__ void k_sorted_pair_counts(const int32_t* __restrict__ dst, const int32_t* __restrict__ rel_ptr, int64_t n_pairs, int R, int ch,
+                                     int32_t* __restrict__ lb, int32_t* __restrict__ cnt, int32_t* __restrict__ icnt) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n_pairs) return;
+    if (j == n_pairs) { cnt[j] = 0; icnt[j] = 0; return; }
+    const int r = (int)(j % (R + 1));
+    const int64_t tile = j / (R + 1);
+    int c = 0, l0 = 0;
+    if (r < R) {
+        const int b = rel_ptr[r], e = rel_ptr[r + 1];
+        l0 = lower_bound_i32(dst, b, e, (int)(tile * HGT_TD));
+        const int l1 = lower_bound_i32(dst, l0, e, (int)((tile + 1) * HGT_TD));
+        c = l1 - l0;
+    }
+    lb[j] = l0;
+    cnt[j] = c;
+    icnt[j] = (c + ch - 1) / ch;
+}
+
+__global__ void k_sorted_segptr(const int32_t* __restrict__ dst, const int32_t* __restrict__ lb, const int32_t* __restrict__ cnt,
+                                const int32_t* __restrict__ base, int64_t n_bins, int R, int64_t E, int32_t* __restrict__ segptr) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_bins) return;
+    if (b == n_bins) { segptr[b] = (int32_t)E; return; }
+    const int64_t j = b / HGT_TD;
+    const int dl = (int)(b % HGT_TD);
+    const int64_t tile = j / (R + 1);
+    const int l0 = lb[j], c = cnt[j];
+    const int pos = lower_bound_i32(dst, l0, l0 + c, (int)(tile * HGT_TD + dl));
+    segptr[b] = base[j] + (pos - l0);
+}
+
+__global__ void k_sorted_scatter(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, const int32_t* __restrict__ etime,
+                                 const int32_t* __restrict__ rel_ptr, const int32_t* __restrict__ type_off, const int32_t* __restrict__ lb,
+                                 const int32_t* __restrict__ base, int64_t E, int T, int R, int64_t N, int64_t NQ,
+                                 int32_t* __restrict__ esrc, int32_t* __restrict__ edst, uint16_t* __restrict__ ertei,
+                                 int32_t* __restrict__ eid, HgtPlanHeader* hdr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    int r = 0;
+    while (r + 1 < R && rel_ptr[r + 1] <= i) ++r;       // R is small (<= 64 relations in the reference's schemas)
+    int s = src[i], d = dst[i];
+    if (s < 0 || s >= N || d < 0 || d >= NQ) { atomicOr(&hdr->bad_index, 1); s = max(0, min(s, (int)N - 1)); d = max(0, min(d, (int)NQ - 1)); }
+    const int64_t j = (int64_t)(d / HGT_TD) * (R + 1) + r;
+    const int p = base[j] + ((int)i - lb[j]);
+    int ts = 0;
+    while (ts + 1 < T && type_off[ts + 1] <= s) ++ts;
+    int tm = etime ? etime[i] : 0;
+    if (tm < 0 || tm >= HGT_RTE_LEN) { atomicOr(&hdr->bad_index, 2); tm = tm < 0 ? 0 : HGT_RTE_LEN - 1; }
+    esrc[p] = s;
+    edst[p] = d;
+    ertei[p] = (uint16_t)(ts * HGT_RTE_LEN + tm);
+    eid[p] = (int32_t)i;
+}
+
+// typed row lists of type-contiguous nodes: rows = identity, offsets given
+__global__ void k_sorted_rows(const int32_t* __restrict__ type_off, int64_t N, int64_t NQ, int T, int32_t* __restrict__ rows_all,
+                              int32_t* __restrict__ off_all, int32_t* __restrict__ rows_q, int32_t* __restrict__ off_q, HgtPlanHeader* hdr) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0) { hdr->n_items = 0; hdr->bad_index = 0; hdr->n_hubs = 0; }
+    if (n < N) { rows_all[n] = (int32_t)n; rows_q[n] = (int32_t)n; }
+    if (n <= T + 1) {
+        const int32_t v = (n <= T) ? type_off[n] : (int32_t)N;          // group T (unknown types) is empty
+        off_all[n] = v;
+        off_q[n] = (int32_t)min((int64_t)v, NQ);
+    }
+}
+
+// exclusive scans of the (small) per-pair counts in ONE workgroup: two arrays at once (edge positions, item positions)
+__global__ __launch_bounds__(1024) void k_scan2_single(const int32_t* __restrict__ a, const int32_t* __restrict__ b, int64_t n,
+                                                        int32_t* __restrict__ oa, int32_t* __restrict__ ob) {
+    __shared__ int sa[1024], sb[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t beg = tid * per, end = min(beg + per, n);
+    int ta = 0, tb = 0;
+    for (int64_t i = beg; i < end; ++i) { ta += a[i]; tb += b[i]; }
+    sa[tid] = ta; sb[tid] = tb;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int va = tid >= o ? sa[tid - o] : 0, vb = tid >= o ? sb[tid - o] : 0;
+        __syncthreads();
+        sa[tid] += va; sb[tid] += vb;
+        __syncthreads();
+    }
+    int ra = sa[tid] - ta, rb = sb[tid] - tb;
+    for (int64_t i = beg; i < end; ++i) { oa[i] = ra; ob[i] = rb; ra += a[i]; rb += b[i]; }
+}
+
 static inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 }  // namespace
@@ -311,6 +420,51 @@ extern "C" int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int
                                       key_bits((uint64_t)T + 1), stream) != hipSuccess) return HGT_ERR_LAUNCH;
     }
     k_type_offsets<<<1, 256, 0, stream>>>(nkeys_out, NQ, T, off_q);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_plan_from_sorted(const int32_t* src, const int32_t* dst, const int32_t* edge_time, const int32_t* rel_ptr,
+                                    const int32_t* type_off, int64_t N, int64_t NQ, int64_t E, int32_t T, int32_t R, void* plan,
+                                    uint64_t plan_bytes, void* tmp, uint64_t tmp_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    hgt_plan_sizes sz;
+    int rc = hgt_plan_sizes_for(N, E, T, R, &sz);
+    if (rc != HGT_OK) return rc;
+    if (!plan || !tmp || !rel_ptr || !type_off || (E > 0 && (!src || !dst)) || NQ < 0 || NQ > N) return HGT_ERR_INVALID_ARG;
+    if (plan_bytes < sz.plan_bytes || tmp_bytes < sz.tmp_bytes) return HGT_ERR_WORKSPACE;
+    HgtPlanLayout L = hgt_plan_layout(N, E, T, R);
+    char* pb = (char*)plan;
+    char* tb = (char*)tmp;
+    HgtPlanHeader* hdr = (HgtPlanHeader*)(pb + L.off_hdr);
+    int32_t* esrc = (int32_t*)(pb + L.off_esrc);
+    int32_t* edst = (int32_t*)(pb + L.off_edst);
+    uint16_t* ertei = (uint16_t*)(pb + L.off_ertei);
+    int32_t* eid = (int32_t*)(pb + L.off_eid);
+    int32_t* segptr = (int32_t*)(pb + L.off_segptr);
+    HgtItem* items = (HgtItem*)(pb + L.off_items);
+    int32_t* tile_items = (int32_t*)(pb + L.off_tile_items);
+    // scratch: four int32 arrays of n_pairs + 1 entries inside the (much larger) sort scratch of hgt_plan_build
+    const uint64_t stride = hgt_align_up((uint64_t)(L.n_pairs + 1) * 4, 256);
+    if (tmp_bytes < 5 * stride) return HGT_ERR_WORKSPACE;
+    int32_t* lb = (int32_t*)tb;
+    int32_t* cnt = (int32_t*)(tb + stride);
+    int32_t* icnt = (int32_t*)(tb + 2 * stride);
+    int32_t* base = (int32_t*)(tb + 3 * stride);
+    int32_t* pair_off = (int32_t*)(tb + 4 * stride);
+    const int BS = 256;
+    const int ch = hgt_item_edges(E);
+    k_sorted_rows<<<nblk(std::max<int64_t>(N, T + 2), BS), BS, 0, stream>>>(type_off, N, NQ, T, (int32_t*)(pb + L.off_rows_all),
+                                                                           (int32_t*)(pb + L.off_off_all), (int32_t*)(pb + L.off_rows_q),
+                                                                           (int32_t*)(pb + L.off_off_q), hdr);
+    k_sorted_pair_counts<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(dst, rel_ptr, L.n_pairs, R, ch, lb, cnt, icnt);
+    k_scan2_single<<<1, 1024, 0, stream>>>(cnt, icnt, L.n_pairs + 1, base, pair_off);
+    if (E > 0)
+        k_sorted_scatter<<<nblk(E, BS), BS, 0, stream>>>(src, dst, edge_time, rel_ptr, type_off, lb, base, E, T, R, N, NQ, esrc, edst, ertei,
+                                                        eid, hdr);
+    k_sorted_segptr<<<nblk(L.n_bins + 1, BS), BS, 0, stream>>>(dst, lb, cnt, base, L.n_bins, R, E, segptr);
+    k_items<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(segptr, pair_off, L.n_pairs, R, ch, items, tile_items, hdr);
+    if (N > 0) k_hub_detect<<<nblk(N, BS), BS, 0, stream>>>(segptr, N, R, (int32_t*)(pb + L.off_hub_slot), (int32_t*)(pb + L.off_hub_list), hdr);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }

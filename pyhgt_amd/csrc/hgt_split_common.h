@@ -27,16 +27,22 @@ __device__ __forceinline__ unsigned short bf16_rne(float f) {
 }
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 
+// fp32 pair -> packed bf16 hi / mid terms (a = hi + mid + O(2^-18 a)) on gfx950's hardware conversion: v_cvt_pk_bf16_f32
+// (round to nearest even, identical to bf16_rne for finite inputs), 5 instructions per pair instead of ~20
+typedef __bf16 hgt_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hgt_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& mid) {
+    const hgt_f32x2 v = {a, b};
+    const hgt_bf16x2 h = __builtin_convertvector(v, hgt_bf16x2);
+    const hgt_f32x2 r = v - __builtin_convertvector(h, hgt_f32x2);
+    const hgt_bf16x2 m = __builtin_convertvector(r, hgt_bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    mid = __builtin_bit_cast(unsigned, m);
+}
+
 __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid) {
-    const float f[4] = {v.x, v.y, v.z, v.w};
-    unsigned short h[4], m[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        h[i] = bf16_rne(f[i]);
-        m[i] = bf16_rne(f[i] - bf16_to_f32(h[i]));
-    }
-    hi = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-    mid = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
+    split2(v.x, v.y, hi.x, mid.x);
+    split2(v.z, v.w, hi.y, mid.y);
 }
 
 template <int CTRL>

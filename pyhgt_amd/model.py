@@ -5,7 +5,8 @@
 followed by `n_layers` GeneralConv('hgt') layers that all receive the same graph tensors (model.py:78-79).
 The adapter runs on the same typed-linear kernels as the layers (no per-type boolean masks, no host sync --
 the reference syncs once per type at model.py:73), and one GraphPlan is built for the whole stack.
-Forward only (eval mode: both dropouts are the identity).  Classifier / Matcher (model.py:3-49) run on the same kernels.
+Inference runs without autograd; with grad enabled the adapter and the layers take their differentiable paths
+(pyhgt_amd/autograd.py).  Classifier / Matcher (model.py:3-49) run on the same kernels.
 """
 import ctypes as C
 import math
@@ -95,14 +96,24 @@ class GNN(nn.Module):
         lib = _lib.load()
         if not node_feature.is_cuda:
             raise RuntimeError("pyhgt_amd.GNN runs only on a ROCm GPU tensor; there is no CPU fallback")
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError("pyhgt_amd.GNN is forward-only: call it under torch.no_grad() or in eval() mode")
-        x = node_feature.detach().float().contiguous()
-        N = x.size(0)
         conv0 = self.gcs[0].base_conv
         plan = GraphPlan.cached(node_type, edge_index, edge_type, edge_time if conv0.use_RTE else None,
                                 conv0.num_types, conv0.num_relations)
         rows = plan.row_lists()
+        if torch.is_grad_enabled() and (node_feature.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # training / differentiable path: the adapter through TypedLinearFunction (typed weight
+            # gradient kernels), tanh + dropout as in model.py:70-76, then the layers' own autograd path
+            from .autograd import TypedLinearFunction
+            w = torch.stack([lin.weight for lin in self.adapt_ws]).float()
+            b = torch.stack([lin.bias for lin in self.adapt_ws]).float()
+            h = TypedLinearFunction.apply((rows.rows_all, rows.off_all, plan), self.num_types, conv0.precision,
+                                          node_feature.float(), w, b)
+            h = self.drop(torch.tanh(h))        # rows of a type no adapter claims stay 0 (model.py:70)
+            for gc in self.gcs:
+                h = gc.base_conv(h, node_type, edge_index, edge_type, edge_time, plan=plan)
+            return h
+        x = node_feature.detach().float().contiguous()
+        N = x.size(0)
         w, b = self._pack_adapter()
         T, n_hid, in_dim = self.num_types, self.n_hid, self.in_dim
         h = torch.empty(N, n_hid, dtype=torch.float32, device=x.device)
@@ -130,6 +141,16 @@ def _dense_linear(x, weight, bias, scale=1.0):
     lib = _lib.load()
     if not x.is_cuda:
         raise RuntimeError("pyhgt_amd heads run only on a ROCm GPU tensor; there is no CPU fallback")
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        # differentiable path: same kernel forward, typed weight-gradient kernels backward (pyhgt_amd/autograd.py)
+        from .autograd import TypedLinearFunction
+        xx = x.float().contiguous()
+        n = xx.size(0)
+        rows = torch.arange(n, dtype=torch.int32, device=x.device)
+        off = torch.tensor([0, n], dtype=torch.int32, device=x.device)
+        w = (weight.float() * scale).unsqueeze(0)
+        b = (bias.float() * scale).unsqueeze(0) if bias is not None else None
+        return TypedLinearFunction.apply((rows.data_ptr(), off.data_ptr(), (rows, off)), 1, "fp32", xx, w, b)
     x = x.detach().float().contiguous()
     n, k = x.shape
     n_out = weight.size(0)
@@ -153,6 +174,8 @@ class Classifier(nn.Module):
 
     def forward(self, x):
         tx = _dense_linear(x.reshape(-1, self.n_hid), self.linear.weight, self.linear.bias)
+        if tx.requires_grad:
+            return torch.log_softmax(tx, dim=-1).reshape(*x.shape[:-1], self.n_out).squeeze()      # model.py:11, under autograd
         out = torch.empty_like(tx)
         _lib.check(_lib.load().hgt_log_softmax_rows(_ptr(tx), tx.size(0), tx.size(1), _ptr(out), _stream()), "hgt_log_softmax_rows")
         return out.reshape(*x.shape[:-1], self.n_out).squeeze()
@@ -181,6 +204,8 @@ class Matcher(nn.Module):
             tx = _dense_linear(x, self.left_linear.weight, self.left_linear.bias)
             if infer:
                 self.cache = tx
+        if pair and (tx.requires_grad or ty.requires_grad):
+            return (tx * ty).sum(dim=-1) / self.sqrt_hd                                            # model.py:41,44, under autograd
         if pair:
             out = torch.empty(tx.size(0), dtype=torch.float32, device=tx.device)
             _lib.check(_lib.load().hgt_row_dot(_ptr(tx), _ptr(ty), tx.size(0), self.n_hid, 1.0 / self.sqrt_hd, _ptr(out), _stream()),

@@ -1,0 +1,157 @@
+"""GPU tests of the backward pass: gradients of pyhgt_amd.HGTConv / GNN w.r.t. the input and EVERY
+parameter of state_dict against oracle.backward_reference (reverse mode through the fp64 closed form, itself pinned against
+autograd through the verbatim reference in tests/test_oracle.py).  Tolerance: 2e-4 relative to the largest entry of each
+gradient tensor."""
+import ctypes as C
+
+import pytest
+import torch
+
+from oracle import hgt_oracle as O
+from pyhgt_amd import HGTConv, GNN, GraphPlan, _lib
+from pyhgt_amd.synth import synthetic_typed_graph
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RTOL = 2e-4
+
+CASES = [
+    # name, T, R, H, d, N, E, use_norm, use_RTE, graph kwargs, tweaks
+    ("c1_like", 3, 4, 4, 64, 2000, 10000, True, True, {}, {}),
+    ("c2_shape", 4, 8, 8, 256, 4000, 40000, True, False, {}, {}),
+    ("dk50_unsorted", 2, 3, 4, 200, 1500, 9000, True, True, dict(sorted_types=False), dict(unknown=True)),
+    ("no_norm_hubs", 3, 5, 2, 32, 3000, 30000, False, False, dict(dst_skew=1.1), dict(hub=True, unclaimed=True)),
+    ("single_head", 2, 2, 1, 16, 300, 2500, True, True, {}, {}),
+    ("three_heads", 2, 3, 3, 96, 1200, 9000, True, True, {}, {}),          # 64 % H != 0: padded head layout
+]
+
+
+def _grads_close(name, got, ref, rtol=RTOL):
+    ref = ref.to(torch.float64)
+    got = got.detach().cpu().to(torch.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = max(ref.abs().max().item(), 1e-12)
+    err = (got - ref).abs().max().item() / scale
+    assert err < rtol, "%s: max |grad - oracle| = %.3e of the largest entry (%.3e)" % (name, err, scale)
+    return err
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_hgtconv_backward_matches_oracle(case, precision):
+    name, T, R, H, d, N, E, use_norm, use_RTE, gk, tw = case
+    sd = O.make_state_dict(d, d, T, R, H, use_norm, use_RTE, seed=11)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=12, **gk)
+    nt, et, ei = nt.clone(), et.clone(), ei.clone()
+    if tw.get("unknown"):
+        nt[::13] = T + 1                    # nodes no typed layer claims: zero output rows, no gradient
+    if tw.get("unclaimed"):
+        et[::7] = R                         # edges no meta relation claims: constant logit 0, no message
+    if tw.get("hub"):
+        ei[1, :4000] = 17                   # > 1024 in-edges: hub path of the aggregations (forward and transposed)
+        ei[0, 4000:7000] = 23               # ... and a node with > 1024 OUT-edges: a hub of the transposed plan
+    g = torch.Generator().manual_seed(5)
+    gout = torch.randn(N, d, generator=g)
+    ref = O.backward_reference(sd, T, R, H, x, nt, ei, et, tm if use_RTE else None, gout, use_norm=use_norm, use_RTE=use_RTE)
+    layer = HGTConv(d, d, T, R, H, 0.2, use_norm, use_RTE, precision=precision).eval()     # eval: no dropout, like the oracle
+    layer.load_state_dict(sd)
+    layer = layer.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    GraphPlan.clear_cache()
+    out = layer(xd, nt.to(DEV), ei.to(DEV), et.to(DEV), tm.to(DEV) if use_RTE else None)
+    fwd = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm if use_RTE else None, use_norm=use_norm, use_RTE=use_RTE)
+    assert (out.detach().cpu().double() - fwd).abs().max().item() < 1e-4
+    out.backward(gout.to(DEV))
+    torch.cuda.synchronize()
+    worst = _grads_close("x", xd.grad, ref["x"])
+    for k, p in layer.named_parameters():
+        if k == "emb.emb.weight" and p.grad is None:
+            continue
+        assert p.grad is not None, k
+        worst = max(worst, _grads_close(k, p.grad, ref[k]))
+    print("backward %s / %s: worst relative gradient error %.2e over %d tensors" % (name, precision, worst,
+                                                                                     1 + len(list(layer.parameters()))))
+
+
+def test_training_mode_runs_with_dropout_and_eval_matches():
+    T, R, H, d, N, E = 3, 4, 4, 64, 1500, 9000
+    sd = O.make_state_dict(d, d, T, R, H, True, True, seed=3)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=4)
+    layer = HGTConv(d, d, T, R, H, 0.2, True, True).to(DEV)
+    layer.load_state_dict(sd)
+    args = [t.to(DEV) for t in (x, nt, ei, et, tm)]
+    layer.train()                                          # the reference's training scripts: model.train() + loss.backward()
+    out = layer(*args)
+    assert out.requires_grad and torch.isfinite(out).all()
+    out.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())
+    layer.eval()
+    with torch.no_grad():
+        inf = layer(*args)                                 # inference path (fused kernels)
+    diff = layer(*args)                                    # differentiable path in eval mode: no dropout -> same numbers
+    assert (inf - diff.detach()).abs().max().item() < 5e-5
+    layer.train()
+    layer.drop.p = 0.0
+    assert (layer(*args).detach() - inf).abs().max().item() < 5e-5
+
+
+def test_gnn_training_step_matches_autograd_through_the_oracle():
+    """Two-layer GNN (adapter + tanh + 2 x HGTConv, model.py:54-80) + Classifier head: gradients of every parameter against
+    torch autograd through the fp64 closed-form oracle composed the same way."""
+    from pyhgt_amd import Classifier
+    T, R, H, in_dim, d, N, E, n_cls = 3, 4, 4, 37, 64, 1200, 8000, 5
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, in_dim, T, R, seed=21)
+    torch.manual_seed(1)
+    gnn = GNN(in_dim, d, T, R, H, 2, dropout=0.0, prev_norm=True, last_norm=True, use_RTE=True).to(DEV).train()
+    head = Classifier(d, n_cls).to(DEV).train()
+    y = torch.randint(0, n_cls, (200,))
+    rep = gnn(x.to(DEV), nt.to(DEV), tm.to(DEV), ei.to(DEV), et.to(DEV))
+    loss = torch.nn.functional.nll_loss(head(rep[:200]), y.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    # the same computation in fp64 torch on the CPU
+    P = {k: v.detach().cpu().double().requires_grad_(True) for k, v in list(gnn.named_parameters()) + [("head." + k, v) for k, v in
+                                                                                                     head.named_parameters()]}
+    h = torch.zeros(N, d, dtype=torch.float64)
+    for t in range(T):
+        idx = (nt == t).nonzero().flatten()
+        h = h.index_add(0, idx, torch.tanh(x[idx].double() @ P["adapt_ws.%d.weight" % t].T + P["adapt_ws.%d.bias" % t]))
+    for li in range(2):
+        sd = {k[len("gcs.%d.base_conv." % li):]: v for k, v in P.items() if k.startswith("gcs.%d.base_conv." % li)}
+        h = O.forward_closed_form(sd, T, R, H, h, nt, ei, et, tm, use_norm=True, use_RTE=True)
+    logp = torch.log_softmax(h[:200] @ P["head.linear.weight"].T + P["head.linear.bias"], dim=-1)
+    ref_loss = torch.nn.functional.nll_loss(logp, y)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-4
+    worst = 0.0
+    for k, v in list(gnn.named_parameters()) + [("head." + k, v) for k, v in head.named_parameters()]:
+        if P[k].grad is None:
+            continue
+        worst = max(worst, _grads_close(k, v.grad, P[k].grad, rtol=5e-4))
+    print("GNN training step: worst relative gradient error %.2e" % worst)
+
+
+@pytest.mark.parametrize("m,n_cols,n", [(256, 256, 5000), (768, 256, 3000), (64, 37, 1000), (100, 400, 700)])
+def test_typed_weight_gradient_kernels(m, n_cols, n):
+    lib = _lib.load()
+    T = 3
+    g = torch.Generator().manual_seed(m + n)
+    A = torch.randn(n, m, generator=g)
+    B = torch.randn(n, n_cols, generator=g)
+    types = torch.randint(0, T + 1, (n,), generator=g)          # type T = rows of no group
+    order = torch.argsort(types, stable=True).to(torch.int32)
+    off = torch.zeros(T + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(torch.bincount(types, minlength=T + 1)[:T], 0)
+    Ad, Bd, od, fd = A.to(DEV), B.to(DEV), order.to(DEV), off.to(DEV)
+    out = torch.zeros(T, m, n_cols, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.hgt_typed_wgrad(Ad.data_ptr(), m, Bd.data_ptr(), n_cols, od.data_ptr(), fd.data_ptr(), T, n, m, n_cols, out.data_ptr(),
+                               m * n_cols, st) == 0
+    cs = torch.zeros(T, m, device=DEV)
+    assert lib.hgt_typed_colsum(Ad.data_ptr(), m, od.data_ptr(), fd.data_ptr(), T, n, m, cs.data_ptr(), m, st) == 0
+    torch.cuda.synchronize()
+    for t in range(T):
+        idx = (types == t).nonzero().flatten()
+        ref = A[idx].double().T @ B[idx].double()
+        assert (out[t].cpu().double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+        assert (cs[t].cpu().double() - A[idx].double().sum(0)).abs().max().item() < 1e-3

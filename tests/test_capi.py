@@ -49,10 +49,14 @@ def test_layout_errors_are_codes_not_crashes():
     lay = _lib.HgtLayout()
     lib = _lib.load()
     assert lib.hgt_layout_for(65, 4, ctypes.byref(lay)) == -1       # d % heads != 0
-    assert lib.hgt_layout_for(96, 3, ctypes.byref(lay)) == -2       # 64 % heads != 0
+    assert lib.hgt_layout_for(64, 32, ctypes.byref(lay)) == -2      # fewer than 4 lanes per head
     assert lib.hgt_layout_for(64, 4, None) == -1
     with pytest.raises(RuntimeError):
-        _lib.layout_for(96, 3)
+        _lib.layout_for(64, 32)
+    # head counts that do not divide 64 (legal in the reference, conv.py:21) run in the next power-of-two layout
+    for d, H, heads, dkp, dpad in [(96, 3, 4, 32, 128), (80, 5, 8, 16, 128), (96, 6, 8, 16, 128), (192, 12, 16, 16, 256)]:
+        assert lib.hgt_layout_for(d, H, ctypes.byref(lay)) == 0
+        assert (lay.heads, lay.d_k, lay.dk_pad, lay.d_pad) == (heads, d // H, dkp, dpad)
 
 
 def test_conv_args_struct_matches_header_field_order():

@@ -203,6 +203,9 @@ def test_hub_targets_with_extreme_logits(scale):
     ei[1, 6000:8000] = 1200             # multi-edge hub: 2000 x the same (source, relation) -> identical logits
     ei[0, 6000:8000] = 77
     et[6000:8000] = 1
+    other = torch.ones(E, dtype=torch.bool)
+    other[6000:8000] = False
+    ei[1, other & (ei[1] == 1200)] = 1201          # nothing else enters the multi-edge hub
     ref, att_ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, None, use_RTE=False, dtype=torch.float64, return_att=True)
     assert (att_ref[6000:8000] - 1.0 / 2000).abs().max().item() < 1e-12
     layer = _layer_from(sd, d, T, R, H, True, False)
@@ -213,6 +216,22 @@ def test_hub_targets_with_extreme_logits(scale):
     assert (out.double() - ref).abs().max().item() < (TOL if abs(scale) <= 60 else 2e-3)
     assert (att[6000:8000].double() - 1.0 / 2000).abs().max().item() < 1e-7
     assert (att.double() - att_ref).abs().max().item() < (1e-4 if abs(scale) <= 60 else 2e-3)   # logits ~ 1e2..1e3 in fp32
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("d,H", [(96, 3), (80, 5), (96, 6), (192, 12)])
+def test_head_counts_that_do_not_divide_64(d, H, precision):
+    """conv.py:21 only needs d % n_heads == 0.  3 / 5 / 6 / 12 heads run in the layout of the next power of two; the padding
+    heads are all-zero and must not leak into the output or into self.att."""
+    T, R, N, E = 3, 4, 2500, 20000
+    sd = O.make_state_dict(d, d, T, R, H, True, True, seed=d + H)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=H)
+    ref, att_ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, dtype=torch.float64, return_att=True)
+    layer = _layer_from(sd, d, T, R, H, True, True, precision=precision)
+    out, att = _run(layer, x, nt, ei, et, tm)
+    assert att.shape == (E, H)
+    assert (out.double() - ref).abs().max().item() < TOL
+    assert (att.double() - att_ref).abs().max().item() < 1e-5
 
 
 def test_no_edges_and_isolated_targets():
@@ -493,6 +512,47 @@ def test_plan_flags_out_of_range_node_ids():
         plan.check_indices()
 
 
+@pytest.mark.parametrize("schema", ["mag", "oag"])
+def test_plan_from_sorted_is_bit_identical_and_the_handoff_matches_the_oracle(schema):
+    """a sampler-shaped batch handed over through pyhgt_amd.sampled.to_device_graph (int32, relation-major,
+    target-sorted -> hgt_plan_from_sorted, no radix sort).  (a) every plan array equals the one hgt_plan_build makes from the
+    int64 tensors of the same edge order; (b) the reference's unchanged call finds the registered plan; (c) a 2-layer GNN on
+    the handed-over tensors matches the oracle run on the reference's own wire format (to_torch order)."""
+    from pyhgt_amd import GNN
+    from pyhgt_amd.sampled import synthetic_sampled_batch, to_torch_layout, to_device_graph
+    batch = synthetic_sampled_batch(schema, n_seed=64, width=48, depth=4, feat_dim=48, mean_degree=8.0, seed=7)
+    GraphPlan.clear_cache()
+    dg = to_device_graph(*batch, device=DEV)
+    x, nt, tm, ei, et, node_dict, edge_dict = dg
+    T, R = len(node_dict), len(edge_dict)
+    built = GraphPlan(nt, ei, et, tm, T, R)
+    torch.cuda.synchronize()
+    a, b = _plan_arrays(dg.plan), _plan_arrays(built)
+    for k in ("n_items", "bad", "n_bins"):
+        assert a[k] == b[k], k
+    for k in ("esrc", "edst", "ertei", "eid", "segptr", "tile_items", "rows_all", "off_all", "rows_q", "off_q"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["items"][:a["n_items"]], b["items"][:b["n_items"]])
+    assert GraphPlan.cached(nt, ei, et, tm, T, R) is dg.plan                       # the model's own lookup hits
+    # oracle on the reference's wire format (different edge order, same graph)
+    xr, ntr, tmr, eir, etr, _, _ = to_torch_layout(*batch)
+    torch.manual_seed(2)
+    gnn = GNN(48, 64, T, R, 4, 2, prev_norm=True, last_norm=True, use_RTE=True).eval()
+    sd = {k: v.detach().clone() for k, v in gnn.state_dict().items()}
+    h = torch.zeros(xr.size(0), 64, dtype=torch.float64)
+    for t in range(T):
+        idx = (ntr == t).nonzero().flatten()
+        h[idx] = torch.tanh(xr[idx].double() @ sd["adapt_ws.%d.weight" % t].double().T + sd["adapt_ws.%d.bias" % t].double())
+    for li in range(2):
+        lsd = {k[len("gcs.%d.base_conv." % li):]: v for k, v in sd.items() if k.startswith("gcs.%d.base_conv." % li)}
+        h = O.forward_closed_form(lsd, T, R, 4, h, ntr, eir, etr, tmr, use_norm=True, use_RTE=True, dtype=torch.float64)
+    gnn = gnn.to(DEV)
+    with torch.no_grad():
+        out = gnn(x, nt, tm, ei, et)
+    assert (out.cpu().double() - h).abs().max().item() < 2e-4                        # two layers
+    GraphPlan.clear_cache()
+
+
 def test_malformed_input_raises_like_the_reference():
     """The reference fails with an IndexError for node ids outside [0, N) (index_select) and for edge_time outside [0, 240)
     (nn.Embedding, conv.py:299).  Here the plan build flags both; the flag reaches the host asynchronously, so forward()
@@ -602,6 +662,45 @@ def test_properties_at_scale():
     ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, None, use_RTE=False, dtype=torch.float32)
     out, _ = _run(layer, x, nt, ei, et, None)
     assert (out - ref).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("variant,precision", [("plain", "bf16x3"), ("plain", "fp32"), ("rte", "bf16x3"), ("zipf", "bf16x3")])
+def test_benchmark_configuration_sampled_parity(variant, precision):
+    """BASELINE.json configs[1] AT ITS OWN SIZE (T4 R8, 1M nodes / 10M edges, d=256, H=8; bench.py's recipe): the 512-edge work
+    items, full-occupancy fused workgroups and the 10M-edge plan that produce the headline number.  ~2000 sampled target rows
+    (type-boundary tiles, first / last tile, max in-degree rows, random rows) are compared with the fp64 oracle run on the
+    sub-graph induced by ALL their in-edges, which is exact for those rows."""
+    from pyhgt_amd.synth import pick_check_targets, induced_in_neighbourhood
+    T, R, H, d, N, E = 4, 8, 8, 256, 1_000_000, 10_000_000
+    use_rte = variant == "rte"
+    g = torch.Generator(device=DEV).manual_seed(99)
+    nt = torch.randint(0, T, (N,), generator=g, device=DEV).sort().values
+    x = torch.randn(N, d, generator=g, device=DEV)
+    src = torch.randint(0, N, (E,), generator=g, device=DEV)
+    dst = torch.randint(0, N, (E,), generator=g, device=DEV)
+    if variant == "zipf":
+        u = torch.rand(E, generator=g, device=DEV)
+        dst = (N * u ** (1.0 / (1.0 - 0.8))).long().clamp(0, N - 1)
+    et = torch.randint(0, R, (E,), generator=g, device=DEV)
+    tm = torch.randint(0, 240, (E,), generator=g, device=DEV) if use_rte else None
+    ei = torch.stack([src, dst], dim=1).t()
+    sd = O.make_state_dict(d, d, T, R, H, True, use_rte, seed=5)
+    layer = _layer_from(sd, d, T, R, H, True, use_rte, keep_att=False, precision=precision)
+    GraphPlan.clear_cache()
+    with torch.no_grad():
+        out = layer(x, nt, ei, et, tm)
+    torch.cuda.synchronize()
+    tg = pick_check_targets(nt, dst, n_random=1500, seed=3)
+    xs, nts, eis, ets, tms, pos = induced_in_neighbourhood(x, nt, ei, et, tm, tg)
+    ref = O.forward_closed_form(sd, T, R, H, xs, nts, eis, ets, tms, use_norm=True, use_RTE=use_rte, dtype=torch.float64)
+    err = (out[tg].cpu().double() - ref[pos]).abs().max().item()
+    print("c2 full size (%s, %s): %d rows, %d edges, max in-degree %d, max|err| %.2e" % (
+        variant, precision, tg.numel(), eis.size(1), int(torch.bincount(eis[1]).max()), err))
+    assert torch.isfinite(out).all()
+    assert err < TOL
+    del out, x
+    GraphPlan.clear_cache()
+    torch.cuda.empty_cache()
 
 
 FUSED_CASES = [
