@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the sampled-target oracle check after the timed region")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (other precision / other halo format)")
+    ap.add_argument("--no-buckets", action="store_true", help="multi-GPU: edge phase after the last halo chunk (stages 1/2/3) instead of "
+                    "the source-bucketed edge phase that overlaps the exchange (stages 1/2/4, pyhgt_amd/dist.py)")
     ap.add_argument("--halo-c24", action="store_true", help="multi-GPU: ship halo rows in the 24-bit transport format in the JUDGED run "
                     "(default: exact fp32 rows; the 24-bit variant is then reported as a secondary figure)")
     ap.add_argument("--halo-fp32", action="store_true", help=argparse.SUPPRESS)   # the default now; kept for old command lines
@@ -263,7 +265,7 @@ def main():
         from pyhgt_amd.dist import PartitionedGraph
         import torch.distributed as dist
         pg = PartitionedGraph(node_type_own, src_global, dst_local, edge_type, edge_time, T, R, Nl, rank, world,
-                              compress=bool(args.halo_c24))
+                              compress=bool(args.halo_c24), bucketed=False if args.no_buckets else None)
         plan_ms = None
         # own features live at the front of the [own ; halo] buffer, so a step does not copy them (pyhgt_amd/dist.py)
         pg.x_local = torch.empty(pg.n_local, d, dtype=torch.float32, device=dev)
@@ -340,10 +342,11 @@ def main():
     # counter-derived figures come from the committed rocprofv3 passes of this same command (profiles/pmc_summary.json names
     # the commit they were taken at); they are not re-measured inside the run
     pmc = {}
-    tpath = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if os.path.isfile(tpath):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")))
+    if cands:      # the newest round's passes
         try:
-            pmc = json.load(open(tpath))
+            pmc = json.load(open(cands[-1]))
         except Exception:
             pmc = {}
     traffic = (pmc.get("traffic_bytes") or {}).get(dom) if (world == 1 and not use_rte and args.dst_skew == 0.0) else None
@@ -385,6 +388,16 @@ def main():
                         "reported for information only" if not args.halo_c24 else "exact fp32 halo rows"}
             pg.compress = bool(args.halo_c24)
             del out2
+            if pg.bucket_plan is not None:      # the other edge-phase schedule (both plans exist; the switch is per forward)
+                pg.bucketed = not pg.bucketed
+                out3, el3, ph3, med3 = timed(make_step(layer), args.steps, 2)
+                ms3 = el3 / args.steps * 1e3
+                par3 = check(out3, layer_sd) if rank == 0 else None
+                secondary["edge_phase_" + ("source_bucketed" if pg.bucketed else "after_last_chunk")] = {
+                    "ms_per_step": ms3, "median_ms_per_step": med3, "edges_per_s": total_edges / (ms3 * 1e-3),
+                    "parity_max_abs_err": None if par3 is None else par3["max_abs_err"]}
+                pg.bucketed = not pg.bucketed
+                del out3
 
     if rank == 0:
         cpu = None
@@ -407,6 +420,9 @@ def main():
                        "halo_exchange_bytes_per_gpu_per_step": 0 if world == 1 else int(pg.halo.n_halo) * d * (3 if pg.compress else 4),
                        "halo_format": None if world == 1 else ("24-bit (sign, 8 exp, 15 mantissa; fp32 arithmetic)" if pg.compress else "fp32"),
                        "halo_chunks": 0 if world == 1 else int(pg.halo.n_chunks),
+                       "edge_phase": None if world == 1 else ("source-bucketed, overlaps the exchange (hgt_conv_forward stages 1/2/4)"
+                                                              if pg.bucketed and args.precision == "bf16x3" else
+                                                              "after the last halo chunk (stages 1/2/3)"),
                        "parallelism": "single" if world == 1 else "dst-partition x%d + RCCL all-to-all halo" % world,
                        "plan_build_ms": plan_ms, "precision": args.precision, "kernel_flags": args.kernel_flags},
             "parity_max_abs_err": None if parity is None else parity["max_abs_err"],

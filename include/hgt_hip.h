@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HGT_ABI_VERSION 3
+#define HGT_ABI_VERSION 4
 
 /* error codes */
 #define HGT_OK 0
@@ -206,6 +206,21 @@ int hgt_edge_aggregate(const void* plan, int64_t n_nodes, int64_t n_edges, int32
                        int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
                        const float* msg_p, const void* msg_frag, float* agg, int64_t n_q_rows, int32_t apply_gelu,
                        void* hub_ws, void* stream);
+/* ABI 4: one slice [rel_lo, rel_hi) of the plan's n_relations + 1 relation buckets (bucket n_relations = unclaimed edges).
+ * hgt_edge_logits_slice writes the logits of the slice's edges only.  hgt_edge_aggregate_slice (matrix-core kernel: msg_frag
+ * required) aggregates the slice and combines it with what earlier slices left: state = f32[n_q_rows][n_heads][2] (softmax
+ * reference, exp-sum) and the un-normalised rows in agg; has_prev = 0 for the first slice; more != 0: leave state + raw rows
+ * for the next slice, more = 0: normalise (+ gelu) -- after it agg equals hgt_edge_aggregate's over all slices (partials merge as
+ * m = max(m_a, m_b), x = x_a e^(m_a - m) + x_b e^(m_b - m): exact up to fp32 rounding).  Hub targets are processed with the
+ * last slice, over all relations. */
+int hgt_edge_logits_slice(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                          int32_t n_heads, int32_t dk_pad, const float* Q, const float* K, const float* rte_k,
+                          const float* att_t, float* logits, int32_t rel_lo, int32_t rel_hi, void* stream);
+int hgt_edge_aggregate_slice(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                             int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
+                             const float* msg_p, const void* msg_frag, float* agg, int64_t n_q_rows, int32_t apply_gelu,
+                             void* hub_ws, int32_t rel_lo, int32_t rel_hi, float* state, int32_t has_prev, int32_t more,
+                             void* stream);
 /* msg_frag (ABI 3): hgt_relation_frag_pack(msg_p) = the relation message matrices as bf16 hi/mid MFMA fragments.  Non-NULL:
  * the per-(target, relation) transforms  (sum att_e v_e) M[rel]  run on the matrix cores, 16 targets x one relation at a time,
  * as 3-term split-bf16 products with fp32 accumulation (relative error of a product <= ~3*2^-18, like the split-bf16 typed
@@ -363,7 +378,12 @@ typedef struct hgt_conv_args {
      *   1  parameter packing + Q|K|V projections of the rows [0, n_q_rows) only (+ temporal tables)
      *   2  K|V projections of the rows listed in proj_rows (typed row list: group t = proj_rows[proj_off[t] ..
      *      proj_off[t+1]), device arrays, n_types+1 offsets) -- call once per received chunk of halo rows
-     *   3  edge phase + update (needs K,V of every source row: stages 1 and 2 done)                              */
+     *   3  edge phase + update (needs K,V of every source row: stages 1 and 2 done)
+     *   4  (ABI 4) edge phase over slice `slice_index` of `slice_count` equal slices of the relation ids, softmax state carried
+     *      from slice to slice in the workspace; the LAST slice also takes the unclaimed edges and runs the update.  For
+     *      source-bucketed graphs: the caller numbers relations bucket * R' + relation (n_relations = slice_count * R', the
+     *      relation parameters repeated slice_count times), so slice b = the edges whose source rows arrived with bucket b
+     *      and the edge phase overlaps the exchange of the later buckets.  bf16x3 precision, HGTConv update only.       */
     int32_t stage;
     const int32_t* proj_rows;
     const int32_t* proj_off;
@@ -382,6 +402,9 @@ typedef struct hgt_conv_args {
     int32_t plan_no_hubs;
     /* ABI 3: bit set of HGT_FLAG_* (0 = the default kernel selection) */
     int32_t flags;
+    /* ABI 4: stage 4 only */
+    int32_t slice_index;
+    int32_t slice_count;
 } hgt_conv_args;
 
 /* hgt_conv_args.flags: explicit kernel-selection switches (A/B measurements, tests); never read from the environment */

@@ -50,10 +50,12 @@ class HgtConvArgs(C.Structure):
         ("prepared", C.c_void_p), ("prepared_bytes", C.c_uint64), ("prepared_valid", C.c_int32),
         ("plan_no_hubs", C.c_int32),
         ("flags", C.c_int32),
+        ("slice_index", C.c_int32),
+        ("slice_count", C.c_int32),
     ]
 
 
-ABI_VERSION = 3          # HGT_ABI_VERSION of include/hgt_hip.h this binding was written against
+ABI_VERSION = 4          # HGT_ABI_VERSION of include/hgt_hip.h this binding was written against
 
 _i32, _i64, _u64, _vp = C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
 
@@ -79,6 +81,9 @@ SIGNATURES = {
     "hgt_zero_rows": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "hgt_relation_pack": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "hgt_edge_logits": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hgt_edge_logits_slice": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "hgt_edge_aggregate_slice": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp,
+                                           _i32, _i32, _vp, _i32, _i32, _vp]),
     "hgt_edge_softmax": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "hgt_edge_aggregate": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "hgt_relation_frag_bytes": (C.c_int, [_i32, _i32, _i32, C.POINTER(_u64)]),

@@ -473,13 +473,13 @@ class HGTConv(nn.Module):
         self._prepared_valid = False      # the device-side weight images (hgt_conv_args.prepared) are stale now
         return packed
 
-    def _prepared_buffer(self, device):
+    def _prepared_buffer(self, device, n_slices=1):
         """Per-layer device buffer for the weight-only preprocessing hgt_conv_forward keeps across calls (packed relation
         matrices, split-bf16 weight tiles, temporal tables): valid until a parameter, the precision or the device changes."""
-        key = (str(device), self.precision)
+        key = (str(device), self.precision, n_slices)
         if getattr(self, "_prepared", None) is None or self._prepared_tag != key:
             n = C.c_uint64()
-            _lib.check(_lib.load().hgt_conv_prepared_bytes(self.in_dim, self.out_dim, self.num_types, self.num_relations,
+            _lib.check(_lib.load().hgt_conv_prepared_bytes(self.in_dim, self.out_dim, self.num_types, self.num_relations * n_slices,
                                                           self.n_heads, int(self.use_RTE), C.byref(n)), "hgt_conv_prepared_bytes")
             self._prepared = torch.empty(max(int(n.value), 256), dtype=torch.uint8, device=device)
             self._prepared_tag = key
@@ -488,7 +488,7 @@ class HGTConv(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def forward(self, node_inp, node_type, edge_index, edge_type, edge_time=None, plan=None, n_q_rows=None,
-                phase_events=None, stage=0, proj=None, workspace=None):
+                phase_events=None, stage=0, proj=None, workspace=None, slices=None):
         """node_inp f32[N,in_dim], node_type i64[N], edge_index i64[2,E] (row 0 = source, row 1 =
         target; any strides), edge_type i64[E], edge_time i64[E] (needed iff use_RTE).
         Returns f32[N,out_dim] (or [n_q_rows,out_dim] when only the first n_q_rows nodes are targets).
@@ -496,6 +496,9 @@ class HGTConv(nn.Module):
         stage / proj: staged execution for pyhgt_amd.dist (hgt_conv_args.stage): 1 = projections of the own rows,
         2 = K|V of the rows in proj = (rows int32[n], offsets int32[T+1]) (one call per received halo chunk),
         3 = edge phase + update (returns the output); stages 1 and 2 return None.
+        slices = (index, count) with stage 4 (count alone matters for stages 1/2 of the same forward): the plan numbers
+        relations `source bucket * num_relations + relation` (count buckets; pyhgt_amd.dist builds it), stage 4 runs the edge
+        phase of bucket `index` with the softmax state carried in the workspace, and the last bucket's call returns the output.
         workspace: caller-owned uint8 device buffer (>= workspace_bytes(N, E)) instead of the per-(device, stream) scratch;
         staged callers MUST pass one (Q/K/V live in it between the stages)."""
         lib = _lib.load()
@@ -519,7 +522,13 @@ class HGTConv(nn.Module):
         if plan is None:
             plan = GraphPlan.cached(node_type, edge_index, edge_type, edge_time if self.use_RTE else None,
                                     self.num_types, self.num_relations, n_q_rows)
-        if plan.N != N or plan.T != self.num_types or plan.R != self.num_relations:
+        n_slices = 1 if slices is None else int(slices[1])
+        if n_slices < 1 or (stage == 4 and not (0 <= int(slices[0]) < n_slices)):
+            raise ValueError("slices must be (index, count) with 0 <= index < count")
+        if n_slices > 1 and (stage == 0 or stage == 3 or self.precision != "bf16x3" or self._UPDATE_MODE != 0):
+            raise ValueError("sliced edge phases run as stages 1 / 2 / 4 of an HGTConv with precision 'bf16x3'")
+        R_plan = self.num_relations * n_slices
+        if plan.N != N or plan.T != self.num_types or plan.R != R_plan:
             raise ValueError("plan was built for a different graph / schema")
         plan.raise_if_bad()
         NQ, E = plan.NQ, plan.E
@@ -535,7 +544,7 @@ class HGTConv(nn.Module):
         if pk["w_qkv"].device != x.device:
             raise RuntimeError("module parameters and node_inp are on different devices")
         nbytes = C.c_uint64()
-        _lib.check(lib.hgt_conv_workspace_bytes(N, E, self.in_dim, self.out_dim, self.num_types, self.num_relations,
+        _lib.check(lib.hgt_conv_workspace_bytes(N, E, self.in_dim, self.out_dim, self.num_types, R_plan,
                                                 self.n_heads, int(self.use_RTE), C.byref(nbytes)), "hgt_conv_workspace_bytes")
         if workspace is not None:
             if workspace.dtype != torch.uint8 or workspace.device != x.device or workspace.numel() < nbytes.value:
@@ -545,22 +554,28 @@ class HGTConv(nn.Module):
             if stage != 0:
                 raise ValueError("staged execution keeps Q/K/V in the workspace between calls: pass workspace=")
             ws = _Workspace.get(x.device, nbytes.value)
-        final = stage in (0, 3)
+        final = stage in (0, 3) or (stage == 4 and int(slices[0]) == n_slices - 1)
         out = torch.empty(NQ, self.out_dim, dtype=torch.float32, device=x.device) if final else None
         att = torch.empty(E, self.n_heads, dtype=torch.float32, device=x.device) if (self.keep_att and final) else None
         ntype = node_type.contiguous()
 
         a = _lib.HgtConvArgs()
         a.n_nodes, a.n_edges = N, E
-        a.in_dim, a.out_dim, a.n_types, a.n_relations, a.n_heads = (self.in_dim, self.out_dim, self.num_types,
-                                                                    self.num_relations, self.n_heads)
+        a.in_dim, a.out_dim, a.n_types, a.n_relations, a.n_heads = (self.in_dim, self.out_dim, self.num_types, R_plan, self.n_heads)
         a.use_norm, a.use_rte = int(self.use_norm), int(self.use_RTE)
         a.precision = {"fp32": 0, "bf16x3": 1}[self.precision]
         a.want_att = int(self.keep_att)
         a.n_q_rows = NQ
         a.x, a.node_type, a.plan = _ptr(x), _ptr(ntype), plan.ptr
         a.w_qkv, a.b_qkv, a.w_a, a.b_a = _ptr(pk["w_qkv"]), _ptr(pk["b_qkv"]), _ptr(pk["w_a"]), _ptr(pk["b_a"])
-        a.relation_att, a.relation_msg, a.relation_pri = _ptr(pk["ratt"]), _ptr(pk["rmsg"]), _ptr(pk["rpri"])
+        if n_slices > 1:      # one copy of the relation parameters per source bucket (relation id = bucket * R + relation)
+            rep = pk.get("rel_rep")
+            if rep is None or rep[0] != n_slices:
+                rep = pk["rel_rep"] = (n_slices, pk["ratt"].repeat(n_slices, 1, 1, 1), pk["rmsg"].repeat(n_slices, 1, 1, 1),
+                                       pk["rpri"].repeat(n_slices, 1))
+            a.relation_att, a.relation_msg, a.relation_pri = _ptr(rep[1]), _ptr(rep[2]), _ptr(rep[3])
+        else:
+            a.relation_att, a.relation_msg, a.relation_pri = _ptr(pk["ratt"]), _ptr(pk["rmsg"]), _ptr(pk["rpri"])
         a.ln_w, a.ln_b = _ptr(pk["ln_w"]), _ptr(pk["ln_b"])
         self._set_update_args(a, pk)
         a.rte_emb, a.rte_w, a.rte_b = _ptr(pk.get("rte_emb")), _ptr(pk.get("rte_w")), _ptr(pk.get("rte_b"))
@@ -568,9 +583,11 @@ class HGTConv(nn.Module):
         a.out, a.att_out = _ptr(out) if final else _ptr(ws), _ptr(att)   # stages 1/2 write no output (non-NULL placeholder)
         a.want_att = int(self.keep_att and final)
         a.stage = int(stage)
+        if stage == 4:
+            a.slice_index, a.slice_count = int(slices[0]), n_slices
         a.plan_no_hubs = int(plan.no_hubs)
         a.flags = int(self.kernel_flags)
-        prep = self._prepared_buffer(x.device)          # after _pack_parameters: a re-pack has invalidated it
+        prep = self._prepared_buffer(x.device, n_slices)          # after _pack_parameters: a re-pack has invalidated it
         a.prepared, a.prepared_bytes, a.prepared_valid = _ptr(prep), prep.numel(), int(self._prepared_valid)
         if stage == 2:
             rows, off = proj
@@ -585,10 +602,10 @@ class HGTConv(nn.Module):
             self._prepared_valid = True                 # every image was written by this forward (or an earlier one)
         return out
 
-    def workspace_bytes(self, n_nodes, n_edges):
+    def workspace_bytes(self, n_nodes, n_edges, n_slices=1):
         n = C.c_uint64()
         _lib.check(_lib.load().hgt_conv_workspace_bytes(int(n_nodes), int(n_edges), self.in_dim, self.out_dim, self.num_types,
-                                                        self.num_relations, self.n_heads, int(self.use_RTE), C.byref(n)),
+                                                        self.num_relations * int(n_slices), self.n_heads, int(self.use_RTE), C.byref(n)),
                    "hgt_conv_workspace_bytes")
         return int(n.value)
 

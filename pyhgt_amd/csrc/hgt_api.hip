@@ -6,7 +6,7 @@ namespace {
 
 struct ConvWorkspace {
     uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p, off_msg_f, off_hub;
-    uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, off_ws_qkv, off_ws_a, off_ws_rte, off_off2, off_pending, total;
+    uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, off_ws_qkv, off_ws_a, off_ws_rte, off_off2, off_pending, off_state, total;
 };
 
 static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim, int out_dim, int T, int R, int /*n_heads*/, int use_rte,
@@ -58,6 +58,7 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
     w.off_ws_rte = take(use_rte ? b : 0);
     w.off_off2 = take(256);
     w.off_pending = take((uint64_t)(NQ / 64 + 1) * 4);
+    w.off_state = take((uint64_t)NQ * H * 2 * 4);   // softmax state carried between relation slices (stage 4)
     w.total = o;
     return w;
 }
@@ -198,7 +199,18 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
         if (a->phase_events && a->phase_events[i]) (void)hipEventRecord((hipEvent_t)a->phase_events[i], stream);
     };
     const int stage = a->stage;
-    if (stage < 0 || stage > 3) return HGT_ERR_INVALID_ARG;
+    if (stage < 0 || stage > 4) return HGT_ERR_INVALID_ARG;
+    // stage 4: the edge phase over ONE slice of the relation buckets (multi-GPU path: relation id = source bucket * R' + relation)
+    const bool sliced = (stage == 4);
+    int sl_lo = 0, sl_hi = R + 1, sl_more = 0;
+    if (sliced) {
+        const int S = a->slice_count, si = a->slice_index;
+        if (S <= 0 || R % S != 0 || si < 0 || si >= S) return HGT_ERR_INVALID_ARG;
+        if (!mfma_agg || dense) return HGT_ERR_UNSUPPORTED;      // the slice merge lives in the matrix-core aggregation kernel
+        sl_lo = si * (R / S);
+        sl_hi = (si + 1) * (R / S) + (si == S - 1 ? 1 : 0);       // the last slice also takes the bucket of unclaimed edges
+        sl_more = (si < S - 1);
+    }
     if (stage == 2 && (a->proj_n < 0 || (a->proj_n > 0 && (!a->proj_rows || !a->proj_off)))) return HGT_ERR_INVALID_ARG;
     if (stage == 0 || stage == 1) mark(0);
     hgt_plan_rows pr;
@@ -242,7 +254,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
         return linear(a->x, din, a->proj_rows, a->proj_off, T, a->proj_n, din, 2 * dp, a->w_qkv + (int64_t)dp * din, wstride, a->b_qkv + dp,
                       3 * dp, K, V, nullptr, dp, 0, ws_a);
     }
-    if (stage == 3) goto edge_phase;
+    if (stage == 3 || stage == 4) goto edge_phase;
     if (stage == 1) {   // own rows only: one fused Q|K|V launch, exactly like the single-GPU layer
         rc = linear(a->x, din, pr.rows_q, pr.off_q, T, NQ, din, 3 * dp, a->w_qkv, wstride, a->b_qkv, 3 * dp, Q, K, V, dp, 0, ws_qkv, 0, !fresh);
         if (rc != HGT_OK) return rc;
@@ -290,7 +302,8 @@ edge_phase:
     mark(1);
     // (4) edge phase: logits, then softmax fused into the aggregation (online, per target sub-tile)
     if (E > 0) {
-        rc = hgt_edge_logits(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, stream);
+        rc = sliced ? hgt_edge_logits_slice(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, sl_lo, sl_hi, stream)
+                    : hgt_edge_logits(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, stream);
         if (rc != HGT_OK) return rc;
     }
     mark(2);
@@ -299,7 +312,7 @@ edge_phase:
     // (graphs below 64k targets take the unfused kernels: hgt_edge_aggregate then runs 4 targets per wavefront, which
     //  matters more in the latency regime than the saved agg round trip)
     const bool fuse_all = split && !dense && dp <= 256 && dout <= dp && (dout & 3) == 0 && (din & 3) == 0 && NQ >= 65536 &&
-                          !(a->flags & HGT_FLAG_NO_FUSED_UPDATE);
+                          !(a->flags & HGT_FLAG_NO_FUSED_UPDATE) && !sliced;
     if (fuse_all) {
         if (fresh || !pb) {
             rc = hgt_split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
@@ -323,8 +336,14 @@ edge_phase:
         if (rc != HGT_ERR_UNSUPPORTED) return rc;   // unsupported layout (head-group split): the unfused kernels below
     }
     // runs for E == 0 too: it writes the zero rows of isolated targets; HGTConv stores gelu(agg) (conv.py:119), DenseHGTConv agg
-    rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ, dense ? 0 : 1,
-                            hub_ws, stream);
+    if (sliced) {
+        rc = hgt_edge_aggregate_slice(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ, 1, hub_ws, sl_lo, sl_hi,
+                                      (float*)(wb + w.off_state), sl_lo > 0, sl_more, stream);
+        if (rc != HGT_OK || sl_more) return rc;      // state + un-normalised rows stay in the workspace for the next slice
+    } else {
+        rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ, dense ? 0 : 1,
+                                hub_ws, stream);
+    }
     if (rc != HGT_OK) return rc;
     if (a->want_att && E > 0) {   // self.att (conv.py:108): normalise the logits in place and un-sort them
         rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);

@@ -28,6 +28,9 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef HGT_AGG_GS
+#define HGT_AGG_GS 4      // column-tile steps whose fragments are requested together at a relation end (8 loads in flight)
+#endif
 #ifndef HGT_AGG_HIDDEN
 #define HGT_AGG_HIDDEN 0     // experiment switch (see agg_mfma_stream): row gathers hidden from hipcc, hand-counted waits
 #endif
@@ -93,8 +96,8 @@ template <int VEC, int LPH, bool RTE, bool HUBS>
 __device__ __forceinline__ void agg_mfma_subtile(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
-    const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, int R, int HT, unsigned hub_mask, int SUBR, int64_t row0,
-    unsigned char* utile, float* s_m, float* s_l, float* s_sc, int raw, f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
+    const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, int R, int rel_lo, int rel_hi, int HT, unsigned hub_mask,
+    int SUBR, int64_t row0, unsigned char* utile, float* s_m, float* s_l, float* s_sc, int raw, f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
     using G = MG<VEC, LPH>;
     constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS;
     constexpr int UN = agg_unroll<VEC>(RTE);
@@ -127,7 +130,7 @@ __device__ __forceinline__ void agg_mfma_subtile(
         my_beg = segptr[bb];
         my_end = segptr[bb + SUBR];
     }
-    for (int rel = 0; rel <= R; ++rel) {
+    for (int rel = rel_lo; rel < min(rel_hi, R + 1); ++rel) {   // (the whole layer: [0, R]; a source bucket of the multi-GPU path: a slice)
         const int64_t b0 = ((int64_t)tile * (R + 1) + rel) * HGT_TD + within;
         const bool claimed = rel < R;   // bucket R: logit 0, no message (conv.py:68-69)
         unsigned rowmask = 0;           // rows of the U tile written for this relation (wave-uniform)
@@ -328,8 +331,8 @@ template <int VEC, int LPH, bool RTE>
 __device__ __forceinline__ void agg_mfma_stream(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
-    const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, int R, int HT, int SUBR, int64_t row0,
-    unsigned char* utile, float* s_m, float* s_l, float* s_sc, int raw, f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
+    const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, int R, int rel_lo, int rel_hi, int HT, int SUBR,
+    int64_t row0, unsigned char* utile, float* s_m, float* s_l, float* s_sc, int raw, f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
     using G = MG<VEC, LPH>;
     constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS;
     constexpr int UN = RTE ? 4 : 8;    // rows per batch; two batches (register buffers A / B) are in flight
@@ -357,7 +360,7 @@ __device__ __forceinline__ void agg_mfma_stream(
     {
         const int64_t bb = ((int64_t)tile * (R + 1) + min(lane, R)) * HGT_TD + within;
         my_beg = segptr[bb];
-        my_len = (lane <= R) ? segptr[bb + SUBR] - my_beg : 0;
+        my_len = (lane <= R && lane >= rel_lo && lane < rel_hi) ? segptr[bb + SUBR] - my_beg : 0;   // relations outside the slice: empty ranges
     }
     int incl = my_len;
 #pragma unroll
@@ -370,47 +373,52 @@ __device__ __forceinline__ void agg_mfma_stream(
     if (total == 0) return;
 
     // stream entries [vbase, vbase + 64) -> lane registers; entries beyond the end replicate the last edge
-    auto load_meta = [&](int vbase, int& m_src, int& m_dst, int& m_rel, int& m_pos, int& m_rte) {
+    // (the relation and the target's position inside the sub-tile travel in ONE register, key = relation << 8 | target - row0:
+    //  one v_readlane and one SGPR per batch slot instead of two -- the kernel is short of both register files)
+    auto load_meta = [&](int vbase, int& m_src, int& m_key, int& m_pos, int& m_rte) {
         const int v = min(vbase + lane, total - 1);
         int rsel = 0;
         for (int r = 0; r <= R; ++r) {
             const int pr = __builtin_amdgcn_readlane(my_pre, r), ln = __builtin_amdgcn_readlane(my_len, r);
             if (ln > 0 && v >= pr) rsel = r;
         }
-        m_rel = rsel;
         m_pos = __shfl(my_beg, rsel) + (v - __shfl(my_pre, rsel));
         m_src = esrc[m_pos];
-        m_dst = edst[m_pos];
+        m_key = (edst[m_pos] - (int)row0) | (rsel << 8);
         m_rte = RTE ? (int)ertei[m_pos] : 0;
     };
 
 #if HGT_AGG_HIDDEN
-    auto load_meta_next = [&](int vbase, int& m_src, int& m_dst, int& m_rel, int& m_pos, int& m_rte) {
+    auto load_meta_next = [&](int vbase, int& m_src, int& m_key, int& m_pos, int& m_rte) {
         const int v = min(vbase + lane, total - 1);
         int rsel = 0;
         for (int r = 0; r <= R; ++r) {
             const int pr = __builtin_amdgcn_readlane(my_pre, r), ln = __builtin_amdgcn_readlane(my_len, r);
             if (ln > 0 && v >= pr) rsel = r;
         }
-        m_rel = rsel;
         m_pos = __shfl(my_beg, rsel) + (v - __shfl(my_pre, rsel));
         hidden_load(m_src, esrc + m_pos);
-        hidden_load(m_dst, edst + m_pos);
+        hidden_load(m_key, edst + m_pos);          /* raw target id: turned into the key after the wait (AGG_META_WAIT) */
+        n_relsel = rsel;
         if constexpr (RTE) hidden_load_u16(m_rte, ertei + m_pos);
         else m_rte = 0;
     };
-#define AGG_META_WAIT asm volatile("s_waitcnt vmcnt(%3)" : "+v"(n_src), "+v"(n_dst), "+v"(n_rte) : "n"(HIDDEN_PER_BATCH));
+#define AGG_META_WAIT asm volatile("s_waitcnt vmcnt(%3)" : "+v"(n_src), "+v"(n_key), "+v"(n_rte) : "n"(HIDDEN_PER_BATCH)); \
+    n_key = (n_key - (int)row0) | (n_relsel << 8);
 #else
 #define load_meta_next load_meta
 #define AGG_META_WAIT
 #endif
-    int c_src, c_dst, c_rel, c_pos, c_rte;          // current chunk
-    int n_src = 0, n_dst = 0, n_rel = 0, n_pos = 0, n_rte = 0;   // next chunk (prefetched)
+    int c_src, c_key, c_pos, c_rte;          // current chunk
+    int n_src = 0, n_key = 0, n_pos = 0, n_rte = 0;   // next chunk (prefetched)
+#if HGT_AGG_HIDDEN
+    int n_relsel = 0;
+#endif
     int vbase = 0, nb = min(64, total);
-    load_meta(0, c_src, c_dst, c_rel, c_pos, c_rte);
-    if (total > 64) load_meta(64, n_src, n_dst, n_rel, n_pos, n_rte);
+    load_meta(0, c_src, c_key, c_pos, c_rte);
+    if (total > 64) load_meta(64, n_src, n_key, n_pos, n_rte);
 
-    int cur_dst = -1, cur_rel = -1;
+    int cur_dl = -1, cur_rel = -1;       // running segment: target position inside the sub-tile / relation
     unsigned rowmask = 0;
     float U[VEC], m_ref = 0.0f, l_seg = 0.0f;
 #pragma unroll
@@ -418,8 +426,8 @@ __device__ __forceinline__ void agg_mfma_stream(
     bool seg_claimed = false;      // relation of the running segment is a real one (its rows go into the U tile)
 
     auto flush = [&]() {
-        if (cur_dst >= 0) {
-            const int dl = cur_dst - (int)row0;
+        if (cur_dl >= 0) {
+            const int dl = cur_dl;
             if (p == 0) {
                 s_l[dl * 16 + h] += l_seg;
                 s_m[dl * 16 + h] = m_ref;
@@ -444,14 +452,14 @@ __device__ __forceinline__ void agg_mfma_stream(
                 rowmask |= 1u << dl;
             }
         }
-        cur_dst = -1;
+        cur_dl = -1;
     };
 
     // end of a relation: Z^T += M_r^T . U_r^T for the rows parked in the tile.  The fragments of M_r come from L2 in groups
     // of GS column-tile steps, eight 1 KB loads in flight at a time, pinned with sched_barrier: left alone, hipcc issued the 32
     // fragment loads of a relation two at a time and waited for each pair with vmcnt(0) (ISA audit of the first version) --
     // sixteen dependent L2 round trips per relation end, the largest single cost of that version.
-    constexpr int STEPS = NCT * NKS, GS = 4, NG = STEPS / GS;
+    constexpr int STEPS = NCT * NKS, GS = HGT_AGG_GS < STEPS ? HGT_AGG_GS : STEPS, NG = STEPS / GS;
     static_assert(STEPS % GS == 0, "column-tile steps come in multiples of 4 (DP is a multiple of 64)");
     auto relation_end = [&](int rel) {
         if (rowmask == 0) return;
@@ -508,18 +516,17 @@ __device__ __forceinline__ void agg_mfma_stream(
     typedef typename RowT<VEC>::type Row;
     Row vrA[UN], trA[RTE ? UN : 1], vrB[UN], trB[RTE ? UN : 1];
     float slA[UN], slB[UN];
-    int dstA[UN], dstB[UN], relA[UN], relB[UN];
+    int keyA[UN], keyB[UN];
     constexpr int HIDDEN_PER_BATCH = UN * (RTE ? 3 : 2);     // rows + logits (+ temporal rows)
 
     // A batch = the next UN entries of the stream (fewer only at a chunk end), whatever their relations.
-#define AGG_ISSUE(VR, SL, TR, DS, RL, I0, CNT)                                                     \
+#define AGG_ISSUE(VR, SL, TR, KY, I0, CNT)                                                         \
     _Pragma("unroll") for (int u = 0; u < UN; ++u) {                                               \
         /* slots beyond the batch re-request its last edge (same address: served by the L1) */     \
         const int idx = min((I0) + u, (I0) + max((CNT), 1) - 1);                                   \
         const int s_ = __builtin_amdgcn_readlane(c_src, idx);                                      \
         const int p_ = __builtin_amdgcn_readlane(c_pos, idx);                                      \
-        DS[u] = __builtin_amdgcn_readlane(c_dst, idx);                                             \
-        RL[u] = __builtin_amdgcn_readlane(c_rel, idx);                                             \
+        KY[u] = __builtin_amdgcn_readlane(c_key, idx);                                             \
         AGG_LOAD(VR[u], V + (int64_t)s_ * ld + co + lane * VEC)                                    \
         AGG_LOAD(SL[u], logits + (int64_t)p_ * HT + hg * H + h)                                    \
         if constexpr (RTE) {                                                                       \
@@ -547,11 +554,11 @@ __device__ __forceinline__ void agg_mfma_stream(
 #define AGG_WAIT(VR, SL, TR)
 #endif
     // Consume a batch: runs [lo, hi) of one relation; the relation-end work sits between the runs (one call site per buffer)
-#define AGG_PROCESS(VR, SL, TR, DS, RL, CNT)                                                       \
+#define AGG_PROCESS(VR, SL, TR, KY, CNT)                                                           \
     for (int lo = 0; lo < (CNT);) {                                                                \
-        int rel_run = RL[0], hi = (CNT);                                                           \
-        _Pragma("unroll") for (int u = 1; u < UN; ++u) if (u <= lo) rel_run = RL[u];               \
-        _Pragma("unroll") for (int u = UN - 1; u >= 1; --u) if (u > lo && u < (CNT) && RL[u] != rel_run) hi = u; \
+        int rel_run = KY[0] >> 8, hi = (CNT);                                                      \
+        _Pragma("unroll") for (int u = 1; u < UN; ++u) if (u <= lo) rel_run = KY[u] >> 8;          \
+        _Pragma("unroll") for (int u = UN - 1; u >= 1; --u) if (u > lo && u < (CNT) && (KY[u] >> 8) != rel_run) hi = u; \
         if (rel_run != cur_rel) {                                                                  \
             flush();                                                                               \
             relation_end(cur_rel);                                                                 \
@@ -560,13 +567,13 @@ __device__ __forceinline__ void agg_mfma_stream(
         const bool claimed_ = rel_run < R;                                                         \
         _Pragma("unroll") for (int u = 0; u < UN; ++u) {                                           \
             if (u >= lo && u < hi) {                                                               \
-                if (DS[u] != cur_dst) {                                                            \
+                if ((KY[u] & 255) != cur_dl) {                                                     \
                     flush();                                                                       \
                     _Pragma("unroll") for (int i = 0; i < VEC; ++i) U[i] = 0.0f;                   \
                     l_seg = 0.0f;                                                                  \
-                    cur_dst = DS[u];                                                               \
+                    cur_dl = KY[u] & 255;                                                          \
                     seg_claimed = claimed_;                                                        \
-                    const float m_t = s_m[(cur_dst - (int)row0) * 16 + h];                         \
+                    const float m_t = s_m[cur_dl * 16 + h];                                        \
                     m_ref = (m_t == HGT_NEG) ? SL[u] : m_t;                                        \
                 }                                                                                  \
                 float dlt = SL[u] - m_ref;                                                         \
@@ -575,7 +582,7 @@ __device__ __forceinline__ void agg_mfma_stream(
                     const float sc = __expf(m_ref - m_new);                                        \
                     _Pragma("unroll") for (int i = 0; i < VEC; ++i) U[i] *= sc;                    \
                     l_seg *= sc;                                                                   \
-                    const int dl = cur_dst - (int)row0;                                            \
+                    const int dl = cur_dl;                                                         \
                     if (p == 0) {                                                                  \
                         s_l[dl * 16 + h] *= sc;                                                    \
                         s_sc[h] = sc;                                                              \
@@ -617,8 +624,8 @@ __device__ __forceinline__ void agg_mfma_stream(
                 vbase += 64;                                                                       \
                 nb = min(64, total - vbase);                                                       \
                 AGG_META_WAIT                                                                      \
-                c_src = n_src; c_dst = n_dst; c_rel = n_rel; c_pos = n_pos; c_rte = n_rte;          \
-                if (vbase + 64 < total) load_meta_next(vbase + 64, n_src, n_dst, n_rel, n_pos, n_rte); \
+                c_src = n_src; c_key = n_key; c_pos = n_pos; c_rte = n_rte;                        \
+                if (vbase + 64 < total) load_meta_next(vbase + 64, n_src, n_key, n_pos, n_rte);     \
                 I0N = 0;                                                                           \
                 CNTN = min(UN, nb);                                                                \
             }                                                                                      \
@@ -629,17 +636,17 @@ __device__ __forceinline__ void agg_mfma_stream(
 
     // Two register buffers: the rows of batch k + 1 are requested before batch k is consumed.
     int i0A = 0, cntA = min(UN, nb), i0B, cntB;
-    AGG_ISSUE(vrA, slA, trA, dstA, relA, 0, cntA)
+    AGG_ISSUE(vrA, slA, trA, keyA, 0, cntA)
     for (;;) {
         AGG_NEXT(i0A, cntA, i0B, cntB)
-        AGG_ISSUE(vrB, slB, trB, dstB, relB, i0B, cntB)
+        AGG_ISSUE(vrB, slB, trB, keyB, i0B, cntB)
         AGG_WAIT(vrA, slA, trA)
-        AGG_PROCESS(vrA, slA, trA, dstA, relA, cntA)
+        AGG_PROCESS(vrA, slA, trA, keyA, cntA)
         if (cntB == 0) break;
         AGG_NEXT(i0B, cntB, i0A, cntA)
-        AGG_ISSUE(vrA, slA, trA, dstA, relA, i0A, cntA)
+        AGG_ISSUE(vrA, slA, trA, keyA, i0A, cntA)
         AGG_WAIT(vrB, slB, trB)
-        AGG_PROCESS(vrB, slB, trB, dstB, relB, cntB)
+        AGG_PROCESS(vrB, slB, trB, keyB, cntB)
         if (cntA == 0) break;
     }
 #if HGT_AGG_HIDDEN
@@ -701,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_mfma(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
     const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, float* __restrict__ agg, int R, int64_t NQ, int apply_gelu,
-    int HT, const int32_t* __restrict__ hub_slot, int sub, int64_t ld_out) {
+    int HT, const int32_t* __restrict__ hub_slot, int sub, int64_t ld_out, HgtRelSlice sl) {
     using G = MG<VEC, LPH>;
     const int raw = (apply_gelu == 2);
     __shared__ __attribute__((aligned(16))) unsigned char s_u[4][2 * G::PLANE];
@@ -719,16 +726,79 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_mfma(
     }
     f32x4 acc[G::NCT];
     if (hub_mask == 0 && R < 64)
-        agg_mfma_stream<VEC, LPH, RTE>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, HT, sub, row0, s_u[wib], s_ml[wib][0],
-                                       s_ml[wib][1], s_scale[wib], raw, acc);
+        agg_mfma_stream<VEC, LPH, RTE>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, sl.lo, sl.hi, HT, sub, row0, s_u[wib],
+                                       s_ml[wib][0], s_ml[wib][1], s_scale[wib], raw, acc);
     else if (hub_mask == 0)
-        agg_mfma_subtile<VEC, LPH, RTE, false>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, HT, 0u, sub, row0, s_u[wib],
-                                               s_ml[wib][0], s_ml[wib][1], s_scale[wib], raw, acc);
+        agg_mfma_subtile<VEC, LPH, RTE, false>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, sl.lo, sl.hi, HT, 0u, sub, row0,
+                                               s_u[wib], s_ml[wib][0], s_ml[wib][1], s_scale[wib], raw, acc);
     else
-        agg_mfma_subtile<VEC, LPH, RTE, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, HT, hub_mask, sub, row0, s_u[wib],
-                                              s_ml[wib][0], s_ml[wib][1], s_scale[wib], raw, acc);
-    agg_mfma_finish<VEC, LPH>(s_ml[wib][1], apply_gelu, acc);
+        agg_mfma_subtile<VEC, LPH, RTE, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, sl.lo, sl.hi, HT, hub_mask, sub, row0,
+                                              s_u[wib], s_ml[wib][0], s_ml[wib][1], s_scale[wib], raw, acc);
+    if (sl.state) {
+        // Source-bucketed multi-GPU edge phase: this launch covered one slice of the relation buckets.  Merge with what the
+        // earlier slices left -- (reference m, exp-sum l) per (target, head) in sl.state, un-normalised rows in agg -- the way
+        // two online-softmax partials combine: m = max(m_a, m_b), x = x_a e^(m_a - m) + x_b e^(m_b - m).
+        float* s_m = s_ml[wib][0];
+        float* s_l = s_ml[wib][1];
+        float* s_sb = reinterpret_cast<float*>(s_u[wib]);      // the U tile is dead: scale of THIS slice's partial
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int hg = blockIdx.y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = j * 64 + lane, t = idx >> 4, hh = idx & 15;
+            const int64_t row = row0 + t;
+            float m_b = s_m[idx], l_b = s_l[idx], m_p = HGT_NEG, l_p = 0.0f;
+            const bool live = (t < sub) && (row < NQ) && (hh < G::H);
+            float* st = sl.state + ((int64_t)row * HT + hg * G::H + hh) * 2;
+            if (live && sl.has_prev) { m_p = st[0]; l_p = st[1]; }
+            const float m = fmaxf(m_b, m_p);
+            const float sp = __expf(m_p - m), sb = __expf(m_b - m);
+            const float l = l_p * sp + l_b * sb;
+            if (live && sl.more) { st[0] = m; st[1] = l; }
+            s_m[idx] = sp;
+            s_l[idx] = l;
+            s_sb[idx] = sb;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int fi = lane & 15, fg = lane >> 4;
+        const int64_t row = row0 + fi;
+        const bool mine = (fi < sub) && (row < NQ) && !((hub_mask >> fi) & 1u);
+        const float* g = agg + row * ld_out + (int64_t)hg * G::DP + 4 * fg;
+#pragma unroll
+        for (int c = 0; c < G::NCT; ++c) {
+            const int hh = (16 * c + 4 * fg) / G::DKP;
+            const float sb = s_sb[fi * 16 + hh], sp = s_m[fi * 16 + hh];
+            float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mine && sl.has_prev) prev = *reinterpret_cast<const float4*>(g + 16 * c);
+            acc[c][0] = acc[c][0] * sb + prev.x * sp;
+            acc[c][1] = acc[c][1] * sb + prev.y * sp;
+            acc[c][2] = acc[c][2] * sb + prev.z * sp;
+            acc[c][3] = acc[c][3] * sb + prev.w * sp;
+        }
+    }
+    if (!sl.more) agg_mfma_finish<VEC, LPH>(s_ml[wib][1], apply_gelu, acc);
     agg_mfma_store<VEC, LPH>(agg, row0, sub, NQ, ld_out, (int)blockIdx.y * G::DP, hub_mask, acc);
+}
+
+// The sub-tile walk of a workgroup that contains a hub target, kept OUT OF LINE (a real call, rare path): inlined next to the
+// streaming walk + fused epilogue it costs the common path 22 spilled VGPRs (92 B of scratch per thread = 0.8 GB of extra HBM
+// traffic per launch at c2, rocprofv3 WRITE_SIZE).
+template <int VEC, int LPH, bool RTE>
+__device__ __attribute__((noinline)) void agg_mfma_hub_workgroup(
+    const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
+    const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
+    const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, float* __restrict__ agg, int R, int64_t NQ, int HT,
+    unsigned hub_mask, int64_t wrow0, unsigned char* utile, float* s_m, float* s_l, float* s_sc) {
+    using G = MG<VEC, LPH>;
+    f32x4 acc[G::NCT];
+    agg_mfma_subtile<VEC, LPH, RTE, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, 0, R + 1, HT, hub_mask, 16, wrow0, utile, s_m, s_l,
+                                          s_sc, 0, acc);
+    agg_mfma_finish<VEC, LPH>(s_l, 1, acc);
+    agg_mfma_store<VEC, LPH>(agg, wrow0, 16, NQ, (int64_t)HT * G::DKP, 0, hub_mask, acc);
 }
 
 // Aggregation + fused node update (see hgt_fused_update.h).  Workgroups that contain a hub target cannot finish their rows
@@ -763,24 +833,20 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
     unsigned char* utile = smem + wib * 2 * G::PLANE;
     float* s_m = s_ml + wib * 512;
     float* s_l = s_m + 256;
+    if (any_hub) {      // (the launcher only takes this kernel for R < 64; hub workgroups walk run by run, all four sub-tiles)
+        if (wrow0 < NQ)
+            agg_mfma_hub_workgroup<VEC, LPH, RTE>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, agg, R, NQ, HT, hub_mask, wrow0, utile,
+                                                  s_m, s_l, s_scale + wib * 16);
+        return;
+    }
     f32x4 acc[G::NCT];
     if (wrow0 < NQ) {
-        // (the launcher only takes this kernel for R < 64; workgroups with a hub take the run-based walk for all four
-        //  sub-tiles: one walk variant less in the kernel keeps the register allocation of the common path spill-free)
-        if (!any_hub)
-            agg_mfma_stream<VEC, LPH, RTE>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, HT, 16, wrow0, utile, s_m, s_l,
-                                           s_scale + wib * 16, 0, acc);
-        else
-            agg_mfma_subtile<VEC, LPH, RTE, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, HT, hub_mask, 16, wrow0, utile, s_m,
-                                                  s_l, s_scale + wib * 16, 0, acc);
+        agg_mfma_stream<VEC, LPH, RTE>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, 0, R + 1, HT, 16, wrow0, utile, s_m, s_l,
+                                       s_scale + wib * 16, 0, acc);
         agg_mfma_finish<VEC, LPH>(s_l, 1, acc);
     } else {
 #pragma unroll
         for (int c = 0; c < G::NCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};   // rows beyond NQ: gelu(0) = 0
-    }
-    if (any_hub) {
-        if (wrow0 < NQ) agg_mfma_store<VEC, LPH>(agg, wrow0, 16, NQ, (int64_t)HT * G::DKP, 0, hub_mask, acc);
-        return;
     }
     __syncthreads();   // every wavefront is done with its U tile and its softmax state: the A slab overlays them
     {
@@ -802,7 +868,7 @@ template <int VEC, int LPH>
 struct LaunchAggMfma {
     static int run(const HgtPlanView& pv, const float* logits, const float* V, const float* rteV, const float* msgP,
                    const unsigned short* msgF, float* agg, int R, int64_t NQ, int apply_gelu, int HT, HgtHubBuffers hb, int64_t ld_out,
-                   hipStream_t stream) {
+                   HgtRelSlice sl, hipStream_t stream) {
         if constexpr (VEC <= 4) {
             // small graphs (the reference's sampled subgraphs): 4 instead of 16 targets per wavefront -> 4x the wavefronts
             const int sub = (NQ < 65536) ? 4 : HGT_SUB;
@@ -812,11 +878,12 @@ struct LaunchAggMfma {
             const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
             if (rteV)
                 k_edge_aggregate_mfma<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
-                                                                               agg, R, NQ, apply_gelu, HT, hub_slot, sub, ld_out);
+                                                                               agg, R, NQ, apply_gelu, HT, hub_slot, sub, ld_out, sl);
             else
                 k_edge_aggregate_mfma<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
-                                                                                agg, R, NQ, apply_gelu, HT, hub_slot, sub, ld_out);
-            if (hb.mx) return hgt_launch_hub(VEC, LPH, pv, logits, V, rteV, msgP, agg, R, NQ, apply_gelu, HT, hb, ny, ld_out, stream);
+                                                                                agg, R, NQ, apply_gelu, HT, hub_slot, sub, ld_out, sl);
+            if (hb.mx && !sl.more)   // hub targets take all their relations at once, after the last slice
+                return hgt_launch_hub(VEC, LPH, pv, logits, V, rteV, msgP, agg, R, NQ, apply_gelu, HT, hb, ny, ld_out, stream);
             return HGT_OK;
         } else {
             return HGT_ERR_UNSUPPORTED;
@@ -919,13 +986,39 @@ extern "C" int hgt_edge_aggregate(const void* plan, int64_t N, int64_t E, int32_
     if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
     HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
     HgtHubBuffers hb = carve_hub(hub_ws, pv, H, E);
+    const HgtRelSlice whole = {0, (int)R + 1, nullptr, 0, 0};
     int rc = HGT_ERR_UNSUPPORTED;
     const int sp = msg_frag ? mfma_split_for(dk_pad / lph, lph) : 0;
     if (sp != 0)
         rc = dispatch_layout<LaunchAggMfma>(dk_pad / lph / sp, lph * sp, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
-                                            (int)R, NQ, (int)(apply_gelu ? 1 : 0), (int)H, hb, (int64_t)H * dk_pad, (hipStream_t)stream);
+                                            (int)R, NQ, (int)(apply_gelu ? 1 : 0), (int)H, hb, (int64_t)H * dk_pad, whole,
+                                            (hipStream_t)stream);
     if (rc == HGT_ERR_UNSUPPORTED)   // exact-fp32 request (msg_frag == NULL) or a layout only the vector-ALU kernel covers
         rc = hgt_valu_aggregate(pv, dk_pad, logits, V, rte_v, msg_p, agg, (int)R, NQ, (int)(apply_gelu ? 1 : 0), (int)H, hb, (hipStream_t)stream);
+    if (rc != HGT_OK) return rc;
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+// One slice [rel_lo, rel_hi) of the relation buckets (include/hgt_hip.h): matrix-core kernel only (msg_frag required).
+extern "C" int hgt_edge_aggregate_slice(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                        const float* logits, const float* V, const float* rte_v, const float* msg_p,
+                                        const void* msg_frag, float* agg, int64_t n_q_rows, int32_t apply_gelu, void* hub_ws,
+                                        int32_t rel_lo, int32_t rel_hi, float* state, int32_t has_prev, int32_t more, void* stream) {
+    if (!plan || !V || !msg_p || !msg_frag || !agg || !state || (E > 0 && !logits) || H <= 0 || 64 % H != 0 || dk_pad <= 0)
+        return HGT_ERR_INVALID_ARG;
+    if (rel_lo < 0 || rel_hi > R + 1 || rel_lo > rel_hi) return HGT_ERR_INVALID_ARG;
+    const int64_t NQ = (n_q_rows > 0 && n_q_rows <= N) ? n_q_rows : N;
+    if (NQ == 0) return HGT_OK;
+    const int lph = 64 / H;
+    if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
+    HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
+    HgtHubBuffers hb = carve_hub(hub_ws, pv, H, E);
+    const HgtRelSlice sl = {(int)rel_lo, (int)rel_hi, state, has_prev ? 1 : 0, more ? 1 : 0};
+    const int sp = mfma_split_for(dk_pad / lph, lph);
+    if (sp == 0) return HGT_ERR_UNSUPPORTED;
+    int rc = dispatch_layout<LaunchAggMfma>(dk_pad / lph / sp, lph * sp, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
+                                            (int)R, NQ, (int)(apply_gelu ? 1 : 0), (int)H, hb, (int64_t)H * dk_pad, sl, (hipStream_t)stream);
     if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();
     return HGT_OK;
@@ -977,7 +1070,7 @@ extern "C" int hgt_edge_spmm(const void* plan, int64_t N, int64_t E, int32_t T, 
     const int sp = mfma_split_for(dk_pad / lph, lph);
     if (sp == 0) return HGT_ERR_UNSUPPORTED;
     int rc = dispatch_layout<LaunchAggMfma>(dk_pad / lph / sp, lph * sp, pv, weights, rows, rte_rows, f_p, (const unsigned short*)f_frag, out,
-                                            (int)R, NQ, 2, (int)H, hb, ld_out, (hipStream_t)stream);
+                                            (int)R, NQ, 2, (int)H, hb, ld_out, HgtRelSlice{0, (int)R + 1, nullptr, 0, 0}, (hipStream_t)stream);
     if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();
     return HGT_OK;

@@ -12,6 +12,15 @@ struct HgtHubBuffers {
 };
 
 // arguments of the fused node update (hgt_fused_update.h)
+// A slice [lo, hi) of the plan's R + 1 relation buckets, and the softmax state carried from slice to slice (multi-GPU path:
+// relation id = source bucket * R + relation, one slice per bucket of arrived source rows -- pyhgt_amd/dist.py).
+struct HgtRelSlice {
+    int lo, hi;
+    float* state;     // f32[NQ][H][2] = (reference, exp-sum) per (target, head); NULL: the whole layer in one launch
+    int has_prev;     // an earlier slice left state + un-normalised rows (in agg): merge with them
+    int more;         // further slices follow: leave state + un-normalised rows instead of finishing
+};
+
 struct HgtFusedUpdate {
     const int64_t* node_type;
     const unsigned short* w_split;   // hgt_split_weights(W_a): [T][1][n_kc][2][8][64][8] bf16

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_edge_logits(
     const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
     const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ Q,
     const float* __restrict__ K, const float* __restrict__ rteK, const float* __restrict__ attT, float* __restrict__ logits, int R,
-    int HT) {
+    int HT, int rel_lo, int rel_hi) {
     // A wave covers DP = 64*VEC consecutive floats of a row = H = 64/LPH heads.  When the row has more heads (HT > H),
     // blockIdx.y selects the head group: used when the full-width relation fragment (dk_pad*vec floats per lane) would
     // not fit in registers (d = 512: 512 floats) -- narrower slices keep it register-resident.
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void k_edge_logits(
     const int beg = __builtin_amdgcn_readfirstlane(it.beg), end = __builtin_amdgcn_readfirstlane(it.end);
     const int rel = __builtin_amdgcn_readfirstlane(it.rel);
     const int h = lane / LPH, p = lane % LPH;
+    if (rel < rel_lo || rel >= rel_hi) return;   // (multi-GPU path: only the relation buckets of the source rows that have arrived)
 
     if (rel >= R) {   // edges no meta relation claims: logit 0 (conv.py:68)
         for (int64_t i = (int64_t)beg * H + lane; i < (int64_t)end * H; i += 64) logits[(i / H) * HT + hg * H + (i % H)] = 0.0f;
@@ -186,13 +187,13 @@ __global__ void k_relation_pack(const float* __restrict__ ratt, const float* __r
 template <int VEC, int LPH>
 struct LaunchLogits {
     static int run(const HgtPlanView& pv, const float* Q, const float* K, const float* rteK, const float* attT, float* logits,
-                   int R, int HT, hipStream_t stream) {
+                   int R, int HT, int rel_lo, int rel_hi, hipStream_t stream) {
         const unsigned blocks = (unsigned)((pv.L.max_items + 3) / 4);
         dim3 grid(blocks, (unsigned)(HT / (64 / LPH)));
         if (rteK)
-            k_edge_logits<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT);
+            k_edge_logits<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi);
         else
-            k_edge_logits<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT);
+            k_edge_logits<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi);
         return HGT_OK;
     }
 };
@@ -210,18 +211,31 @@ extern "C" int hgt_relation_pack(const float* relation_att, const float* relatio
     return HGT_OK;
 }
 
-extern "C" int hgt_edge_logits(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
-                               const float* Q, const float* K, const float* rte_k, const float* att_t, float* logits, void* stream) {
+static int edge_logits_impl(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad, const float* Q,
+                            const float* K, const float* rte_k, const float* att_t, float* logits, int rel_lo, int rel_hi, void* stream) {
     if (!plan || !Q || !K || !att_t || !logits || H <= 0 || 64 % H != 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
+    if (rel_lo < 0 || rel_hi > R + 1 || rel_lo > rel_hi) return HGT_ERR_INVALID_ARG;
     if (E == 0) return HGT_OK;
     const int lph = 64 / H;
     if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
     HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
     const int sp = head_split_for(dk_pad / lph, lph, dk_pad);
-    int rc = dispatch_layout<LaunchLogits>(dk_pad / lph / sp, lph * sp, pv, Q, K, rte_k, att_t, logits, (int)R, (int)H, (hipStream_t)stream);
+    int rc = dispatch_layout<LaunchLogits>(dk_pad / lph / sp, lph * sp, pv, Q, K, rte_k, att_t, logits, (int)R, (int)H, rel_lo, rel_hi,
+                                           (hipStream_t)stream);
     if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();
     return HGT_OK;
+}
+
+extern "C" int hgt_edge_logits(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                               const float* Q, const float* K, const float* rte_k, const float* att_t, float* logits, void* stream) {
+    return edge_logits_impl(plan, N, E, T, R, H, dk_pad, Q, K, rte_k, att_t, logits, 0, R + 1, stream);
+}
+
+extern "C" int hgt_edge_logits_slice(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                     const float* Q, const float* K, const float* rte_k, const float* att_t, float* logits,
+                                     int32_t rel_lo, int32_t rel_hi, void* stream) {
+    return edge_logits_impl(plan, N, E, T, R, H, dk_pad, Q, K, rte_k, att_t, logits, rel_lo, rel_hi, stream);
 }
 
 extern "C" int hgt_edge_softmax(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, float* logits_att,

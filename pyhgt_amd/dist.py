@@ -23,6 +23,21 @@ halo part of the local buffer is ordered (chunk, peer, row).  A step then runs
 through hgt_conv_forward's stages 1/2/3, so the exchange (RCCL's own stream) overlaps the own-row
 projections, the packing and the halo projections of the earlier chunks; only the edge phase needs
 every source row.
+
+Source-bucketed edge phase (bucketed=True, the default where it applies: split-bf16 precision and
+(n_chunks + 1) * num_relations < 64).  The edge phase does not have to wait for the last chunk either: a rank's edges are
+bucketed by where their SOURCE row comes from -- bucket 0 = own rows, bucket c + 1 = halo chunk c -- by numbering relations
+`bucket * R + relation` in the plan (the relation parameters are repeated per bucket, a few MB).  The plan then keeps, inside
+every target tile, the edges of one bucket together, and hgt_conv_forward's stage 4 runs logits + aggregation over ONE bucket,
+carrying the online-softmax state (reference, exp-sum, un-normalised rows) from bucket to bucket in the workspace:
+
+    pack(all chunks), all-to-all(c0 .. c_last, async, back to back on RCCL's stream) |
+    Q|K|V of the own rows | edge phase of bucket 0 (own sources) |
+    wait(c0), K|V of chunk 0, edge phase of bucket 1 | ... | wait(c_last), K|V, edge phase of the last bucket + update
+
+so that only the last chunk's projections, its bucket of edges and the node update are behind the exchange.  Partial softmax
+results combine exactly (m = max, rescale both sides): the result equals the one-call layer up to fp32 rounding
+(tests/test_hgt_gpu.py::test_bucketed_edge_phase_matches_one_call_layer).
 """
 import torch
 import torch.distributed as dist
@@ -151,6 +166,14 @@ class HaloPlan:
             lists.append((rows, off.to(torch.int32).contiguous()))
         return lists
 
+    def edge_buckets(self):
+        """Source bucket of every edge (module docstring): 0 = the source is an own row, 1 + c = it arrives with halo chunk c
+        (halo rows are stored in chunk order)."""
+        bounds = torch.tensor(self.recv_chunk_off[1:], dtype=torch.int64, device=self.src_local.device)
+        halo_pos = self.src_local - self.n_own
+        in_chunk = torch.searchsorted(bounds, halo_pos.clamp(min=0), right=True)
+        return torch.where(halo_pos >= 0, 1 + in_chunk, torch.zeros_like(halo_pos))
+
     def exchange_chunk(self, c, x_own, x_local, pack=None, async_op=False, compress=False):
         """One slice of the exchange: pack the rows of chunk c the peers need, all-to-all them into the halo rows of
         chunk c.  Returns (work, buffers) when async_op: work.wait() makes the current stream wait for the rows (and, with
@@ -208,28 +231,47 @@ class PartitionedGraph:
     """One rank's share of a destination-partitioned typed graph + the per-layer forward."""
 
     def __init__(self, node_type_own, src_global, dst_local, edge_type, edge_time, num_types, num_relations,
-                 nodes_per_rank, rank, world, group=None, node_offsets=None, n_chunks=4, halo=None, compress=False):
+                 nodes_per_rank, rank, world, group=None, node_offsets=None, n_chunks=4, halo=None, compress=False, bucketed=None):
         """halo: a prebuilt HaloPlan for this rank (tests build it on CPU over gloo and move it to the device with
-        HaloPlan.to); otherwise it is negotiated here with three small all-to-alls."""
+        HaloPlan.to); otherwise it is negotiated here with three small all-to-alls.
+        bucketed: source-bucketed edge phase (module docstring); None = wherever it applies (decided per layer in forward:
+        it needs the split-bf16 precision), False = the edge phase waits for the last chunk (stages 1/2/3)."""
         from .conv import GraphPlan
         if node_offsets is None:
             node_offsets = [nodes_per_rank * r for r in range(world + 1)]
         self.halo = halo if halo is not None else HaloPlan(node_type_own, src_global, node_offsets, rank, world, group,
                                                             n_chunks=n_chunks)
         self.compress = bool(compress)     # 24-bit halo rows on the links (exchange_chunk); off: exact fp32 rows
-        self.chunk_lists = self.halo.chunk_row_lists(num_types) if self.halo.n_chunks > 1 else None
+        C = self.halo.n_chunks
+        self.n_buckets = C + 1
+        can_bucket = self.n_buckets * num_relations < 64        # the streaming walk keeps one range per relation id in a lane
+        self.bucketed = can_bucket if bucketed is None else bool(bucketed)
+        if self.bucketed and not can_bucket:
+            raise ValueError("bucketed edge phase needs (n_chunks + 1) * num_relations < 64")
+        self.chunk_lists = self.halo.chunk_row_lists(num_types) if (C > 1 or self.bucketed) else None
         self.n_own, self.n_local = self.halo.n_own, self.halo.n_local
         self.edge_index = torch.stack([self.halo.src_local, dst_local], dim=0).contiguous()
         self.edge_type, self.edge_time = edge_type, edge_time
         self.node_type_local = self.halo.node_type_local
+        self.num_relations = num_relations
         self.plan = GraphPlan(self.node_type_local, self.edge_index, edge_type, edge_time, num_types, num_relations,
                               n_q_rows=self.n_own)
+        self.bucket_plan = None
+        if self.bucketed:
+            # bucket of an edge = where its source row comes from: 0 own, 1 + c halo chunk c (halo rows are in chunk order)
+            bucket = self.halo.edge_buckets()
+            claimed = (edge_type >= 0) & (edge_type < num_relations)
+            self.edge_type_bucketed = torch.where(claimed, bucket * num_relations + edge_type,
+                                                  torch.full_like(edge_type, self.n_buckets * num_relations))
+            self.bucket_plan = GraphPlan(self.node_type_local, self.edge_index, self.edge_type_bucketed, edge_time, num_types,
+                                         self.n_buckets * num_relations, n_q_rows=self.n_own)
         self.x_local = None
         self.workspace = None      # owned here: Q/K/V stay in it between the stages of one step
 
     def forward(self, layer, x_own, phase_events=None):
         d = x_own.size(1)
-        need = layer.workspace_bytes(self.n_local, self.plan.E)
+        bucketed = self.bucketed and getattr(layer, "precision", None) == "bf16x3" and getattr(layer, "_UPDATE_MODE", 0) == 0
+        need = layer.workspace_bytes(self.n_local, self.plan.E, self.n_buckets if bucketed else 1)
         if self.workspace is None or self.workspace.numel() < need or self.workspace.device != x_own.device:
             self.workspace = torch.empty(need, dtype=torch.uint8, device=x_own.device)
         if self.x_local is None or self.x_local.size(1) != d:
@@ -242,6 +284,22 @@ class PartitionedGraph:
                 self.halo.exchange_chunk(c, x_own_v, self.x_local, compress=self.compress)
             return layer(self.x_local, self.node_type_local, self.edge_index, self.edge_type, self.edge_time,
                          plan=self.plan, n_q_rows=self.n_own, phase_events=phase_events, workspace=self.workspace)
+        if bucketed:
+            S, C = self.n_buckets, self.halo.n_chunks
+            args = (self.x_local, self.node_type_local, self.edge_index, self.edge_type_bucketed, self.edge_time)
+            kw = dict(plan=self.bucket_plan, n_q_rows=self.n_own, workspace=self.workspace)
+            # every chunk is packed and queued on the links up front: the transfers run back to back on RCCL's stream
+            pending = [self.halo.exchange_chunk(c, x_own_v, self.x_local, async_op=True, compress=self.compress) for c in range(C)]
+            layer(*args, stage=1, slices=(0, S), phase_events=phase_events, **kw)     # Q|K|V of the own rows
+            out = layer(*args, stage=4, slices=(0, S), **kw)                           # edges whose source is an own row
+            for c in range(C):
+                work, bufs = pending[c]
+                work.wait()
+                for b in bufs:
+                    b.record_stream(torch.cuda.current_stream())
+                layer(*args, stage=2, proj=self.chunk_lists[c], slices=(0, S), **kw)   # K|V of the halo rows of chunk c
+                out = layer(*args, stage=4, slices=(c + 1, S), phase_events=phase_events if c == C - 1 else None, **kw)
+            return out
         # pipelined: chunk c+1 is packed and put on the links while chunk c's halo rows are projected
         args = (self.x_local, self.node_type_local, self.edge_index, self.edge_type, self.edge_time)
         kw = dict(plan=self.plan, n_q_rows=self.n_own, workspace=self.workspace)

@@ -58,6 +58,13 @@ def _worker(rank, world, port, N, E, d, T, R, H, offsets, tmpdir, n_chunks=1):
             for t in range(T):
                 assert (hp.node_type_local[rows[off[t]:off[t + 1]].long()] == t).all()
             seen.append(rows.long())
+        # source buckets of the bucketed edge phase: 0 <=> own source, 1 + c <=> the source row arrives with chunk c
+        bucket = hp.edge_buckets()
+        assert bucket.shape == hp.src_local.shape and int(bucket.min()) >= 0 and int(bucket.max()) <= n_chunks
+        assert torch.equal(bucket == 0, hp.src_local < hp.n_own)
+        for c in range(n_chunks):
+            a, b = hp.n_own + hp.recv_chunk_off[c], hp.n_own + hp.recv_chunk_off[c + 1]
+            assert torch.equal(bucket == c + 1, (hp.src_local >= a) & (hp.src_local < b))
         seen = torch.cat(seen)
         valid = (hp.node_type_local[hp.n_own:] >= 0) & (hp.node_type_local[hp.n_own:] < T)
         assert torch.equal(torch.sort(seen).values, hp.n_own + valid.nonzero(as_tuple=True)[0])

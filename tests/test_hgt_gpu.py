@@ -804,12 +804,14 @@ def test_c24_transport_format_round_trip():
     assert torch.equal(back[0, :4], x[0, :4])
 
 
-@pytest.mark.parametrize("precision,compress", [("fp32", False), ("bf16x3", False), ("bf16x3", True)])
-def test_pipelined_partitioned_forward_with_real_halos(precision, compress, tmp_path):
+@pytest.mark.parametrize("precision,compress,bucketed", [("fp32", False, None), ("bf16x3", False, None), ("bf16x3", True, None),
+                                                         ("bf16x3", False, False)])
+def test_pipelined_partitioned_forward_with_real_halos(precision, compress, bucketed, tmp_path):
     """The multi-GPU step of pyhgt_amd/dist.py (chunked exchange + hgt_conv_forward stages 1/2/3) on ONE GPU: the halo
     plans of a 3-rank partition are negotiated over gloo in CPU worker processes, every rank's pipelined forward then
     runs on the device with the all-to-all replaced by a copy out of the global feature table, and the stitched outputs
-    must equal the oracle on the whole graph."""
+    must equal the oracle on the whole graph.  bucketed=None: the source-bucketed edge phase (stages 1/2/4) wherever it applies
+    (split-bf16 precision); False: the edge phase after the last chunk (stages 1/2/3)."""
     import socket
     import torch.multiprocessing as mp
     from pyhgt_amd.dist import PartitionedGraph
@@ -840,12 +842,56 @@ def test_pipelined_partitioned_forward_with_real_halos(precision, compress, tmp_
             return (_Done(), (x_local[:0],)) if async_op else None
         hp.exchange_chunk = fake_exchange
         pg = PartitionedGraph(None, None, (ei[1][mine] - lo).to(DEV), et[mine].to(DEV), tm[mine].to(DEV), T, R, 0, rank, world,
-                              node_offsets=offsets, halo=hp, compress=compress)
+                              node_offsets=offsets, halo=hp, compress=compress, bucketed=bucketed)
+        assert pg.bucketed == (bucketed is None) and (pg.bucket_plan is not None) == pg.bucketed
         GraphPlan.clear_cache()
         with torch.no_grad():
             out = pg.forward(layer, xg[lo:hi].contiguous())
         assert out.shape == (hi - lo, d)
         assert (out.cpu().double() - ref[lo:hi]).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("use_rte,n_slices,N,E", [(False, 4, 70000, 700000), (True, 3, 70000, 500000), (True, 5, 3000, 40000)])
+def test_bucketed_edge_phase_matches_one_call_layer(use_rte, n_slices, N, E):
+    """hgt_conv_forward stage 4: the edges are bucketed by source-row range, relation ids become
+    bucket * R + relation, and the edge phase runs bucket by bucket with the softmax state carried in the workspace.  The result
+    must agree with the one-call layer to the split-bf16 bound (<= 5e-5: a (target, relation) partial sum is rounded to bf16 hi/mid
+    once per BUCKET here and once per relation there, so the 2^-17-relative rounding points differ; the softmax merge itself is
+    exact up to fp32 rounding) and with the fp64 oracle like every other path (TOL) -- with hub targets (> 1024 in-edges, processed with the last
+    bucket), unclaimed edges, unknown node types, targets whose edges all sit in one bucket and targets with none."""
+    T, R, H, d = 3, 4, 8, 256
+    sd = O.make_state_dict(d, d, T, R, H, True, use_rte, seed=41)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=42, sorted_types=False)
+    nt, ei, et = nt.clone(), ei.clone(), et.clone()
+    ei[1, :3000] = 5                       # a hub target
+    ei[1, 3000:3040] = 9                   # a target all of whose edges come from one source range
+    ei[0, 3000:3040] = torch.arange(40) % 7
+    et[::11] = R + 2                       # edges no relation claims
+    nt[::17] = T                           # nodes of no known type
+    x[:, :] *= 3.0                         # wider logit range: the partial references of the buckets differ
+    layer = _layer_from(sd, d, T, R, H, True, use_rte, keep_att=True, precision="bf16x3")
+    xd, ntd, eid, etd, tmd = _to_dev(x, nt, ei, et, tm)
+    GraphPlan.clear_cache()
+    with torch.no_grad():
+        ref = layer(xd, ntd, eid, etd, tmd).clone()
+        att_ref = layer.att.clone()
+    bucket = (ei[0] * n_slices // N).clamp(max=n_slices - 1)
+    claimed = (et >= 0) & (et < R)
+    et_b = torch.where(claimed, bucket * R + et, torch.full_like(et, n_slices * R)).to(DEV)
+    plan = GraphPlan(ntd, eid, et_b, tmd, T, n_slices * R)
+    ws = torch.empty(layer.workspace_bytes(N, E, n_slices), dtype=torch.uint8, device=DEV)
+    with torch.no_grad():
+        kw = dict(plan=plan, workspace=ws)
+        assert layer(xd, ntd, eid, et_b, tmd, stage=1, slices=(0, n_slices), **kw) is None
+        for b in range(n_slices):
+            out = layer(xd, ntd, eid, et_b, tmd, stage=4, slices=(b, n_slices), **kw)
+            assert (out is None) == (b < n_slices - 1)
+    torch.cuda.synchronize()
+    assert (out - ref).abs().max().item() <= 5e-5
+    datt = (layer.att - att_ref).abs()
+    assert datt.max().item() <= 1e-5      # fp32 summation order of the softmax denominators (3000-term hub sums)
+    fwd = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm if use_rte else None, use_norm=True, use_RTE=use_rte)
+    assert (out.cpu().double() - fwd).abs().max().item() < TOL
 
 
 def test_forward_is_hip_graph_capturable():

@@ -9,6 +9,7 @@ HGT_BENCH_DEVICE=0 HGT_BENCH_BACKEND=gloo timeout 600 python -m torch.distribute
 python tools/fuzz_parity.py 80 > gpurun_out/fuzz_r2e.log 2>&1; tail -1 gpurun_out/fuzz_r2e.log; grep -c FAIL gpurun_out/fuzz_r2e.log
 python tools/fuzz_parity.py 16 big > gpurun_out/fuzz_big_r2e.log 2>&1; tail -1 gpurun_out/fuzz_big_r2e.log
 tools/profile_pmc.sh r02 > gpurun_out/prof_r02.log 2>&1
+python tools/bench_small.py > gpurun_out/bench_small_r2e.log 2>&1; tail -1 gpurun_out/bench_small_r2e.log
 tail -12 gpurun_out/pytest_r2e.log
 for f in gpurun_out/bench_r2e*.json; do python - "$f" <<'PY'
 import json,sys
