@@ -28,8 +28,11 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef HGT_FU_NSTG
+#define HGT_FU_NSTG 2     // W_a fragment stages of the fused epilogue (hgt_fused_update.h)
+#endif
 #ifndef HGT_AGG_GS
-#define HGT_AGG_GS 4      // column-tile steps whose fragments are requested together at a relation end (8 loads in flight)
+#define HGT_AGG_GS 8      // column-tile steps whose fragments are requested together at a relation end (16 loads in flight)
 #endif
 #ifndef HGT_AGG_HIDDEN
 #define HGT_AGG_HIDDEN 0     // experiment switch (see agg_mfma_stream): row gathers hidden from hipcc, hand-counted waits
@@ -335,7 +338,13 @@ __device__ __forceinline__ void agg_mfma_stream(
     int64_t row0, unsigned char* utile, float* s_m, float* s_l, float* s_sc, int raw, f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
     using G = MG<VEC, LPH>;
     constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS;
-    constexpr int UN = RTE ? 4 : 8;    // rows per batch; two batches (register buffers A / B) are in flight
+#ifndef HGT_AGG_UN
+#define HGT_AGG_UN 4
+#endif
+#ifndef HGT_AGG_UN_RTE
+#define HGT_AGG_UN_RTE 3
+#endif
+    constexpr int UN = RTE ? HGT_AGG_UN_RTE : HGT_AGG_UN;    // rows per batch; two batches (register buffers A / B) are in flight
     const int hg = blockIdx.y;
     const int64_t ld = (int64_t)HT * DKP;
     const int co = hg * DP;
@@ -861,7 +870,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
             *reinterpret_cast<uint2*>(prow + A_PLANE + c * 32) = mid;
         }
     }
-    fused_update_tail<VEC, 2>(smem, smem + FRONT, row0, NQ, fu);
+    fused_update_tail<VEC, HGT_FU_NSTG>(smem, smem + FRONT, row0, NQ, fu);
 }
 
 template <int VEC, int LPH>

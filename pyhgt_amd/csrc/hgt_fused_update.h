@@ -101,6 +101,8 @@ __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned 
             // The sched barriers pin "next A -> 12 MFMAs -> refill of the consumed stage" (see k_typed_linear_pc: left alone,
             // hipcc sinks the loads next to their uses and every wait becomes a wait for a load that was just issued).
             bf16x8 s0h0, s0h1, s0m0, s0m1, s1h0, s1h1, s1m0, s1m1, s2h0, s2h1, s2m0, s2m1, s3h0, s3h1, s3m0, s3m1;
+            bf16x8 s4h0, s4h1, s4m0, s4m1, s5h0, s5h1, s5m0, s5m1, s6h0, s6h1, s6m0, s6m1, s7h0, s7h1, s7m0, s7m1;   // (NSTG == 8 only)
+            constexpr int NST = (NSTG == 8 && NKC % 8 != 0) ? 4 : NSTG;      // eight stages need a multiple of eight k-chunks
             bf16x8 e_h0, e_m0, e_h1, e_m1, o_h0, o_m0, o_h1, o_m1;
 #define FU_LOAD_B(S, KCI)                                                                            \
     {                                                                                                \
@@ -133,7 +135,7 @@ __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned 
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##h0, acc[0][1], 0, 0, 0);                 \
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##h1, acc[1][0], 0, 0, 0);                 \
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##h1, acc[1][1], 0, 0, 0);                 \
-        FU_LOAD_B(S, (KCI) + NSTG)                                                                                 \
+        FU_LOAD_B(S, (KCI) + NST)                                                                                  \
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  /* 4 DS reads   */                                     \
         __builtin_amdgcn_sched_group_barrier(0x008, 12, 0); /* 12 MFMAs     */                                     \
         __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);  /* 4 VMEM reads */                                     \
@@ -141,13 +143,28 @@ __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned 
     }
             FU_LOAD_B(0, 0)
             FU_LOAD_B(1, 1)
-            if constexpr (NSTG == 4) {
+            if constexpr (NST >= 4) {
                 FU_LOAD_B(2, 2)
                 FU_LOAD_B(3, 3)
             }
+            if constexpr (NST == 8) {
+                FU_LOAD_B(4, 4)
+                FU_LOAD_B(5, 5)
+                FU_LOAD_B(6, 6)
+                FU_LOAD_B(7, 7)
+            }
             FU_LOAD_A(e, 0)
-            for (int kq = 0; kq < NKC; kq += 4) {
-                if constexpr (NSTG == 4) {
+            for (int kq = 0; kq < NKC; kq += (NST == 8 ? 8 : 4)) {
+                if constexpr (NST == 8) {
+                    FU_STEP(0, kq, e, o)
+                    FU_STEP(1, kq + 1, o, e)
+                    FU_STEP(2, kq + 2, e, o)
+                    FU_STEP(3, kq + 3, o, e)
+                    FU_STEP(4, kq + 4, e, o)
+                    FU_STEP(5, kq + 5, o, e)
+                    FU_STEP(6, kq + 6, e, o)
+                    FU_STEP(7, kq + 7, o, e)
+                } else if constexpr (NST == 4) {
                     FU_STEP(0, kq, e, o)
                     FU_STEP(1, kq + 1, o, e)
                     FU_STEP(2, kq + 2, e, o)

@@ -254,7 +254,8 @@ __global__ void k_sorted_scatter(const int32_t* __restrict__ src, const int32_t*
     int s = src[i], d = dst[i];
     if (s < 0 || s >= N || d < 0 || d >= NQ) { atomicOr(&hdr->bad_index, 1); s = max(0, min(s, (int)N - 1)); d = max(0, min(d, (int)NQ - 1)); }
     const int64_t j = (int64_t)(d / HGT_TD) * (R + 1) + r;
-    const int p = base[j] + ((int)i - lb[j]);
+    int p = base[j] + ((int)i - lb[j]);
+    if (p < 0 || p >= E) { atomicOr(&hdr->bad_index, 1); p = (int)i; }   // (only with malformed input: unsorted targets / ids out of range)
     int ts = 0;
     while (ts + 1 < T && type_off[ts + 1] <= s) ++ts;
     int tm = etime ? etime[i] : 0;
@@ -297,6 +298,129 @@ __global__ __launch_bounds__(1024) void k_scan2_single(const int32_t* __restrict
     }
     int ra = sa[tid] - ta, rb = sb[tid] - tb;
     for (int64_t i = beg; i < end; ++i) { oa[i] = ra; ob[i] = rb; ra += a[i]; rb += b[i]; }
+}
+
+// ---- small graphs (the reference's sampled batches): the same plan in three launches instead of seven ----
+// (a) ONE workgroup: typed row lists, per-pair lower bounds / counts, both exclusive scans (the pair table fits in LDS)
+constexpr int SMALL_PAIRS = 4096;     // (n_pairs + 1) <= SMALL_PAIRS: 4 table entries per thread of a 1024-thread workgroup
+__global__ __launch_bounds__(1024) void k_sorted_small_head(
+    const int32_t* __restrict__ dst, const int32_t* __restrict__ rel_ptr, const int32_t* __restrict__ type_off, int64_t N, int64_t NQ,
+    int T, int R, int n_pairs, int ch, int32_t* __restrict__ lb, int32_t* __restrict__ cnt, int32_t* __restrict__ base,
+    int32_t* __restrict__ pair_off, int32_t* __restrict__ rows_all, int32_t* __restrict__ off_all, int32_t* __restrict__ rows_q,
+    int32_t* __restrict__ off_q, HgtPlanHeader* hdr) {
+    __shared__ int s_lb[SMALL_PAIRS + 1];
+    __shared__ int s_a[1024], s_b[1024];
+    const int tid = threadIdx.x;
+    if (tid == 0) { hdr->n_items = 0; hdr->bad_index = 0; hdr->n_hubs = 0; }
+    for (int64_t n = tid; n < N; n += 1024) { rows_all[n] = (int32_t)n; rows_q[n] = (int32_t)n; }
+    if (tid <= T + 1) {
+        const int32_t v = (tid <= T) ? type_off[tid] : (int32_t)N;
+        off_all[tid] = v;
+        off_q[tid] = (int32_t)min((int64_t)v, NQ);
+    }
+    // lower bound of every (tile, relation) pair: ONE binary search per pair; its end is the next tile's lower bound
+    for (int j = tid; j < n_pairs; j += 1024) {
+        const int r = j % (R + 1), tile = j / (R + 1);
+        int l0 = 0;
+        if (r < R) l0 = lower_bound_i32(dst, rel_ptr[r], rel_ptr[r + 1], tile * HGT_TD);
+        s_lb[j] = l0;
+    }
+    __syncthreads();
+    // thread t owns the contiguous entries [4t, 4t + 4) of the pair table (entry n_pairs = the end sentinel, count 0)
+    int c[4], ic[4], ta = 0, tb = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = 4 * tid + u;
+        c[u] = 0;
+        if (j < n_pairs) {
+            const int r = j % (R + 1);
+            if (r < R) {
+                const int l1 = (j + R + 1 < n_pairs) ? s_lb[j + R + 1] : rel_ptr[r + 1];
+                c[u] = l1 - s_lb[j];
+            }
+        }
+        ic[u] = (c[u] + ch - 1) / ch;
+        ta += c[u];
+        tb += ic[u];
+    }
+    s_a[tid] = ta; s_b[tid] = tb;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int va = tid >= o ? s_a[tid - o] : 0, vb = tid >= o ? s_b[tid - o] : 0;
+        __syncthreads();
+        s_a[tid] += va; s_b[tid] += vb;
+        __syncthreads();
+    }
+    int ra = s_a[tid] - ta, rb = s_b[tid] - tb;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = 4 * tid + u;
+        if (j <= n_pairs) {
+            lb[j] = (j < n_pairs) ? s_lb[j] : 0;
+            cnt[j] = c[u];
+            base[j] = ra;
+            pair_off[j] = rb;
+        }
+        ra += c[u];
+        rb += ic[u];
+    }
+}
+
+// (b) ONE wide launch: blocks [0, nb_e) scatter the edges, [nb_e, nb_e + nb_b) write segptr, the rest cut the work items
+//     (an item range comes from base / cnt, not from segptr, so that the three roles only depend on launch (a))
+__global__ void k_sorted_small_body(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, const int32_t* __restrict__ etime,
+                                    const int32_t* __restrict__ rel_ptr, const int32_t* __restrict__ type_off,
+                                    const int32_t* __restrict__ lb, const int32_t* __restrict__ cnt, const int32_t* __restrict__ base,
+                                    const int32_t* __restrict__ pair_off, int64_t E, int T, int R, int64_t N, int64_t NQ, int64_t n_bins,
+                                    int n_pairs, int ch, unsigned nb_e, unsigned nb_b, int32_t* __restrict__ esrc,
+                                    int32_t* __restrict__ edst, uint16_t* __restrict__ ertei, int32_t* __restrict__ eid,
+                                    int32_t* __restrict__ segptr, HgtItem* __restrict__ items, int32_t* __restrict__ tile_items,
+                                    HgtPlanHeader* hdr) {
+    if (blockIdx.x < nb_e) {
+        const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= E) return;
+        int r = 0;
+        while (r + 1 < R && rel_ptr[r + 1] <= i) ++r;
+        int s = src[i], d = dst[i];
+        if (s < 0 || s >= N || d < 0 || d >= NQ) { atomicOr(&hdr->bad_index, 1); s = max(0, min(s, (int)N - 1)); d = max(0, min(d, (int)NQ - 1)); }
+        const int64_t j = (int64_t)(d / HGT_TD) * (R + 1) + r;
+        int p = base[j] + ((int)i - lb[j]);
+        if (p < 0 || p >= E) { atomicOr(&hdr->bad_index, 1); p = (int)i; }   // (only with malformed input: unsorted targets / ids out of range)
+        int ts = 0;
+        while (ts + 1 < T && type_off[ts + 1] <= s) ++ts;
+        int tm = etime ? etime[i] : 0;
+        if (tm < 0 || tm >= HGT_RTE_LEN) { atomicOr(&hdr->bad_index, 2); tm = tm < 0 ? 0 : HGT_RTE_LEN - 1; }
+        esrc[p] = s;
+        edst[p] = d;
+        ertei[p] = (uint16_t)(ts * HGT_RTE_LEN + tm);
+        eid[p] = (int32_t)i;
+    } else if (blockIdx.x < nb_e + nb_b) {
+        const int64_t b = (int64_t)(blockIdx.x - nb_e) * blockDim.x + threadIdx.x;
+        if (b > n_bins) return;
+        if (b == n_bins) { segptr[b] = (int32_t)E; return; }
+        const int64_t j = b / HGT_TD;
+        const int dl = (int)(b % HGT_TD);
+        const int64_t tile = j / (R + 1);
+        const int l0 = lb[j], c = cnt[j];
+        const int pos = (c == 0) ? l0 : lower_bound_i32(dst, l0, l0 + c, (int)(tile * HGT_TD + dl));
+        segptr[b] = base[j] + (pos - l0);
+    } else {
+        const int64_t j = (int64_t)(blockIdx.x - nb_e - nb_b) * blockDim.x + threadIdx.x;
+        if (j > n_pairs) return;
+        if (j % (R + 1) == 0) tile_items[j / (R + 1)] = pair_off[j];
+        if (j == n_pairs) { hdr->n_items = pair_off[n_pairs]; return; }
+        const int32_t beg = base[j], end = beg + cnt[j];
+        int32_t o = pair_off[j];
+        const int32_t rel = (int32_t)(j % (R + 1)), tile = (int32_t)(j / (R + 1));
+        for (int32_t b = beg; b < end; b += ch) {
+            HgtItem it;
+            it.beg = b;
+            it.end = (b + ch < end) ? b + ch : end;
+            it.rel = rel;
+            it.tile = tile;
+            items[o++] = it;
+        }
+    }
 }
 
 static inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
@@ -454,6 +578,19 @@ extern "C" int hgt_plan_from_sorted(const int32_t* src, const int32_t* dst, cons
     int32_t* pair_off = (int32_t*)(tb + 4 * stride);
     const int BS = 256;
     const int ch = hgt_item_edges(E);
+    if (L.n_pairs + 1 <= SMALL_PAIRS && N <= 262144 && T + 2 <= 1024) {
+        // sampled-batch sizes: three launches (pair table + scans in one workgroup; scatter + segptr + items side by side; hubs)
+        k_sorted_small_head<<<1, 1024, 0, stream>>>(dst, rel_ptr, type_off, N, NQ, T, R, (int)L.n_pairs, ch, lb, cnt, base, pair_off,
+                                                    (int32_t*)(pb + L.off_rows_all), (int32_t*)(pb + L.off_off_all),
+                                                    (int32_t*)(pb + L.off_rows_q), (int32_t*)(pb + L.off_off_q), hdr);
+        const unsigned nb_e = nblk(E, BS), nb_b = nblk(L.n_bins + 1, BS), nb_i = nblk(L.n_pairs + 1, BS);
+        k_sorted_small_body<<<nb_e + nb_b + nb_i, BS, 0, stream>>>(src, dst, edge_time, rel_ptr, type_off, lb, cnt, base, pair_off, E, T, R, N,
+                                                                  NQ, L.n_bins, (int)L.n_pairs, ch, nb_e, nb_b, esrc, edst, ertei, eid, segptr,
+                                                                  items, tile_items, hdr);
+        if (N > 0) k_hub_detect<<<nblk(N, BS), BS, 0, stream>>>(segptr, N, R, (int32_t*)(pb + L.off_hub_slot), (int32_t*)(pb + L.off_hub_list), hdr);
+        HGT_CHECK_LAUNCH();
+        return HGT_OK;
+    }
     k_sorted_rows<<<nblk(std::max<int64_t>(N, T + 2), BS), BS, 0, stream>>>(type_off, N, NQ, T, (int32_t*)(pb + L.off_rows_all),
                                                                            (int32_t*)(pb + L.off_off_all), (int32_t*)(pb + L.off_rows_q),
                                                                            (int32_t*)(pb + L.off_off_q), hdr);
