@@ -857,6 +857,12 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
 #pragma unroll
         for (int c = 0; c < G::NCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};   // rows beyond NQ: gelu(0) = 0
     }
+    // row types for the epilogue, requested before the barrier: the round trip overlaps the wait for the slowest wavefront
+    int type_pre = -1;
+    if (wib == 0 && row0 + lane < NQ) {
+        const int64_t t = fu.node_type[row0 + lane];
+        type_pre = (t >= 0 && t < fu.n_types) ? (int)t : -1;
+    }
     __syncthreads();   // every wavefront is done with its U tile and its softmax state: the A slab overlays them
     {
         // accumulator layout -> A slab: target (lane & 15) of this wavefront, columns 16 c + 4 (lane >> 4) .. + 3
@@ -870,64 +876,54 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
             *reinterpret_cast<uint2*>(prow + A_PLANE + c * 32) = mid;
         }
     }
-    fused_update_tail<VEC, HGT_FU_NSTG>(smem, smem + FRONT, row0, NQ, fu);
+    fused_update_tail<VEC, HGT_FU_NSTG, true>(smem, smem + FRONT, row0, NQ, fu, type_pre);
 }
 
-template <int VEC, int LPH>
-struct LaunchAggMfma {
-    static int run(const HgtPlanView& pv, const float* logits, const float* V, const float* rteV, const float* msgP,
-                   const unsigned short* msgF, float* agg, int R, int64_t NQ, int apply_gelu, int HT, HgtHubBuffers hb, int64_t ld_out,
-                   HgtRelSlice sl, hipStream_t stream) {
-        if constexpr (VEC <= 4) {
-            // small graphs (the reference's sampled subgraphs): 4 instead of 16 targets per wavefront -> 4x the wavefronts
-            const int sub = (NQ < 65536) ? 4 : HGT_SUB;
-            const int64_t tiles = (NQ + 4 * sub - 1) / (4 * sub);
-            const unsigned ny = (unsigned)(HT / (64 / LPH));
-            dim3 grid((unsigned)tiles, ny);
-            const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
-            if (rteV)
-                k_edge_aggregate_mfma<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
-                                                                               agg, R, NQ, apply_gelu, HT, hub_slot, sub, ld_out, sl);
-            else
-                k_edge_aggregate_mfma<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
-                                                                                agg, R, NQ, apply_gelu, HT, hub_slot, sub, ld_out, sl);
-            if (hb.mx && !sl.more)   // hub targets take all their relations at once, after the last slice
-                return hgt_launch_hub(VEC, LPH, pv, logits, V, rteV, msgP, agg, R, NQ, apply_gelu, HT, hb, ny, ld_out, stream);
-            return HGT_OK;
-        } else {
-            return HGT_ERR_UNSUPPORTED;
-        }
-    }
-};
+// ---------------------------------------------------------------------------------------------
+// Launchers.  This file is compiled SEVEN times (csrc/Makefile): once as the main translation unit (C entry points, dispatch) and
+// once per (VEC, RTE) PART, which instantiates the kernels of its five lane layouts -- the 30 x 2 kernel instantiations are then
+// built in parallel instead of in one eight-minute hipcc run.  -DHGT_MFMA_PART_VEC=v -DHGT_MFMA_PART_RTE=r selects a part.
+// ---------------------------------------------------------------------------------------------
+#define HGT_MFMA_AGG_ARGS                                                                                                         \
+    const HgtPlanView &pv, const float *logits, const float *V, const float *rteV, const float *msgP, const unsigned short *msgF,  \
+        float *agg, int R, int64_t NQ, int apply_gelu, int HT, HgtHubBuffers hb, int64_t ld_out, HgtRelSlice sl, hipStream_t stream
+#define HGT_MFMA_AGGUPD_ARGS                                                                                                      \
+    const HgtPlanView &pv, const float *logits, const float *V, const float *rteV, const float *msgP, const unsigned short *msgF,  \
+        float *agg, int R, int64_t NQ, int HT, HgtHubBuffers hb, int32_t *pending, HgtFusedUpdate fu, hipStream_t stream
 
-template <int VEC, int LPH>
-struct LaunchAggUpdateMfma {
-    static int run(const HgtPlanView& pv, const float* logits, const float* V, const float* rteV, const float* msgP,
-                   const unsigned short* msgF, float* agg, int R, int64_t NQ, int HT, HgtHubBuffers hb, int32_t* pending,
-                   HgtFusedUpdate fu, hipStream_t stream) {
-        if constexpr (VEC <= 4) {
-            if (HT != 64 / LPH) return HGT_ERR_UNSUPPORTED;   // a head-group split leaves a workgroup with part of the row
-            if (R >= 64) return HGT_ERR_UNSUPPORTED;          // the streaming walk keeps the R + 1 ranges in lane registers
-            const int64_t tiles = (NQ + 63) / 64;
-            dim3 grid((unsigned)tiles, 1);
-            const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
-            if (rteV)
-                k_edge_aggregate_update_mfma<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV,
-                                                                                      msgF, agg, R, NQ, HT, hub_slot, pending, fu);
-            else
-                k_edge_aggregate_update_mfma<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV,
-                                                                                       msgF, agg, R, NQ, HT, hub_slot, pending, fu);
-            if (hb.mx) {   // hub path + the update of the workgroups that had to wait for it
-                int rc = hgt_launch_hub(VEC, LPH, pv, logits, V, rteV, msgP, agg, R, NQ, 1, HT, hb, 1u, (int64_t)HT * (VEC * LPH), stream);
-                if (rc != HGT_OK) return rc;
-                k_update_pending<VEC><<<grid, 256, 0, stream>>>(agg, (int64_t)HT * (VEC * LPH), NQ, pending, fu);
-            }
-            return HGT_OK;
-        } else {
-            return HGT_ERR_UNSUPPORTED;
-        }
+#ifdef HGT_MFMA_PART_VEC
+template <int VEC, int LPH, bool RTE>
+static int launch_agg_mfma(HGT_MFMA_AGG_ARGS) {
+    // small graphs (the reference's sampled subgraphs): 4 instead of 16 targets per wavefront -> 4x the wavefronts
+    const int sub = (NQ < 65536) ? 4 : HGT_SUB;
+    const int64_t tiles = (NQ + 4 * sub - 1) / (4 * sub);
+    const unsigned ny = (unsigned)(HT / (64 / LPH));
+    dim3 grid((unsigned)tiles, ny);
+    const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
+    k_edge_aggregate_mfma<VEC, LPH, RTE><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF, agg, R, NQ,
+                                                                  apply_gelu, HT, hub_slot, sub, ld_out, sl);
+    if (hb.mx && !sl.more)   // hub targets take all their relations at once, after the last slice
+        return hgt_launch_hub(VEC, LPH, pv, logits, V, rteV, msgP, agg, R, NQ, apply_gelu, HT, hb, ny, ld_out, stream);
+    return HGT_OK;
+}
+
+template <int VEC, int LPH, bool RTE>
+static int launch_aggupd_mfma(HGT_MFMA_AGGUPD_ARGS) {
+    if (HT != 64 / LPH) return HGT_ERR_UNSUPPORTED;   // a head-group split leaves a workgroup with part of the row
+    if (R >= 64) return HGT_ERR_UNSUPPORTED;          // the streaming walk keeps the R + 1 ranges in lane registers
+    const int64_t tiles = (NQ + 63) / 64;
+    dim3 grid((unsigned)tiles, 1);
+    const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
+    k_edge_aggregate_update_mfma<VEC, LPH, RTE><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF, agg, R,
+                                                                         NQ, HT, hub_slot, pending, fu);
+    if (hb.mx) {   // hub path + the update of the workgroups that had to wait for it
+        int rc = hgt_launch_hub(VEC, LPH, pv, logits, V, rteV, msgP, agg, R, NQ, 1, HT, hb, 1u, (int64_t)HT * (VEC * LPH), stream);
+        if (rc != HGT_OK) return rc;
+        k_update_pending<VEC><<<grid, 256, 0, stream>>>(agg, (int64_t)HT * (VEC * LPH), NQ, pending, fu);
     }
-};
+    return HGT_OK;
+}
+#endif
 
 // head-group split of the matrix-core kernels: the wave's slice must be <= 256 columns (VEC <= 4): 16 KB of U tile per wave
 static int mfma_split_for(int vec_full, int lph_full) {
@@ -947,6 +943,67 @@ static HgtHubBuffers carve_hub(void* hub_ws, const HgtPlanView& pv, int H, int64
     return hb;
 }
 
+}  // namespace
+
+#define HGT_MFMA_CAT2(a, b, c, d) a##b##c##d
+#define HGT_MFMA_NAME(base, v, r) HGT_MFMA_CAT2(base, v, r_, r)
+// hgt_mfma_agg_v<VEC>r_<RTE>(lph, ...), hgt_mfma_aggupd_v<VEC>r_<RTE>(lph, ...): one pair per part
+#define HGT_MFMA_DECL(v, r)                                             \
+    __attribute__((visibility("hidden"))) int HGT_MFMA_NAME(hgt_mfma_agg_v, v, r)(int lph, HGT_MFMA_AGG_ARGS); \
+    __attribute__((visibility("hidden"))) int HGT_MFMA_NAME(hgt_mfma_aggupd_v, v, r)(int lph, HGT_MFMA_AGGUPD_ARGS);
+HGT_MFMA_DECL(1, 0) HGT_MFMA_DECL(1, 1) HGT_MFMA_DECL(2, 0) HGT_MFMA_DECL(2, 1) HGT_MFMA_DECL(4, 0) HGT_MFMA_DECL(4, 1)
+
+#ifdef HGT_MFMA_PART_VEC
+// ------------------------------------------------------------------------------------------------ a (VEC, RTE) part
+#ifdef HGT_DEV_LAYOUTS   // development builds: d = 256 / 8 heads and d = 64 / 4 heads only
+#define HGT_MFMA_LPH_CASES(F) \
+    if ((HGT_MFMA_PART_VEC == 4 && lph == 8)) return F(8); \
+    if ((HGT_MFMA_PART_VEC == 1 && lph == 16)) return F(16);
+#else
+#define HGT_MFMA_LPH_CASES(F) \
+    if (lph == 4) return F(4);  \
+    if (lph == 8) return F(8);  \
+    if (lph == 16) return F(16); \
+    if (lph == 32) return F(32); \
+    if (lph == 64) return F(64);
+#endif
+int HGT_MFMA_NAME(hgt_mfma_agg_v, HGT_MFMA_PART_VEC, HGT_MFMA_PART_RTE)(int lph, HGT_MFMA_AGG_ARGS) {
+#define HGT_MFMA_F(L) \
+    launch_agg_mfma<HGT_MFMA_PART_VEC, L, (HGT_MFMA_PART_RTE != 0)>(pv, logits, V, rteV, msgP, msgF, agg, R, NQ, apply_gelu, HT, hb, ld_out, sl, stream)
+    HGT_MFMA_LPH_CASES(HGT_MFMA_F)
+#undef HGT_MFMA_F
+    return HGT_ERR_UNSUPPORTED;
+}
+int HGT_MFMA_NAME(hgt_mfma_aggupd_v, HGT_MFMA_PART_VEC, HGT_MFMA_PART_RTE)(int lph, HGT_MFMA_AGGUPD_ARGS) {
+#define HGT_MFMA_F(L) \
+    launch_aggupd_mfma<HGT_MFMA_PART_VEC, L, (HGT_MFMA_PART_RTE != 0)>(pv, logits, V, rteV, msgP, msgF, agg, R, NQ, HT, hb, pending, fu, stream)
+    HGT_MFMA_LPH_CASES(HGT_MFMA_F)
+#undef HGT_MFMA_F
+    return HGT_ERR_UNSUPPORTED;
+}
+#else
+// ------------------------------------------------------------------------------------------------ the main translation unit
+namespace {
+int mfma_agg_dispatch(int vec, int lph, HGT_MFMA_AGG_ARGS) {
+#define HGT_MFMA_CALL(v) \
+    return rteV ? hgt_mfma_agg_v##v##r_1(lph, pv, logits, V, rteV, msgP, msgF, agg, R, NQ, apply_gelu, HT, hb, ld_out, sl, stream) \
+                : hgt_mfma_agg_v##v##r_0(lph, pv, logits, V, rteV, msgP, msgF, agg, R, NQ, apply_gelu, HT, hb, ld_out, sl, stream);
+    if (vec == 1) { HGT_MFMA_CALL(1) }
+    if (vec == 2) { HGT_MFMA_CALL(2) }
+    if (vec == 4) { HGT_MFMA_CALL(4) }
+#undef HGT_MFMA_CALL
+    return HGT_ERR_UNSUPPORTED;      // a wave's slice wider than 256 columns: the vector-ALU kernel
+}
+int mfma_aggupd_dispatch(int vec, int lph, HGT_MFMA_AGGUPD_ARGS) {
+#define HGT_MFMA_CALL(v) \
+    return rteV ? hgt_mfma_aggupd_v##v##r_1(lph, pv, logits, V, rteV, msgP, msgF, agg, R, NQ, HT, hb, pending, fu, stream) \
+                : hgt_mfma_aggupd_v##v##r_0(lph, pv, logits, V, rteV, msgP, msgF, agg, R, NQ, HT, hb, pending, fu, stream);
+    if (vec == 1) { HGT_MFMA_CALL(1) }
+    if (vec == 2) { HGT_MFMA_CALL(2) }
+    if (vec == 4) { HGT_MFMA_CALL(4) }
+#undef HGT_MFMA_CALL
+    return HGT_ERR_UNSUPPORTED;
+}
 }  // namespace
 
 extern "C" int hgt_relation_frag_bytes(int32_t R, int32_t H, int32_t dk_pad, uint64_t* out) {
@@ -999,7 +1056,7 @@ extern "C" int hgt_edge_aggregate(const void* plan, int64_t N, int64_t E, int32_
     int rc = HGT_ERR_UNSUPPORTED;
     const int sp = msg_frag ? mfma_split_for(dk_pad / lph, lph) : 0;
     if (sp != 0)
-        rc = dispatch_layout<LaunchAggMfma>(dk_pad / lph / sp, lph * sp, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
+        rc = mfma_agg_dispatch(dk_pad / lph / sp, lph * sp, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
                                             (int)R, NQ, (int)(apply_gelu ? 1 : 0), (int)H, hb, (int64_t)H * dk_pad, whole,
                                             (hipStream_t)stream);
     if (rc == HGT_ERR_UNSUPPORTED)   // exact-fp32 request (msg_frag == NULL) or a layout only the vector-ALU kernel covers
@@ -1026,7 +1083,7 @@ extern "C" int hgt_edge_aggregate_slice(const void* plan, int64_t N, int64_t E, 
     const HgtRelSlice sl = {(int)rel_lo, (int)rel_hi, state, has_prev ? 1 : 0, more ? 1 : 0};
     const int sp = mfma_split_for(dk_pad / lph, lph);
     if (sp == 0) return HGT_ERR_UNSUPPORTED;
-    int rc = dispatch_layout<LaunchAggMfma>(dk_pad / lph / sp, lph * sp, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
+    int rc = mfma_agg_dispatch(dk_pad / lph / sp, lph * sp, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
                                             (int)R, NQ, (int)(apply_gelu ? 1 : 0), (int)H, hb, (int64_t)H * dk_pad, sl, (hipStream_t)stream);
     if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();
@@ -1055,7 +1112,7 @@ extern "C" int hgt_edge_aggregate_update(const void* plan, int64_t N, int64_t E,
     HgtFusedUpdate fu = {node_type, (const unsigned short*)w_a_split, b_a, x_skip, ld_skip, skip, ln_w, ln_b, use_norm, T, n_out, out};
     int rc = HGT_ERR_UNSUPPORTED;
     if (msg_frag && mfma_split_for(dk_pad / lph, lph) == 1)
-        rc = dispatch_layout<LaunchAggUpdateMfma>(dk_pad / lph, lph, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
+        rc = mfma_aggupd_dispatch(dk_pad / lph, lph, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
                                                   (int)R, NQ, (int)H, hb, pending, fu, (hipStream_t)stream);
     if (rc == HGT_ERR_UNSUPPORTED && !msg_frag)
         rc = hgt_valu_aggregate_update(pv, dk_pad, logits, V, rte_v, msg_p, agg, (int)R, NQ, (int)H, hb, pending, fu, (hipStream_t)stream);
@@ -1078,9 +1135,10 @@ extern "C" int hgt_edge_spmm(const void* plan, int64_t N, int64_t E, int32_t T, 
     HgtHubBuffers hb = carve_hub(hub_ws, pv, H, E);
     const int sp = mfma_split_for(dk_pad / lph, lph);
     if (sp == 0) return HGT_ERR_UNSUPPORTED;
-    int rc = dispatch_layout<LaunchAggMfma>(dk_pad / lph / sp, lph * sp, pv, weights, rows, rte_rows, f_p, (const unsigned short*)f_frag, out,
+    int rc = mfma_agg_dispatch(dk_pad / lph / sp, lph * sp, pv, weights, rows, rte_rows, f_p, (const unsigned short*)f_frag, out,
                                             (int)R, NQ, 2, (int)H, hb, ld_out, HgtRelSlice{0, (int)R + 1, nullptr, 0, 0}, (hipStream_t)stream);
     if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }
+#endif   // main translation unit

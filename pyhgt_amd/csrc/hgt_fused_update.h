@@ -51,9 +51,14 @@ __device__ __forceinline__ void fused_slab_from_rows(const float (&vals)[16][VEC
 // written by every wavefront before this call (no barrier needed in between: the first thing here is one);
 // `tables` = 2.5 KB of LDS for the row types and the LayerNorm partial sums.
 // NSTG = k-chunks of W_a fragments prefetched ahead (4: fastest; 2: 32 registers fewer, for callers that would spill)
-template <int VEC, int NSTG = 4>
+// XPRE: the 16 skip-connection loads of a lane (x rows of the tile) are requested BEFORE the product and consumed after it.
+// Written next to their uses they are conditional loads inside an unrolled loop, and hipcc waits for each one with vmcnt(0)
+// right before its use: 16 dependent HBM round trips per tile, ~30 us of a workgroup's ~125 us at c2 (measured by removing the
+// epilogue: 3.61 -> 2.66 ms) -- the whole cost of the fused epilogue.  Unconditional (clamped) loads ahead of the MFMA loop take one.
+constexpr int FU_NO_TYPE = -0x7fffffff;
+template <int VEC, int NSTG = 4, bool XPRE = false>
 __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned char* tables, int64_t row0, int64_t NQ,
-                                                  const HgtFusedUpdate& fu) {
+                                                  const HgtFusedUpdate& fu, int type_pre = FU_NO_TYPE) {
     constexpr int DP = 64 * VEC;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -61,8 +66,12 @@ __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned 
     float* s_sum = reinterpret_cast<float*>(tables + 256);         // [64][4]
     float* s_var = s_sum + 256;                                    // [64][4]
     if (tid < 64) {
-        const int64_t row = row0 + tid;
-        int64_t t = (row < NQ) ? fu.node_type[row] : -1;
+        // type_pre: the caller requested node_type[row0 + lane] before its own barrier (one round trip off the critical path)
+        int64_t t = type_pre;
+        if (type_pre == FU_NO_TYPE) {
+            const int64_t row = row0 + tid;
+            t = (row < NQ) ? fu.node_type[row] : -1;
+        }
         s_type[tid] = (t >= 0 && t < fu.n_types) ? (int)t : -1;
     }
     __syncthreads();
@@ -95,6 +104,32 @@ __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned 
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.0f;
+        float4 xpre[XPRE ? 16 : 1], bpre[XPRE ? 2 : 1], wpre[XPRE ? 2 : 1], cpre[XPRE ? 2 : 1];
+        float skip_pre = 0.0f;
+        if constexpr (XPRE) {
+            skip_pre = fu.skip[g];
+            int lane_x = lane;
+            asm volatile("" : "+v"(lane_x));            // (keeps the address arithmetic out of the walk, like lane_e below)
+            const int rt0x = (lane_x & 3) + 4 * (lane_x >> 5);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int col = wave * 64 + c * 32 + ((lane_x & 31) >> 2) * 4;
+                const int colc = col < n_out ? col : 0;
+                // bias and LayerNorm rows of this lane's columns as well: loaded where they are used (behind `if (col_ok)`), the
+                // waits for them land inside the store loop as vmcnt(0), which also waits for the previous STORE's acknowledge:
+                // sixteen serialised write round trips per tile (ISA audit)
+                bpre[c] = *reinterpret_cast<const float4*>(fu.bias + (int64_t)g * n_out + colc);
+                const float* lw = fu.use_norm ? fu.lnw : fu.bias;      // (always a valid address; ignored without LayerNorm)
+                const float* lb = fu.use_norm ? fu.lnb : fu.bias;
+                wpre[c] = *reinterpret_cast<const float4*>(lw + (int64_t)g * n_out + colc);
+                cpre[c] = *reinterpret_cast<const float4*>(lb + (int64_t)g * n_out + colc);
+#pragma unroll
+                for (int jq = 0; jq < 8; ++jq) {
+                    const int64_t row = min(row0 + rt0x + 32 * (jq >> 2) + 8 * (jq & 3), NQ - 1);
+                    xpre[c * 8 + jq] = *reinterpret_cast<const float4*>(fu.xs + row * fu.ldxs + colc);
+                }
+            }
+        }
         if (wave * 64 < n_out) {
             const unsigned short* __restrict__ wf = fu.w_split + (int64_t)g * NKC * 2 * W_PLANE_ELEMS + ((2 * wave) * 64 + lane) * 8;
             // B fragments of two column tiles, NSTG k-chunks ahead in named register stages; A fragments one chunk ahead.
@@ -187,7 +222,7 @@ __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned 
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int rt0e = (lane_e & 3) + 4 * (lane_e >> 5);
-        const float alpha = 1.0f / (1.0f + expf(-fu.skip[g]));
+        const float alpha = 1.0f / (1.0f + expf(-(XPRE ? skip_pre : fu.skip[g])));
         float y[16][4];                                // [c*8 + j*4 + q][4 consecutive columns]
         int orow[8];                                   // row of group (j, q); -1 = not a row of this type
 #pragma unroll
@@ -200,7 +235,11 @@ __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned 
             const int col = wave * 64 + c * 32 + ((lane_e & 31) >> 2) * 4;
             const bool col_ok = col < n_out;
             float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col_ok) b4 = *reinterpret_cast<const float4*>(fu.bias + (int64_t)g * n_out + col);
+            if constexpr (XPRE) {
+                if (col_ok) b4 = bpre[c];
+            } else {
+                if (col_ok) b4 = *reinterpret_cast<const float4*>(fu.bias + (int64_t)g * n_out + col);
+            }
 #pragma unroll
             for (int jq = 0; jq < 8; ++jq) {
                 const int j = jq >> 2, q = jq & 3;
@@ -209,7 +248,11 @@ __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned 
                 // (requesting these rows before the workgroup barrier was measured slower: the loads only queue behind the
                 // gathers of the workgroup sharing the CU, and 64 more live registers spill)
                 float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (col_ok && orow[jq] >= 0) xv = *reinterpret_cast<const float4*>(fu.xs + (row0 + orow[jq]) * fu.ldxs + col);
+                if constexpr (XPRE) {
+                    if (col_ok && orow[jq] >= 0) xv = xpre[c * 8 + jq];
+                } else {
+                    if (col_ok && orow[jq] >= 0) xv = *reinterpret_cast<const float4*>(fu.xs + (row0 + orow[jq]) * fu.ldxs + col);
+                }
                 y[c * 8 + jq][0] = col_ok ? (v0 + b4.x) * alpha + xv.x * (1.0f - alpha) : 0.0f;
                 y[c * 8 + jq][1] = col_ok ? (v1 + b4.y) * alpha + xv.y * (1.0f - alpha) : 0.0f;
                 y[c * 8 + jq][2] = col_ok ? (v2 + b4.z) * alpha + xv.z * (1.0f - alpha) : 0.0f;
@@ -251,7 +294,9 @@ __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned 
             const int col = wave * 64 + c * 32 + ((lane_e & 31) >> 2) * 4;
             const bool col_ok = col < n_out;
             float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f), c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (fu.use_norm && col_ok) {
+            if constexpr (XPRE) {
+                if (fu.use_norm && col_ok) { w4 = wpre[c]; c4 = cpre[c]; }
+            } else if (fu.use_norm && col_ok) {
                 w4 = *reinterpret_cast<const float4*>(fu.lnw + (int64_t)g * n_out + col);
                 c4 = *reinterpret_cast<const float4*>(fu.lnb + (int64_t)g * n_out + col);
             }
