@@ -324,6 +324,11 @@ int hgt_gelu_bwd(const float* dg, const float* agg, float* out, int64_t n, void*
 int hgt_mul_inplace(float* x, const float* m, int64_t n, void* stream);
 int hgt_typed_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, const int32_t* rows, const int32_t* group_off,
                     int32_t n_groups, int64_t n_rows, int32_t m, int32_t n_cols, float* out, int64_t out_group_stride, void* stream);
+/* hgt_typed_wgrad as 3-term split-bf16 products (relative error of a product ~3*2^-18, like the forward typed linears); colsum
+ * (optional, [n_groups][colsum_group_stride]) += the column sums of A per group (the bias gradient) from the same pass. */
+int hgt_typed_wgrad_bf16x3(const float* A, int64_t lda, const float* B, int64_t ldb, const int32_t* rows, const int32_t* group_off,
+                           int32_t n_groups, int64_t n_rows, int32_t m, int32_t n_cols, float* out, int64_t out_group_stride,
+                           float* colsum, int64_t colsum_group_stride, void* stream);
 int hgt_typed_colsum(const float* A, int64_t lda, const int32_t* rows, const int32_t* group_off, int32_t n_groups, int64_t n_rows,
                      int32_t m, float* out, int64_t out_group_stride, void* stream);
 

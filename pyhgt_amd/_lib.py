@@ -101,6 +101,7 @@ SIGNATURES = {
     "hgt_gelu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "hgt_mul_inplace": (C.c_int, [_vp, _vp, _i64, _vp]),
     "hgt_typed_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i64, _vp]),
+    "hgt_typed_wgrad_bf16x3": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "hgt_typed_colsum": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _vp, _i64, _vp]),
     "hgt_log_softmax_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "hgt_row_dot": (C.c_int, [_vp, _vp, _i64, _i32, C.c_float, _vp, _vp]),

@@ -67,11 +67,20 @@ class _Ops:
             _chk("hgt_typed_linear", lib.hgt_typed_linear(_p(x), ldx, rows, off, n_groups, n_rows, k, n_out, wp, wgs, bp, bgs,
                                                         o[0], o[1], o[2], block_cols, by_pos, prologue, 0, _st()))
 
-    def wgrad(self, A, lda, B, ldb, rows, off, n_groups, n_rows, m, n_cols):
+    def wgrad(self, A, lda, B, ldb, rows, off, n_groups, n_rows, m, n_cols, with_colsum=False):
+        """dW[g] = A_g^T B_g (and, with_colsum, db[g] = column sums of A_g from the same pass): split-bf16 x3 MFMA kernel for
+        bf16x3 layers, the exact fp32 MFMA kernel (+ the column-sum kernel) otherwise."""
         out = torch.zeros(n_groups, m, n_cols, dtype=torch.float32, device=self.dev)
-        _chk("hgt_typed_wgrad", self.lib.hgt_typed_wgrad(_p(A), lda, _p(B), ldb, rows, off, n_groups, n_rows, m, n_cols, _p(out), m * n_cols,
-                                                       _st()))
-        return out
+        cs = torch.zeros(n_groups, m, dtype=torch.float32, device=self.dev) if with_colsum else None
+        if self.split:
+            _chk("hgt_typed_wgrad_bf16x3", self.lib.hgt_typed_wgrad_bf16x3(_p(A), lda, _p(B), ldb, rows, off, n_groups, n_rows, m, n_cols,
+                                                                         _p(out), m * n_cols, _p(cs), m, _st()))
+        else:
+            _chk("hgt_typed_wgrad", self.lib.hgt_typed_wgrad(_p(A), lda, _p(B), ldb, rows, off, n_groups, n_rows, m, n_cols, _p(out),
+                                                           m * n_cols, _st()))
+            if with_colsum:
+                _chk("hgt_typed_colsum", self.lib.hgt_typed_colsum(_p(A), lda, rows, off, n_groups, n_rows, m, _p(cs), m, _st()))
+        return (out, cs) if with_colsum else out
 
     def colsum(self, A, lda, rows, off, n_groups, n_rows, m):
         out = torch.zeros(n_groups, m, dtype=torch.float32, device=self.dev)
@@ -205,7 +214,8 @@ class _HGTConvTrain(torch.autograd.Function):
         lib = _lib.load()
         T, R, H = layer.num_types, layer.num_relations, layer.n_heads
         ops = _Ops(plan, lay, T, R, H, layer.precision)
-        ops.split = False                                   # gradients on the exact fp32 typed-linear kernel
+        # (data gradients d gelu(agg), dx run on the layer's own typed-linear kernels: split-bf16 x3 by default, relative error
+        #  ~1e-5, two orders below the gradient tolerance; precision='fp32' layers keep the exact kernel)
         N, E, din, dout, dp, dk, dkp = plan.N, plan.E, layer.in_dim, layer.out_dim, lay.d_pad, lay.d_k, lay.dk_pad
         Hr, H = H, lay.heads                                 # model heads / layout heads
         dev = x.device
@@ -231,8 +241,7 @@ class _HGTConvTrain(torch.autograd.Function):
         d_skip = d_alpha * alpha * (1.0 - alpha)
         # a_linear: trans = gelu(agg) W_a^T + b_a
         g = torch.nn.functional.gelu(agg)                                           # exact erf form, conv.py:119
-        d_w_a = ops.wgrad(d_trans, dout, g, dp, rows.rows_q, rows.off_q, T, N, dout, dp)
-        d_b_a = ops.colsum(d_trans, dout, rows.rows_q, rows.off_q, T, N, dout)
+        d_w_a, d_b_a = ops.wgrad(d_trans, dout, g, dp, rows.rows_q, rows.off_q, T, N, dout, dp, with_colsum=True)
         del g
         w_a_t = w_a.transpose(1, 2).contiguous()                                     # [T][dp][dout]
         dg = torch.empty(N, dp, dtype=torch.float32, device=dev)
@@ -295,10 +304,9 @@ class _HGTConvTrain(torch.autograd.Function):
             d_w_qkv_extra = gkv
 
         # ---- projections backward (conv.py:96-97,103)
-        d_w_qkv = ops.wgrad(dqkv, 3 * dp, x, din, rows.rows_all, rows.off_all, T, N, 3 * dp, din)
+        d_w_qkv, d_b_qkv = ops.wgrad(dqkv, 3 * dp, x, din, rows.rows_all, rows.off_all, T, N, 3 * dp, din, with_colsum=True)
         if d_w_qkv_extra is not None:
             d_w_qkv[:, dp:3 * dp, :] += d_w_qkv_extra
-        d_b_qkv = ops.colsum(dqkv, 3 * dp, rows.rows_all, rows.off_all, T, N, 3 * dp)
         dx = None
         if ctx.needs_input_grad[3]:
             w_qkv_t = w_qkv.transpose(1, 2).contiguous()                             # [T][din][3dp]
@@ -349,7 +357,7 @@ class TypedLinearFunction(torch.autograd.Function):
         else:
             _chk("hgt_typed_linear", lib.hgt_typed_linear(_p(x), k, rows, off, n_groups, n, k, n_out, _p(wc), n_out * k, _p(bc), n_out, _p(y), 0, 0,
                                                         n_out, 0, 0, 0, _st()))
-        ctx.plan_rows, ctx.n_groups, ctx.has_bias = plan_rows, n_groups, b is not None
+        ctx.plan_rows, ctx.n_groups, ctx.has_bias, ctx.precision = plan_rows, n_groups, b is not None, precision
         ctx.save_for_backward(x, wc)
         return y
 
@@ -364,11 +372,14 @@ class TypedLinearFunction(torch.autograd.Function):
         n_out = w.shape[1]
         dev = x.device
         dw = torch.zeros(G, n_out, k, dtype=torch.float32, device=dev)
-        _chk("hgt_typed_wgrad", lib.hgt_typed_wgrad(_p(gy), n_out, _p(x), k, rows, off, G, n, n_out, k, _p(dw), n_out * k, _st()))
-        db = None
-        if ctx.has_bias:
-            db = torch.zeros(G, n_out, dtype=torch.float32, device=dev)
-            _chk("hgt_typed_colsum", lib.hgt_typed_colsum(_p(gy), n_out, rows, off, G, n, n_out, _p(db), n_out, _st()))
+        db = torch.zeros(G, n_out, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        if ctx.precision == "bf16x3":
+            _chk("hgt_typed_wgrad_bf16x3", lib.hgt_typed_wgrad_bf16x3(_p(gy), n_out, _p(x), k, rows, off, G, n, n_out, k, _p(dw), n_out * k,
+                                                                    _p(db), n_out, _st()))
+        else:
+            _chk("hgt_typed_wgrad", lib.hgt_typed_wgrad(_p(gy), n_out, _p(x), k, rows, off, G, n, n_out, k, _p(dw), n_out * k, _st()))
+            if ctx.has_bias:
+                _chk("hgt_typed_colsum", lib.hgt_typed_colsum(_p(gy), n_out, rows, off, G, n, n_out, _p(db), n_out, _st()))
         dx = None
         if ctx.needs_input_grad[3]:
             wt = w.transpose(1, 2).contiguous()

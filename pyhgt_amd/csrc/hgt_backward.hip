@@ -16,10 +16,10 @@
 // Everything is enqueued on the caller's stream; small parameter gradients are accumulated with fp32 atomics into
 // caller-zeroed buffers (run-to-run differences of the summation order only).
 #include "hgt_edge_common.h"
+#include "hgt_split_common.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -178,19 +178,20 @@ __global__ void k_gather_sorted(const int32_t* __restrict__ eid, const float* __
     out[i] = in[(int64_t)eid[p] * H + (i % H)];
 }
 
-// rho[n][h] = <a[n][h*dkp .. +dkp], b[n][...]>
+// rho[n][h] = <a[n][h*dkp .. +dkp], b[n][...]>: a thread per 4 consecutive columns (coalesced 16 B loads of both rows), partial
+// dots reduced over the dkp/4 consecutive threads of a head (dkp is a power of two)
 __global__ void k_head_dot(const float* __restrict__ a, const float* __restrict__ b, int64_t n_rows, int H, int dkp, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows * H) return;
-    const float* pa = a + i * dkp;
-    const float* pb = b + i * dkp;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index
+    const int64_t total = n_rows * H * (dkp / 4);
     float s = 0.0f;
-    for (int k = 0; k < dkp; k += 4) {
-        const float4 u = *reinterpret_cast<const float4*>(pa + k);
-        const float4 v = *reinterpret_cast<const float4*>(pb + k);
-        s += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+    if (i < total) {
+        const float4 u = *reinterpret_cast<const float4*>(a + 4 * i);
+        const float4 v = *reinterpret_cast<const float4*>(b + 4 * i);
+        s = u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
     }
-    out[i] = s;
+    const int tph = dkp / 4;                                               // threads per head: 1 .. 64
+    for (int o = 1; o < tph; o <<= 1) s += __shfl_xor(s, o);
+    if (i < total && (i % tph) == 0) out[i / tph] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -260,6 +261,143 @@ __global__ __launch_bounds__(256) void k_typed_wgrad(const float* __restrict__ A
         const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), n = n0 + wn + (lane & 31);
         if (m < M && n < Nc) unsafeAtomicAdd(&o[(int64_t)m * Nc + n], acc[r]);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same weight gradient as 3-term split-bf16 products on v_mfma_f32_32x32x16_bf16 (relative error of a product ~3 * 2^-18, like
+// the forward typed linears): 8x the matrix-core rate of the fp32 instruction and 128 x 128 output tiles, so that A and B are
+// re-read Nc/128 and M/128 times instead of Nc/64 and M/64 (the fp32 kernel above moved 33 GB per training step at c2 = 11 ms).
+// Both MFMA operands need the ROW index along K, i.e. eight consecutive rows of one column per lane: the 32-row chunks of A and B
+// are therefore staged through LDS TRANSPOSED -- a thread reads eight rows of one column (coalesced 256 B per wavefront and row),
+// splits them into bf16 hi / mid and writes one 16 B fragment piece per plane; column stride 80 B: conflict-free writes and reads.
+// The next chunk's rows are in flight (registers) while the current one is multiplied.  Optionally also the column sums of A
+// (bias gradient), from the registers that pass through anyway.
+// ---------------------------------------------------------------------------------------------
+constexpr int WX_T = 128;            // tile edge (columns of A = rows of dW, columns of B)
+constexpr int WX_KR = 32;            // rows per chunk
+constexpr int WX_CS = 80;            // LDS bytes per column: 32 rows x 2 B + 16 B of padding
+constexpr int WX_PLANE = WX_T * WX_CS;
+constexpr int WX_ROWS = 4096;        // rows of one group per workgroup
+
+__global__ __launch_bounds__(256) void k_typed_wgrad_x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                        const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off,
+                                                        int n_groups, int M, int Nc, int n_mt, float* __restrict__ out,
+                                                        int64_t out_group_stride, float* __restrict__ colsum, int64_t cs_group_stride) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * WX_PLANE];   // A hi | A mid | B hi | B mid
+    // tile index fastest: the workgroups that share a row chunk are neighbours in launch order (their rows meet in the L2)
+    const int mt = blockIdx.x % n_mt, nt = blockIdx.x / n_mt;
+    int slot = blockIdx.y, g = 0, gbeg = 0, gend = 0, before = 0;
+    for (; g < n_groups; ++g) {
+        gbeg = group_off[g];
+        gend = group_off[g + 1];
+        const int nch = (gend - gbeg + WX_ROWS - 1) / WX_ROWS;
+        if (slot < before + nch) break;
+        before += nch;
+    }
+    if (g >= n_groups) return;
+    const int p0 = gbeg + (slot - before) * WX_ROWS, p1 = min(p0 + WX_ROWS, gend);
+    const int m0 = mt * WX_T, n0 = nt * WX_T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    // staging role: column c of the tile, row octets o0 and o0 + 2 of the chunk, for A and for B
+    const int c = tid & 127, o0 = tid >> 7;
+    const bool a_ok = m0 + c < M, b_ok = n0 + c < Nc;
+    const float* __restrict__ pa = A + (a_ok ? m0 + c : 0);
+    const float* __restrict__ pb = B + (b_ok ? n0 + c : 0);
+    float va[16], vb[16];
+    int rid[16], rid_next[16];       // row ids of the chunk in flight / of the one after it (no id -> row dependency inside the loop)
+    auto load_ids = [&](int pbase, int (&ids)[16]) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int p = pbase + 8 * (o0 + 2 * (j >> 3)) + (j & 7);
+            ids[j] = (p < p1) ? rows[p] : -1;
+        }
+    };
+    auto load_rows = [&]() {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int64_t r = max(rid[j], 0);
+            va[j] = pa[r * lda];
+            vb[j] = pb[r * ldb];
+        }
+    };
+    float csum = 0.0f;
+    auto commit = [&]() {       // registers -> transposed bf16 hi / mid planes (rows beyond the chunk and columns beyond M / Nc: 0)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float fa[8], fb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool live = rid[half * 8 + j] >= 0;
+                fa[j] = (live && a_ok) ? va[half * 8 + j] : 0.0f;
+                fb[j] = (live && b_ok) ? vb[half * 8 + j] : 0.0f;
+                csum += fa[j];
+            }
+            uint4 ah, am, bh, bm;
+            split2(fa[0], fa[1], ah.x, am.x); split2(fa[2], fa[3], ah.y, am.y); split2(fa[4], fa[5], ah.z, am.z); split2(fa[6], fa[7], ah.w, am.w);
+            split2(fb[0], fb[1], bh.x, bm.x); split2(fb[2], fb[3], bh.y, bm.y); split2(fb[4], fb[5], bh.z, bm.z); split2(fb[6], fb[7], bh.w, bm.w);
+            unsigned char* w = smem + c * WX_CS + (o0 + 2 * half) * 16;
+            *reinterpret_cast<uint4*>(w) = ah;
+            *reinterpret_cast<uint4*>(w + WX_PLANE) = am;
+            *reinterpret_cast<uint4*>(w + 2 * WX_PLANE) = bh;
+            *reinterpret_cast<uint4*>(w + 3 * WX_PLANE) = bm;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    load_ids(p0, rid);
+    load_rows();
+    load_ids(p0 + WX_KR, rid_next);
+    for (int pbase = p0; pbase < p1; pbase += WX_KR) {
+        __syncthreads();                 // the previous chunk's fragments have been read
+        commit();
+        if (pbase + WX_KR < p1) {        // next chunk's rows (in flight during the products below), the ids of the one after it
+#pragma unroll
+            for (int j = 0; j < 16; ++j) rid[j] = rid_next[j];
+            load_rows();
+            load_ids(pbase + 2 * WX_KR, rid_next);
+        }
+        __syncthreads();
+        const unsigned char* fa = smem + (wm + (lane & 31)) * WX_CS + (lane >> 5) * 16;
+        const unsigned char* fb = smem + 2 * WX_PLANE + (wn + (lane & 31)) * WX_CS + (lane >> 5) * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[2], am[2], bh[2], bm[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(fa + i * 32 * WX_CS + ks * 32);
+                am[i] = *reinterpret_cast<const bf16x8*>(fa + WX_PLANE + i * 32 * WX_CS + ks * 32);
+                bh[i] = *reinterpret_cast<const bf16x8*>(fb + i * 32 * WX_CS + ks * 32);
+                bm[i] = *reinterpret_cast<const bf16x8*>(fb + WX_PLANE + i * 32 * WX_CS + ks * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    // C layout of a 32 x 32 tile: col (n) = lane & 31, row (m) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float* o = out + (int64_t)g * out_group_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), n = n0 + wn + 32 * j + (lane & 31);
+                if (m < M && n < Nc) unsafeAtomicAdd(&o[(int64_t)m * Nc + n], acc[i][j][r]);
+            }
+    if (colsum && nt == 0 && a_ok) unsafeAtomicAdd(&colsum[(int64_t)g * cs_group_stride + m0 + c], csum);
 }
 
 // out[g][c] += sum_{rows p of group g} A[rows[p]][c]    (bias gradients)
@@ -343,38 +481,51 @@ __global__ __launch_bounds__(256) void k_relation_outer(
                 const int li = base + min(lane, nb - 1);
                 const int my_src = esrc[li], my_dst = edst[li];
                 const int my_rte = RTE ? (int)ertei[li] : 0;
-                for (int e = 0; e < nb; ++e) {
-                    const int s = __builtin_amdgcn_readlane(my_src, e), dd = __builtin_amdgcn_readlane(my_dst, e);
-                    float av[VEC], bv[VEC];
-                    load_vec<VEC>(a + (int64_t)s * ld + co + lane * VEC, av);
-                    if constexpr (RTE) {
-                        const int ri = __builtin_amdgcn_readlane(my_rte, e);
-                        float tv[VEC];
-                        load_vec<VEC>(rte_a + (int64_t)ri * ld + co + lane * VEC, tv);
+                // UB edges per batch: all their row / weight loads are issued (unconditionally: slots beyond the chunk re-read
+                // its last edge) before the first one is consumed -- one memory round trip per batch instead of one per edge
+                // (the per-edge form ran 15.7 ms at c2, the whole backward pass 68 ms)
+                constexpr int UB = (VEC * DKP <= 128 && !RTE) ? 8 : 4;      // (more would push the kernel past 256 registers = one wavefront per SIMD)
+                for (int e0 = 0; e0 < nb; e0 += UB) {
+                    float av[UB][VEC], bv[UB][VEC], tv[RTE ? UB : 1][VEC], we[UB];
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) av[i] += tv[i];
+                    for (int u = 0; u < UB; ++u) {
+                        const int idx = min(e0 + u, nb - 1);
+                        const int s = __builtin_amdgcn_readlane(my_src, idx), dd = __builtin_amdgcn_readlane(my_dst, idx);
+                        load_vec<VEC>(a + (int64_t)s * ld + co + lane * VEC, av[u]);
+                        if constexpr (RTE) {
+                            const int ri = __builtin_amdgcn_readlane(my_rte, idx);
+                            load_vec<VEC>(rte_a + (int64_t)ri * ld + co + lane * VEC, tv[u]);
+                        }
+                        load_vec<VEC>(b + (int64_t)dd * ld + co + lane * VEC, bv[u]);
+                        we[u] = w[(int64_t)(base + idx) * HT + hg * H + h];
                     }
-                    load_vec<VEC>(b + (int64_t)dd * ld + co + lane * VEC, bv);
-                    const float we = w[(int64_t)(base + e) * HT + hg * H + h];
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) av[i] *= we;
-                    store_vec_lds<VEC>(bounce + lane * VEC + (lane / LPH) * 4, bv);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const float* xb = bounce + h * (DKP + 4);
+                    for (int u = 0; u < UB; ++u) {
+                        if (e0 + u < nb) {
 #pragma unroll
-                    for (int c4 = 0; c4 < DKP / 4; ++c4) {
-                        const float4 bb = *reinterpret_cast<const float4*>(xb + 4 * c4);
+                            for (int i = 0; i < VEC; ++i) {
+                                if constexpr (RTE) av[u][i] += tv[u][i];
+                                av[u][i] *= we[u];
+                            }
+                            store_vec_lds<VEC>(bounce + lane * VEC + (lane / LPH) * 4, bv[u]);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            const float* xb = bounce + h * (DKP + 4);
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) {
-                            acc[i][4 * c4 + 0] = fmaf(av[i], bb.x, acc[i][4 * c4 + 0]);
-                            acc[i][4 * c4 + 1] = fmaf(av[i], bb.y, acc[i][4 * c4 + 1]);
-                            acc[i][4 * c4 + 2] = fmaf(av[i], bb.z, acc[i][4 * c4 + 2]);
-                            acc[i][4 * c4 + 3] = fmaf(av[i], bb.w, acc[i][4 * c4 + 3]);
+                            for (int c4 = 0; c4 < DKP / 4; ++c4) {
+                                const float4 bb = *reinterpret_cast<const float4*>(xb + 4 * c4);
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) {
+                                    acc[i][4 * c4 + 0] = fmaf(av[u][i], bb.x, acc[i][4 * c4 + 0]);
+                                    acc[i][4 * c4 + 1] = fmaf(av[u][i], bb.y, acc[i][4 * c4 + 1]);
+                                    acc[i][4 * c4 + 2] = fmaf(av[u][i], bb.z, acc[i][4 * c4 + 2]);
+                                    acc[i][4 * c4 + 3] = fmaf(av[u][i], bb.w, acc[i][4 * c4 + 3]);
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
                         }
                     }
-                    __builtin_amdgcn_wave_barrier();
                 }
             }
         }
@@ -393,8 +544,9 @@ struct LaunchOuter {
     static int run(const HgtPlanView& pv, const float* w, const float* a, const float* rte_a, const float* b, float* out, int R, int HT,
                    hipStream_t stream) {
         if constexpr (VEC * LPH * VEC <= 128 && VEC * LPH >= 4) {
-            // ~64 items of the selected relation per wavefront (items are ordered (tile, relation))
-            const int ipw = 64 * (R + 1);
+            // ~16 items of the selected relation per wavefront (items are ordered (tile, relation)): at c2 3 000 wavefronts for
+            // 1 024 SIMDs (64 items left the chip with fewer wavefronts than SIMDs) against 25 M flush atomics
+            const int ipw = 16 * (R + 1);
             const int64_t waves = (pv.L.max_items + ipw - 1) / ipw;
             dim3 grid((unsigned)((waves + 3) / 4), (unsigned)(HT / (64 / LPH)), (unsigned)R);
             if (rte_a)
@@ -468,7 +620,8 @@ extern "C" int hgt_edge_gather_sorted(const void* plan, int64_t N, int64_t E, in
 extern "C" int hgt_head_dot(const float* a, const float* b, int64_t n_rows, int32_t n_heads, int32_t dk_pad, float* out, void* stream) {
     if (!a || !b || !out || n_rows < 0 || n_heads <= 0 || dk_pad <= 0 || (dk_pad & 3) != 0) return HGT_ERR_INVALID_ARG;
     if (n_rows == 0) return HGT_OK;
-    k_head_dot<<<nblk(n_rows * n_heads, 256), 256, 0, (hipStream_t)stream>>>(a, b, n_rows, n_heads, dk_pad, out);
+    if (dk_pad > 256 || (dk_pad & (dk_pad - 1)) != 0) return HGT_ERR_INVALID_ARG;
+    k_head_dot<<<nblk(n_rows * n_heads * (dk_pad / 4), 256), 256, 0, (hipStream_t)stream>>>(a, b, n_rows, n_heads, dk_pad, out);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }
@@ -482,6 +635,21 @@ extern "C" int hgt_typed_wgrad(const float* A, int64_t lda, const float* B, int6
     const int64_t chunks = (n_rows + WG_ROWS - 1) / WG_ROWS + n_groups;   // device-side group sizes: launch the upper bound
     dim3 grid((unsigned)chunks, (unsigned)((m + 63) / 64), (unsigned)((n_cols + 63) / 64));
     k_typed_wgrad<<<grid, 256, 0, (hipStream_t)stream>>>(A, lda, B, ldb, rows, group_off, n_groups, m, n_cols, out, out_group_stride, vecA, vecB);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_typed_wgrad_bf16x3(const float* A, int64_t lda, const float* B, int64_t ldb, const int32_t* rows,
+                                      const int32_t* group_off, int32_t n_groups, int64_t n_rows, int32_t m, int32_t n_cols, float* out,
+                                      int64_t out_group_stride, float* colsum, int64_t colsum_group_stride, void* stream) {
+    if (!A || !B || !rows || !group_off || !out || n_groups <= 0 || n_rows < 0 || m <= 0 || n_cols <= 0) return HGT_ERR_INVALID_ARG;
+    if (n_rows == 0) return HGT_OK;
+    const int n_mt = (m + WX_T - 1) / WX_T, n_nt = (n_cols + WX_T - 1) / WX_T;
+    const int64_t chunks = (n_rows + WX_ROWS - 1) / WX_ROWS + n_groups;    // device-side group sizes: launch the upper bound
+    if (chunks > 65535) return HGT_ERR_TOO_LARGE;
+    dim3 grid((unsigned)(n_mt * n_nt), (unsigned)chunks);
+    k_typed_wgrad_x3<<<grid, 256, 0, (hipStream_t)stream>>>(A, lda, B, ldb, rows, group_off, n_groups, m, n_cols, n_mt, out, out_group_stride,
+                                                          colsum, colsum_group_stride);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }

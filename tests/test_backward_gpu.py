@@ -149,9 +149,17 @@ def test_typed_weight_gradient_kernels(m, n_cols, n):
                                m * n_cols, st) == 0
     cs = torch.zeros(T, m, device=DEV)
     assert lib.hgt_typed_colsum(Ad.data_ptr(), m, od.data_ptr(), fd.data_ptr(), T, n, m, cs.data_ptr(), m, st) == 0
+    # the split-bf16 x3 form (128 x 128 tiles, transposed LDS staging) with the column sums from the same pass
+    out3 = torch.zeros(T, m, n_cols, device=DEV)
+    cs3 = torch.zeros(T, m, device=DEV)
+    assert lib.hgt_typed_wgrad_bf16x3(Ad.data_ptr(), m, Bd.data_ptr(), n_cols, od.data_ptr(), fd.data_ptr(), T, n, m, n_cols, out3.data_ptr(),
+                                      m * n_cols, cs3.data_ptr(), m, st) == 0
     torch.cuda.synchronize()
     for t in range(T):
         idx = (types == t).nonzero().flatten()
         ref = A[idx].double().T @ B[idx].double()
-        assert (out[t].cpu().double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+        scale = max(1.0, ref.abs().max().item())
+        assert (out[t].cpu().double() - ref).abs().max().item() < 1e-4 * scale
+        assert (out3[t].cpu().double() - ref).abs().max().item() < 1e-4 * scale
         assert (cs[t].cpu().double() - A[idx].double().sum(0)).abs().max().item() < 1e-3
+        assert (cs3[t].cpu().double() - A[idx].double().sum(0)).abs().max().item() < 1e-3
