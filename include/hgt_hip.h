@@ -320,6 +320,14 @@ int hgt_node_update_bwd(const float* grad_out, const float* trans, const float* 
                         const float* skip, const float* ln_w, int32_t use_norm, const float* drop_mask, int64_t n_rows, int32_t d,
                         int32_t n_types, float* d_trans, float* dx, int64_t ld_dx, float* d_alpha, float* d_ln_w, float* d_ln_b,
                         void* stream);
+/* the reverse of hgt_node_update_ex (DenseHGTConv.update, conv.py:250-274): skip == NULL = plain residual y = o + x (no gate;
+ * d_alpha unused), shared_norm != 0 = one LayerNorm for every type (row 0 of ln_w / d_ln_w / d_ln_b) */
+int hgt_node_update_bwd_ex(const float* grad_out, const float* trans, const float* x, int64_t ldx, const int64_t* node_type,
+                           const float* skip, const float* ln_w, int32_t use_norm, int32_t shared_norm, const float* drop_mask,
+                           int64_t n_rows, int32_t d, int32_t n_types, float* d_trans, float* dx, int64_t ld_dx, float* d_alpha,
+                           float* d_ln_w, float* d_ln_b, void* stream);
+/* off2[0..1] = {0, group_off[n_groups]}: the rows of every valid group as one group (shared dense layer of DenseHGTConv) */
+int hgt_single_group_offsets(const int32_t* group_off, int32_t n_groups, int32_t* off2, void* stream);
 int hgt_gelu_bwd(const float* dg, const float* agg, float* out, int64_t n, void* stream);
 int hgt_mul_inplace(float* x, const float* m, int64_t n, void* stream);
 int hgt_typed_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, const int32_t* rows, const int32_t* group_off,

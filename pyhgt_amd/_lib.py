@@ -97,6 +97,9 @@ SIGNATURES = {
     "hgt_edge_gather_sorted": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "hgt_head_dot": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "hgt_relation_outer": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hgt_node_update_bwd_ex": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp,
+                                         _vp]),
+    "hgt_single_group_offsets": (C.c_int, [_vp, _i32, _vp, _vp]),
     "hgt_node_update_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "hgt_gelu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "hgt_mul_inplace": (C.c_int, [_vp, _vp, _i64, _vp]),

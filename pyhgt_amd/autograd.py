@@ -1,4 +1,4 @@
-"""Training path of HGTConv: forward that keeps its intermediates + the hand-written backward.
+"""Training path of HGTConv / DenseHGTConv: forward that keeps its intermediates + the hand-written backward.
 
 The reference trains through autograd over conv.py:60-134 (`loss.backward()`, OAG/train_paper_field.py:249,
 ogbn-mag/train_ogbn_mag.py:172).  Here a `torch.autograd.Function` wraps the HIP kernels: the forward is the same
@@ -155,25 +155,26 @@ def _rte_row_lists(T, dev):
 
 
 class _HGTConvTrain(torch.autograd.Function):
-    """forward(layer, plan, drop_mask, x, *packed parameters) -> out; the packed parameters are the differentiable
-    stack/cat/pad images HGTConv._pack_parameters builds (their gradients reach the reference-named parameters through
-    ordinary autograd)."""
+    """HGTConv / DenseHGTConv forward + backward on the HIP kernels.  The message path (conv.py:60-111) is shared; the update is
+    conv.py:114-134 (HGTConv: gelu, a_linear, dropout, gated skip, LayerNorm) or conv.py:250-274 (DenseHGTConv: a_linear, dropout,
+    plain residual, LayerNorm, then the shared dense layer with its own dropout and out_norm)."""
 
     @staticmethod
-    def forward(ctx, layer, plan, drop_mask, x, w_qkv, b_qkv, w_a, b_a, ratt, rmsg, rpri, skip, ln_w, ln_b, rte_emb, rte_w, rte_b):
+    def forward(ctx, layer, plan, drop_masks, x, w_qkv, b_qkv, w_a, b_a, ratt, rmsg, rpri, skip, ln_w, ln_b, rte_emb, rte_w, rte_b,
+                mid_w, mid_b, out_w, out_b, oln_w, oln_b):
         lib = _lib.load()
         lay = _lib.layout_for(layer.out_dim, layer.n_heads)
         T, R, H = layer.num_types, layer.num_relations, layer.n_heads
         ops = _Ops(plan, lay, T, R, H, layer.precision)
-        N, E, din, dout, dp = plan.N, plan.E, layer.in_dim, layer.out_dim, lay.d_pad
+        N, din, dout, dp = plan.N, layer.in_dim, layer.out_dim, lay.d_pad
         dev = x.device
         use_rte, use_norm = bool(layer.use_RTE), bool(layer.use_norm)
+        dense = mid_w is not None
         rows = plan.row_lists()
         x = x.contiguous()
-        # relation matrices (conv.py:98-99,104): att_t = A^T * pri / sqrt(dk), msg_p = M, + the MFMA image of M
         att_t, msg_p = ops.pack(ratt, rmsg, rpri)
         msg_f = ops.frags(msg_p)
-        # typed projections once per node (conv.py:96-97,103)
+        # projections (conv.py:96-97,103 once per node)
         qkv = torch.empty(3, N, dp, dtype=torch.float32, device=dev)
         ops.typed_linear(x, din, rows.rows_all, rows.off_all, T, N, din, 3 * dp, w_qkv, 0, 3 * dp * din, b_qkv, 0, 3 * dp,
                          [qkv[0], qkv[1], qkv[2]], dp)
@@ -192,25 +193,51 @@ class _HGTConvTrain(torch.autograd.Function):
         # aggregation (conv.py:104,109-111 + scatter-add): agg = sum_r (sum_e att_e v_e) M_r
         agg = torch.empty(N, dp, dtype=torch.float32, device=dev)
         ops.spmm(plan, att, qkv[2].data_ptr(), rte_v, msg_p, msg_f, agg, 0, dp, N)
-        # update (conv.py:119-133): a_linear(gelu(agg)) -> dropout -> gated skip -> LayerNorm
+        m1, m2 = drop_masks if drop_masks is not None else (None, None)
+        empty = x.new_empty(0)
         trans = torch.empty(N, dout, dtype=torch.float32, device=dev)
-        ops.typed_linear(agg, dp, rows.rows_q, rows.off_q, T, N, dp, dout, w_a, 0, dout * dp, b_a, 0, dout, [trans], dout, prologue=1)
-        if drop_mask is not None:
-            _chk("hgt_mul_inplace", lib.hgt_mul_inplace(_p(trans), _p(drop_mask), trans.numel(), _st()))
         out = torch.empty(N, dout, dtype=torch.float32, device=dev)
-        _chk("hgt_node_update", lib.hgt_node_update(_p(trans), _p(x), din, _p(plan.node_type), _p(skip), _p(ln_w), _p(ln_b), int(use_norm),
-                                                  N, dout, T, _p(out), _st()))
+        if not dense:
+            # update (conv.py:119-133): a_linear(gelu(agg)) -> dropout -> gated skip -> LayerNorm
+            ops.typed_linear(agg, dp, rows.rows_q, rows.off_q, T, N, dp, dout, w_a, 0, dout * dp, b_a, 0, dout, [trans], dout, prologue=1)
+            if m1 is not None:
+                _chk("hgt_mul_inplace", lib.hgt_mul_inplace(_p(trans), _p(m1), trans.numel(), _st()))
+            _chk("hgt_node_update", lib.hgt_node_update(_p(trans), _p(x), din, _p(plan.node_type), _p(skip), _p(ln_w), _p(ln_b), int(use_norm),
+                                                      N, dout, T, _p(out), _st()))
+            y1 = mid = trans2 = off2 = empty
+        else:
+            # DenseHGTConv.update (conv.py:250-274): y1 = LN_t(drop(a_linear(agg)) + x); out = out_norm(drop(out_linear(gelu(mid_linear(y1)))) + y1)
+            ops.typed_linear(agg, dp, rows.rows_q, rows.off_q, T, N, dp, dout, w_a, 0, dout * dp, b_a, 0, dout, [trans], dout)
+            if m1 is not None:
+                _chk("hgt_mul_inplace", lib.hgt_mul_inplace(_p(trans), _p(m1), trans.numel(), _st()))
+            y1 = torch.empty(N, dout, dtype=torch.float32, device=dev)
+            _chk("hgt_node_update_ex", lib.hgt_node_update_ex(_p(trans), _p(x), din, _p(plan.node_type), None, _p(ln_w), _p(ln_b),
+                                                            int(use_norm), 0, N, dout, T, _p(y1), _st()))
+            off2 = torch.empty(2, dtype=torch.int32, device=dev)
+            _chk("hgt_single_group_offsets", lib.hgt_single_group_offsets(rows.off_q, T, _p(off2), _st()))
+            mid = torch.zeros(N, 2 * dout, dtype=torch.float32, device=dev)
+            ops.typed_linear(y1, dout, rows.rows_q, off2.data_ptr(), 1, N, dout, 2 * dout, mid_w, 0, 0, mid_b, 0, 0, [mid], 2 * dout)
+            trans2 = torch.zeros(N, dout, dtype=torch.float32, device=dev)
+            ops.typed_linear(mid, 2 * dout, rows.rows_q, off2.data_ptr(), 1, N, 2 * dout, dout, out_w, 0, 0, out_b, 0, 0, [trans2], dout,
+                             prologue=1)
+            if m2 is not None:
+                _chk("hgt_mul_inplace", lib.hgt_mul_inplace(_p(trans2), _p(m2), trans2.numel(), _st()))
+            _chk("hgt_node_update_ex", lib.hgt_node_update_ex(_p(trans2), _p(y1), dout, _p(plan.node_type), None, _p(oln_w), _p(oln_b), 1, 1,
+                                                            N, dout, T, _p(out), _st()))
         ctx.layer, ctx.plan, ctx.lay = layer, plan, lay
-        ctx.use_rte, ctx.use_norm = use_rte, use_norm
-        ctx.save_for_backward(x, w_qkv, w_a, ratt, rmsg, rpri, skip, ln_w, rte_emb, rte_w, rte_b, qkv, att, agg, trans,
-                              drop_mask if drop_mask is not None else x.new_empty(0), rte_k if use_rte else x.new_empty(0),
-                              rte_v if use_rte else x.new_empty(0))
+        ctx.use_rte, ctx.use_norm, ctx.dense = use_rte, use_norm, dense
+        ctx.save_for_backward(x, w_qkv, w_a, ratt, rmsg, rpri, skip if skip is not None else empty, ln_w if ln_w is not None else empty,
+                              rte_emb, rte_w, rte_b, qkv, att, agg, trans,
+                              m1 if m1 is not None else empty, m2 if m2 is not None else empty, rte_k if use_rte else empty,
+                              rte_v if use_rte else empty, y1, mid, trans2, off2,
+                              mid_w if dense else empty, out_w if dense else empty, oln_w if dense else empty)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         layer, plan, lay = ctx.layer, ctx.plan, ctx.lay
-        (x, w_qkv, w_a, ratt, rmsg, rpri, skip, ln_w, rte_emb, rte_w, rte_b, qkv, att, agg, trans, drop_mask, rte_k, rte_v) = ctx.saved_tensors
+        (x, w_qkv, w_a, ratt, rmsg, rpri, skip, ln_w, rte_emb, rte_w, rte_b, qkv, att, agg, trans, m1, m2, rte_k, rte_v, y1, mid, trans2,
+         off2, mid_w, out_w, oln_w) = ctx.saved_tensors
         lib = _lib.load()
         T, R, H = layer.num_types, layer.num_relations, layer.n_heads
         ops = _Ops(plan, lay, T, R, H, layer.precision)
@@ -219,38 +246,70 @@ class _HGTConvTrain(torch.autograd.Function):
         N, E, din, dout, dp, dk, dkp = plan.N, plan.E, layer.in_dim, layer.out_dim, lay.d_pad, lay.d_k, lay.dk_pad
         Hr, H = H, lay.heads                                 # model heads / layout heads
         dev = x.device
-        use_rte, use_norm = ctx.use_rte, ctx.use_norm
+        use_rte, use_norm, dense = ctx.use_rte, ctx.use_norm, ctx.dense
         rows = plan.row_lists()
         gout = gout.contiguous().float()
-        if drop_mask.numel() == 0:
-            drop_mask = None
+        m1 = None if m1.numel() == 0 else m1
+        m2 = None if m2.numel() == 0 else m2
         if not use_rte:
             rte_k = rte_v = None
         Q, K, V = qkv[0], qkv[1], qkv[2]
-
-        # ---- update backward (conv.py:125-133)
-        d_trans = torch.empty(N, dout, dtype=torch.float32, device=dev)
-        dx_skip = torch.empty(N, din, dtype=torch.float32, device=dev)
-        d_alpha = torch.zeros(T, dtype=torch.float32, device=dev)
+        d_skip = d_mid_w = d_mid_b = d_out_w = d_out_b = d_oln_w = d_oln_b = None
         d_lnw = torch.zeros(T, dout, dtype=torch.float32, device=dev) if use_norm else None
         d_lnb = torch.zeros(T, dout, dtype=torch.float32, device=dev) if use_norm else None
-        _chk("hgt_node_update_bwd", lib.hgt_node_update_bwd(_p(gout), _p(trans), _p(x), din, _p(plan.node_type), _p(skip), _p(ln_w),
-                                                          int(use_norm), _p(drop_mask), N, dout, T, _p(d_trans), _p(dx_skip), din,
-                                                          _p(d_alpha), _p(d_lnw), _p(d_lnb), _st()))
-        alpha = torch.sigmoid(skip)
-        d_skip = d_alpha * alpha * (1.0 - alpha)
-        # a_linear: trans = gelu(agg) W_a^T + b_a
-        g = torch.nn.functional.gelu(agg)                                           # exact erf form, conv.py:119
-        d_w_a, d_b_a = ops.wgrad(d_trans, dout, g, dp, rows.rows_q, rows.off_q, T, N, dout, dp, with_colsum=True)
-        del g
-        w_a_t = w_a.transpose(1, 2).contiguous()                                     # [T][dp][dout]
-        dg = torch.empty(N, dp, dtype=torch.float32, device=dev)
-        ops.typed_linear(d_trans, dout, rows.rows_q, rows.off_q, T, N, dout, dp, w_a_t, 0, dp * dout, None, 0, 0, [dg], dp)
+        d_trans = torch.empty(N, dout, dtype=torch.float32, device=dev)
+        dx_skip = torch.empty(N, din, dtype=torch.float32, device=dev)
         dagg = torch.empty(N, dp, dtype=torch.float32, device=dev)
-        _chk("hgt_gelu_bwd", lib.hgt_gelu_bwd(_p(dg), _p(agg), _p(dagg), dagg.numel(), _st()))
+        w_a_t = w_a.transpose(1, 2).contiguous()                                     # [T][dp][dout]
+        if not dense:
+            # ---- update backward (conv.py:125-133)
+            d_alpha = torch.zeros(T, dtype=torch.float32, device=dev)
+            _chk("hgt_node_update_bwd", lib.hgt_node_update_bwd(_p(gout), _p(trans), _p(x), din, _p(plan.node_type), _p(skip), _p(ln_w),
+                                                              int(use_norm), _p(m1), N, dout, T, _p(d_trans), _p(dx_skip), din,
+                                                              _p(d_alpha), _p(d_lnw), _p(d_lnb), _st()))
+            alpha = torch.sigmoid(skip)
+            d_skip = d_alpha * alpha * (1.0 - alpha)
+            # a_linear: trans = gelu(agg) W_a^T + b_a
+            g = torch.nn.functional.gelu(agg)                                       # exact erf form, conv.py:119
+            d_w_a, d_b_a = ops.wgrad(d_trans, dout, g, dp, rows.rows_q, rows.off_q, T, N, dout, dp, with_colsum=True)
+            del g
+            dg = torch.empty(N, dp, dtype=torch.float32, device=dev)
+            ops.typed_linear(d_trans, dout, rows.rows_q, rows.off_q, T, N, dout, dp, w_a_t, 0, dp * dout, None, 0, 0, [dg], dp)
+            _chk("hgt_gelu_bwd", lib.hgt_gelu_bwd(_p(dg), _p(agg), _p(dagg), dagg.numel(), _st()))
+            del dg
+        else:
+            # ---- DenseHGTConv.update backward (conv.py:250-274 in reverse)
+            d_oln_w = torch.zeros(1, dout, dtype=torch.float32, device=dev)
+            d_oln_b = torch.zeros(1, dout, dtype=torch.float32, device=dev)
+            d_t2 = torch.empty(N, dout, dtype=torch.float32, device=dev)           # gradient of out_linear's (dropped) output
+            d_y1 = torch.empty(N, dout, dtype=torch.float32, device=dev)           # residual branch of y1
+            _chk("hgt_node_update_bwd_ex", lib.hgt_node_update_bwd_ex(_p(gout), _p(trans2), _p(y1), dout, _p(plan.node_type), None, _p(oln_w),
+                                                                    1, 1, _p(m2), N, dout, T, _p(d_t2), _p(d_y1), dout, None, _p(d_oln_w),
+                                                                    _p(d_oln_b), _st()))
+            g2 = torch.nn.functional.gelu(mid)
+            d_out_w, d_out_b = ops.wgrad(d_t2, dout, g2, 2 * dout, rows.rows_q, off2.data_ptr(), 1, N, dout, 2 * dout, with_colsum=True)
+            del g2
+            out_w_t = out_w.t().contiguous()                                           # [2 dout][dout]
+            d_g2 = torch.zeros(N, 2 * dout, dtype=torch.float32, device=dev)
+            ops.typed_linear(d_t2, dout, rows.rows_q, off2.data_ptr(), 1, N, dout, 2 * dout, out_w_t, 0, 0, None, 0, 0, [d_g2], 2 * dout)
+            d_mid = torch.empty_like(d_g2)
+            _chk("hgt_gelu_bwd", lib.hgt_gelu_bwd(_p(d_g2), _p(mid), _p(d_mid), d_mid.numel(), _st()))
+            del d_g2
+            d_mid_w, d_mid_b = ops.wgrad(d_mid, 2 * dout, y1, dout, rows.rows_q, off2.data_ptr(), 1, N, 2 * dout, dout, with_colsum=True)
+            mid_w_t = mid_w.t().contiguous()                                           # [dout][2 dout]
+            d_y1b = torch.zeros(N, dout, dtype=torch.float32, device=dev)
+            ops.typed_linear(d_mid, 2 * dout, rows.rows_q, off2.data_ptr(), 1, N, 2 * dout, dout, mid_w_t, 0, 0, None, 0, 0, [d_y1b], dout)
+            d_y1 += d_y1b
+            del d_mid, d_y1b
+            _chk("hgt_node_update_bwd_ex", lib.hgt_node_update_bwd_ex(_p(d_y1), _p(trans), _p(x), din, _p(plan.node_type), None, _p(ln_w),
+                                                                    int(use_norm), 0, _p(m1), N, dout, T, _p(d_trans), _p(dx_skip), din,
+                                                                    None, _p(d_lnw), _p(d_lnb), _st()))
+            d_w_a, d_b_a = ops.wgrad(d_trans, dout, agg, dp, rows.rows_q, rows.off_q, T, N, dout, dp, with_colsum=True)
+            ops.typed_linear(d_trans, dout, rows.rows_q, rows.off_q, T, N, dout, dp, w_a_t, 0, dp * dout, None, 0, 0, [dagg], dp)
+            d_oln_w, d_oln_b = d_oln_w[0], d_oln_b[0]
+            d_out_w, d_out_b, d_mid_w, d_mid_b = d_out_w[0], d_out_b[0], d_mid_w[0], d_mid_b[0]
         # rows of an unknown type get no a_linear (their agg gradient is zero): typed_linear leaves them unwritten
         _chk("hgt_zero_rows", lib.hgt_zero_rows(rows.rows_q, rows.off_q + 4 * T, dp, _p(dagg), _st()))
-        del dg
 
         # ---- aggregation / attention backward (conv.py:98-111)
         sqrt_dk = math.sqrt(dk)
@@ -314,22 +373,24 @@ class _HGTConvTrain(torch.autograd.Function):
             ops.typed_linear(dqkv, 3 * dp, rows.rows_all, rows.off_all, T, N, 3 * dp, din, w_qkv_t, 0, din * 3 * dp, None, 0, 0, [dx], din)
             dx += dx_skip
         return (None, None, None, dx, d_w_qkv, d_b_qkv, d_w_a, d_b_a, d_ratt, d_msg.contiguous(), d_rpri, d_skip, d_lnw, d_lnb,
-                d_rte_emb, d_rte_w, d_rte_b)
+                d_rte_emb, d_rte_w, d_rte_b, d_mid_w, d_mid_b, d_out_w, d_out_b, d_oln_w, d_oln_b)
 
 
 def hgt_conv_train(layer, plan, x, packed, drop_p):
-    """Training-mode forward of `layer` (HGTConv) through the autograd Function.  `packed` = layer._pack_parameters() built with
-    grad enabled; drop_p = dropout probability of conv.py:125 (0 in eval mode)."""
+    """Training-mode forward of `layer` (HGTConv or DenseHGTConv) through the autograd Function.  `packed` =
+    layer._pack_parameters(grad=True); drop_p = dropout probability of conv.py:125 / 259,271 (0 in eval mode)."""
     if plan.NQ != plan.N:
         raise NotImplementedError("pyhgt_amd: the backward pass covers single-GPU graphs (n_q_rows == n_nodes)")
-    mask = None
+    dense = "mid_w" in packed
+    masks = None
     if drop_p > 0.0:
         keep = 1.0 - drop_p
-        mask = torch.bernoulli(torch.full((plan.N, layer.out_dim), keep, dtype=torch.float32, device=x.device)) / keep
-    z = x.new_empty(0)
-    return _HGTConvTrain.apply(layer, plan, mask, x, packed["w_qkv"], packed["b_qkv"], packed["w_a"], packed["b_a"], packed["ratt"],
-                               packed["rmsg"], packed["rpri"], packed["skip"], packed.get("ln_w"), packed.get("ln_b"),
-                               packed.get("rte_emb"), packed.get("rte_w"), packed.get("rte_b"))
+        draw = lambda: torch.bernoulli(torch.full((plan.N, layer.out_dim), keep, dtype=torch.float32, device=x.device)) / keep
+        masks = (draw(), draw() if dense else None)          # DenseHGTConv drops twice (conv.py:259 and conv.py:271)
+    return _HGTConvTrain.apply(layer, plan, masks, x, packed["w_qkv"], packed["b_qkv"], packed["w_a"], packed["b_a"], packed["ratt"],
+                               packed["rmsg"], packed["rpri"], packed.get("skip"), packed.get("ln_w"), packed.get("ln_b"),
+                               packed.get("rte_emb"), packed.get("rte_w"), packed.get("rte_b"), packed.get("mid_w"), packed.get("mid_b"),
+                               packed.get("out_w"), packed.get("out_b"), packed.get("out_ln_w"), packed.get("out_ln_b"))
 
 
 class TypedLinearFunction(torch.autograd.Function):

@@ -506,9 +506,9 @@ class HGTConv(nn.Module):
             raise RuntimeError("pyhgt_amd.HGTConv runs only on a ROCm GPU tensor; there is no CPU fallback "
                                "(the CPU oracle lives under oracle/ and is test infrastructure)")
         needs_grad = torch.is_grad_enabled() and (node_inp.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if needs_grad and (self._UPDATE_MODE != 0 or stage != 0 or n_q_rows is not None):
-            raise RuntimeError("pyhgt_amd: the backward pass covers HGTConv on a single GPU (SURVEY.md section 8f-2); "
-                               "DenseHGTConv / staged multi-GPU forwards run under torch.no_grad() only")
+        if needs_grad and (stage != 0 or n_q_rows is not None):
+            raise RuntimeError("pyhgt_amd: the backward pass covers HGTConv / DenseHGTConv on a single GPU (SURVEY.md section 8f-2); "
+                               "staged multi-GPU forwards run under torch.no_grad() only")
         if node_inp.dtype != torch.float32:
             raise TypeError("node_inp must be float32 (the reference layer is fp32-only, conv.py:68-69)")
         if self.in_dim != self.out_dim:
@@ -631,7 +631,7 @@ class DenseHGTConv(HGTConv):
         self.out_norm = nn.LayerNorm(out_dim)                           # conv.py:191
 
     def _pack_update_parameters(self, grad=False):
-        f = lambda t: t.detach().float().contiguous()
+        f = (lambda t: t.float().contiguous()) if grad else (lambda t: t.detach().float().contiguous())
         return dict(mid_w=f(self.mid_linear.weight), mid_b=f(self.mid_linear.bias), out_w=f(self.out_linear.weight),
                     out_b=f(self.out_linear.bias), out_ln_w=f(self.out_norm.weight), out_ln_b=f(self.out_norm.bias))
 

@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void k_node_update_bwd(
     const float* __restrict__ gout, const float* __restrict__ trans, const float* __restrict__ x, int64_t ldx,
     const int64_t* __restrict__ node_type, const float* __restrict__ skip, const float* __restrict__ lnw, int use_norm,
     const float* __restrict__ drop_mask, int64_t NQ, int d, int T, float* __restrict__ d_trans, float* __restrict__ dx, int64_t ld_dx,
-    float* __restrict__ d_alpha, float* __restrict__ d_lnw, float* __restrict__ d_lnb) {
+    float* __restrict__ d_alpha, float* __restrict__ d_lnw, float* __restrict__ d_lnb, int shared_norm) {
+    // skip == NULL: plain residual y = o + x (DenseHGTConv.update, conv.py:259,271), no gate gradient;
+    // shared_norm: ONE LayerNorm for every type (out_norm, conv.py:272): its parameters / gradients are row 0 of lnw / d_lnw / d_lnb
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t r0 = wave * NUB_ROWS;
@@ -55,14 +57,17 @@ __global__ __launch_bounds__(256) void k_node_update_bwd(
                 for (int c = 0; c < NUB_MAXC; ++c) {
                     const int col = c * 64 + lane;
                     if (c < nc && col < d) {
-                        unsafeAtomicAdd(&d_lnw[(int64_t)cur_t * d + col], gw[c]);
-                        unsafeAtomicAdd(&d_lnb[(int64_t)cur_t * d + col], gb[c]);
+                        const int64_t lrow = shared_norm ? 0 : cur_t;
+                        unsafeAtomicAdd(&d_lnw[lrow * d + col], gw[c]);
+                        unsafeAtomicAdd(&d_lnb[lrow * d + col], gb[c]);
                     }
                     gw[c] = gb[c] = 0.0f;
                 }
             }
-            ga = wave_sum(ga);
-            if (lane == 0) unsafeAtomicAdd(&d_alpha[cur_t], ga);
+            if (skip) {
+                ga = wave_sum(ga);
+                if (lane == 0) unsafeAtomicAdd(&d_alpha[cur_t], ga);
+            }
             ga = 0.0f;
         }
     };
@@ -78,7 +83,8 @@ __global__ __launch_bounds__(256) void k_node_update_bwd(
             }
             continue;
         }
-        const float alpha = 1.0f / (1.0f + expf(-skip[t]));
+        const float alpha = skip ? 1.0f / (1.0f + expf(-skip[t])) : 1.0f;
+        const float beta = skip ? 1.0f - alpha : 1.0f;           // weight of the residual row
         float o[NUB_MAXC], xv[NUB_MAXC], g[NUB_MAXC], y[NUB_MAXC];
         float s1 = 0.0f;
 #pragma unroll
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256) void k_node_update_bwd(
             o[c] = ok ? trans[r * d + col] : 0.0f;
             xv[c] = ok ? x[r * ldx + col] : 0.0f;
             g[c] = ok ? gout[r * d + col] : 0.0f;
-            y[c] = o[c] * alpha + xv[c] * (1.0f - alpha);
+            y[c] = o[c] * alpha + xv[c] * beta;
             s1 += y[c];
         }
         float dy[NUB_MAXC];
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(256) void k_node_update_bwd(
                 const int col = c * 64 + lane;
                 const bool ok = c < nc && col < d;
                 y[c] *= rstd;                                            // y = normalised row
-                const float w = ok ? lnw[(int64_t)t * d + col] : 0.0f;
+                const float w = ok ? lnw[(int64_t)(shared_norm ? 0 : t) * d + col] : 0.0f;
                 gw[c] += g[c] * y[c];
                 gb[c] += g[c];
                 gh[c] = g[c] * w;
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256) void k_node_update_bwd(
                 float dt = dy[c] * alpha;
                 if (drop_mask) dt *= drop_mask[r * d + col];            // o = mask * (a_linear output), conv.py:125
                 d_trans[r * d + col] = dt;
-                dx[r * ld_dx + col] = dy[c] * (1.0f - alpha);
+                dx[r * ld_dx + col] = dy[c] * beta;
             }
         }
     }
@@ -566,17 +572,47 @@ static inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) 
 
 }  // namespace
 
-extern "C" int hgt_node_update_bwd(const float* grad_out, const float* trans, const float* x, int64_t ldx, const int64_t* node_type,
-                                   const float* skip, const float* ln_w, int32_t use_norm, const float* drop_mask, int64_t n_rows,
-                                   int32_t d, int32_t n_types, float* d_trans, float* dx, int64_t ld_dx, float* d_alpha, float* d_ln_w,
-                                   float* d_ln_b, void* stream) {
-    if (!grad_out || !trans || !x || !node_type || !skip || !d_trans || !dx || !d_alpha || n_rows < 0 || d <= 0 || d > 64 * NUB_MAXC)
+static int node_update_bwd_impl(const float* grad_out, const float* trans, const float* x, int64_t ldx, const int64_t* node_type,
+                                const float* skip, const float* ln_w, int32_t use_norm, int32_t shared_norm, const float* drop_mask,
+                                int64_t n_rows, int32_t d, int32_t n_types, float* d_trans, float* dx, int64_t ld_dx, float* d_alpha,
+                                float* d_ln_w, float* d_ln_b, void* stream) {
+    if (!grad_out || !trans || !x || !node_type || !d_trans || !dx || (skip && !d_alpha) || n_rows < 0 || d <= 0 || d > 64 * NUB_MAXC)
         return HGT_ERR_INVALID_ARG;
     if (use_norm && (!ln_w || !d_ln_w || !d_ln_b)) return HGT_ERR_INVALID_ARG;
     if (n_rows == 0) return HGT_OK;
     const int64_t waves = (n_rows + NUB_ROWS - 1) / NUB_ROWS;
     k_node_update_bwd<<<nblk(waves, 4), 256, 0, (hipStream_t)stream>>>(grad_out, trans, x, ldx, node_type, skip, ln_w, use_norm, drop_mask,
-                                                                       n_rows, d, n_types, d_trans, dx, ld_dx, d_alpha, d_ln_w, d_ln_b);
+                                                                       n_rows, d, n_types, d_trans, dx, ld_dx, d_alpha, d_ln_w, d_ln_b,
+                                                                       shared_norm);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+extern "C" int hgt_node_update_bwd(const float* grad_out, const float* trans, const float* x, int64_t ldx, const int64_t* node_type,
+                                   const float* skip, const float* ln_w, int32_t use_norm, const float* drop_mask, int64_t n_rows,
+                                   int32_t d, int32_t n_types, float* d_trans, float* dx, int64_t ld_dx, float* d_alpha, float* d_ln_w,
+                                   float* d_ln_b, void* stream) {
+    if (!skip) return HGT_ERR_INVALID_ARG;
+    return node_update_bwd_impl(grad_out, trans, x, ldx, node_type, skip, ln_w, use_norm, 0, drop_mask, n_rows, d, n_types, d_trans, dx,
+                                ld_dx, d_alpha, d_ln_w, d_ln_b, stream);
+}
+
+// reverse of hgt_node_update_ex: skip == NULL = plain residual (no gate, d_alpha unused), shared_norm = one LayerNorm for all types
+extern "C" int hgt_node_update_bwd_ex(const float* grad_out, const float* trans, const float* x, int64_t ldx, const int64_t* node_type,
+                                      const float* skip, const float* ln_w, int32_t use_norm, int32_t shared_norm, const float* drop_mask,
+                                      int64_t n_rows, int32_t d, int32_t n_types, float* d_trans, float* dx, int64_t ld_dx,
+                                      float* d_alpha, float* d_ln_w, float* d_ln_b, void* stream) {
+    return node_update_bwd_impl(grad_out, trans, x, ldx, node_type, skip, ln_w, use_norm, shared_norm, drop_mask, n_rows, d, n_types,
+                                d_trans, dx, ld_dx, d_alpha, d_ln_w, d_ln_b, stream);
+}
+
+// off2 = {0, off[n_groups]}: every row of a valid group as ONE group (the shared dense layer of DenseHGTConv)
+__global__ void k_single_group_offsets(const int32_t* __restrict__ off, int n_groups, int32_t* __restrict__ off2) {
+    if (threadIdx.x == 0) { off2[0] = 0; off2[1] = off[n_groups]; }
+}
+extern "C" int hgt_single_group_offsets(const int32_t* group_off, int32_t n_groups, int32_t* off2, void* stream) {
+    if (!group_off || !off2 || n_groups <= 0) return HGT_ERR_INVALID_ARG;
+    k_single_group_offsets<<<1, 64, 0, (hipStream_t)stream>>>(group_off, n_groups, off2);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }

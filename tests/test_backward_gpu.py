@@ -73,6 +73,57 @@ def test_hgtconv_backward_matches_oracle(case, precision):
                                                                                      1 + len(list(layer.parameters()))))
 
 
+DENSE_CASES = [
+    ("dense_c1_like", 3, 4, 4, 64, 2000, 10000, True, True, {}, {}),
+    ("dense_no_norm_unknown", 2, 3, 4, 128, 1500, 9000, False, False, dict(sorted_types=False), dict(unknown=True, unclaimed=True)),
+    ("dense_c2_shape", 4, 8, 8, 256, 3000, 30000, True, False, {}, dict(hub=True)),
+]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("case", DENSE_CASES, ids=[c[0] for c in DENSE_CASES])
+def test_dense_hgtconv_backward_matches_oracle(case, precision):
+    """DenseHGTConv (conv.py:143-280): gradients of the input and of every parameter (a_linears, norms, mid_linear, out_linear,
+    out_norm, relation_*, q/k/v_linears, emb) against reverse mode through the fp64 closed form with the dense update."""
+    from pyhgt_amd import DenseHGTConv
+    name, T, R, H, d, N, E, use_norm, use_RTE, gk, tw = case
+    sd = O.make_state_dict(d, d, T, R, H, use_norm, use_RTE, seed=31, dense=True)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=32, **gk)
+    nt, et, ei = nt.clone(), et.clone(), ei.clone()
+    if tw.get("unknown"):
+        nt[::13] = T + 1
+    if tw.get("unclaimed"):
+        et[::7] = R
+    if tw.get("hub"):
+        ei[1, :4000] = 17
+    g = torch.Generator().manual_seed(6)
+    gout = torch.randn(N, d, generator=g)
+    ref = O.backward_reference(sd, T, R, H, x, nt, ei, et, tm if use_RTE else None, gout, use_norm=use_norm, use_RTE=use_RTE, dense=True)
+    layer = DenseHGTConv(d, d, T, R, H, 0.2, use_norm, use_RTE, precision=precision).eval()
+    layer.load_state_dict(sd)
+    layer = layer.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    GraphPlan.clear_cache()
+    out = layer(xd, nt.to(DEV), ei.to(DEV), et.to(DEV), tm.to(DEV) if use_RTE else None)
+    fwd = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm if use_RTE else None, use_norm=use_norm, use_RTE=use_RTE, dense=True)
+    assert (out.detach().cpu().double() - fwd).abs().max().item() < 1e-4
+    out.backward(gout.to(DEV))
+    torch.cuda.synchronize()
+    worst = _grads_close("x", xd.grad, ref["x"])
+    for k, p in layer.named_parameters():
+        if k == "emb.emb.weight" and p.grad is None:
+            continue
+        assert p.grad is not None, k
+        worst = max(worst, _grads_close(k, p.grad, ref[k]))
+    print("dense backward %s / %s: worst relative gradient error %.2e" % (name, precision, worst))
+    # training mode: two dropouts (conv.py:259,271), finite gradients
+    layer.train()
+    layer.zero_grad()
+    o2 = layer(xd, nt.to(DEV), ei.to(DEV), et.to(DEV), tm.to(DEV) if use_RTE else None)
+    o2.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for k, p in layer.named_parameters() if k != "emb.emb.weight")
+
+
 def test_training_mode_runs_with_dropout_and_eval_matches():
     T, R, H, d, N, E = 3, 4, 4, 64, 1500, 9000
     sd = O.make_state_dict(d, d, T, R, H, True, True, seed=3)
