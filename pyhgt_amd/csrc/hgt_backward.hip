@@ -545,6 +545,105 @@ __global__ __launch_bounds__(256) void k_relation_outer(
     }
 }
 
+// The same sums on the matrix cores for 32-wide heads (d_k = 32: c2, c3): the outer products of an edge batch are one
+// v_mfma_f32_32x32x2_f32 per (head, pair of edges) -- operand A = the two scaled source rows' 32 head columns, B = the two target
+// rows' -- exact fp32 products, 256 matrix-core cycles per edge instead of ~550 vector-ALU cycles (128 FMAs per lane, LDS bounce,
+// two wave barriers per edge).  The rows of a batch are parked in LDS as [edge][column] (288-float stride: the two edges of a pair
+// fall into different bank halves); the 8 head blocks accumulate in 128 registers and are flushed once per wavefront.
+template <int VEC, bool RTE>
+__global__ __launch_bounds__(256, 2) void k_relation_outer_mfma(
+    const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
+    const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ w, const float* __restrict__ a,
+    const float* __restrict__ rte_a, const float* __restrict__ b, float* __restrict__ out, int R, int HT, int items_per_wave) {
+    constexpr int DKP = 32, LPH = DKP / VEC, DP = 64 * VEC, H = 64 / LPH, UB = 8, RS = DP + 32;   // RS: LDS row stride in floats
+    static_assert(DP % 32 == 0 && H * DKP == DP, "32-wide heads");
+    __shared__ __attribute__((aligned(16))) float s_rows[4][2][UB][RS];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hg = blockIdx.y, rel_sel = blockIdx.z;
+    const int64_t ld = (int64_t)HT * DKP;
+    const int co = hg * DP;
+    const int h = lane / LPH;
+    float (*sa)[RS] = s_rows[wib][0];
+    float (*sb)[RS] = s_rows[wib][1];
+    const int n_items = hdr->n_items;
+    const int first = (blockIdx.x * 4 + wib) * items_per_wave;
+    if (first >= n_items) return;
+    f32x16 acc[H];
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[hh][r] = 0.0f;
+    bool any = false;
+    for (int ib = first; ib < min(first + items_per_wave, n_items); ib += 64) {
+        const int my_i = min(ib + lane, n_items - 1);
+        const HgtItem mine = items[my_i];
+        const bool take = (ib + lane < min(first + items_per_wave, n_items)) && mine.rel == rel_sel;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(take);
+        while (todo) {
+            const int li_ = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int beg = __builtin_amdgcn_readlane(mine.beg, li_), end = __builtin_amdgcn_readlane(mine.end, li_);
+            any = true;
+            for (int base = beg; base < end; base += 64) {
+                const int nb = min(64, end - base);
+                const int li = base + min(lane, nb - 1);
+                const int my_src = esrc[li], my_dst = edst[li];
+                const int my_rte = RTE ? (int)ertei[li] : 0;
+                for (int e0 = 0; e0 < nb; e0 += UB) {
+                    float av[UB][VEC], bv[UB][VEC], tv[RTE ? UB : 1][VEC], we[UB];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const int idx = min(e0 + u, nb - 1);
+                        const int s = __builtin_amdgcn_readlane(my_src, idx), dd = __builtin_amdgcn_readlane(my_dst, idx);
+                        load_vec<VEC>(a + (int64_t)s * ld + co + lane * VEC, av[u]);
+                        if constexpr (RTE) {
+                            const int ri = __builtin_amdgcn_readlane(my_rte, idx);
+                            load_vec<VEC>(rte_a + (int64_t)ri * ld + co + lane * VEC, tv[u]);
+                        }
+                        load_vec<VEC>(b + (int64_t)dd * ld + co + lane * VEC, bv[u]);
+                        we[u] = w[(int64_t)(base + idx) * HT + hg * H + h];
+                    }
+                    __builtin_amdgcn_wave_barrier();          // the previous batch's operands have been read
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const float sc = (e0 + u < nb) ? we[u] : 0.0f;      // slots beyond the chunk contribute nothing
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            if constexpr (RTE) av[u][i] += tv[u][i];
+                            av[u][i] *= sc;
+                        }
+                        store_vec_lds<VEC>(&sa[u][lane * VEC], av[u]);
+                        store_vec_lds<VEC>(&sb[u][lane * VEC], bv[u]);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int er = lane >> 5, cc = lane & 31;
+#pragma unroll
+                    for (int hh = 0; hh < H; ++hh)
+#pragma unroll
+                        for (int pr = 0; pr < UB / 2; ++pr)
+                            acc[hh] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[2 * pr + er][hh * 32 + cc], sb[2 * pr + er][hh * 32 + cc], acc[hh],
+                                                                          0, 0, 0);
+                }
+            }
+        }
+    }
+    if (any) {
+        // C layout of a 32 x 32 block: column c = lane & 31, row k = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) {
+            float* o = out + ((int64_t)rel_sel * HT + hg * H + hh) * DKP * DKP;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                unsafeAtomicAdd(&o[k * DKP + (lane & 31)], acc[hh][r]);
+            }
+        }
+    }
+}
+
 template <int VEC, int LPH>
 struct LaunchOuter {
     static int run(const HgtPlanView& pv, const float* w, const float* a, const float* rte_a, const float* b, float* out, int R, int HT,
@@ -555,6 +654,15 @@ struct LaunchOuter {
             const int ipw = 16 * (R + 1);
             const int64_t waves = (pv.L.max_items + ipw - 1) / ipw;
             dim3 grid((unsigned)((waves + 3) / 4), (unsigned)(HT / (64 / LPH)), (unsigned)R);
+            if constexpr (VEC * LPH == 32 && VEC <= 4) {          // 32-wide heads: matrix-core form
+                if (rte_a)
+                    k_relation_outer_mfma<VEC, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, w, a, rte_a, b, out,
+                                                                              R, HT, ipw);
+                else
+                    k_relation_outer_mfma<VEC, false><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, w, a, rte_a, b, out,
+                                                                               R, HT, ipw);
+                return HGT_OK;
+            }
             if (rte_a)
                 k_relation_outer<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, w, a, rte_a, b, out, R,
                                                                           HT, ipw);
