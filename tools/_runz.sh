@@ -1,4 +1,8 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_backward_gpu.py -m gpu -q -x 2>&1 | tail -4
-python tools/bench_train.py
-HGT_TRAIN_N=3200 HGT_TRAIN_E=31000 python tools/bench_train.py
+for extra in "" "--kernel-flags 1"; do
+python bench.py $extra --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
+import json,sys
+j=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('[$extra]', 'ms', round(j['ms_per_step'],3), 'parity', j['parity_max_abs_err'], j['roofline']['phase_ms'])
+"
+done
