@@ -1,3 +1,7 @@
+#!/bin/bash
+# Full GPU validation of a build (run through gpurun from the repo root): pytest -m gpu, the judged bench line + RTE / Zipf variants,
+# a 2-rank walk of the multi-GPU path on one device (gloo, host-staged exchange), the parity fuzzers, the rocprofv3 passes of
+# tools/profile_pmc.sh, the latency-regime and training-step timings.  Writes gpurun_out/*; summaries are copied to profiles/ by hand.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export HGT_COMMIT=$(cat .commit 2>/dev/null || echo unknown)
@@ -10,6 +14,7 @@ python tools/fuzz_parity.py 80 > gpurun_out/fuzz_r2e.log 2>&1; tail -1 gpurun_ou
 python tools/fuzz_parity.py 16 big > gpurun_out/fuzz_big_r2e.log 2>&1; tail -1 gpurun_out/fuzz_big_r2e.log
 tools/profile_pmc.sh r02 > gpurun_out/prof_r02.log 2>&1
 python tools/bench_small.py > gpurun_out/bench_small_r2e.log 2>&1; tail -1 gpurun_out/bench_small_r2e.log
+python tools/bench_train.py > gpurun_out/bench_train_r2e.log 2>&1; tail -1 gpurun_out/bench_train_r2e.log
 tail -12 gpurun_out/pytest_r2e.log
 for f in gpurun_out/bench_r2e*.json; do python - "$f" <<'PY'
 import json,sys
