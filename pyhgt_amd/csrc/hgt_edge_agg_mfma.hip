@@ -526,7 +526,9 @@ __device__ __forceinline__ void agg_mfma_stream(
     Row vrA[UN], trA[RTE ? UN : 1], vrB[UN], trB[RTE ? UN : 1];
     float slA[UN], slB[UN];
     int keyA[UN], keyB[UN];
+#if HGT_AGG_HIDDEN
     constexpr int HIDDEN_PER_BATCH = UN * (RTE ? 3 : 2);     // rows + logits (+ temporal rows)
+#endif
 
     // A batch = the next UN entries of the stream (fewer only at a chunk end), whatever their relations.
 #define AGG_ISSUE(VR, SL, TR, KY, I0, CNT)                                                         \

@@ -92,7 +92,6 @@ __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned 
     const unsigned char* abase = slab + frow * A_STRIDE + khalf * 16;
     const bool o1 = lane & 1, o2 = lane & 2;
     const float inv_n = 1.0f / (float)n_out;
-    const int rt0 = (lane & 3) + 4 * (lane >> 5);      // row of register group (j, q): rt0 + 32 j + 8 q
 
     for (int g = tmin; g <= tmax; ++g) {               // empty range when no row has a valid type
         if (__builtin_amdgcn_ballot_w64(my_t == g) == 0) continue;
