@@ -12,7 +12,9 @@ export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-secondary $*"
 cd /tmp
 rocprofv3 -L 2>&1 | grep -oE "^\s*(gpu-agent[0-9]+:)?\s*[A-Za-z_0-9]+" | sort -u | head -400 > "$OUT/counters_available.txt" || true
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- $BENCH > "$OUT/stats.log" 2>&1
+# the timing pass runs more steps than the counter passes: with 4 launches the average is dominated by the first (cold) one
+BENCH_T="python $ROOT/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-parity --no-secondary $*"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- $BENCH_T > "$OUT/stats.log" 2>&1
 pass() {  # name counters...
     local name=$1; shift
     timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d "$OUT/$name" -o p -- $BENCH > "$OUT/$name.log" 2>&1 || echo "pass $name failed" >> "$OUT/failed.txt"
