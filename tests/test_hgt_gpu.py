@@ -553,6 +553,39 @@ def test_plan_from_sorted_is_bit_identical_and_the_handoff_matches_the_oracle(sc
     GraphPlan.clear_cache()
 
 
+def test_plan_from_sorted_large_and_empty_graphs():
+    """Both builders of hgt_plan_from_sorted: sampled-batch sizes take three launches (pair table in one workgroup), larger graphs
+    the seven-launch form (more than 4095 (tile, relation) pairs) -- each bit-identical to hgt_plan_build; and a graph without
+    edges."""
+    T, R = 3, 5
+    g = torch.Generator().manual_seed(11)
+    for N, E in ((300000, 900000), (5000, 0), (1, 0)):
+        per = [N // T + (1 if t < N % T else 0) for t in range(T)]
+        nt = torch.repeat_interleave(torch.arange(T), torch.tensor(per))
+        rel = torch.sort(torch.randint(0, R, (E,), generator=g)).values
+        dst = torch.randint(0, N, (E,), generator=g) if E else torch.zeros(0, dtype=torch.int64)
+        order = torch.argsort(rel * N + dst, stable=True)
+        rel, dst = rel[order], dst[order]
+        src = torch.randint(0, N, (E,), generator=g) if E else torch.zeros(0, dtype=torch.int64)
+        tm = torch.randint(100, 140, (E,), generator=g) if E else torch.zeros(0, dtype=torch.int64)
+        ei = torch.stack([src, dst])
+        ntd, eid, etd, tmd = _to_dev(nt, ei, rel, tm)
+        rel_ptr = torch.searchsorted(rel, torch.arange(R + 1)).int().to(DEV)
+        type_off = torch.searchsorted(nt, torch.arange(T + 1)).int().to(DEV)
+        plan = GraphPlan.from_sorted(ntd, eid, etd, tmd, eid[0].int().contiguous(), eid[1].int().contiguous(), tmd.int().contiguous(),
+                                     rel_ptr, type_off, T, R)
+        built = GraphPlan(ntd, eid, etd, tmd, T, R)
+        torch.cuda.synchronize()
+        a, b = _plan_arrays(plan), _plan_arrays(built)
+        for k in ("n_items", "bad", "n_bins"):
+            assert a[k] == b[k], (N, E, k)
+        for k in ("esrc", "edst", "ertei", "eid", "segptr", "tile_items", "rows_all", "off_all", "rows_q", "off_q"):
+            assert np.array_equal(a[k], b[k]), (N, E, k)
+        assert np.array_equal(a["items"][:a["n_items"]], b["items"][:b["n_items"]])
+        plan.raise_if_bad(wait=True)
+    GraphPlan.clear_cache()
+
+
 def test_malformed_input_raises_like_the_reference():
     """The reference fails with an IndexError for node ids outside [0, N) (index_select) and for edge_time outside [0, 240)
     (nn.Embedding, conv.py:299).  Here the plan build flags both; the flag reaches the host asynchronously, so forward()
