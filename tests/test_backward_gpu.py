@@ -214,3 +214,18 @@ def test_typed_weight_gradient_kernels(m, n_cols, n):
         assert (out3[t].cpu().double() - ref).abs().max().item() < 1e-4 * scale
         assert (cs[t].cpu().double() - A[idx].double().sum(0)).abs().max().item() < 1e-3
         assert (cs3[t].cpu().double() - A[idx].double().sum(0)).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("conv", ["hgt", "dense_hgt"])
+def test_training_loop_reduces_the_loss(conv):
+    """examples/train_synthetic.py: the reference's training-loop shape (sampled batch -> to_device_graph -> GNN -> Classifier ->
+    nll_loss -> backward -> AdamW) on the HIP forward + backward; the loss of a learnable synthetic task must fall."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("train_synthetic", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                 "examples", "train_synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    losses = mod.run("mag", steps=40, conv=conv, verbose=False)
+    assert all(l == l for l in losses)                              # finite
+    assert sum(losses[-8:]) / 8 < 0.8 * sum(losses[:4]) / 4, (losses[:4], losses[-8:])
