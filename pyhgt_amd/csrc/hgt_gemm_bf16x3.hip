@@ -27,6 +27,9 @@
 #include <algorithm>
 
 
+#ifndef HGT_GEMM_NST8
+#define HGT_GEMM_NST8 1    // plain linear layers: eight W stages, rows stored at the end of each pass (see k_typed_linear_pc)
+#endif
 #ifndef HGT_GEMM_PC4
 #define HGT_GEMM_PC4 0     // 1: plain linear layers on the four-consumer form of the persistent kernel (k_typed_linear_pc4):
                            //    measured slower (1.52-1.62 vs 1.45 ms at c2); kept as an experiment switch
@@ -574,7 +577,7 @@ __device__ __forceinline__ void pc_stage_pass(f32x16 (&acc)[2], int pass, int wa
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 }
 
-template <int PROLOGUE, bool UPD>
+template <int PROLOGUE, bool UPD, int NSTP = 0>
 __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off,
     int n_groups, int k, int n_out, const unsigned short* __restrict__ wsplit, const float* __restrict__ bias, int64_t bgs,
@@ -655,6 +658,7 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
         tile_lookup(first + i * stride, group_off, n_groups, g, row0, nrows);
         const unsigned short* __restrict__ wfrag = wsplit + (int64_t)g * total * 2 * W_PLANE_ELEMS + (wave * 64 + lane) * 8;
         bf16x8 s0h, s0m, s1h, s1m, s2h, s2m, s3h, s3m;
+        bf16x8 s4h, s4m, s5h, s5m, s6h, s6m, s7h, s7m;      // (NSTP == 8 only)
 #define PC_LOAD_STAGE(S, T)                                                                           \
     {                                                                                                 \
         const unsigned short* t_ = wfrag + (int64_t)min((T), total - 1) * 2 * W_PLANE_ELEMS;          \
@@ -662,12 +666,22 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
         s##S##m = *reinterpret_cast<const bf16x8*>(t_ + W_PLANE_ELEMS);                               \
     }
         // B fragments are prefetched NST k-chunks ahead (the fused-update variant has fewer registers to spare)
-        constexpr int NST = UPD ? 2 : 4;
+        // NSTP == 8 (plain linear layers with a multiple of 8 k-chunks): eight stages AND no parked rows -- the 32 registers of the
+        // parked rows hold four more W stages instead, and a pass's rows are stored in one burst at its end.  Reason: the hidden
+        // stores share vmcnt with the W loads, so every store in flight makes the counted waits of the loop stricter by one load:
+        // with ~3 parked-row stores in flight the effective prefetch distance of four stages shrinks to ~1.5 k-chunks.
+        constexpr int NST = UPD ? 2 : (NSTP == 8 ? 8 : 4);
         PC_LOAD_STAGE(0, 0)
         PC_LOAD_STAGE(1, 1)
-        if constexpr (NST == 4) {
+        if constexpr (NST >= 4) {
             PC_LOAD_STAGE(2, 2)
             PC_LOAD_STAGE(3, 3)
+        }
+        if constexpr (NST == 8) {
+            PC_LOAD_STAGE(4, 4)
+            PC_LOAD_STAGE(5, 5)
+            PC_LOAD_STAGE(6, 6)
+            PC_LOAD_STAGE(7, 7)
         }
         pc_barrier();                                      // B_i: slab[i&1] holds tile i
         const unsigned char* slab = sA[i & 1] + frow * A_STRIDE + khalf * 16;
@@ -725,17 +739,35 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
             __builtin_amdgcn_sched_barrier(0);                                                                     \
         }                                                                                                          \
     }
+#define PC_BODY8(B)                                                                                                \
+    {                                                                                                              \
+        const int kq = 8 * (B);                                                                                    \
+        const int knext = (kq + 8 == n_kc) ? 0 : kq + 8;                                                           \
+        PC_STEP(0, tbase + kq, e, o, kq + 1)                                                                       \
+        PC_STEP(1, tbase + kq + 1, o, e, kq + 2)                                                                   \
+        PC_STEP(2, tbase + kq + 2, e, o, kq + 3)                                                                   \
+        PC_STEP(3, tbase + kq + 3, o, e, kq + 4)                                                                   \
+        PC_STEP(4, tbase + kq + 4, e, o, kq + 5)                                                                   \
+        PC_STEP(5, tbase + kq + 5, o, e, kq + 6)                                                                   \
+        PC_STEP(6, tbase + kq + 6, e, o, kq + 7)                                                                   \
+        PC_STEP(7, tbase + kq + 7, o, e, knext)                                                                    \
+    }
         PC_LOAD_A(e, 0)
         for (int pass = 0; pass < n_pass; ++pass) {
             const int tbase = pass * n_kc;
-            PC_BODY(0)
-            if (n_kc > 4) PC_BODY(1)
-            if (n_kc > 8) PC_BODY(2)
-            if (n_kc > 12) PC_BODY(3)
-            // k < 256: the bodies that did not run leave their rows behind
-            if (n_kc <= 12) { PC_STORE(6) PC_STORE(7) }
-            if (n_kc <= 8) { PC_STORE(4) PC_STORE(5) }
-            if (n_kc <= 4) { PC_STORE(2) PC_STORE(3) }
+            if constexpr (NST == 8) {
+                PC_BODY8(0)
+                if (n_kc > 8) PC_BODY8(1)
+            } else {
+                PC_BODY(0)
+                if (n_kc > 4) PC_BODY(1)
+                if (n_kc > 8) PC_BODY(2)
+                if (n_kc > 12) PC_BODY(3)
+                // k < 256: the bodies that did not run leave their rows behind
+                if (n_kc <= 12) { PC_STORE(6) PC_STORE(7) }
+                if (n_kc <= 8) { PC_STORE(4) PC_STORE(5) }
+                if (n_kc <= 4) { PC_STORE(2) PC_STORE(3) }
+            }
             if constexpr (UPD) {
                 pc_store_update(acc, wave, lane, g, n_out, nrows, s_rid[i % 3], bias, bgs, out0, upd, s_red[i & 1][0], s_red[i & 1][1], pr);
 #pragma unroll
@@ -750,7 +782,12 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
             pr.row0 = row0;
             pr.nrows = nrows;
             pr.by_pos = UPD ? 0 : by_pos;
+            if constexpr (NST == 8) {      // no parking: the pass's rows leave in one burst
+                PC_STORE(0) PC_STORE(1) PC_STORE(2) PC_STORE(3) PC_STORE(4) PC_STORE(5) PC_STORE(6) PC_STORE(7)
+                have_pend = false;
+            }
         }
+#undef PC_BODY8
 #undef PC_LOAD_A
 #undef PC_STEP
 #undef PC_BODY
@@ -1063,6 +1100,26 @@ extern "C" int hgt_typed_linear_bf16x3(const float* x, int64_t ldx, const int32_
                                                                    bias, b_group_stride, out0, out1, out2, block_cols, out_by_position, vec_ok);
         HGT_CHECK_LAUNCH();
         return HGT_OK;
+#endif
+#if HGT_GEMM_NST8
+        {
+            int n_pass_, n_kc_;
+            split_dims(k, n_out, &n_pass_, &n_kc_);
+            if (n_kc_ % 8 == 0) {
+                if (prologue == 0)
+                    k_typed_linear_pc<0, false, 8><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
+                                                                                    (const unsigned short*)w_split, bias, b_group_stride,
+                                                                                    out0, out1, out2, block_cols, out_by_position, vec_ok,
+                                                                                    noupd);
+                else
+                    k_typed_linear_pc<1, false, 8><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
+                                                                                    (const unsigned short*)w_split, bias, b_group_stride,
+                                                                                    out0, out1, out2, block_cols, out_by_position, vec_ok,
+                                                                                    noupd);
+                HGT_CHECK_LAUNCH();
+                return HGT_OK;
+            }
+        }
 #endif
         if (prologue == 0)
             k_typed_linear_pc<0, false><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
