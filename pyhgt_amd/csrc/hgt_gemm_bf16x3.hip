@@ -28,7 +28,8 @@
 
 
 #ifndef HGT_GEMM_NST8
-#define HGT_GEMM_NST8 1    // plain linear layers: eight W stages, rows stored at the end of each pass (see k_typed_linear_pc)
+#define HGT_GEMM_NST8 0    // 1: plain linear layers with eight W stages and rows stored in a burst at the end of each pass
+                           //    (see k_typed_linear_pc): measured 1.50 vs 1.45-1.48 ms at c2, kept as an experiment switch
 #endif
 #ifndef HGT_GEMM_PC4
 #define HGT_GEMM_PC4 0     // 1: plain linear layers on the four-consumer form of the persistent kernel (k_typed_linear_pc4):
