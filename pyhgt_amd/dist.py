@@ -174,6 +174,13 @@ class HaloPlan:
         in_chunk = torch.searchsorted(bounds, halo_pos.clamp(min=0), right=True)
         return torch.where(halo_pos >= 0, 1 + in_chunk, torch.zeros_like(halo_pos))
 
+    def bucketed_edge_types(self, edge_type, num_relations):
+        """Relation ids of the source-bucketed plan: bucket * R + relation for the edges a relation claims, (n_chunks + 1) * R
+        (= the plan's unclaimed bucket) for relation ids outside [0, R) (conv.py:68-69: logit 0, no message, still in the softmax)."""
+        claimed = (edge_type >= 0) & (edge_type < num_relations)
+        return torch.where(claimed, self.edge_buckets() * num_relations + edge_type,
+                           torch.full_like(edge_type, (self.n_chunks + 1) * num_relations))
+
     def exchange_chunk(self, c, x_own, x_local, pack=None, async_op=False, compress=False):
         """One slice of the exchange: pack the rows of chunk c the peers need, all-to-all them into the halo rows of
         chunk c.  Returns (work, buffers) when async_op: work.wait() makes the current stream wait for the rows (and, with
@@ -259,10 +266,7 @@ class PartitionedGraph:
         self.bucket_plan = None
         if self.bucketed:
             # bucket of an edge = where its source row comes from: 0 own, 1 + c halo chunk c (halo rows are in chunk order)
-            bucket = self.halo.edge_buckets()
-            claimed = (edge_type >= 0) & (edge_type < num_relations)
-            self.edge_type_bucketed = torch.where(claimed, bucket * num_relations + edge_type,
-                                                  torch.full_like(edge_type, self.n_buckets * num_relations))
+            self.edge_type_bucketed = self.halo.bucketed_edge_types(edge_type, num_relations)
             self.bucket_plan = GraphPlan(self.node_type_local, self.edge_index, self.edge_type_bucketed, edge_time, num_types,
                                          self.n_buckets * num_relations, n_q_rows=self.n_own)
         self.x_local = None

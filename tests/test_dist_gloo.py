@@ -65,6 +65,21 @@ def _worker(rank, world, port, N, E, d, T, R, H, offsets, tmpdir, n_chunks=1):
         for c in range(n_chunks):
             a, b = hp.n_own + hp.recv_chunk_off[c], hp.n_own + hp.recv_chunk_off[c + 1]
             assert torch.equal(bucket == c + 1, (hp.src_local >= a) & (hp.src_local < b))
+        # relation ids of the bucketed plan: bucket * R + relation, unclaimed relation ids -> (n_chunks + 1) * R; and the
+        # oracle on the re-numbered graph (relation parameters repeated per bucket) equals the oracle on the original one
+        et_m = et[mine].clone()
+        et_m[::9] = R + 3
+        et_b = hp.bucketed_edge_types(et_m, R)
+        ok = (et_m >= 0) & (et_m < R)
+        assert torch.equal(et_b[ok], bucket[ok] * R + et_m[ok]) and (et_b[~ok] == (n_chunks + 1) * R).all()
+        B = n_chunks + 1
+        sd_b = dict(sd)
+        for k in ("relation_att", "relation_msg"):
+            sd_b[k] = sd[k].repeat(B, 1, 1, 1)
+        sd_b["relation_pri"] = sd["relation_pri"].repeat(B, 1)
+        out_b = O.forward_closed_form(sd_b, T, B * R, H, x_local, hp.node_type_local, torch.stack([hp.src_local, dst_l]), et_b, tm[mine])
+        out_o = O.forward_closed_form(sd, T, R, H, x_local, hp.node_type_local, torch.stack([hp.src_local, dst_l]), et_m, tm[mine])
+        assert (out_b - out_o).abs().max().item() < 1e-12
         seen = torch.cat(seen)
         valid = (hp.node_type_local[hp.n_own:] >= 0) & (hp.node_type_local[hp.n_own:] < T)
         assert torch.equal(torch.sort(seen).values, hp.n_own + valid.nonzero(as_tuple=True)[0])
