@@ -13,7 +13,11 @@ namespace {
 //   k_hub_finalize   agg[hub] = gelu(acc / (l + 1e-16))
 // All three exit immediately when the plan found no hub (hdr->n_hubs == 0).
 // ---------------------------------------------------------------------------------------------
-constexpr int HUB_CHUNKS = 64;
+#ifndef HGT_HUB_CHUNKS
+#define HGT_HUB_CHUNKS 32      // pieces per (hub, relation) range: 64 -> 8.8 ms, 32 -> 8.4 ms, 16 -> 8.7 ms at c2 with Zipf(0.8) targets (the longest pieces of
+                               // the largest hub against the per-piece fixed cost)
+#endif
+constexpr int HUB_CHUNKS = HGT_HUB_CHUNKS;
 constexpr int HUB_GRID_WAVES = 8192;
 
 __device__ __forceinline__ int f2ord(float f) { const int b = __builtin_bit_cast(int, f); return b ^ ((b >> 31) & 0x7fffffff); }
