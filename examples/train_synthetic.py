@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""End-to-end training loop in the shape of the reference's scripts (ogbn-mag/train_ogbn_mag.py:150-200,
-OAG/train_paper_field.py:210-250): sampled batch -> to_device_graph (instead of to_torch + .to(device)) -> GNN -> Classifier
+"""End-to-end training loop in the shape of the reference's scripts (ogbn-mag/train_ogbn_mag.py:141-198,
+OAG/train_paper_field.py:218-279): sampled batch -> to_device_graph (instead of to_torch + .to(device)) -> GNN -> Classifier
 -> nll_loss -> backward -> optimizer step, on sampler-shaped synthetic batches (the datasets are not available offline).
 
     python examples/train_synthetic.py [--schema mag|oag] [--steps 30] [--conv hgt|dense_hgt]
@@ -24,7 +24,7 @@ def run(schema="mag", steps=30, conv="hgt", n_hid=128, n_heads=8, n_layers=2, n_
     torch.manual_seed(seed)
     feat_dim = 129 if schema == "mag" else 256
     batches = []
-    for b in range(4):      # a small pool of sampled batches, cycled like an epoch of pre-sampled jobs (train_ogbn_mag.py:113-123)
+    for b in range(4):      # a small pool of sampled batches, cycled like an epoch of pre-sampled jobs (train_ogbn_mag.py:82-104)
         fe, ti, el, graph = synthetic_sampled_batch(schema, n_seed=batch_size, width=64, depth=4, feat_dim=feat_dim, mean_degree=6.0,
                                                     seed=seed * 100 + b)
         dg = to_device_graph(fe, ti, el, graph, device=device)
