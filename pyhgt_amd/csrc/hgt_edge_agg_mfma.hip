@@ -34,14 +34,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef HGT_AGG_GS
 #define HGT_AGG_GS 8      // column-tile steps whose fragments are requested together at a relation end (16 loads in flight)
 #endif
-#ifndef HGT_AGG_HIDDEN
-#define HGT_AGG_HIDDEN 0     // experiment switch (see agg_mfma_stream): row gathers hidden from hipcc, hand-counted waits
-#endif
-__device__ __forceinline__ void hidden_load(f32x4& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p)); }
-__device__ __forceinline__ void hidden_load(f32x2& d, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p)); }
-__device__ __forceinline__ void hidden_load(float& d, const float* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p)); }
-__device__ __forceinline__ void hidden_load(int& d, const int32_t* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p)); }
-__device__ __forceinline__ void hidden_load_u16(int& d, const uint16_t* p) { asm volatile("global_load_ushort %0, %1, off" : "=v"(d) : "v"(p)); }
 template <int VEC> struct RowT;
 template <> struct RowT<4> { typedef f32x4 type; };
 template <> struct RowT<2> { typedef f32x2 type; };
@@ -397,32 +389,10 @@ __device__ __forceinline__ void agg_mfma_stream(
         m_rte = RTE ? (int)ertei[m_pos] : 0;
     };
 
-#if HGT_AGG_HIDDEN
-    auto load_meta_next = [&](int vbase, int& m_src, int& m_key, int& m_pos, int& m_rte) {
-        const int v = min(vbase + lane, total - 1);
-        int rsel = 0;
-        for (int r = 0; r <= R; ++r) {
-            const int pr = __builtin_amdgcn_readlane(my_pre, r), ln = __builtin_amdgcn_readlane(my_len, r);
-            if (ln > 0 && v >= pr) rsel = r;
-        }
-        m_pos = __shfl(my_beg, rsel) + (v - __shfl(my_pre, rsel));
-        hidden_load(m_src, esrc + m_pos);
-        hidden_load(m_key, edst + m_pos);          /* raw target id: turned into the key after the wait (AGG_META_WAIT) */
-        n_relsel = rsel;
-        if constexpr (RTE) hidden_load_u16(m_rte, ertei + m_pos);
-        else m_rte = 0;
-    };
-#define AGG_META_WAIT asm volatile("s_waitcnt vmcnt(%3)" : "+v"(n_src), "+v"(n_key), "+v"(n_rte) : "n"(HIDDEN_PER_BATCH)); \
-    n_key = (n_key - (int)row0) | (n_relsel << 8);
-#else
 #define load_meta_next load_meta
 #define AGG_META_WAIT
-#endif
     int c_src, c_key, c_pos, c_rte;          // current chunk
     int n_src = 0, n_key = 0, n_pos = 0, n_rte = 0;   // next chunk (prefetched)
-#if HGT_AGG_HIDDEN
-    int n_relsel = 0;
-#endif
     int vbase = 0, nb = min(64, total);
     load_meta(0, c_src, c_key, c_pos, c_rte);
     if (total > 64) load_meta(64, n_src, n_key, n_pos, n_rte);
@@ -526,9 +496,6 @@ __device__ __forceinline__ void agg_mfma_stream(
     Row vrA[UN], trA[RTE ? UN : 1], vrB[UN], trB[RTE ? UN : 1];
     float slA[UN], slB[UN];
     int keyA[UN], keyB[UN];
-#if HGT_AGG_HIDDEN
-    constexpr int HIDDEN_PER_BATCH = UN * (RTE ? 3 : 2);     // rows + logits (+ temporal rows)
-#endif
 
     // A batch = the next UN entries of the stream (fewer only at a chunk end), whatever their relations.
 #define AGG_ISSUE(VR, SL, TR, KY, I0, CNT)                                                         \
@@ -545,25 +512,8 @@ __device__ __forceinline__ void agg_mfma_stream(
             AGG_LOAD(TR[u], rteV + (int64_t)ri * ld + co + lane * VEC)                             \
         }                                                                                          \
     }
-#if HGT_AGG_HIDDEN
-#define AGG_LOAD(D, P) hidden_load(D, P);
-    // the hidden loads of THIS batch have landed once at most HIDDEN_PER_BATCH (= the next batch's) loads are outstanding
-#define AGG_WAIT(VR, SL, TR)                                                                       \
-    if constexpr (!RTE) {                                                                          \
-        asm volatile("s_waitcnt vmcnt(%16)"                                                        \
-                     : "+v"(VR[0]), "+v"(VR[1]), "+v"(VR[2]), "+v"(VR[3]), "+v"(VR[4]), "+v"(VR[5]), "+v"(VR[6]), "+v"(VR[7]),      \
-                       "+v"(SL[0]), "+v"(SL[1]), "+v"(SL[2]), "+v"(SL[3]), "+v"(SL[4]), "+v"(SL[5]), "+v"(SL[6]), "+v"(SL[7])       \
-                     : "n"(HIDDEN_PER_BATCH));                                                     \
-    } else {                                                                                       \
-        asm volatile("s_waitcnt vmcnt(%12)"                                                        \
-                     : "+v"(VR[0]), "+v"(VR[1]), "+v"(VR[2]), "+v"(VR[3]), "+v"(SL[0]), "+v"(SL[1]), "+v"(SL[2]), "+v"(SL[3]),      \
-                       "+v"(TR[0]), "+v"(TR[1]), "+v"(TR[2]), "+v"(TR[3])                          \
-                     : "n"(HIDDEN_PER_BATCH));                                                     \
-    }
-#else
 #define AGG_LOAD(D, P) D = *reinterpret_cast<const __typeof__(D)*>(P);
 #define AGG_WAIT(VR, SL, TR)
-#endif
     // Consume a batch: runs [lo, hi) of one relation; the relation-end work sits between the runs (one call site per buffer)
 #define AGG_PROCESS(VR, SL, TR, KY, CNT)                                                           \
     for (int lo = 0; lo < (CNT);) {                                                                \
@@ -660,20 +610,13 @@ __device__ __forceinline__ void agg_mfma_stream(
         AGG_PROCESS(vrB, slB, trB, keyB, cntB)
         if (cntA == 0) break;
     }
-#if HGT_AGG_HIDDEN
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    AGG_WAIT(vrA, slA, trA)
-    AGG_WAIT(vrB, slB, trB)
-#endif
     flush();
     relation_end(cur_rel);
 #undef AGG_ISSUE
 #undef AGG_LOAD
 #undef AGG_WAIT
 #undef AGG_META_WAIT
-#if !HGT_AGG_HIDDEN
 #undef load_meta_next
-#endif
 #undef AGG_PROCESS
 #undef AGG_NEXT
 }

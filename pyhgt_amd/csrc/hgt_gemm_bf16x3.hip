@@ -27,14 +27,6 @@
 #include <algorithm>
 
 
-#ifndef HGT_GEMM_NST8
-#define HGT_GEMM_NST8 0    // 1: plain linear layers with eight W stages and rows stored in a burst at the end of each pass
-                           //    (see k_typed_linear_pc): measured 1.50 vs 1.45-1.48 ms at c2, kept as an experiment switch
-#endif
-#ifndef HGT_GEMM_PC4
-#define HGT_GEMM_PC4 0     // 1: plain linear layers on the four-consumer form of the persistent kernel (k_typed_linear_pc4):
-                           //    measured slower (1.52-1.62 vs 1.45 ms at c2); kept as an experiment switch
-#endif
 namespace {
 
 // W [n_groups][n_out][k] fp32 -> [g][pass][kchunk][plane][col tile 8][lane 64][8] bf16 (zero padded): the 8 bf16 of
@@ -578,7 +570,7 @@ __device__ __forceinline__ void pc_stage_pass(f32x16 (&acc)[2], int pass, int wa
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 }
 
-template <int PROLOGUE, bool UPD, int NSTP = 0>
+template <int PROLOGUE, bool UPD>
 __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off,
     int n_groups, int k, int n_out, const unsigned short* __restrict__ wsplit, const float* __restrict__ bias, int64_t bgs,
@@ -659,7 +651,6 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
         tile_lookup(first + i * stride, group_off, n_groups, g, row0, nrows);
         const unsigned short* __restrict__ wfrag = wsplit + (int64_t)g * total * 2 * W_PLANE_ELEMS + (wave * 64 + lane) * 8;
         bf16x8 s0h, s0m, s1h, s1m, s2h, s2m, s3h, s3m;
-        bf16x8 s4h, s4m, s5h, s5m, s6h, s6m, s7h, s7m;      // (NSTP == 8 only)
 #define PC_LOAD_STAGE(S, T)                                                                           \
     {                                                                                                 \
         const unsigned short* t_ = wfrag + (int64_t)min((T), total - 1) * 2 * W_PLANE_ELEMS;          \
@@ -667,22 +658,12 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
         s##S##m = *reinterpret_cast<const bf16x8*>(t_ + W_PLANE_ELEMS);                               \
     }
         // B fragments are prefetched NST k-chunks ahead (the fused-update variant has fewer registers to spare)
-        // NSTP == 8 (plain linear layers with a multiple of 8 k-chunks): eight stages AND no parked rows -- the 32 registers of the
-        // parked rows hold four more W stages instead, and a pass's rows are stored in one burst at its end.  Reason: the hidden
-        // stores share vmcnt with the W loads, so every store in flight makes the counted waits of the loop stricter by one load:
-        // with ~3 parked-row stores in flight the effective prefetch distance of four stages shrinks to ~1.5 k-chunks.
-        constexpr int NST = UPD ? 2 : (NSTP == 8 ? 8 : 4);
+        constexpr int NST = UPD ? 2 : 4;
         PC_LOAD_STAGE(0, 0)
         PC_LOAD_STAGE(1, 1)
         if constexpr (NST >= 4) {
             PC_LOAD_STAGE(2, 2)
             PC_LOAD_STAGE(3, 3)
-        }
-        if constexpr (NST == 8) {
-            PC_LOAD_STAGE(4, 4)
-            PC_LOAD_STAGE(5, 5)
-            PC_LOAD_STAGE(6, 6)
-            PC_LOAD_STAGE(7, 7)
         }
         pc_barrier();                                      // B_i: slab[i&1] holds tile i
         const unsigned char* slab = sA[i & 1] + frow * A_STRIDE + khalf * 16;
@@ -740,35 +721,17 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
             __builtin_amdgcn_sched_barrier(0);                                                                     \
         }                                                                                                          \
     }
-#define PC_BODY8(B)                                                                                                \
-    {                                                                                                              \
-        const int kq = 8 * (B);                                                                                    \
-        const int knext = (kq + 8 == n_kc) ? 0 : kq + 8;                                                           \
-        PC_STEP(0, tbase + kq, e, o, kq + 1)                                                                       \
-        PC_STEP(1, tbase + kq + 1, o, e, kq + 2)                                                                   \
-        PC_STEP(2, tbase + kq + 2, e, o, kq + 3)                                                                   \
-        PC_STEP(3, tbase + kq + 3, o, e, kq + 4)                                                                   \
-        PC_STEP(4, tbase + kq + 4, e, o, kq + 5)                                                                   \
-        PC_STEP(5, tbase + kq + 5, o, e, kq + 6)                                                                   \
-        PC_STEP(6, tbase + kq + 6, e, o, kq + 7)                                                                   \
-        PC_STEP(7, tbase + kq + 7, o, e, knext)                                                                    \
-    }
         PC_LOAD_A(e, 0)
         for (int pass = 0; pass < n_pass; ++pass) {
             const int tbase = pass * n_kc;
-            if constexpr (NST == 8) {
-                PC_BODY8(0)
-                if (n_kc > 8) PC_BODY8(1)
-            } else {
-                PC_BODY(0)
-                if (n_kc > 4) PC_BODY(1)
-                if (n_kc > 8) PC_BODY(2)
-                if (n_kc > 12) PC_BODY(3)
-                // k < 256: the bodies that did not run leave their rows behind
-                if (n_kc <= 12) { PC_STORE(6) PC_STORE(7) }
-                if (n_kc <= 8) { PC_STORE(4) PC_STORE(5) }
-                if (n_kc <= 4) { PC_STORE(2) PC_STORE(3) }
-            }
+            PC_BODY(0)
+            if (n_kc > 4) PC_BODY(1)
+            if (n_kc > 8) PC_BODY(2)
+            if (n_kc > 12) PC_BODY(3)
+            // k < 256: the bodies that did not run leave their rows behind
+            if (n_kc <= 12) { PC_STORE(6) PC_STORE(7) }
+            if (n_kc <= 8) { PC_STORE(4) PC_STORE(5) }
+            if (n_kc <= 4) { PC_STORE(2) PC_STORE(3) }
             if constexpr (UPD) {
                 pc_store_update(acc, wave, lane, g, n_out, nrows, s_rid[i % 3], bias, bgs, out0, upd, s_red[i & 1][0], s_red[i & 1][1], pr);
 #pragma unroll
@@ -783,12 +746,7 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
             pr.row0 = row0;
             pr.nrows = nrows;
             pr.by_pos = UPD ? 0 : by_pos;
-            if constexpr (NST == 8) {      // no parking: the pass's rows leave in one burst
-                PC_STORE(0) PC_STORE(1) PC_STORE(2) PC_STORE(3) PC_STORE(4) PC_STORE(5) PC_STORE(6) PC_STORE(7)
-                have_pend = false;
-            }
         }
-#undef PC_BODY8
 #undef PC_LOAD_A
 #undef PC_STEP
 #undef PC_BODY
@@ -799,242 +757,6 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
 #undef PC_STORE
 }
 
-#if HGT_GEMM_PC4
-// =============================================================================================
-// Second form of the persistent kernel for the plain linear layers: FOUR consumer wavefronts (one per SIMD), each a 64 x 64 output
-// tile per pass (2 x 2 MFMA tiles, 64 accumulator registers), + four producers = 8 waves per CU (256-register budget).
-// Why (elimination experiments at c2): with eight consumers of 64 x 32 the loop is bound by LDS reads -- every
-// wavefront reads the same 4 KB of A fragments per k-chunk, 32 KB per chunk and CU = 256 LDS cycles next to 384 MFMA cycles;
-// halving those reads alone took the store-free kernel from 1.03 to 0.81 ms.  RESULT: correct, but 1.52-1.62 ms against 1.45 ms for
-// the eight-consumer form -- one MFMA-issuing wavefront per SIMD exposes every non-MFMA instruction between its MFMA groups
-// (row-id lookups, address arithmetic, the parked-row store), which two wavefronts per SIMD hide for each other.  Here a k-chunk is 4 A reads + 4 W loads for 12 MFMAs
-// per wavefront: half the LDS traffic per MFMA, the same W traffic, and a W prefetch distance of three chunks = 1150 cycles.
-// Output rows are parked in 16 registers per pass and stored one per k-chunk of the next pass (hidden stores, as above).
-// =============================================================================================
-constexpr int PC4_CONS = 4, PC4_THREADS = 64 * (PC4_CONS + PC_PROD);
-
-struct PendingRows4 {    // one pass worth of finished output of this lane: 16 x (row, 4 consecutive columns)
-    f32x4 v[16];         // index u = (j * 2 + c) * 4 + q : row tile j, column tile c, row group q
-    float* base[2];      // per column tile, column offset applied; nullptr = columns out of range
-    int ld;
-    const int* rid;
-    int row0, nrows, by_pos;
-    // branch-free (the only MFMA-issuing wavefront of its SIMD runs this between MFMA groups): the LDS table is always read
-    __device__ __forceinline__ int row(int u, int lane) const {
-        const int rt = (u >> 3) * 32 + (lane & 3) + 8 * (u & 3) + 4 * (lane >> 5);      // < 64
-        const int from_table = rid[rt];
-        const int r = by_pos ? row0 + rt : from_table;
-        return (base[(u >> 2) & 1] != nullptr && rt < nrows) ? r : -1;
-    }
-};
-
-template <int PROLOGUE>
-__global__ __launch_bounds__(PC4_THREADS) void k_typed_linear_pc4(
-    const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off,
-    int n_groups, int k, int n_out, const unsigned short* __restrict__ wsplit, const float* __restrict__ bias, int64_t bgs,
-    float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos, int vec_ok) {
-    __shared__ __attribute__((aligned(16))) unsigned char sA[2][2 * A_PLANE];   // [slab][plane][64][528]
-    __shared__ int s_rid[3][BM];
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int total_tiles = 0;
-    for (int g = 0; g < n_groups; ++g) total_tiles += (group_off[g + 1] - group_off[g] + BM - 1) / BM;
-    const int first = blockIdx.x, stride = gridDim.x;
-    const int n_mine = (total_tiles > first) ? (total_tiles - first + stride - 1) / stride : 0;
-    if (n_mine == 0) return;
-
-    if (wave >= PC4_CONS) {
-        // ------------------------------------------------ producers (identical to k_typed_linear_pc)
-        const int pw = wave - PC4_CONS;
-        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        float4 a[PC_AREGS];
-        int v_rid, g, row0, nrows;
-        tile_lookup(first, group_off, n_groups, g, row0, nrows);
-        pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
-        pc_commit<PROLOGUE>(a, v_rid, pw, lane, sA[0], s_rid[0]);
-        if (n_mine > 1) {
-            tile_lookup(first + stride, group_off, n_groups, g, row0, nrows);
-            pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
-        }
-        pc_barrier();                                   // B_0
-        for (int i = 0; i < n_mine; ++i) {
-            if (i + 1 < n_mine) {
-                pc_commit<PROLOGUE>(a, v_rid, pw, lane, sA[(i + 1) & 1], s_rid[(i + 1) % 3]);
-                if (i + 2 < n_mine) {
-                    tile_lookup(first + (i + 2) * stride, group_off, n_groups, g, row0, nrows);
-                    pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
-                }
-                pc_barrier();                           // B_{i+1}
-            }
-        }
-        return;
-    }
-
-    // ---------------------------------------------------- consumers: wave w owns columns [64 w, 64 w + 64) of every pass
-    const int lane = tid & 63;
-    const int n_pass = (n_out + BNP - 1) / BNP;
-    const int n_kc = ((k + KC - 1) / KC + 3) & ~3;
-    const int total = n_pass * n_kc;
-    const int frow = lane & 31, khalf = lane >> 5;
-    f32x16 acc[2][2];       // [row tile][column tile]
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][c][r] = 0.0f;
-    PendingRows4 pr;
-    bool have_pend = false;   // wave-uniform
-#pragma unroll
-    for (int u = 0; u < 16; ++u) pr.v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    pr.base[0] = pr.base[1] = nullptr;
-    pr.ld = 0;
-    pr.rid = s_rid[0];
-    pr.row0 = pr.nrows = pr.by_pos = 0;
-#define PC4_STORE(U)                                                                                  \
-    if (have_pend) {                                                                                  \
-        const int r_ = pr.row(U, lane);                                                               \
-        if (r_ >= 0) hidden_store16(pr.base[((U) >> 2) & 1] + (int64_t)r_ * pr.ld, pr.v[U]);          \
-    }
-
-    for (int i = 0; i < n_mine; ++i) {
-        int g, row0, nrows;
-        tile_lookup(first + i * stride, group_off, n_groups, g, row0, nrows);
-        // W fragments: per (pass, k-chunk) eight 32-column slices of 512 elements per plane; this wave takes slices 2 w and 2 w + 1
-        const unsigned short* __restrict__ wfrag = wsplit + (int64_t)g * total * 2 * W_PLANE_ELEMS + (2 * wave * 64 + lane) * 8;
-        bf16x8 s0h0, s0m0, s0h1, s0m1, s1h0, s1m0, s1h1, s1m1, s2h0, s2m0, s2h1, s2m1, s3h0, s3m0, s3h1, s3m1;
-#define PC4_LOAD_STAGE(S, T)                                                                          \
-    {                                                                                                 \
-        const unsigned short* t_ = wfrag + (int64_t)min((T), total - 1) * 2 * W_PLANE_ELEMS;          \
-        s##S##h0 = *reinterpret_cast<const bf16x8*>(t_);                                              \
-        s##S##h1 = *reinterpret_cast<const bf16x8*>(t_ + 512);                                        \
-        s##S##m0 = *reinterpret_cast<const bf16x8*>(t_ + W_PLANE_ELEMS);                              \
-        s##S##m1 = *reinterpret_cast<const bf16x8*>(t_ + W_PLANE_ELEMS + 512);                        \
-    }
-        PC4_LOAD_STAGE(0, 0)
-        PC4_LOAD_STAGE(1, 1)
-        PC4_LOAD_STAGE(2, 2)
-        PC4_LOAD_STAGE(3, 3)
-        pc_barrier();                                      // B_i: slab[i&1] holds tile i
-        const unsigned char* slab = sA[i & 1] + frow * A_STRIDE + khalf * 16;
-        bf16x8 e_h0, e_m0, e_h1, e_m1, o_h0, o_m0, o_h1, o_m1;
-#define PC4_LOAD_A(P, KCP)                                                                            \
-    {                                                                                                 \
-        const unsigned char* a_ = slab + (KCP) * (KC * 2);                                            \
-        P##_h0 = *reinterpret_cast<const bf16x8*>(a_);                                                \
-        P##_m0 = *reinterpret_cast<const bf16x8*>(a_ + A_PLANE);                                      \
-        P##_h1 = *reinterpret_cast<const bf16x8*>(a_ + 32 * A_STRIDE);                                \
-        P##_m1 = *reinterpret_cast<const bf16x8*>(a_ + A_PLANE + 32 * A_STRIDE);                      \
-    }
-        // One k-chunk: 12 MFMAs (small terms first; the four accumulators rotate), then the refill of the consumed W stage and
-        // one parked output row of the previous pass
-#define PC4_STEP(S, T, P, PN, KNEXT, U)                                                                            \
-    {                                                                                                              \
-        /* one MFMA-issuing wavefront per SIMD: nothing may stall between the MFMA groups.  The row id of the parked row   \
-           that is stored in THIS step was fetched (LDS) a step ago and the store sits between two MFMA groups; the W stage \
-           is refilled plane by plane as soon as its last use has been issued. */                                   \
-        const int r_now = r_pend;                                                                                  \
-        r_pend = have_pend ? pr.row(((U) + 1) & 15, lane) : -1;                                                    \
-        PC4_LOAD_A(PN, KNEXT)                                                                                      \
-        const unsigned short* t_ = wfrag + (int64_t)min((T) + 4, total - 1) * 2 * W_PLANE_ELEMS;                   \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m0, s##S##h0, acc[0][0], 0, 0, 0);                 \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m1, s##S##h0, acc[1][0], 0, 0, 0);                 \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m0, s##S##h1, acc[0][1], 0, 0, 0);                 \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m1, s##S##h1, acc[1][1], 0, 0, 0);                 \
-        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);  /* 4 A reads + the next row id */                      \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-        if (r_now >= 0) hidden_store16(pr.base[((U) >> 2) & 1] + (int64_t)r_now * pr.ld, pr.v[U]);                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##m0, acc[0][0], 0, 0, 0);                 \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##m0, acc[1][0], 0, 0, 0);                 \
-        s##S##m0 = *reinterpret_cast<const bf16x8*>(t_ + W_PLANE_ELEMS);                                           \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##m1, acc[0][1], 0, 0, 0);                 \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##m1, acc[1][1], 0, 0, 0);                 \
-        s##S##m1 = *reinterpret_cast<const bf16x8*>(t_ + W_PLANE_ELEMS + 512);                                     \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##h0, acc[0][0], 0, 0, 0);                 \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##h0, acc[1][0], 0, 0, 0);                 \
-        s##S##h0 = *reinterpret_cast<const bf16x8*>(t_);                                                           \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##h1, acc[0][1], 0, 0, 0);                 \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##h1, acc[1][1], 0, 0, 0);                 \
-        s##S##h1 = *reinterpret_cast<const bf16x8*>(t_ + 512);                                                     \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                         \
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                         \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                         \
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                         \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                         \
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                         \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                         \
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-    }
-#define PC4_BODY(B)                                                                                                \
-    {                                                                                                              \
-        const int kq = 4 * (B);                                                                                    \
-        const int knext = (kq + 4 == n_kc) ? 0 : kq + 4; /* the next pass starts over on the same slab */          \
-        PC4_STEP(0, tbase + kq, e, o, kq + 1, 4 * (B))                                                             \
-        PC4_STEP(1, tbase + kq + 1, o, e, kq + 2, 4 * (B) + 1)                                                     \
-        PC4_STEP(2, tbase + kq + 2, e, o, kq + 3, 4 * (B) + 2)                                                     \
-        PC4_STEP(3, tbase + kq + 3, o, e, knext, 4 * (B) + 3)                                                      \
-    }
-        PC4_LOAD_A(e, 0)
-        for (int pass = 0; pass < n_pass; ++pass) {
-            const int tbase = pass * n_kc;
-            int r_pend = have_pend ? pr.row(0, lane) : -1;      // row id of the parked row the first step stores
-            PC4_BODY(0)
-            if (n_kc > 4) PC4_BODY(1)
-            if (n_kc > 8) PC4_BODY(2)
-            if (n_kc > 12) PC4_BODY(3)
-            // k < 256: the bodies that did not run leave their rows behind
-            if (n_kc <= 12) { PC4_STORE(12) PC4_STORE(13) PC4_STORE(14) PC4_STORE(15) }
-            if (n_kc <= 8) { PC4_STORE(8) PC4_STORE(9) PC4_STORE(10) PC4_STORE(11) }
-            if (n_kc <= 4) { PC4_STORE(4) PC4_STORE(5) PC4_STORE(6) PC4_STORE(7) }
-            // ---- park this pass: bias, 4 x 4 quad transpose (4 rows x 1 column -> 1 row x 4 columns per lane), rows in pr
-            const bool o1 = lane & 1, o2 = lane & 2;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int col = pass * BNP + wave * 64 + c * 32 + ((lane & 31) >> 2) * 4;
-                const bool col_ok = col < n_out;
-                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (col_ok && bias) b4 = *reinterpret_cast<const float4*>(bias + (int64_t)g * bgs + col);
-                const int blk = col_ok ? col / block_cols : 0, cc = col - blk * block_cols;
-                float* __restrict__ ob = (blk == 0) ? out0 : ((blk == 1) ? out1 : out2);
-                pr.base[c] = col_ok ? ob + cc : nullptr;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float v0 = acc[j][c][4 * q], v1 = acc[j][c][4 * q + 1], v2 = acc[j][c][4 * q + 2], v3 = acc[j][c][4 * q + 3];
-                        quad_transpose(v0, v1, v2, v3, o1, o2);
-                        pr.v[(j * 2 + c) * 4 + q] = f32x4{v0 + b4.x, v1 + b4.y, v2 + b4.z, v3 + b4.w};
-                    }
-            }
-            pr.ld = block_cols;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[j][c][r] = 0.0f;
-            have_pend = true;
-            pr.rid = s_rid[i % 3];
-            pr.row0 = row0;
-            pr.nrows = nrows;
-            pr.by_pos = by_pos;
-        }
-#undef PC4_LOAD_A
-#undef PC4_STEP
-#undef PC4_BODY
-#undef PC4_LOAD_STAGE
-    }
-    // the rows of the very last pass
-    PC4_STORE(0) PC4_STORE(1) PC4_STORE(2) PC4_STORE(3) PC4_STORE(4) PC4_STORE(5) PC4_STORE(6) PC4_STORE(7)
-    PC4_STORE(8) PC4_STORE(9) PC4_STORE(10) PC4_STORE(11) PC4_STORE(12) PC4_STORE(13) PC4_STORE(14) PC4_STORE(15)
-#undef PC4_STORE
-}
-
-#endif   // HGT_GEMM_PC4
 
 static int pc_grid() {
     static int n_cu = 0;
@@ -1092,36 +814,6 @@ extern "C" int hgt_typed_linear_bf16x3(const float* x, int64_t ldx, const int32_
     UpdateArgs noupd = {nullptr, 0, nullptr, nullptr, nullptr, 0};
     if (k <= KP) {   // persistent producer/consumer kernel, one workgroup per CU
         const unsigned grid = (unsigned)std::min<int64_t>(row_tiles, pc_grid());
-#if HGT_GEMM_PC4
-        if (prologue == 0)
-            k_typed_linear_pc4<0><<<grid, PC4_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out, (const unsigned short*)w_split,
-                                                                   bias, b_group_stride, out0, out1, out2, block_cols, out_by_position, vec_ok);
-        else
-            k_typed_linear_pc4<1><<<grid, PC4_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out, (const unsigned short*)w_split,
-                                                                   bias, b_group_stride, out0, out1, out2, block_cols, out_by_position, vec_ok);
-        HGT_CHECK_LAUNCH();
-        return HGT_OK;
-#endif
-#if HGT_GEMM_NST8
-        {
-            int n_pass_, n_kc_;
-            split_dims(k, n_out, &n_pass_, &n_kc_);
-            if (n_kc_ % 8 == 0) {
-                if (prologue == 0)
-                    k_typed_linear_pc<0, false, 8><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
-                                                                                    (const unsigned short*)w_split, bias, b_group_stride,
-                                                                                    out0, out1, out2, block_cols, out_by_position, vec_ok,
-                                                                                    noupd);
-                else
-                    k_typed_linear_pc<1, false, 8><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
-                                                                                    (const unsigned short*)w_split, bias, b_group_stride,
-                                                                                    out0, out1, out2, block_cols, out_by_position, vec_ok,
-                                                                                    noupd);
-                HGT_CHECK_LAUNCH();
-                return HGT_OK;
-            }
-        }
-#endif
         if (prologue == 0)
             k_typed_linear_pc<0, false><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
                                                                          (const unsigned short*)w_split, bias, b_group_stride, out0, out1,
