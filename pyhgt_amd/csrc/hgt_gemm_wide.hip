@@ -24,6 +24,34 @@
 #include "hgt_split_common.h"
 #include <algorithm>
 
+// Experiment switches (tools/lab builds only; the product build uses the defaults)
+#ifndef WD_NST
+#define WD_NST 2             // W stages in registers = prefetch distance in k-chunks
+#endif
+#ifndef WD_X_NOSTORE
+#define WD_X_NOSTORE 0       // timing only: no output stores
+#endif
+#ifndef WD_X_STORE_TOP
+#define WD_X_STORE_TOP 0     // parked row stored at the top of a k-chunk instead of its end
+#endif
+#ifndef WD_X_DUMMY
+#define WD_X_DUMMY 0         // n visible 4-byte loads after every hidden store (see WD_DUMMY)
+#endif
+#ifndef WD_X_NODMA
+#define WD_X_NODMA 0         // timing only: only tile 0 is DMA'd
+#endif
+#ifndef WD_X_NOSPLIT
+#define WD_X_NOSPLIT 0       // timing only: raw bits used as fragments
+#endif
+#ifndef WD_X_NOB
+#define WD_X_NOB 0           // timing only: no W refills
+#endif
+#ifndef WD_SUFFIX
+#define WD_SUFFIX
+#endif
+#define WD_CAT2(a, b) a##b
+#define WD_CAT(a, b) WD_CAT2(a, b)
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -105,7 +133,7 @@ __device__ __forceinline__ void wd_dma_tile(unsigned char* smem, unsigned lds_ba
 }
 
 template <int NKC>
-__global__ __launch_bounds__(WD_THREADS, 2) void k_typed_linear_wide(
+__global__ __launch_bounds__(WD_THREADS, 2) void WD_CAT(k_typed_linear_wide, WD_SUFFIX)(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off, int n_groups,
     int k, int n_out, const unsigned short* __restrict__ wsplit, const float* __restrict__ bias, int64_t bgs, float* __restrict__ out0,
     float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos) {
@@ -172,13 +200,14 @@ __global__ __launch_bounds__(WD_THREADS, 2) void k_typed_linear_wide(
     // parked row UU of the previous item: the row id comes out of the LDS table (read unconditionally and FIRST in a k-chunk, so
     // that the wait for it is a counted lgkmcnt behind the chunk's A reads, not a drain), the store is predicated
     const int rt0 = (lane & 3) + 4 * (lane >> 5);
-#define WD_ROWID(UU) const int rid_c = pr.rid[rt0 + (((UU) >> 2) & 1) * 32 + 8 * ((UU)&3)];
+#define WD_ROWOFF(UU) ((((UU) >> 2) & 1) * 32 + 8 * ((UU)&3))
+#define WD_ROWID(UU) const int rid_c = pr.rid[rt0 + WD_ROWOFF(UU)];
 #define WD_STORE_R(UU)                                                                                \
     {                                                                                                 \
-        const int rt_ = rt0 + (((UU) >> 2) & 1) * 32 + 8 * ((UU)&3);                                  \
+        const int rt_ = rt0 + WD_ROWOFF(UU);                                                          \
         const int r_ = pr.by_pos ? pr.row0 + rt_ : rid_c;                                             \
         float* b_ = pr.base[(UU) >> 3];                                                               \
-        const bool ok_ = have_pend && b_ != nullptr && rt_ < pr.nrows;                                \
+        const bool ok_ = !WD_X_NOSTORE && have_pend && b_ != nullptr && rt_ < pr.nrows;               \
         wd_hidden_store16(b_ + (uint64_t)(unsigned)r_ * pr.ld, pr.v[UU], __builtin_amdgcn_ballot_w64(ok_)); \
     }
 #define WD_STORE(UU) { WD_ROWID(UU) WD_STORE_R(UU) }
@@ -198,6 +227,13 @@ __global__ __launch_bounds__(WD_THREADS, 2) void k_typed_linear_wide(
         raw.a1 = *reinterpret_cast<const f32x4*>(p_ + 32 * WD_ROW);                                   \
         raw.b1 = *reinterpret_cast<const f32x4*>(p_ + 32 * WD_ROW + 16);                              \
     }
+#if WD_X_NOSPLIT
+#define WD_SPLIT(F)                                                                                   \
+    {                                                                                                 \
+        fr[F].h0 = __builtin_bit_cast(bf16x8, raw.a0); fr[F].m0 = __builtin_bit_cast(bf16x8, raw.b0); \
+        fr[F].h1 = __builtin_bit_cast(bf16x8, raw.a1); fr[F].m1 = __builtin_bit_cast(bf16x8, raw.b1); \
+    }
+#else
 #define WD_SPLIT(F)                                                                                   \
     {                                                                                                 \
         uint2 h_, m_, h2_, m2_;                                                                       \
@@ -210,6 +246,7 @@ __global__ __launch_bounds__(WD_THREADS, 2) void k_typed_linear_wide(
         fr[F].h1 = __builtin_bit_cast(bf16x8, make_uint4(h_.x, h_.y, h2_.x, h2_.y));                  \
         fr[F].m1 = __builtin_bit_cast(bf16x8, make_uint4(m_.x, m_.y, m2_.x, m2_.y));                  \
     }
+#endif
     // 12 MFMAs of one k-chunk: small terms first, hi*hi last; every accumulator is touched once per group of four
 #define WD_MFMA(F, ST)                                                                                                  \
     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[F].m0, bst[ST].h0, acc[0], 0, 0, 0);                             \
@@ -225,27 +262,56 @@ __global__ __launch_bounds__(WD_THREADS, 2) void k_typed_linear_wide(
     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[F].h0, bst[ST].h1, acc[1], 0, 0, 0);                             \
     acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[F].h1, bst[ST].h1, acc[3], 0, 0, 0);
     // k-chunk KCX (a literal): raw holds chunk KCX+1 -> split it into the other fragment set, request chunk KCX+2, the chunk's
-    // MFMAs, refill of the W stage just consumed, one parked row of the previous item
+    // MFMAs, refill of the W stage just consumed, one parked row of the previous item (its row id was requested a chunk ahead)
+#if WD_X_DUMMY
+    // a VISIBLE 4-byte load behind every hidden store: hipcc's counted vmcnt waits see only its own loads, so a pending hidden
+    // store makes every wait stricter by one load -- it then waits for a W fragment requested moments ago.  The dummy load is
+    // counted (one more younger load allowed) and, being older than the W refills, it retires right behind the stage waited for.
+#define WD_DUMMY(KCX)                                                                                 \
+    _Pragma("unroll") for (int d_ = 0; d_ < WD_X_DUMMY; ++d_) {                                       \
+        dsink ^= dval[((KCX) + 1) & 1][d_];                                                           \
+        dval[(KCX)&1][d_] = *reinterpret_cast<const volatile int*>(dptr + d_ * 64);                   \
+    }
+#else
+#define WD_DUMMY(KCX)
+#endif
+#define WD_STORE_AT(KCX)                                                                              \
+        WD_STORE_R(KCX)                                                                               \
+        WD_DUMMY(KCX)                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);
+#if WD_X_STORE_TOP
+#define WD_STORE_TOP(KCX) WD_STORE_AT(KCX)
+#define WD_STORE_END(KCX)
+#else
+#define WD_STORE_TOP(KCX)
+#define WD_STORE_END(KCX) WD_STORE_AT(KCX)
+#endif
+#if WD_X_NOB
+#define WD_REFILL_B(KCX)
+#else
+#define WD_REFILL_B(KCX) WD_LOAD_B((KCX) % WD_NST, (KCX) + WD_NST)
+#endif
 #define WD_CHUNK(KCX)                                                                                 \
     {                                                                                                 \
-        WD_ROWID(KCX)                                                                                 \
+        const int rid_c = rid_nx;                                                                     \
+        rid_nx = pr.rid[rt0 + WD_ROWOFF(((KCX) + 1) & 15)];                                           \
+        WD_STORE_TOP(KCX)                                                                             \
         /* the split's inputs are made opaque HERE: pure arithmetic has no chain, and instruction selection otherwise  */ \
         /* places it above the previous chunk's scheduling barrier, outside the region the groups below apply to       */ \
         asm volatile("" : "+v"(raw.a0), "+v"(raw.b0), "+v"(raw.a1), "+v"(raw.b1));                    \
         WD_SPLIT(((KCX) + 1) & 1)                                                                     \
         WD_LOAD_RAW((KCX) + 2)                                                                        \
-        WD_MFMA((KCX)&1, (KCX)&1)                                                                     \
-        WD_LOAD_B((KCX)&1, (KCX) + 2)                                                                 \
-        /* pin: row-id read, then the split's VALU work spread between the MFMAs (left alone, hipcc runs the ~45 VALU */ \
-        /* instructions of the split as one block in front of the MFMAs and the matrix pipe drains meanwhile), then   */ \
+        WD_MFMA((KCX)&1, (KCX) % WD_NST)                                                              \
+        WD_REFILL_B(KCX)                                                                              \
+        /* pin: next row id, then the split's VALU work spread between the MFMAs (left alone, hipcc runs the ~45 VALU  */ \
+        /* instructions of the split as one block in front of the MFMAs and the matrix pipe drains meanwhile), then    */ \
         /* the W refill and the next A reads                                                                           */ \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
         WD_SCHED4 WD_SCHED4 WD_SCHED4                                                                 \
         __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                                            \
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                            \
         __builtin_amdgcn_sched_barrier(0);                                                            \
-        WD_STORE_R(KCX)                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
+        WD_STORE_END(KCX)                                                                             \
     }
 #define WD_SCHED1 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
 #define WD_SCHED4 WD_SCHED1 WD_SCHED1 WD_SCHED1 WD_SCHED1
@@ -257,14 +323,20 @@ __global__ __launch_bounds__(WD_THREADS, 2) void k_typed_linear_wide(
 
     WdRaw raw;
     WdFrag fr[2];
-    WdB bst[2];
+    WdB bst[WD_NST];
+    int rid_nx = 0;
+#if WD_X_DUMMY
+    int dsink = 0, dval[2][WD_X_DUMMY] = {};
+    const int* dptr = reinterpret_cast<const int*>(wsplit) + lane;      // any resident, readable address
+#endif
     WdItem it = get_item(0);
     const unsigned short* w0 = wptr(it.g, it.ct0);
     const unsigned short* w1 = wptr(it.g, it.ct0 + 1);
-    if (it.valid) {
-        WD_LOAD_B(0, 0)
-        WD_LOAD_B(1, 1)
+#define WD_FIRST_STAGES                                                                               \
+    if (it.valid) {                                                                                   \
+        _Pragma("unroll") for (int st_ = 0; st_ < WD_NST; ++st_) WD_LOAD_B(st_, st_)                  \
     }
+    WD_FIRST_STAGES
 
     for (int s = 0; s < n_steps; ++s) {
         wd_barrier();                             // everything requested during step s-1 has landed (its issuer waited)
@@ -272,7 +344,7 @@ __global__ __launch_bounds__(WD_THREADS, 2) void k_typed_linear_wide(
         bool dma_out = false;
         if (duty) {                               // the tile whose first step is s+1 (its slab was released by the barrier above)
             const int jc = (WD_WAVES * (s + 1) + U - 1) / U;
-            if (jc < n_mine && jc * U < WD_WAVES * (s + 2)) {
+            if (!WD_X_NODMA && jc < n_mine && jc * U < WD_WAVES * (s + 2)) {
                 int g, row0, nrows;
                 wd_tile_lookup(first + jc * stride, group_off, n_groups, g, row0, nrows);
                 wd_dma_tile(smem, lds_base, jc & 1, jc & 3, row0, nrows, rows, x, ldx, k, lane);
@@ -289,6 +361,7 @@ __global__ __launch_bounds__(WD_THREADS, 2) void k_typed_linear_wide(
                 if (bias != nullptr && col < n_out) b4[c] = *reinterpret_cast<const float4*>(bias + (int64_t)it.g * bgs + col);
             }
             const unsigned char* aptr = smem + (it.tile & 1) * WD_SLAB + frow * WD_ROW + khalf * 32;
+            rid_nx = pr.rid[rt0 + WD_ROWOFF(0)];
             WD_LOAD_RAW(0)
             WD_SPLIT(0)
             WD_LOAD_RAW(1)
@@ -339,16 +412,23 @@ __global__ __launch_bounds__(WD_THREADS, 2) void k_typed_linear_wide(
         it = get_item(s + 1);
         w0 = wptr(it.g, it.ct0);
         w1 = wptr(it.g, it.ct0 + 1);
-        if (it.valid) {
-            WD_LOAD_B(0, 0)
-            WD_LOAD_B(1, 1)
-        }
+        WD_FIRST_STAGES
         if (dma_out) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // the rows of the very last item
     WD_STORE(0) WD_STORE(1) WD_STORE(2) WD_STORE(3) WD_STORE(4) WD_STORE(5) WD_STORE(6) WD_STORE(7)
     WD_STORE(8) WD_STORE(9) WD_STORE(10) WD_STORE(11) WD_STORE(12) WD_STORE(13) WD_STORE(14) WD_STORE(15)
+#if WD_X_DUMMY
+    asm volatile("" ::"v"(dsink));
+#endif
 #undef WD_BODY
+#undef WD_FIRST_STAGES
+#undef WD_STORE_AT
+#undef WD_STORE_TOP
+#undef WD_STORE_END
+#undef WD_REFILL_B
+#undef WD_DUMMY
+#undef WD_ROWOFF
 #undef WD_CHUNK
 #undef WD_MFMA
 #undef WD_SPLIT
@@ -365,7 +445,7 @@ __global__ __launch_bounds__(WD_THREADS, 2) void k_typed_linear_wide(
 
 // Launcher used by hgt_typed_linear_bf16x3 (hgt_gemm_bf16x3.hip).  Returns HGT_ERR_UNSUPPORTED when the shape is outside
 // this kernel's contract (the caller then takes the older kernel), HGT_OK after a launch.
-int hgt_launch_typed_linear_wide(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
+int WD_CAT(hgt_launch_typed_linear_wide, WD_SUFFIX)(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
                                  int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias,
                                  int64_t b_group_stride, float* out0, float* out1, float* out2, int32_t block_cols,
                                  int32_t out_by_position, int n_cu, hipStream_t stream) {
@@ -382,7 +462,7 @@ int hgt_launch_typed_linear_wide(const float* x, int64_t ldx, const int32_t* row
     const unsigned grid = (unsigned)std::min<int64_t>(row_tiles, n_cu);
     const int n_kc = ((k + KC - 1) / KC + 3) & ~3;
 #define WD_LAUNCH(NKC)                                                                                                       \
-    k_typed_linear_wide<NKC><<<grid, WD_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out, (const unsigned short*)w_split, \
+    WD_CAT(k_typed_linear_wide, WD_SUFFIX)<NKC><<<grid, WD_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out, (const unsigned short*)w_split, \
                                                               bias, b_group_stride, out0, out1, out2, block_cols, out_by_position)
     switch (n_kc) {
         case 4: WD_LAUNCH(4); break;
