@@ -148,10 +148,7 @@ int hgt_typed_linear(const float* x, int64_t ldx, const int32_t* rows, const int
 /* Split-bf16 x3 variant of the typed linear layer (same contract as hgt_typed_linear): operands are
  * split into bf16 hi+mid terms and a product is evaluated as mid*hi + hi*mid + hi*hi on the bf16 matrix
  * cores with fp32 accumulation (relative error of a product <= ~3*2^-18).  W is split and tiled once per
- * forward by hgt_split_weights into a caller-owned buffer of hgt_split_weights_bytes() bytes.
- * prologue: bit 0 as above; bit 1 (HGT_LINEAR_KEEP_PC) keeps the round-2 persistent kernel where the wide persistent
- * form (hgt_gemm_wide.hip: k <= 256, n_out >= 512, no GELU) would run -- A/B measurements and tests only. */
-#define HGT_LINEAR_KEEP_PC 2
+ * forward by hgt_split_weights into a caller-owned buffer of hgt_split_weights_bytes() bytes. */
 int hgt_split_weights_bytes(int32_t n_groups, int32_t k, int32_t n_out, uint64_t* out_host);
 int hgt_split_weights(const float* W, int64_t w_group_stride, int32_t n_groups, int32_t k, int32_t n_out,
                       void* w_split, void* stream);
@@ -426,7 +423,6 @@ typedef struct hgt_conv_args {
 /* hgt_conv_args.flags: explicit kernel-selection switches (A/B measurements, tests); never read from the environment */
 #define HGT_FLAG_NO_FUSED_UPDATE 1   /* aggregation writes agg, the node update runs as its own kernel(s) */
 #define HGT_FLAG_VALU_AGGREGATE  2   /* relation transforms of the aggregation on the vector ALU (round-1 kernel) instead of MFMA */
-#define HGT_FLAG_GEMM_PC         4   /* Q|K|V on the round-2 persistent GEMM (k_typed_linear_pc) instead of the wide form */
 
 /* phase boundaries at which hgt_conv_forward records phase_events[i]:
  *   0 start | 1 relation pack + Q/K/V (+ temporal tables) done | 2 logits done | 3 softmax done |

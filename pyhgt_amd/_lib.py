@@ -14,8 +14,6 @@ HGT_RTE_LEN = 240
 HGT_N_PHASE_EVENTS = 7
 HGT_FLAG_NO_FUSED_UPDATE = 1
 HGT_FLAG_VALU_AGGREGATE = 2
-HGT_FLAG_GEMM_PC = 4
-HGT_LINEAR_KEEP_PC = 2
 
 
 class HgtLayout(C.Structure):

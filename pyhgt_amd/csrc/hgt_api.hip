@@ -240,8 +240,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
             int r2 = hgt_split_weights(Wp, wgs, ng, kk, nout, wsplit, stream);
             if (r2 != HGT_OK) return r2;
         }
-        return hgt_typed_linear_bf16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos,
-                                       prologue | ((a->flags & HGT_FLAG_GEMM_PC) ? HGT_LINEAR_KEEP_PC : 0), stream);
+        return hgt_typed_linear_bf16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos, prologue, stream);
     };
     void* ws_qkv_scratch = wb + w.off_ws_qkv;                       // K|V-only tiles of the halo branch
     void* ws_qkv = pb ? (void*)(pb + pl.off_ws_qkv) : ws_qkv_scratch; // tiles of the full [Q|K|V] weight

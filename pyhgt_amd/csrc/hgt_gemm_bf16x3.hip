@@ -25,6 +25,7 @@
 #include "hgt_common.h"
 #include "hgt_split_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 
 namespace {
@@ -434,7 +435,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // vmcnt(N), N = younger LOADS -- still sufficient: loads return in order, so a pending target load implies N+1
 // pending loads, i.e. counter > N.  Pending stores only make the wait a little stricter than necessary.
 __device__ __forceinline__ void hidden_store16(float* p, f32x4 v) {
+#ifdef HGT_LAB_STORE_NT   // tools/lab A/B: streaming (non-temporal) output stores
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" : : "v"(p), "v"(v));
+#else
     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" : : "v"(p), "v"(v));
+#endif
 }
 
 // workgroup barrier that orders LDS only (a __syncthreads() would also drain every outstanding global load AND store)
@@ -804,17 +809,17 @@ extern "C" int hgt_typed_linear_bf16x3(const float* x, int64_t ldx, const int32_
         return HGT_ERR_INVALID_ARG;
     const int n_blocks_out = (n_out + block_cols - 1) / block_cols;
     if (n_blocks_out > 3 || (n_blocks_out > 1 && !out1) || (n_blocks_out > 2 && !out2)) return HGT_ERR_INVALID_ARG;
-    if (prologue < 0 || prologue > 3) return HGT_ERR_INVALID_ARG;
-    const bool keep_pc = (prologue & HGT_LINEAR_KEEP_PC) != 0;         // A/B runs: stay on the round-2 persistent kernel
-    prologue &= 1;
+    if (prologue != 0 && prologue != 1) return HGT_ERR_INVALID_ARG;
     if (((n_out | block_cols) & 3) != 0) return HGT_ERR_UNSUPPORTED;   // 16-byte epilogue stores; use hgt_typed_linear (fp32) instead
     if (n_rows == 0) return HGT_OK;
     hipStream_t stream = (hipStream_t)stream_;
-    if (prologue == 0 && !keep_pc) {   // wide persistent form (hgt_gemm_wide.hip) wherever its contract holds
+#ifdef HGT_LAB_WIDE   // tools/lab only: the wide persistent form measured in round 3 (slower)
+    if (prologue == 0 && getenv("HGT_WD_VARIANT") != nullptr) {
         const int rw = hgt_launch_typed_linear_wide(x, ldx, rows, group_off, n_groups, n_rows, k, n_out, w_split, bias, b_group_stride, out0,
                                                     out1, out2, block_cols, out_by_position, pc_grid(), stream);
         if (rw != HGT_ERR_UNSUPPORTED) return rw;
     }
+#endif
     const int64_t row_tiles = (n_rows + BM - 1) / BM + n_groups;   // device-side group sizes: launch the upper bound
     if (row_tiles > 0x7fffffffLL) return HGT_ERR_TOO_LARGE;
     const int vec_ok = (ldx % 4 == 0) && (k % 4 == 0) && (((uintptr_t)x & 15) == 0);

@@ -655,61 +655,6 @@ def test_typed_linear_against_torch_fp32(k, n_out, prologue, precision, tol):
     assert err < tol
 
 
-@pytest.mark.parametrize("k,n_out,bc,by_pos,with_bias,sizes", [
-    (256, 768, 256, 0, True, [5000, 0, 3777, 64, 1]),          # Q|K|V of c2: 12 column pairs, a tile spans 1.5 steps; empty / tiny groups
-    (256, 768, 256, 1, True, [70000, 33000]),                  # more tiles than CUs: several tiles per workgroup, output by position
-    (256, 512, 256, 0, False, [1900, 1900, 77]),               # K|V of halo rows: 8 pairs = one tile per step, no bias
-    (128, 768, 256, 0, True, [3000, 1000]),                    # k < 256: lanes beyond k keep the zero-initialised slab columns
-    (64, 1024, 512, 0, True, [2500]),                          # 16 pairs (two steps per tile), two output blocks of 512
-    (200, 768, 768, 0, True, [4100, 900]),                     # k = 12.5 chunks: zero tail inside the last chunk; one output block
-])
-def test_wide_typed_linear_is_bit_identical_to_the_round2_kernel(k, n_out, bc, by_pos, with_bias, sizes):
-    """hgt_gemm_wide.hip (LDS-DMA'd raw rows, on-the-fly split, 64x64 wavefront tiles) against k_typed_linear_pc on the same
-    inputs: both accumulate the k-chunks in the same order with the same three products per chunk, so the results must agree
-    BIT FOR BIT; and both are within the split-bf16 bound of the fp64 product."""
-    lib = _lib.load()
-    T, N = len(sizes), sum(sizes)
-    g = torch.Generator().manual_seed(k * 7 + n_out)
-    x = torch.randn(N + 3, k, generator=g)
-    W = torch.randn(T, n_out, k, generator=g) / k ** 0.5
-    b = torch.randn(T, n_out, generator=g)
-    nt = torch.cat([torch.full((n,), t, dtype=torch.long) for t, n in enumerate(sizes)])
-    perm = torch.randperm(N, generator=g)
-    node_of_pos = perm                                            # typed row list: position p -> node id (scattered ids)
-    ntype_of_node = torch.empty(N, dtype=torch.long)
-    ntype_of_node[perm] = nt
-    rows = node_of_pos.int()
-    off = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32)
-    ref = torch.empty(N, n_out, dtype=torch.float64)
-    for t in range(T):
-        m = ntype_of_node == t
-        ref[m] = x[:N][m].double() @ W[t].double().T + (b[t].double() if with_bias else 0.0)
-    xd = torch.full((N + 3, k + 4), float("nan"), device=DEV)     # row stride k + 4: rows stay 16-byte aligned but are not packed
-    xd[:, :k] = x.to(DEV)
-    Wd, bd, rd, od = _to_dev(W, b, rows, off)
-    nblk = n_out // bc
-    st = torch.cuda.current_stream().cuda_stream
-    nb = C.c_uint64()
-    assert lib.hgt_split_weights_bytes(T, k, n_out, C.byref(nb)) == 0
-    ws = torch.empty(nb.value, dtype=torch.uint8, device=DEV)
-    assert lib.hgt_split_weights(Wd.data_ptr(), n_out * k, T, k, n_out, ws.data_ptr(), st) == 0
-    res = {}
-    for name, prol in (("wide", 0), ("pc", _lib.HGT_LINEAR_KEEP_PC)):
-        outs = [torch.full((N, bc), float("nan"), device=DEV) for _ in range(nblk)]
-        optr = [o.data_ptr() for o in outs] + [0, 0]
-        rc = lib.hgt_typed_linear_bf16x3(xd.data_ptr(), xd.stride(0), rd.data_ptr(), od.data_ptr(), T, N, k, n_out, ws.data_ptr(),
-                                         bd.data_ptr() if with_bias else None, n_out, optr[0], optr[1], optr[2], bc, by_pos, prol, st)
-        assert rc == 0
-        torch.cuda.synchronize()
-        res[name] = torch.cat([o.cpu() for o in outs], dim=1)
-    want = ref[node_of_pos] if by_pos else ref                   # by position: output row p belongs to node rows[p]
-    assert torch.isfinite(res["wide"]).all()
-    err = (res["wide"].double() - want).abs().max().item()
-    print("wide typed_linear k=%d n=%d rows=%s err %.2e" % (k, n_out, sizes, err))
-    assert err < 1e-4
-    assert torch.equal(res["wide"], res["pc"])
-
-
 def test_gather_rows_bit_exact():
     lib = _lib.load()
     x = torch.randn(1000, 100)

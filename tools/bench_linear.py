@@ -20,7 +20,6 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--which", default="both")
     ap.add_argument("--bypos", type=int, default=0)
-    ap.add_argument("--keep-pc", action="store_true", help="stay on the round-2 persistent kernel (HGT_LINEAR_KEEP_PC)")
     args = ap.parse_args()
     lib = _lib.load()
     dev = "cuda:0"
@@ -47,7 +46,7 @@ def main():
     def run_split():
         assert lib.hgt_split_weights(W.data_ptr(), n_out * k, T, k, n_out, ws.data_ptr(), st) == 0
         assert lib.hgt_typed_linear_bf16x3(x.data_ptr(), k, rows.data_ptr(), off.data_ptr(), T, N, k, n_out, ws.data_ptr(),
-                                           b.data_ptr(), n_out, optr[0], optr[1], optr[2], bc, args.bypos, 2 if args.keep_pc else 0, st) == 0
+                                           b.data_ptr(), n_out, optr[0], optr[1], optr[2], bc, args.bypos, 0, st) == 0
 
     for name, fn in (("fp32", run_fp32), ("bf16x3", run_split)):
         if args.which not in ("both", name):

@@ -46,6 +46,21 @@
 #ifndef WD_X_NOB
 #define WD_X_NOB 0           // timing only: no W refills
 #endif
+#ifndef WD_X_PRIO
+#define WD_X_PRIO 0          // 1: wavefronts 0-3 run at s_setprio 1
+#endif
+#ifndef WD_X_SKEW
+#define WD_X_SKEW 0          // n: wavefronts 4-7 sleep n x 64 cycles after every step barrier (anti-phase with their SIMD partner)
+#endif
+#ifndef WD_X_STORE_FLAVOUR
+#define WD_X_STORE_FLAVOUR 0 // 0 plain, 1 nt, 2 sc1, 3 sc0 sc1
+#endif
+#ifndef WD_X_SCRATCH_STORE
+#define WD_X_SCRATCH_STORE 0 // timing only: every store goes to the same few KB (no HBM write traffic)
+#endif
+#ifndef WD_X_TRACE
+#define WD_X_TRACE 0         // s_memtime phase totals of wavefronts 0 and 4 of workgroup 0 into hgt_wd_trace
+#endif
 #ifndef WD_SUFFIX
 #define WD_SUFFIX
 #endif
@@ -70,10 +85,10 @@ struct WdItem { int valid, tile, g, row0, nrows, ct0; };
 
 struct WdPending {        // one item's finished output of this lane: 16 x (row, 4 consecutive columns); u = c * 8 + j * 4 + q
     f32x4 v[16];
-    float* base[2];       // per column tile: block pointer + column offset; nullptr = columns out of range
+    float* base[2];       // per column tile: block pointer + column offset
+    uint64_t cols[2];     // per column tile: lanes whose columns exist (0 while nothing is parked)
     unsigned ld;
-    const int* rid;       // LDS row-id table of the tile the rows belong to
-    int row0, nrows, by_pos;
+    const int* rid;       // LDS table of the output rows of the tile these rows belong to
 };
 
 // stores the compiler does not see (see hidden_store16 in hgt_gemm_bf16x3.hip), predicated INSIDE the statement with the lane
@@ -83,7 +98,16 @@ struct WdPending {        // one item's finished output of this lane: 16 x (row,
 // overwritten by the next instruction before the store has read them.
 __device__ __forceinline__ void wd_hidden_store16(float* p, f32x4 v, uint64_t lanes) {
     uint64_t saved;
-    asm volatile("s_and_saveexec_b64 %0, %3\n\tglobal_store_dwordx4 %1, %2, off\n\ts_nop 1\n\ts_mov_b64 exec, %0"
+#if WD_X_STORE_FLAVOUR == 1
+#define WD_ST_FL " nt"
+#elif WD_X_STORE_FLAVOUR == 2
+#define WD_ST_FL " sc1"
+#elif WD_X_STORE_FLAVOUR == 3
+#define WD_ST_FL " sc0 sc1"
+#else
+#define WD_ST_FL ""
+#endif
+    asm volatile("s_and_saveexec_b64 %0, %3\n\tglobal_store_dwordx4 %1, %2, off" WD_ST_FL "\n\ts_nop 1\n\ts_mov_b64 exec, %0"
                  : "=&s"(saved)
                  : "v"(p), "v"(v), "s"(lanes)
                  : "memory");
@@ -119,9 +143,11 @@ __device__ __forceinline__ bool wd_tile_lookup(int t, const int32_t* __restrict_
 // one wavefront: row ids of a tile into the LDS table, its 64 rows HBM -> slab (rows beyond the tile repeat its last row:
 // their products are never stored).  Lanes beyond k leave their (zero-initialised) 16 bytes alone.
 __device__ __forceinline__ void wd_dma_tile(unsigned char* smem, unsigned lds_base, int slab, int slot, int row0, int nrows,
-                                            const int32_t* __restrict__ rows, const float* __restrict__ x, int64_t ldx, int k, int lane) {
+                                            const int32_t* __restrict__ rows, const float* __restrict__ x, int64_t ldx, int k, int lane,
+                                            int by_pos) {
     const int rid = rows[row0 + min(lane, nrows - 1)];
-    reinterpret_cast<int*>(smem + WD_RID)[slot * BM + lane] = (lane < nrows) ? rid : -1;
+    // the table holds the OUTPUT row of every tile row (its position in the row list or its node id), -1 beyond the tile
+    reinterpret_cast<int*>(smem + WD_RID)[slot * BM + lane] = (lane < nrows) ? (by_pos ? row0 + lane : rid) : -1;
     const unsigned dst0 = lds_base + (unsigned)slab * WD_SLAB;
     if (lane * 4 < k) {
 #pragma unroll 8
@@ -163,7 +189,7 @@ __global__ __launch_bounds__(WD_THREADS, 2) void WD_CAT(k_typed_linear_wide, WD_
     if (wave == 0) {                              // tile 0 (the only tile whose first step is 0)
         int g, row0, nrows;
         wd_tile_lookup(first, group_off, n_groups, g, row0, nrows);
-        wd_dma_tile(smem, lds_base, 0, 0, row0, nrows, rows, x, ldx, k, lane);
+        wd_dma_tile(smem, lds_base, 0, 0, row0, nrows, rows, x, ldx, k, lane, by_pos);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
@@ -178,23 +204,25 @@ __global__ __launch_bounds__(WD_THREADS, 2) void WD_CAT(k_typed_linear_wide, WD_
         return it;
     };
     // B fragments of (group g, column tile ct): [g][pass][k-chunk][plane][column tile 8][lane][8] (hgt_split_weights)
+    // -> wave-uniform BYTE offset of the fragments of (g, ct) inside the W image (SGPRs); the lane's 16 bytes sit at + 16 * lane,
+    // so that a load is "SGPR base + 32-bit VGPR offset" with no per-lane 64-bit address arithmetic
     auto wptr = [&](int g, int ct) {
-        return wsplit + ((int64_t)(g * n_pass + (ct >> 3)) * n_kc * 2) * W_PLANE_ELEMS + ((ct & 7) * 64 + lane) * 8;
+        const uint64_t a = 2 * (((uint64_t)(g * n_pass + (ct >> 3)) * n_kc * 2) * W_PLANE_ELEMS + (uint64_t)((ct & 7) * 64) * 8);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return reinterpret_cast<const unsigned char*>(wsplit) + (((uint64_t)hi << 32) | lo);
     };
+    const unsigned wlane = (unsigned)lane * 16u;
 
     const int frow = lane & 31, khalf = lane >> 5;
-    f32x16 acc[4];                                // [j * 2 + c]: row tile j, column tile c
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+    f32x16 acc[4];                                // [j * 2 + c]: row tile j, column tile c; the first k-chunk starts them from 0
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     WdPending pr;
 #pragma unroll
     for (int u = 0; u < 16; ++u) pr.v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     pr.base[0] = pr.base[1] = nullptr;
+    pr.cols[0] = pr.cols[1] = 0;
     pr.ld = 0;
     pr.rid = reinterpret_cast<const int*>(smem + WD_RID);
-    pr.row0 = pr.nrows = pr.by_pos = 0;
     bool have_pend = false;                       // wave-uniform
 
     // parked row UU of the previous item: the row id comes out of the LDS table (read unconditionally and FIRST in a k-chunk, so
@@ -204,20 +232,19 @@ __global__ __launch_bounds__(WD_THREADS, 2) void WD_CAT(k_typed_linear_wide, WD_
 #define WD_ROWID(UU) const int rid_c = pr.rid[rt0 + WD_ROWOFF(UU)];
 #define WD_STORE_R(UU)                                                                                \
     {                                                                                                 \
-        const int rt_ = rt0 + WD_ROWOFF(UU);                                                          \
-        const int r_ = pr.by_pos ? pr.row0 + rt_ : rid_c;                                             \
         float* b_ = pr.base[(UU) >> 3];                                                               \
-        const bool ok_ = !WD_X_NOSTORE && have_pend && b_ != nullptr && rt_ < pr.nrows;               \
-        wd_hidden_store16(b_ + (uint64_t)(unsigned)r_ * pr.ld, pr.v[UU], __builtin_amdgcn_ballot_w64(ok_)); \
+        const uint64_t m_ = __builtin_amdgcn_ballot_w64(rid_c >= 0) & pr.cols[(UU) >> 3];             \
+        float* p_ = WD_X_SCRATCH_STORE ? out0 + (threadIdx.x & 511) * 4 : b_ + (uint64_t)(unsigned)rid_c * pr.ld; \
+        wd_hidden_store16(p_, pr.v[UU], m_);                                                          \
     }
 #define WD_STORE(UU) { WD_ROWID(UU) WD_STORE_R(UU) }
 #define WD_LOAD_B(ST, KCX)                                                                            \
     {                                                                                                 \
-        const int64_t o_ = (int64_t)min((KCX), n_kc - 1) * 2 * W_PLANE_ELEMS;                         \
-        bst[ST].h0 = *reinterpret_cast<const bf16x8*>(w0 + o_);                                       \
-        bst[ST].m0 = *reinterpret_cast<const bf16x8*>(w0 + o_ + W_PLANE_ELEMS);                       \
-        bst[ST].h1 = *reinterpret_cast<const bf16x8*>(w1 + o_);                                       \
-        bst[ST].m1 = *reinterpret_cast<const bf16x8*>(w1 + o_ + W_PLANE_ELEMS);                       \
+        const unsigned o_ = (unsigned)min((KCX), n_kc - 1) * (2 * W_PLANE_ELEMS * 2);                 \
+        bst[ST].h0 = *reinterpret_cast<const bf16x8*>(w0 + o_ + wlane);                               \
+        bst[ST].m0 = *reinterpret_cast<const bf16x8*>(w0 + o_ + W_PLANE_ELEMS * 2 + wlane);           \
+        bst[ST].h1 = *reinterpret_cast<const bf16x8*>(w1 + o_ + wlane);                               \
+        bst[ST].m1 = *reinterpret_cast<const bf16x8*>(w1 + o_ + W_PLANE_ELEMS * 2 + wlane);           \
     }
 #define WD_LOAD_RAW(KCX)                                                                              \
     {                                                                                                 \
@@ -248,11 +275,11 @@ __global__ __launch_bounds__(WD_THREADS, 2) void WD_CAT(k_typed_linear_wide, WD_
     }
 #endif
     // 12 MFMAs of one k-chunk: small terms first, hi*hi last; every accumulator is touched once per group of four
-#define WD_MFMA(F, ST)                                                                                                  \
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[F].m0, bst[ST].h0, acc[0], 0, 0, 0);                             \
-    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[F].m1, bst[ST].h0, acc[2], 0, 0, 0);                             \
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[F].m0, bst[ST].h1, acc[1], 0, 0, 0);                             \
-    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[F].m1, bst[ST].h1, acc[3], 0, 0, 0);                             \
+#define WD_MFMA(F, ST, FIRST)                                                                                           \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[F].m0, bst[ST].h0, (FIRST) ? zero16 : acc[0], 0, 0, 0);          \
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[F].m1, bst[ST].h0, (FIRST) ? zero16 : acc[2], 0, 0, 0);          \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[F].m0, bst[ST].h1, (FIRST) ? zero16 : acc[1], 0, 0, 0);          \
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[F].m1, bst[ST].h1, (FIRST) ? zero16 : acc[3], 0, 0, 0);          \
     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[F].h0, bst[ST].m0, acc[0], 0, 0, 0);                             \
     acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[F].h1, bst[ST].m0, acc[2], 0, 0, 0);                             \
     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[F].h0, bst[ST].m1, acc[1], 0, 0, 0);                             \
@@ -301,7 +328,7 @@ __global__ __launch_bounds__(WD_THREADS, 2) void WD_CAT(k_typed_linear_wide, WD_
         asm volatile("" : "+v"(raw.a0), "+v"(raw.b0), "+v"(raw.a1), "+v"(raw.b1));                    \
         WD_SPLIT(((KCX) + 1) & 1)                                                                     \
         WD_LOAD_RAW((KCX) + 2)                                                                        \
-        WD_MFMA((KCX)&1, (KCX) % WD_NST)                                                              \
+        WD_MFMA((KCX)&1, (KCX) % WD_NST, (KCX) == 0)                                                           \
         WD_REFILL_B(KCX)                                                                              \
         /* pin: next row id, then the split's VALU work spread between the MFMAs (left alone, hipcc runs the ~45 VALU  */ \
         /* instructions of the split as one block in front of the MFMAs and the matrix pipe drains meanwhile), then    */ \
@@ -330,16 +357,22 @@ __global__ __launch_bounds__(WD_THREADS, 2) void WD_CAT(k_typed_linear_wide, WD_
     const int* dptr = reinterpret_cast<const int*>(wsplit) + lane;      // any resident, readable address
 #endif
     WdItem it = get_item(0);
-    const unsigned short* w0 = wptr(it.g, it.ct0);
-    const unsigned short* w1 = wptr(it.g, it.ct0 + 1);
+    const unsigned char* w0 = wptr(it.g, it.ct0);
+    const unsigned char* w1 = wptr(it.g, it.ct0 + 1);
 #define WD_FIRST_STAGES                                                                               \
     if (it.valid) {                                                                                   \
         _Pragma("unroll") for (int st_ = 0; st_ < WD_NST; ++st_) WD_LOAD_B(st_, st_)                  \
     }
     WD_FIRST_STAGES
 
+#if WD_X_PRIO
+    if (wave < 4) __builtin_amdgcn_s_setprio(1);
+#endif
     for (int s = 0; s < n_steps; ++s) {
         wd_barrier();                             // everything requested during step s-1 has landed (its issuer waited)
+#if WD_X_SKEW
+        if (wave >= 4) __builtin_amdgcn_s_sleep(WD_X_SKEW);
+#endif
         const bool duty = (wave == (s & (WD_WAVES - 1)));
         bool dma_out = false;
         if (duty) {                               // the tile whose first step is s+1 (its slab was released by the barrier above)
@@ -347,7 +380,7 @@ __global__ __launch_bounds__(WD_THREADS, 2) void WD_CAT(k_typed_linear_wide, WD_
             if (!WD_X_NODMA && jc < n_mine && jc * U < WD_WAVES * (s + 2)) {
                 int g, row0, nrows;
                 wd_tile_lookup(first + jc * stride, group_off, n_groups, g, row0, nrows);
-                wd_dma_tile(smem, lds_base, jc & 1, jc & 3, row0, nrows, rows, x, ldx, k, lane);
+                wd_dma_tile(smem, lds_base, jc & 1, jc & 3, row0, nrows, rows, x, ldx, k, lane, by_pos);
                 dma_out = true;
             }
         }
@@ -381,7 +414,8 @@ __global__ __launch_bounds__(WD_THREADS, 2) void WD_CAT(k_typed_linear_wide, WD_
                 const bool col_ok = col < n_out;
                 const int blk = col_ok ? col / block_cols : 0, cc = col - blk * block_cols;
                 float* ob = (blk == 0) ? out0 : ((blk == 1) ? out1 : out2);
-                pr.base[c] = col_ok ? ob + cc : nullptr;
+                pr.base[c] = ob + cc;
+                pr.cols[c] = WD_X_NOSTORE ? 0ull : __builtin_amdgcn_ballot_w64(col_ok);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -393,20 +427,14 @@ __global__ __launch_bounds__(WD_THREADS, 2) void WD_CAT(k_typed_linear_wide, WD_
                     }
                 }
             }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
             pr.ld = (unsigned)block_cols;
             pr.rid = reinterpret_cast<const int*>(smem + WD_RID) + (it.tile & 3) * BM;
-            pr.row0 = it.row0;
-            pr.nrows = it.nrows;
-            pr.by_pos = by_pos;
             have_pend = true;
         } else if (have_pend) {                   // no item in this step (tail): the parked rows leave now
             WD_STORE(0) WD_STORE(1) WD_STORE(2) WD_STORE(3) WD_STORE(4) WD_STORE(5) WD_STORE(6) WD_STORE(7)
             WD_STORE(8) WD_STORE(9) WD_STORE(10) WD_STORE(11) WD_STORE(12) WD_STORE(13) WD_STORE(14) WD_STORE(15)
             have_pend = false;
+            pr.cols[0] = pr.cols[1] = 0;
         }
         // the next item's first W stages are requested BEFORE the barrier (they do not depend on the slab)
         it = get_item(s + 1);

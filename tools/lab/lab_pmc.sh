@@ -8,7 +8,7 @@ export HGT_LIB_PATH=$GRAFT_REPO_ROOT/pyhgt_amd/lib_lab/libhgt_hip.so
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp
 for v in "$@"; do
-  EXTRA=""; if [ "$v" = "pc" ]; then EXTRA="--keep-pc"; else export HGT_WD_VARIANT=$v; fi
+  EXTRA=""; if [ "$v" = "pc" ]; then unset HGT_WD_VARIANT; else export HGT_WD_VARIANT=$v; fi
   for pass in A B; do
     if [ $pass = A ]; then C="SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU";
     else C="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; fi
