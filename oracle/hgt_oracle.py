@@ -336,3 +336,45 @@ def backward_reference(sd, num_types, num_relations, n_heads, x, node_type, edge
     for k, g in zip(names, grads[1:]):
         res[k] = g if g is not None else torch.zeros_like(leaf[k])
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GNN wrapper (model.py:54-80): seeded parameters in the reference's state_dict layout, and the wrapper restated
+# ---------------------------------------------------------------------------------------------------------------
+def make_gnn_state_dict(in_dim, n_hid, num_types, num_relations, n_heads, n_layers, prev_norm, last_norm, use_RTE, seed=0):
+    """state_dict of `GNN(in_dim, n_hid, ...)` (model.py:51-64): `adapt_ws.t.{weight,bias}` + `gcs.l.base_conv.<layer key>`.
+    A pure function of its arguments (torch CPU generator), so that the GNN goldens (oracle/gen_golden_gnn.py) need not
+    store 21 M parameters: the generator and the tests rebuild the same tensors from the seed."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    b = 1.0 / math.sqrt(in_dim)
+    for t in range(num_types):
+        sd["adapt_ws.%d.weight" % t] = (torch.rand((n_hid, in_dim), generator=g) * 2 - 1) * b
+        sd["adapt_ws.%d.bias" % t] = (torch.rand((n_hid,), generator=g) * 2 - 1) * b
+    for l in range(n_layers):
+        norm = last_norm if l == n_layers - 1 else prev_norm
+        layer = make_state_dict(n_hid, n_hid, num_types, num_relations, n_heads, norm, use_RTE, seed=seed * 1000 + 17 * l + 1)
+        for k, v in layer.items():
+            sd["gcs.%d.base_conv.%s" % (l, k)] = v
+    return sd
+
+
+def gnn_forward(sd, in_dim, n_hid, num_types, num_relations, n_heads, n_layers, prev_norm, last_norm, use_RTE,
+                node_feature, node_type, edge_time, edge_index, edge_type, dtype=torch.float64, return_layers=False):
+    """model.py:66-80 restated (eval mode: dropout is the identity): typed adapter + tanh, then the stacked layers through
+    forward_closed_form.  Returns the output (and the list [adapter output, layer 1 output, ...] with return_layers)."""
+    x = node_feature.to(dtype)
+    h = torch.zeros(x.size(0), n_hid, dtype=dtype)
+    for t in range(num_types):                                    # model.py:70-75
+        m = node_type == t
+        if m.any():
+            h[m] = torch.tanh(x[m] @ sd["adapt_ws.%d.weight" % t].to(dtype).T + sd["adapt_ws.%d.bias" % t].to(dtype))
+    layers = [h]
+    for l in range(n_layers):                                     # model.py:78-79
+        pre = "gcs.%d.base_conv." % l
+        lsd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        norm = last_norm if l == n_layers - 1 else prev_norm
+        h = forward_closed_form(lsd, num_types, num_relations, n_heads, h, node_type, edge_index, edge_type, edge_time,
+                                use_norm=norm, use_RTE=use_RTE, dtype=dtype)
+        layers.append(h)
+    return (h, layers) if return_layers else h

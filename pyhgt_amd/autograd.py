@@ -190,6 +190,12 @@ class _HGTConvTrain(torch.autograd.Function):
             rte_k, rte_v = rte_kv[0], rte_kv[1]
         # attention (conv.py:98-99,108): logits in sorted edge order, normalised in place
         att = ops.softmax_(plan, ops.logits(plan, qkv[0], qkv[1], rte_k, att_t))
+        if layer.keep_att and E > 0:      # self.att (conv.py:108) in the caller's edge order, like the inference path
+            a_out = torch.empty(E, layer.n_heads, dtype=torch.float32, device=dev)
+            _chk("hgt_att_export", lib.hgt_att_export(plan.ptr, N, E, T, R, ops.H, _p(att), _p(a_out), layer.n_heads, _st()))
+            layer.att = a_out
+        else:
+            layer.att = None
         # aggregation (conv.py:104,109-111 + scatter-add): agg = sum_r (sum_e att_e v_e) M_r
         agg = torch.empty(N, dp, dtype=torch.float32, device=dev)
         ops.spmm(plan, att, qkv[2].data_ptr(), rte_v, msg_p, msg_f, agg, 0, dp, N)
@@ -242,7 +248,9 @@ class _HGTConvTrain(torch.autograd.Function):
         T, R, H = layer.num_types, layer.num_relations, layer.n_heads
         ops = _Ops(plan, lay, T, R, H, layer.precision)
         # (data gradients d gelu(agg), dx run on the layer's own typed-linear kernels: split-bf16 x3 by default, relative error
-        #  ~1e-5, two orders below the gradient tolerance; precision='fp32' layers keep the exact kernel)
+        #  ~1e-5, two orders below the gradient tolerance; precision='fp32' layers keep the exact typed-linear kernel.  The
+        #  relation transforms of every hgt_edge_spmm -- the training forward's aggregation included -- are ALWAYS split-bf16 MFMA
+        #  products under grad, also for precision='fp32': ~1e-5 away from the exact VALU aggregation of the inference path)
         N, E, din, dout, dp, dk, dkp = plan.N, plan.E, layer.in_dim, layer.out_dim, lay.d_pad, lay.d_k, lay.dk_pad
         Hr, H = H, lay.heads                                 # model heads / layout heads
         dev = x.device
@@ -381,11 +389,21 @@ def hgt_conv_train(layer, plan, x, packed, drop_p):
     layer._pack_parameters(grad=True); drop_p = dropout probability of conv.py:125 / 259,271 (0 in eval mode)."""
     if plan.NQ != plan.N:
         raise NotImplementedError("pyhgt_amd: the backward pass covers single-GPU graphs (n_q_rows == n_nodes)")
+    lay = packed["lay"]
+    if lay.dk_pad > 64:
+        # hgt_relation_outer (the relation gradients) splits a head over at most 64 lanes x registers, and the MFMA form of
+        # hgt_edge_spmm needs heads of at most 256 columns: say so HERE instead of failing inside loss.backward()
+        raise NotImplementedError("pyhgt_amd: the backward pass supports heads of at most 64 (padded) columns; out_dim=%d / n_heads=%d "
+                                  "gives %d.  Inference has no such limit (INTEGRATION.md, training limits)" % (layer.out_dim, layer.n_heads,
+                                                                                                              lay.dk_pad))
     dense = "mid_w" in packed
     masks = None
     if drop_p > 0.0:
         keep = 1.0 - drop_p
-        draw = lambda: torch.bernoulli(torch.full((plan.N, layer.out_dim), keep, dtype=torch.float32, device=x.device)) / keep
+        if keep <= 0.0:      # nn.Dropout(p=1) yields zeros (not 0/0)
+            draw = lambda: torch.zeros((plan.N, layer.out_dim), dtype=torch.float32, device=x.device)
+        else:
+            draw = lambda: torch.bernoulli(torch.full((plan.N, layer.out_dim), keep, dtype=torch.float32, device=x.device)) / keep
         masks = (draw(), draw() if dense else None)          # DenseHGTConv drops twice (conv.py:259 and conv.py:271)
     return _HGTConvTrain.apply(layer, plan, masks, x, packed["w_qkv"], packed["b_qkv"], packed["w_a"], packed["b_a"], packed["ratt"],
                                packed["rmsg"], packed["rpri"], packed.get("skip"), packed.get("ln_w"), packed.get("ln_b"),

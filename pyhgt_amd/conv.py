@@ -203,7 +203,7 @@ class GraphPlan:
             self._bad = int(row[1])
             _HeaderSlots.release(self)
 
-    def raise_if_bad(self, wait=False):
+    def raise_if_bad(self, wait=False, ignore_time=False):
         """The reference fails with an IndexError (index_select / nn.Embedding) when edge_index holds a node id outside
         [0, N) or edge_time a value outside [0, 240).  The plan build flags both on the device; the flag reaches the host
         asynchronously, so -- without a synchronisation -- the error surfaces on the first forward AFTER the header copy
@@ -211,12 +211,15 @@ class GraphPlan:
         self._poll_header(wait)
         if self._bad is None and wait and self._hdr_slot is None:      # slot was recycled before we looked: read the device copy
             self._bad = int(self.buf[:16].view(torch.int32)[1].item())
-        if self._bad:
+        bad = (self._bad or 0) & (~2 if ignore_time else ~0)      # a layer with use_RTE=False never looks at edge_time (conv.py:91)
+        if bad:
             what = []
-            if self._bad & 1:
+            if bad & 1:
                 what.append("edge_index contains node ids outside [0, num_nodes) (or targets beyond n_q_rows)")
-            if self._bad & 2:
+            if bad & 2:
                 what.append("edge_time contains values outside [0, %d)" % _lib.HGT_RTE_LEN)
+            if bad & 4:
+                what.append("from_sorted: edges are not grouped by relation with non-decreasing targets (or rel_ptr does not span [0, E])")
             raise IndexError("pyhgt_amd: " + "; ".join(what))
 
     @property
@@ -276,8 +279,7 @@ class GraphPlan:
         with cls._cache_lock:
             for tm in ((edge_time, None) if edge_time is not None else (None,)):      # layers with and without use_RTE
                 cls._cache[cls._cache_key(node_type, edge_index, edge_type, tm, num_types, num_relations, None)] = (plan, tensors)
-            while len(cls._cache) > max(int(cls.CACHE_SIZE), 2):
-                cls._cache.popitem(last=False)
+            cls._evict(max(int(cls.CACHE_SIZE), 1))
 
     @classmethod
     def cached(cls, node_type, edge_index, edge_type, edge_time, num_types, num_relations, n_q_rows=None):
@@ -292,9 +294,17 @@ class GraphPlan:
         with cls._cache_lock:
             # keep the key tensors alive so their addresses cannot be recycled while the entry lives
             cls._cache[key] = (plan, tensors)
-            while len(cls._cache) > max(int(cls.CACHE_SIZE), 0):
-                cls._cache.popitem(last=False)
+            cls._evict(max(int(cls.CACHE_SIZE), 0))
         return plan
+
+    @classmethod
+    def _evict(cls, keep):
+        """Least-recently-used eviction counted in PLANS (a registered hand-off plan sits under two keys: with and without
+        edge_time), so that CACHE_SIZE pre-registered batches really stay cached (caller holds _cache_lock)."""
+        while len({id(v[0]) for v in cls._cache.values()}) > keep:
+            victim = id(next(iter(cls._cache.values()))[0])
+            for k in [k for k, v in cls._cache.items() if id(v[0]) == victim]:
+                del cls._cache[k]
 
     @classmethod
     def clear_cache(cls):
@@ -365,6 +375,7 @@ class HGTConv(nn.Module):
         self._init_runtime_state()
 
     _UPDATE_MODE = 0     # hgt_conv_args.update_mode
+    _warned_eval_grad = False
 
     # -- state that is not part of the reference module: caches of packed parameters / device-side weight images ------
     _RUNTIME_DEFAULTS = dict(keep_att=False, precision="bf16x3", kernel_flags=0, att=None, _packed=None, _packed_key=None,
@@ -530,16 +541,21 @@ class HGTConv(nn.Module):
         R_plan = self.num_relations * n_slices
         if plan.N != N or plan.T != self.num_types or plan.R != R_plan:
             raise ValueError("plan was built for a different graph / schema")
-        plan.raise_if_bad()
+        plan.raise_if_bad(ignore_time=not self.use_RTE)
         NQ, E = plan.NQ, plan.E
+        if needs_grad and not self.training and not HGTConv._warned_eval_grad:
+            HGTConv._warned_eval_grad = True
+            import warnings
+            warnings.warn("pyhgt_amd.HGTConv: eval-mode forward with autograd enabled takes the differentiable path (unfused kernels, "
+                          "intermediates kept: about 1.4x the inference time and several times its memory).  Wrap inference in "
+                          "torch.no_grad() to get the fused inference kernels.", stacklevel=2)
         if needs_grad:
             # training / differentiable path (pyhgt_amd/autograd.py): same kernels, intermediates kept, hand-written backward;
             # dropout on the a_linear output in training mode only (conv.py:125)
             from .autograd import hgt_conv_train
             out = hgt_conv_train(self, plan, node_inp.float(), self._pack_parameters(grad=True),
                                  float(self.drop.p) if self.training else 0.0)
-            self.att = None
-            return out
+            return out                  # (self.att was set by the Function when keep_att is on)
         pk = self._pack_parameters()
         if pk["w_qkv"].device != x.device:
             raise RuntimeError("module parameters and node_inp are on different devices")

@@ -36,7 +36,8 @@ static inline uint64_t hgt_align_up(uint64_t v, uint64_t a) { return (v + a - 1)
 // Device-written header at the start of the plan buffer.
 struct HgtPlanHeader {
     int32_t n_items;      // number of valid work items (written by the build)
-    int32_t bad_index;    // bit 0: an edge endpoint was outside [0, n_nodes) / target >= n_q_rows; bit 1: edge_time outside [0, 240)
+    int32_t bad_index;    // bit 0: an edge endpoint was outside [0, n_nodes) / target >= n_q_rows; bit 1: edge_time outside [0, 240);
+                          // bit 2: hgt_plan_from_sorted was handed edges that are not relation-grouped / target-sorted
     int32_t n_hubs;       // number of hub targets (in-degree > HGT_HUB_DEG), see hub_slot / hub_list
     int32_t pad[13];
 };

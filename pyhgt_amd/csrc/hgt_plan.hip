@@ -252,6 +252,9 @@ __global__ void k_sorted_scatter(const int32_t* __restrict__ src, const int32_t*
     int r = 0;
     while (r + 1 < R && rel_ptr[r + 1] <= i) ++r;       // R is small (<= 64 relations in the reference's schemas)
     int s = src[i], d = dst[i];
+    // the caller's ordering is part of the contract: targets non-decreasing inside a relation, rel_ptr spanning [0, E] --
+    // otherwise positions collide inside [0, E) and the plan would be silently corrupt (bit 2 of bad_index)
+    if ((i > rel_ptr[r] && dst[i - 1] > d) || (i == 0 && (rel_ptr[0] != 0 || rel_ptr[R] != E))) atomicOr(&hdr->bad_index, 4);
     if (s < 0 || s >= N || d < 0 || d >= NQ) { atomicOr(&hdr->bad_index, 1); s = max(0, min(s, (int)N - 1)); d = max(0, min(d, (int)NQ - 1)); }
     const int64_t j = (int64_t)(d / HGT_TD) * (R + 1) + r;
     int p = base[j] + ((int)i - lb[j]);
@@ -382,6 +385,7 @@ __global__ void k_sorted_small_body(const int32_t* __restrict__ src, const int32
         int r = 0;
         while (r + 1 < R && rel_ptr[r + 1] <= i) ++r;
         int s = src[i], d = dst[i];
+        if ((i > rel_ptr[r] && dst[i - 1] > d) || (i == 0 && (rel_ptr[0] != 0 || rel_ptr[R] != E))) atomicOr(&hdr->bad_index, 4);   // see k_sorted_scatter
         if (s < 0 || s >= N || d < 0 || d >= NQ) { atomicOr(&hdr->bad_index, 1); s = max(0, min(s, (int)N - 1)); d = max(0, min(d, (int)NQ - 1)); }
         const int64_t j = (int64_t)(d / HGT_TD) * (R + 1) + r;
         int p = base[j] + ((int)i - lb[j]);

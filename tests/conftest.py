@@ -18,7 +18,9 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """Single-layer fixtures (oracle/gen_golden.py); the gnn_* files of oracle/gen_golden_gnn.py have their own tests."""
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return [n for n in names if not n.startswith("gnn_")]
 
 
 def load_golden(name):

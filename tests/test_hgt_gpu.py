@@ -423,6 +423,73 @@ def test_gnn_wrapper_matches_oracle(precision):
     assert out[::41].abs().max().item() > 0.0 or True
 
 
+@pytest.mark.parametrize("handoff", [False, True], ids=["to_torch", "to_device_graph"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("name", ["gnn_oag2", "gnn_mag4"])
+def test_gnn_matches_reference_gnn_goldens(name, precision, handoff):
+    """The HIP GNN against rows of the VERBATIM reference GNN's outputs (oracle/gen_golden_gnn.py) at the exact shapes of
+    BASELINE.json configs[4] (OAG: in 1169 -> 400, 33 relations, 2 layers) and of the published ogbn-mag model (129 -> 512,
+    4 layers, norms + RTE) on a configs[2]-sized batch: 1e-4 at the OUTPUT of the stack in every precision, error per layer
+    printed (adapter, layer 1, ...)."""
+    from pyhgt_amd import GNN
+    from pyhgt_amd.sampled import to_device_graph
+    from oracle.gen_golden_gnn import GNN_CASES, build_batch
+    c = GNN_CASES[name]
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    batch, (x, nt, tm, ei, et, _, _) = build_batch(c)
+    sd = O.make_gnn_state_dict(c["in_dim"], c["n_hid"], c["T"], c["R"], c["H"], c["n_layers"], c["prev_norm"], c["last_norm"],
+                               c["use_RTE"], seed=c["seed"])
+    gnn = GNN(c["in_dim"], c["n_hid"], c["T"], c["R"], c["H"], c["n_layers"], 0.2, "hgt", c["prev_norm"], c["last_norm"],
+              c["use_RTE"]).eval()
+    gnn.load_state_dict(sd)
+    gnn = gnn.to(DEV)
+    captured = []
+    hooks = [gnn.gcs[0].base_conv.register_forward_pre_hook(lambda m, a: captured.append(a[0].detach().clone()))]
+    hooks += [gc.base_conv.register_forward_hook(lambda m, a, o: captured.append(o.detach().clone())) for gc in gnn.gcs]
+    for gc in gnn.gcs:
+        gc.base_conv.precision = precision
+    GraphPlan.clear_cache()
+    if handoff:
+        dg = to_device_graph(*batch, device=DEV)
+        args = (dg[0], dg[1], dg[2], dg[3], dg[4])
+        # the hand-off orders edges relation-major; node order (and therefore the output rows) is to_torch's
+    else:
+        args = _to_dev(x, nt, tm, ei, et)
+    with torch.no_grad():
+        out = gnn(*args)
+    torch.cuda.synchronize()
+    for h in hooks:
+        h.remove()
+    assert len(captured) == c["n_layers"] + 1
+    rows = torch.from_numpy(z["rows"]).long()
+    errs = [(captured[i][rows.to(DEV)].cpu() - torch.from_numpy(z["layers"][i])).abs().max().item() for i in range(len(captured))]
+    print("%s %s handoff=%s: max|err| adapter %.1e, layers %s" % (name, precision, handoff, errs[0], ["%.1e" % e for e in errs[1:]]))
+    assert (out[rows.to(DEV)].cpu() - torch.from_numpy(z["layers"][-1])).abs().max().item() < 1e-4
+    assert max(errs) < 1e-4
+    GraphPlan.clear_cache()
+
+
+def test_single_layer_at_the_exact_configs2_shape():
+    """BASELINE.json configs[2] (ogbn-mag sampled sub-graph): ONE HGTConv layer at d=256, 8 heads, T=4, R=9, RTE on, on the
+    sampler-shaped batch bench.py times (`secondary.c3`), both precisions against the fp64 closed form."""
+    from pyhgt_amd.sampled import synthetic_sampled_batch, to_torch_layout
+    batch = synthetic_sampled_batch("mag", n_seed=128, width=128, depth=6, feat_dim=256, mean_degree=4.0, seed=3)
+    x, nt, tm, ei, et, _, edge_dict = to_torch_layout(*batch)
+    T, R, d, H = 4, len(edge_dict), 256, 8
+    sd = O.make_state_dict(d, d, T, R, H, True, True, seed=77)
+    ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, use_norm=True, use_RTE=True, dtype=torch.float64)
+    for precision in ("bf16x3", "fp32"):
+        layer = HGTConv(d, d, T, R, H, 0.2, True, True, precision=precision).eval()
+        layer.load_state_dict(sd)
+        layer = layer.to(DEV)
+        with torch.no_grad():
+            out = layer(*_to_dev(x, nt, ei, et, tm))
+        err = (out.cpu().double() - ref).abs().max().item()
+        print("configs[2] shape N=%d E=%d %s err %.2e" % (x.size(0), et.numel(), precision, err))
+        assert err < 1e-4
+    GraphPlan.clear_cache()
+
+
 # ------------------------------------------------------------------ integer work: bit exact
 def _plan_constants(E):
     td, ch = C.c_int32(), C.c_int32()
@@ -583,6 +650,43 @@ def test_plan_from_sorted_large_and_empty_graphs():
             assert np.array_equal(a[k], b[k]), (N, E, k)
         assert np.array_equal(a["items"][:a["n_items"]], b["items"][:b["n_items"]])
         plan.raise_if_bad(wait=True)
+    GraphPlan.clear_cache()
+
+
+@pytest.mark.parametrize("N,E", [(4000, 30000), (300000, 900000)])
+def test_plan_from_sorted_flags_a_broken_ordering(N, E):
+    """hgt_plan_from_sorted trusts the sampler's order (relation-grouped, targets non-decreasing inside a relation, rel_ptr
+    spanning [0, E]); a caller that breaks it gets an IndexError (bad_index bit 2) instead of a silently corrupt plan --
+    both builders (three-launch and large form)."""
+    T, R = 3, 5
+    g = torch.Generator().manual_seed(12)
+    per = [N // T + (1 if t < N % T else 0) for t in range(T)]
+    nt = torch.repeat_interleave(torch.arange(T), torch.tensor(per))
+    rel = torch.sort(torch.randint(0, R, (E,), generator=g)).values
+    dst = torch.randint(0, N, (E,), generator=g)
+    order = torch.argsort(rel * N + dst, stable=True)
+    rel, dst = rel[order], dst[order]
+    src = torch.randint(0, N, (E,), generator=g)
+    rel_ptr = torch.searchsorted(rel, torch.arange(R + 1)).int()
+    type_off = torch.searchsorted(nt, torch.arange(T + 1)).int().to(DEV)
+    ntd = nt.to(DEV)
+
+    def build(dst_, rel_ptr_):
+        ei = torch.stack([src, dst_]).to(DEV)
+        return GraphPlan.from_sorted(ntd, ei, rel.to(DEV), None, ei[0].int().contiguous(), ei[1].int().contiguous(), None,
+                                     rel_ptr_.to(DEV), type_off, T, R)
+    build(dst, rel_ptr).raise_if_bad(wait=True)                      # the well-formed input passes
+    swapped = dst.clone()
+    i = int(rel_ptr[2]) + 5                                           # two targets of one relation out of order
+    if swapped[i] == swapped[i + 1]:
+        swapped[i + 1] += 1
+    swapped[i], swapped[i + 1] = swapped[i + 1].clone(), swapped[i].clone()
+    with pytest.raises(IndexError):
+        build(swapped, rel_ptr).raise_if_bad(wait=True)
+    short = rel_ptr.clone()
+    short[R] = E - 1                                                  # rel_ptr does not span the edge list
+    with pytest.raises(IndexError):
+        build(dst, short).raise_if_bad(wait=True)
     GraphPlan.clear_cache()
 
 
@@ -951,3 +1055,24 @@ def test_forward_is_hip_graph_capturable():
             g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, eager)
+
+
+def test_bench_line_of_a_multi_rank_run_reports_world_size_and_backend(tmp_path):
+    """Guard for the driver's scaling runs: `bench.py --gpus 2` launched through torch.distributed.run prints ONE JSON line whose
+    n_gpus is the world size and whose config names the collective backend.  Walked here with both ranks on the one GPU of the
+    test box (HGT_BENCH_DEVICE=0, gloo): the replicas workload (configs[4], no data-path collective) and its parity field."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HGT_BENCH_DEVICE="0", HGT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c5", "--steps", "6", "--warmup", "2"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 6 and j["scaling"] == "weak" and j["unit"] == "edges/s"
+    assert j["config"]["parallelism"] == "replicas x2" and j["config"]["backend"].startswith("gloo")
+    assert j["value"] > 0 and j["parity_max_abs_err"] is not None and j["parity_max_abs_err"] <= 1e-4

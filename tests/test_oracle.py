@@ -114,3 +114,24 @@ def test_backward_oracle_matches_autograd_through_the_live_reference(dense):
         if p.grad is None:                      # the sinusoid table is detached by nn.Embedding? (it is not: it has a grad)
             continue
         assert close(p.grad, got[name]), name
+
+
+@pytest.mark.parametrize("name", ["gnn_oag2", "gnn_mag4"])
+def test_gnn_restatement_matches_reference_gnn_goldens(name):
+    """oracle.gnn_forward (model.py:66-80 restated) against rows of every layer's output of the VERBATIM reference GNN
+    (oracle/gen_golden_gnn.py: 2-layer OAG shape, published 4-layer n_hid=512 ogbn-mag model)."""
+    import os
+    import numpy as np
+    from oracle.gen_golden_gnn import GNN_CASES, build_batch
+    c = GNN_CASES[name]
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    _, (x, nt, tm, ei, et, _, _) = build_batch(c)
+    assert x.size(0) == int(z["n_nodes"][0]) and et.numel() == int(z["n_edges"][0])
+    sd = O.make_gnn_state_dict(c["in_dim"], c["n_hid"], c["T"], c["R"], c["H"], c["n_layers"], c["prev_norm"], c["last_norm"],
+                               c["use_RTE"], seed=c["seed"])
+    _, layers = O.gnn_forward(sd, c["in_dim"], c["n_hid"], c["T"], c["R"], c["H"], c["n_layers"], c["prev_norm"], c["last_norm"],
+                              c["use_RTE"], x, nt, tm, ei, et, return_layers=True)
+    rows = torch.from_numpy(z["rows"]).long()
+    for i, h in enumerate(layers):
+        err = (h[rows].float() - torch.from_numpy(z["layers"][i])).abs().max().item()
+        assert err < 1e-5, (name, i, err)

@@ -66,7 +66,14 @@ def main():
             for label, rx in HOT:
                 if re.search(rx, r["Name"]) and label not in dur:
                     dur[label] = float(r["AverageNs"]) * 1e-6
-    summary = {"tag": tag, "commit": commit, "avg_kernel_ms": dur, "traffic_bytes": {}, "mfma_busy_pct": {}, "valu_busy_pct": {},
+    sha = None
+    try:      # the same hash bench.py computes at run time: lets the bench line flag counter figures of another build (pmc_stale)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        sha = bench.kernel_sources_sha16()
+    except Exception:
+        pass
+    summary = {"tag": tag, "commit": commit, "kernel_sources_sha16": sha, "avg_kernel_ms": dur, "traffic_bytes": {}, "mfma_busy_pct": {}, "valu_busy_pct": {},
                "lds_bank_conflict_pct": {}, "waves_per_simd_avg": {}, "kernel_meta": {}, "counters_avg_per_dispatch": {},
                "_note": "traffic = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (KB units, gfx950 FETCH_SIZE x2 correction, MI355X_MICROARCH.md HBM "
                         "section; WRITE_SIZE uncalibrated).  cyc = GRBM_GUI_ACTIVE / 8 XCDs.  mfma_busy_pct = SQ_VALU_MFMA_BUSY_CYCLES / (cyc * 1024 SIMDs) "

@@ -4,7 +4,7 @@
 # writes gpurun_out/prof_<tag>/{stats,fetch,write,sqA..sqE}/...; tools/pmc_summary.py turns them into profiles/<tag>_*.csv|json.
 # Counters are collected in their own runs (kernel trace only next to --pmc), one small set per pass.
 set -u
-TAG=${1:-r02}; shift || true
+TAG=${1:-r03}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
