@@ -379,7 +379,7 @@ class HGTConv(nn.Module):
 
     # -- state that is not part of the reference module: caches of packed parameters / device-side weight images ------
     _RUNTIME_DEFAULTS = dict(keep_att=False, precision="bf16x3", kernel_flags=0, att=None, _packed=None, _packed_key=None,
-                             _prepared=None, _prepared_tag=None, _prepared_valid=False)
+                             _prepared=None, _prepared_tag=None, _prepared_valid=False, _plist=None)
 
     def _init_runtime_state(self):
         for k, v in self._RUNTIME_DEFAULTS.items():
@@ -388,7 +388,7 @@ class HGTConv(nn.Module):
 
     def __getstate__(self):
         st = dict(self.__dict__)
-        for k in ("_packed", "_packed_key", "_prepared", "_prepared_tag"):     # derived device buffers: rebuilt on demand
+        for k in ("_packed", "_packed_key", "_prepared", "_prepared_tag", "_plist"):     # derived device buffers: rebuilt on demand
             st[k] = None
         st["_prepared_valid"] = False
         st["att"] = None
@@ -406,12 +406,15 @@ class HGTConv(nn.Module):
             self.sqrt_dk = math.sqrt(self.d_k)
 
     def invalidate(self):
-        """Drop the packed-parameter cache and the device-side weight images.  They are keyed on every parameter's
-        (data_ptr, _version), which optimizer steps, load_state_dict, .to()/.float() and in-place torch ops all change --
-        but writes through `.data` (`p.data.copy_()`, `p.data[...] = x`; EMA / manual initialisation code) do NOT bump
-        `_version`: call invalidate() after such an update (training mode re-packs on every forward anyway)."""
+        """Drop the packed-parameter cache and the device-side weight images.  They are keyed on the parameters' version
+        counters, which optimizer steps, load_state_dict and in-place torch ops all change (.to()/.float() pass through
+        _apply, which calls this) -- but writes through `.data` (`p.data.copy_()`, `p.data[...] = x`; EMA / manual
+        initialisation code) do NOT bump `_version`, and neither does replacing a Parameter object of a sub-module
+        (`layer.k_linears[0].weight = nn.Parameter(...)`): call invalidate() after such an update (training mode re-packs
+        on every forward anyway)."""
         self._packed = self._packed_key = None
         self._prepared_valid = False
+        self.__dict__["_plist"] = None
 
     def _load_from_state_dict(self, *args, **kwargs):
         self.invalidate()
@@ -436,8 +439,16 @@ class HGTConv(nn.Module):
         """Stack the per-type Linear / LayerNorm parameters into the contiguous, head-padded arrays
         hgt_conv_forward takes (pure data movement; cached until a parameter changes).  grad=True: built with autograd
         recording (never cached), so that gradients of the packed arrays flow back to the reference-named parameters."""
-        params = list(self.parameters())
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        # cache key: the SUM of the parameters' version counters over a parameter list that is itself cached -- a few
+        # microseconds per forward (the round-2 key, a 47-tuple of (data_ptr, _version), cost ~50 us of host time per layer and
+        # would have bounded the latency regime).  Optimizer steps, in-place torch ops and load_state_dict bump a version;
+        # .to() / .float() / load_state_dict also pass through _apply / _load_from_state_dict (invalidate()).
+        plist = self.__dict__.get("_plist")
+        if plist is None:
+            plist = self.__dict__["_plist"] = list(self.parameters())
+        key = 0
+        for p in plist:
+            key += p._version
         if not grad and self._packed is not None and self._packed_key == key and not self.training:
             return self._packed
         lay = _lib.layout_for(self.out_dim, self.n_heads)

@@ -41,6 +41,7 @@ class GNN(nn.Module):
     def __getstate__(self):
         st = dict(self.__dict__)
         st["_packed"] = st["_packed_key"] = None
+        st.pop("_plist", None)
         st.pop("_tiles", None)
         st.pop("_tiles_key", None)
         return st
@@ -56,21 +57,28 @@ class GNN(nn.Module):
         `.data`, which do not bump the parameter versions the caches are keyed on; see HGTConv.invalidate)."""
         self._packed = self._packed_key = None
         self.__dict__.pop("_tiles_key", None)
+        self.__dict__.pop("_plist", None)
         for gc in self.gcs:
             if hasattr(gc.base_conv, "invalidate"):
                 gc.base_conv.invalidate()
 
     def _load_from_state_dict(self, *args, **kwargs):
         self._packed = self._packed_key = None
+        self.__dict__.pop("_plist", None)
         return super()._load_from_state_dict(*args, **kwargs)
 
     def _apply(self, fn, *args, **kwargs):
         self._packed = self._packed_key = None
+        self.__dict__.pop("_plist", None)
         return super()._apply(fn, *args, **kwargs)
 
     def _pack_adapter(self):
-        params = [p for lin in self.adapt_ws for p in lin.parameters()]
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        plist = self.__dict__.get("_plist")
+        if plist is None:
+            plist = self.__dict__["_plist"] = [p for lin in self.adapt_ws for p in lin.parameters()]
+        key = 0                                  # sum of version counters (see HGTConv._pack_parameters)
+        for p in plist:
+            key += p._version
         if self._packed is None or self._packed_key != key or self.training:
             with torch.no_grad():
                 w = torch.stack([lin.weight for lin in self.adapt_ws]).float().contiguous()   # [T, n_hid, in_dim]
