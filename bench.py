@@ -201,7 +201,7 @@ def small_regime(dev):
     gold = os.path.join(ROOT, "tests", "golden")
     # ---- c1
     z = np.load(os.path.join(gold, "c1_full.npz"))
-    N, E, d, H, T, R, use_norm, use_rte, _ = [int(v) for v in z["meta"]]
+    N, E, d, H, T, R, use_norm, use_rte = [int(v) for v in z["meta"]][:8]
     sd = {k[len("param::"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param::")}
     x = torch.from_numpy(z["node_feature"]).to(dev)
     nt = torch.from_numpy(z["node_type"]).long().to(dev)
