@@ -48,10 +48,11 @@ struct __attribute__((aligned(16))) HgtItem {
 };
 
 // Edges per logits work item.  HGT_CH for large graphs; small graphs (the sampled subgraphs of the reference: E ~ 30k)
-// get shorter items so that there are a few thousand wavefronts instead of ~100 walking 512 edges each one after the other.
+// get shorter items so that there are a few thousand wavefronts instead of ~100 walking 512 edges each one after the other
+// (round 3: down to 16 edges -- at E = 31k the logits kernel ran 27 us with 64-edge items, one dependent batch chain per item).
 static inline int hgt_item_edges(int64_t E) {
     int ch = HGT_CH;
-    while (ch > 64 && E / ch < 4096) ch >>= 1;
+    while (ch > 16 && E / ch < 4096) ch >>= 1;   // (16-edge items at the sizes of the reference's sampled batches: E ~ 30-150k)
     return ch;
 }
 

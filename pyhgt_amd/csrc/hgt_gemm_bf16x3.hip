@@ -231,11 +231,15 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off,
     int n_groups, int k, int n_out, const unsigned short* __restrict__ wsplit, const float* __restrict__ bias, int64_t bgs,
     float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos, int vec_ok,
-    UpdateArgs upd) {
+    UpdateArgs upd, int pass_split) {
     __shared__ __attribute__((aligned(16))) unsigned char sA[2 * A_PLANE];        // [plane][64][528]
     __shared__ int s_rid[BM];
 
-    const int slot = blockIdx.x;
+    // pass_split = n_pass (small problems: fewer row tiles than CUs): a workgroup owns ONE 256-column pass of a row tile, so that
+    // tiles x passes workgroups share the work (sampled sub-graphs of a few thousand nodes: 50-64 row tiles for 256 CUs);
+    // pass_split = 1: a workgroup owns a row tile and walks all passes
+    const int slot = blockIdx.x / pass_split;
+    const int pass_only = (pass_split > 1) ? (int)(blockIdx.x % pass_split) : -1;
     int g = 0, gbeg = 0, gend = 0, tiles_before = 0;
     for (; g < n_groups; ++g) {
         gbeg = group_off[g];
@@ -283,11 +287,12 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
         s##S##h = *reinterpret_cast<const bf16x8*>(t_);                                               \
         s##S##m = *reinterpret_cast<const bf16x8*>(t_ + W_PLANE_ELEMS);                               \
     }
-    HGT_LOAD_STAGE(0, 0)
-    HGT_LOAD_STAGE(1, 1)
+    const int pass_lo = (pass_only >= 0) ? pass_only : 0, pass_hi = (pass_only >= 0) ? pass_only + 1 : n_pass;
+    HGT_LOAD_STAGE(0, pass_lo * n_kc)
+    HGT_LOAD_STAGE(1, pass_lo * n_kc + 1)
 #if HGT_NSTAGE == 4
-    HGT_LOAD_STAGE(2, 2)
-    HGT_LOAD_STAGE(3, 3)
+    HGT_LOAD_STAGE(2, pass_lo * n_kc + 2)
+    HGT_LOAD_STAGE(3, pass_lo * n_kc + 3)
 #endif
 
     load_a_panel<PROLOGUE>(0, tid, s_rid, x, ldx, k, vec_ok, sA, false);
@@ -310,9 +315,9 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1], 0, 0, 0);                                \
     }
 
-    for (int pass = 0; pass < n_pass; ++pass) {
+    for (int pass = pass_lo; pass < pass_hi; ++pass) {
         for (int panel = 0; panel < n_panel; ++panel) {
-            if (n_panel > 1 && (pass | panel) != 0) load_a_panel<PROLOGUE>(panel * KP, tid, s_rid, x, ldx, k, vec_ok, sA, true);
+            if (n_panel > 1 && (pass != pass_lo || panel != 0)) load_a_panel<PROLOGUE>(panel * KP, tid, s_rid, x, ldx, k, vec_ok, sA, true);
             const int nkc_p = min(KP / KC, n_kc - panel * (KP / KC));
             const int tbase = pass * n_kc + panel * (KP / KC);
             for (int kq = 0; kq < nkc_p; kq += 4) {
@@ -435,11 +440,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // vmcnt(N), N = younger LOADS -- still sufficient: loads return in order, so a pending target load implies N+1
 // pending loads, i.e. counter > N.  Pending stores only make the wait a little stricter than necessary.
 __device__ __forceinline__ void hidden_store16(float* p, f32x4 v) {
-#ifdef HGT_LAB_STORE_NT   // tools/lab A/B: streaming (non-temporal) output stores
-    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" : : "v"(p), "v"(v));
-#else
     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" : : "v"(p), "v"(v));
-#endif
 }
 
 // workgroup barrier that orders LDS only (a __syncthreads() would also drain every outstanding global load AND store)
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off,
     int n_groups, int k, int n_out, const unsigned short* __restrict__ wsplit, const float* __restrict__ bias, int64_t bgs,
     float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos, int vec_ok,
-    UpdateArgs upd) {
+    UpdateArgs upd, int pass_split) {
     __shared__ __attribute__((aligned(16))) unsigned char sA[2][2 * A_PLANE];   // [slab][plane][64][528]
     __shared__ int s_rid[3][BM];   // three tables: the parked rows of tile i are written while tile i+2 is being loaded
     __shared__ __attribute__((aligned(16))) float s_red[2][2][BM * 8];          // [parity][sum|var][row][wave]
@@ -588,8 +589,11 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // number of tiles of this workgroup (the same value in every wave: barrier counts must agree)
+    // work items: row tiles, or (row tile, 256-column pass) pairs when pass_split = n_pass > 1 (small problems: more workgroups
+    // than row tiles -- a sampled sub-graph has ~50 row tiles for 256 CUs)
     int total_tiles = 0;
     for (int g = 0; g < n_groups; ++g) total_tiles += (group_off[g + 1] - group_off[g] + BM - 1) / BM;
+    total_tiles *= pass_split;
     const int first = blockIdx.x, stride = gridDim.x;
     const int n_mine = (total_tiles > first) ? (total_tiles - first + stride - 1) / stride : 0;
     if (n_mine == 0) return;
@@ -601,11 +605,11 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
         const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         float4 a[PC_AREGS];
         int v_rid, g, row0, nrows;
-        tile_lookup(first, group_off, n_groups, g, row0, nrows);
+        tile_lookup(first / pass_split, group_off, n_groups, g, row0, nrows);
         pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
         pc_commit<PROLOGUE>(a, v_rid, pw, lane, sA[0], s_rid[0]);
         if (n_mine > 1) {
-            tile_lookup(first + stride, group_off, n_groups, g, row0, nrows);
+            tile_lookup((first + stride) / pass_split, group_off, n_groups, g, row0, nrows);
             pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
         }
         pc_barrier();                                   // B_0
@@ -613,7 +617,7 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
             if (i + 1 < n_mine) {
                 pc_commit<PROLOGUE>(a, v_rid, pw, lane, sA[(i + 1) & 1], s_rid[(i + 1) % 3]);
                 if (i + 2 < n_mine) {
-                    tile_lookup(first + (i + 2) * stride, group_off, n_groups, g, row0, nrows);
+                    tile_lookup((first + (i + 2) * stride) / pass_split, group_off, n_groups, g, row0, nrows);
                     pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
                 }
             }
@@ -653,7 +657,9 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
 
     for (int i = 0; i < n_mine; ++i) {
         int g, row0, nrows;
-        tile_lookup(first + i * stride, group_off, n_groups, g, row0, nrows);
+        const int vt = first + i * stride;
+        tile_lookup(vt / pass_split, group_off, n_groups, g, row0, nrows);
+        const int pass_lo = (pass_split > 1) ? vt % pass_split : 0, pass_hi = (pass_split > 1) ? pass_lo + 1 : n_pass;
         const unsigned short* __restrict__ wfrag = wsplit + (int64_t)g * total * 2 * W_PLANE_ELEMS + (wave * 64 + lane) * 8;
         bf16x8 s0h, s0m, s1h, s1m, s2h, s2m, s3h, s3m;
 #define PC_LOAD_STAGE(S, T)                                                                           \
@@ -664,11 +670,11 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
     }
         // B fragments are prefetched NST k-chunks ahead (the fused-update variant has fewer registers to spare)
         constexpr int NST = UPD ? 2 : 4;
-        PC_LOAD_STAGE(0, 0)
-        PC_LOAD_STAGE(1, 1)
+        PC_LOAD_STAGE(0, pass_lo * n_kc)
+        PC_LOAD_STAGE(1, pass_lo * n_kc + 1)
         if constexpr (NST >= 4) {
-            PC_LOAD_STAGE(2, 2)
-            PC_LOAD_STAGE(3, 3)
+            PC_LOAD_STAGE(2, pass_lo * n_kc + 2)
+            PC_LOAD_STAGE(3, pass_lo * n_kc + 3)
         }
         pc_barrier();                                      // B_i: slab[i&1] holds tile i
         const unsigned char* slab = sA[i & 1] + frow * A_STRIDE + khalf * 16;
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
         }                                                                                                          \
     }
         PC_LOAD_A(e, 0)
-        for (int pass = 0; pass < n_pass; ++pass) {
+        for (int pass = pass_lo; pass < pass_hi; ++pass) {
             const int tbase = pass * n_kc;
             PC_BODY(0)
             if (n_kc > 4) PC_BODY(1)
@@ -824,27 +830,31 @@ extern "C" int hgt_typed_linear_bf16x3(const float* x, int64_t ldx, const int32_
     if (row_tiles > 0x7fffffffLL) return HGT_ERR_TOO_LARGE;
     const int vec_ok = (ldx % 4 == 0) && (k % 4 == 0) && (((uintptr_t)x & 15) == 0);
     UpdateArgs noupd = {nullptr, 0, nullptr, nullptr, nullptr, 0};
+    // latency regime (sampled sub-graphs: fewer row tiles than CUs): one workgroup per (row tile, 256-column pass)
+    const int n_pass = (n_out + BNP - 1) / BNP;
+    const int pass_split = (n_pass > 1 && row_tiles * 2 <= pc_grid()) ? n_pass : 1;
     if (k <= KP) {   // persistent producer/consumer kernel, one workgroup per CU
-        const unsigned grid = (unsigned)std::min<int64_t>(row_tiles, pc_grid());
+        const unsigned grid = (unsigned)std::min<int64_t>(row_tiles * pass_split, pc_grid());
         if (prologue == 0)
             k_typed_linear_pc<0, false><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
                                                                          (const unsigned short*)w_split, bias, b_group_stride, out0, out1,
-                                                                         out2, block_cols, out_by_position, vec_ok, noupd);
+                                                                         out2, block_cols, out_by_position, vec_ok, noupd, pass_split);
         else
             k_typed_linear_pc<1, false><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
                                                                          (const unsigned short*)w_split, bias, b_group_stride, out0, out1,
-                                                                         out2, block_cols, out_by_position, vec_ok, noupd);
+                                                                         out2, block_cols, out_by_position, vec_ok, noupd, pass_split);
         HGT_CHECK_LAUNCH();
         return HGT_OK;
     }
+    const unsigned grid_s = (unsigned)(row_tiles * pass_split);
     if (prologue == 0)
-        k_typed_linear_split<0, false><<<(unsigned)row_tiles, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
-                                                                                (const unsigned short*)w_split, bias, b_group_stride,
-                                                                                out0, out1, out2, block_cols, out_by_position, vec_ok, noupd);
+        k_typed_linear_split<0, false><<<grid_s, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out, (const unsigned short*)w_split,
+                                                                   bias, b_group_stride, out0, out1, out2, block_cols, out_by_position, vec_ok,
+                                                                   noupd, pass_split);
     else
-        k_typed_linear_split<1, false><<<(unsigned)row_tiles, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
-                                                                                (const unsigned short*)w_split, bias, b_group_stride,
-                                                                                out0, out1, out2, block_cols, out_by_position, vec_ok, noupd);
+        k_typed_linear_split<1, false><<<grid_s, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out, (const unsigned short*)w_split,
+                                                                   bias, b_group_stride, out0, out1, out2, block_cols, out_by_position, vec_ok,
+                                                                   noupd, pass_split);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }
@@ -868,13 +878,13 @@ extern "C" int hgt_linear_update_bf16x3(const float* agg, int64_t ld_agg, const 
         const unsigned grid = (unsigned)std::min<int64_t>(row_tiles, pc_grid());
         k_typed_linear_pc<0, true><<<grid, PC_THREADS, 0, stream>>>(agg, ld_agg, rows, group_off, n_groups, k, n_out,
                                                                     (const unsigned short*)w_split, bias, b_group_stride, out, nullptr,
-                                                                    nullptr, n_out, 0, vec_ok, u);
+                                                                    nullptr, n_out, 0, vec_ok, u, 1);
         HGT_CHECK_LAUNCH();
         return HGT_OK;
     }
     k_typed_linear_split<0, true><<<(unsigned)row_tiles, 512, 0, stream>>>(agg, ld_agg, rows, group_off, n_groups, k, n_out,
                                                                            (const unsigned short*)w_split, bias, b_group_stride, out,
-                                                                           nullptr, nullptr, n_out, 0, vec_ok, u);
+                                                                           nullptr, nullptr, n_out, 0, vec_ok, u, 1);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }

@@ -495,7 +495,7 @@ def _plan_constants(E):
     td, ch = C.c_int32(), C.c_int32()
     assert _lib.load().hgt_plan_constants(C.byref(td), C.byref(ch)) == 0
     ce = C.c_int32()
-    assert _lib.load().hgt_plan_item_edges(E, C.byref(ce)) == 0 and 64 <= ce.value <= ch.value
+    assert _lib.load().hgt_plan_item_edges(E, C.byref(ce)) == 0 and 16 <= ce.value <= ch.value
     return td.value, ce.value
 
 
