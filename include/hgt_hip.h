@@ -409,9 +409,11 @@ typedef struct hgt_conv_args {
     void* prepared;
     uint64_t prepared_bytes;
     int32_t prepared_valid;
-    /* != 0: the caller KNOWS (from the plan header, read back asynchronously -- pyhgt_amd.GraphPlan.no_hubs) that the plan
-     * found no hub target, so the hub kernels of the aggregation (4-5 launches that would exit at once) are not enqueued.
-     * 0 = unknown: they are enqueued. */
+    /* What the caller KNOWS about the plan (from the plan header, read back asynchronously -- pyhgt_amd.GraphPlan), as a bit set;
+     * 0 = nothing known: every kernel is enqueued.
+     *   bit 0: the plan found no hub target, so the hub kernels of the aggregation (4-5 launches that would exit at once)
+     *          are not enqueued;
+     *   bit 1: every target row has a valid node type, so hgt_zero_rows (output rows of unknown type := 0) is not enqueued. */
     int32_t plan_no_hubs;
     /* ABI 3: bit set of HGT_FLAG_* (0 = the default kernel selection) */
     int32_t flags;

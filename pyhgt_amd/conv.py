@@ -145,6 +145,7 @@ class GraphPlan:
         # plan header (n_items, bad_index, n_hubs) copied to pinned host memory WITHOUT synchronising; `no_hubs` /
         # `raise_if_bad` read it once the copy has completed (from the second layer on, in practice)
         self._no_hubs = None
+        self._no_unknown = None
         self._bad = None
         self._hdr_slot = _HeaderSlots.acquire(self)
         _HeaderSlots.buf[self._hdr_slot].copy_(self.buf[:16].view(torch.int32), non_blocking=True)
@@ -194,12 +195,19 @@ class GraphPlan:
         self._poll_header()
         return bool(self._no_hubs)
 
+    @property
+    def no_unknown_rows(self):
+        """True once it is known (no synchronisation) that every target row has a valid node type (hgt_zero_rows has no work)."""
+        self._poll_header()
+        return bool(self._no_unknown)
+
     def _poll_header(self, wait=False):
         if self._no_hubs is None and self._hdr_slot is not None and (wait or self._hdr_event.query()):
             if wait:
                 self._hdr_event.synchronize()
             row = _HeaderSlots.buf[self._hdr_slot]
             self._no_hubs = int(row[2]) == 0
+            self._no_unknown = int(row[3]) == 0
             self._bad = int(row[1])
             _HeaderSlots.release(self)
 
@@ -612,7 +620,7 @@ class HGTConv(nn.Module):
         a.stage = int(stage)
         if stage == 4:
             a.slice_index, a.slice_count = int(slices[0]), n_slices
-        a.plan_no_hubs = int(plan.no_hubs)
+        a.plan_no_hubs = int(plan.no_hubs) | (2 if plan.no_unknown_rows else 0)
         a.flags = int(self.kernel_flags)
         prep = self._prepared_buffer(x.device, n_slices)          # after _pack_parameters: a re-pack has invalidated it
         a.prepared, a.prepared_bytes, a.prepared_valid = _ptr(prep), prep.numel(), int(self._prepared_valid)

@@ -182,7 +182,8 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     PreparedLayout pl = prepared_layout(din, dout, T, R, H, a->use_rte, lay);
     if (pb && a->prepared_bytes < pl.total) return HGT_ERR_WORKSPACE;
     const bool fresh = !(pb && a->prepared_valid);          // derive the weight images in this call
-    void* hub_ws = a->plan_no_hubs ? nullptr : (void*)(wb + w.off_hub);
+    void* hub_ws = (a->plan_no_hubs & 1) ? nullptr : (void*)(wb + w.off_hub);
+    const bool no_unknown_rows = (a->plan_no_hubs & 2) != 0;     // the caller knows that every target row has a valid type
     void* msg_f = wb + w.off_msg_f;
     if (pb) {
         att_t = (float*)(pb + pl.off_att_t);
@@ -385,7 +386,7 @@ edge_phase:
                                       a->ln_b, a->use_norm, a->out, stream);
         if (rc != HGT_OK) return rc;
         mark(5);
-        rc = hgt_zero_rows(pr.rows_q, pr.off_q + T, dout, a->out, stream);   // nodes of unknown type -> 0 (conv.py:120)
+        if (!no_unknown_rows) rc = hgt_zero_rows(pr.rows_q, pr.off_q + T, dout, a->out, stream);   // nodes of unknown type -> 0 (conv.py:120)
     } else {
         rc = linear(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, a->w_a, (int64_t)dout * dp, a->b_a, dout, trans, nullptr, nullptr, dout,
                     0, ws_a);

@@ -14,6 +14,9 @@
 #define HGT_CH 512       // max edges per wavefront work item
 #endif
 #define HGT_WAVE 64
+#ifndef HGT_MIN_ITEM
+#define HGT_MIN_ITEM 16   // shortest logits work item (edges)
+#endif
 #ifndef HGT_HUB_DEG
 #define HGT_HUB_DEG 1024  // targets with more in-edges are "hubs": aggregated by many wavefronts (hgt_edge.hip, hub path)
 #endif
@@ -39,7 +42,8 @@ struct HgtPlanHeader {
     int32_t bad_index;    // bit 0: an edge endpoint was outside [0, n_nodes) / target >= n_q_rows; bit 1: edge_time outside [0, 240);
                           // bit 2: hgt_plan_from_sorted was handed edges that are not relation-grouped / target-sorted
     int32_t n_hubs;       // number of hub targets (in-degree > HGT_HUB_DEG), see hub_slot / hub_list
-    int32_t pad[13];
+    int32_t n_unknown_q;  // target rows [0, n_q_rows) whose node type is outside [0, n_types): their output rows are zeroed
+    int32_t pad[12];
 };
 
 // One wavefront work item: sorted edge positions [beg, end) all in one (dst tile, relation) bucket.
@@ -52,7 +56,7 @@ struct __attribute__((aligned(16))) HgtItem {
 // (round 3: down to 16 edges -- at E = 31k the logits kernel ran 27 us with 64-edge items, one dependent batch chain per item).
 static inline int hgt_item_edges(int64_t E) {
     int ch = HGT_CH;
-    while (ch > 16 && E / ch < 4096) ch >>= 1;   // (16-edge items at the sizes of the reference's sampled batches: E ~ 30-150k)
+    while (ch > HGT_MIN_ITEM && E / ch < 4096) ch >>= 1;   // (16-edge items at the sizes of the reference's sampled batches: E ~ 30-150k)
     return ch;
 }
 

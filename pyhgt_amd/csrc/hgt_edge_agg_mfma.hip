@@ -840,7 +840,13 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
 template <int VEC, int LPH, bool RTE>
 static int launch_agg_mfma(HGT_MFMA_AGG_ARGS) {
     // small graphs (the reference's sampled subgraphs): 4 instead of 16 targets per wavefront -> 4x the wavefronts
-    const int sub = (NQ < 65536) ? 4 : HGT_SUB;
+    // (round 3: 2 targets per wavefront for sampled-batch sizes when the row is not split over head groups and the schema has
+    //  few relations -- c3: 92 -> 82 us per layer; with 33 relations and a head-group split (c5) 4 stays faster: 519 vs 546 us)
+#ifndef HGT_SMALL_SUB
+#define HGT_SMALL_SUB 2
+#endif
+    const unsigned ny_ = (unsigned)(HT / (64 / LPH));
+    const int sub = (NQ < 65536) ? ((NQ < 16384 && ny_ == 1 && R <= 16) ? HGT_SMALL_SUB : 4) : HGT_SUB;
     const int64_t tiles = (NQ + 4 * sub - 1) / (4 * sub);
     const unsigned ny = (unsigned)(HT / (64 / LPH));
     dim3 grid((unsigned)tiles, ny);

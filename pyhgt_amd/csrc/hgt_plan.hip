@@ -180,15 +180,19 @@ __global__ void k_node_keys(const int64_t* __restrict__ ntype, int64_t N, int T,
 }
 
 // off[g] = lower bound of g in the sorted type keys, g = 0..T+1
-__global__ void k_type_offsets(const uint32_t* __restrict__ keys_sorted, int64_t N, int T, int32_t* __restrict__ off) {
+// (hdr != nullptr: also record how many of the N rows have no valid type -- the layer then knows whether hgt_zero_rows has work)
+__global__ void k_type_offsets(const uint32_t* __restrict__ keys_sorted, int64_t N, int T, int32_t* __restrict__ off, HgtPlanHeader* hdr) {
     int g = threadIdx.x;
-    if (g > T + 1) return;
-    int64_t lo = 0, hi = N;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)keys_sorted[mid] < g) lo = mid + 1; else hi = mid;
+    if (g <= T + 1) {
+        int64_t lo = 0, hi = N;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)keys_sorted[mid] < g) lo = mid + 1; else hi = mid;
+        }
+        off[g] = (int32_t)lo;
     }
-    off[g] = (int32_t)lo;
+    __syncthreads();
+    if (hdr != nullptr && g == 0) hdr->n_unknown_q = off[T + 1] - off[T];
 }
 
 
@@ -273,7 +277,10 @@ __global__ void k_sorted_scatter(const int32_t* __restrict__ src, const int32_t*
 __global__ void k_sorted_rows(const int32_t* __restrict__ type_off, int64_t N, int64_t NQ, int T, int32_t* __restrict__ rows_all,
                               int32_t* __restrict__ off_all, int32_t* __restrict__ rows_q, int32_t* __restrict__ off_q, HgtPlanHeader* hdr) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n == 0) { hdr->n_items = 0; hdr->bad_index = 0; hdr->n_hubs = 0; }
+    if (n == 0) {
+        hdr->n_items = 0; hdr->bad_index = 0; hdr->n_hubs = 0;
+        hdr->n_unknown_q = (int32_t)(min(N, NQ) - min((int64_t)type_off[T], NQ));
+    }
     if (n < N) { rows_all[n] = (int32_t)n; rows_q[n] = (int32_t)n; }
     if (n <= T + 1) {
         const int32_t v = (n <= T) ? type_off[n] : (int32_t)N;          // group T (unknown types) is empty
@@ -314,7 +321,10 @@ __global__ __launch_bounds__(1024) void k_sorted_small_head(
     __shared__ int s_lb[SMALL_PAIRS + 1];
     __shared__ int s_a[1024], s_b[1024];
     const int tid = threadIdx.x;
-    if (tid == 0) { hdr->n_items = 0; hdr->bad_index = 0; hdr->n_hubs = 0; }
+    if (tid == 0) {
+        hdr->n_items = 0; hdr->bad_index = 0; hdr->n_hubs = 0;
+        hdr->n_unknown_q = (int32_t)(min(N, NQ) - min((int64_t)type_off[T], NQ));
+    }
     for (int64_t n = tid; n < N; n += 1024) { rows_all[n] = (int32_t)n; rows_q[n] = (int32_t)n; }
     if (tid <= T + 1) {
         const int32_t v = (tid <= T) ? type_off[tid] : (int32_t)N;
@@ -541,13 +551,13 @@ extern "C" int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int
         if (rocprim::radix_sort_pairs(sort_tmp, sort_bytes, nkeys_in, nkeys_out, nvals_in, rows_all, (size_t)N, 0,
                                       key_bits((uint64_t)T + 1), stream) != hipSuccess) return HGT_ERR_LAUNCH;
     }
-    k_type_offsets<<<1, 256, 0, stream>>>(nkeys_out, N, T, off_all);
+    k_type_offsets<<<1, 256, 0, stream>>>(nkeys_out, N, T, off_all, nullptr);
     if (NQ > 0) {
         sort_bytes = (size_t)tl.sort_tmp_bytes;
         if (rocprim::radix_sort_pairs(sort_tmp, sort_bytes, nkeys_in, nkeys_out, nvals_in, rows_q, (size_t)NQ, 0,
                                       key_bits((uint64_t)T + 1), stream) != hipSuccess) return HGT_ERR_LAUNCH;
     }
-    k_type_offsets<<<1, 256, 0, stream>>>(nkeys_out, NQ, T, off_q);
+    k_type_offsets<<<1, 256, 0, stream>>>(nkeys_out, NQ, T, off_q, hdr);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }
