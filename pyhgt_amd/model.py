@@ -137,7 +137,8 @@ class GNN(nn.Module):
                                             _ptr(b), n_hid, _ptr(h), 0, 0, n_hid, 0, 0, 0, st), "hgt_typed_linear(adapter)")
         # nodes whose type no adapter claims stay zero like the reference's zero-initialised `res` (model.py:70);
         # rows_all[off_all[T] .. off_all[T+1]) are exactly those nodes
-        _lib.check(lib.hgt_zero_rows(rows.rows_all, rows.off_all + 4 * T, n_hid, _ptr(h), st), "hgt_zero_rows")
+        if not (plan.NQ == plan.N and plan.no_unknown_rows):      # (skipped once the plan header says every row has a valid type)
+            _lib.check(lib.hgt_zero_rows(rows.rows_all, rows.off_all + 4 * T, n_hid, _ptr(h), st), "hgt_zero_rows")
         _lib.check(lib.hgt_tanh_inplace(_ptr(h), N * n_hid, st), "hgt_tanh_inplace")
         for gc in self.gcs:
             h = gc.base_conv(h, node_type, edge_index, edge_type, edge_time, plan=plan)
