@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HGT_ABI_VERSION 4
+#define HGT_ABI_VERSION 5
 
 /* error codes */
 #define HGT_OK 0
@@ -157,6 +157,18 @@ int hgt_typed_linear_bf16x3(const float* x, int64_t ldx, const int32_t* rows, co
                             const float* bias, int64_t b_group_stride, float* out0, float* out1, float* out2,
                             int32_t block_cols, int32_t out_by_position, int32_t prologue, void* stream);
 
+/* fp16 hi / lo variant of the split products (ABI 5, precision "f16x3"): the same three MFMAs per step with 11 + 11 mantissa bits
+ * per operand instead of 8 + 8 (relative error of a product ~2^-22: the layer's output is within ~3e-7 of the fp64 result), at the
+ * same cost.  fp16 has 5 exponent bits, so every x row is scaled by a power of two (found on the fly) and every weight group by
+ * one (found by hgt_split_weights_f16, kept in the image's tail); the inverse scales go onto the fp32 accumulators.  Same
+ * arguments and the same image size (hgt_split_weights_bytes) as the bf16 functions; an image must be used with its own kind. */
+int hgt_split_weights_f16(const float* W, int64_t w_group_stride, int32_t n_groups, int32_t k, int32_t n_out,
+                          void* w_split, void* stream);
+int hgt_typed_linear_f16x3(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off,
+                           int32_t n_groups, int64_t n_rows, int32_t k, int32_t n_out, const void* w_split,
+                           const float* bias, int64_t b_group_stride, float* out0, float* out1, float* out2,
+                           int32_t block_cols, int32_t out_by_position, int32_t prologue, void* stream);
+
 /* a_linear (conv.py:125) with the node update (conv.py:129-133, see hgt_node_update) fused into its epilogue:
  *   out[n] = LN_t( (agg[n] @ W_a[t]^T + b_a[t]) * sigmoid(skip[t]) + x_skip[n] * (1 - sigmoid(skip[t])) )
  * for the rows of every group; split-bf16 x3 MFMA; needs n_out <= 256 and n_out % 4 == 0 (HGT_ERR_UNSUPPORTED
@@ -166,6 +178,12 @@ int hgt_linear_update_bf16x3(const float* agg, int64_t ld_agg, const int32_t* ro
                              const float* bias, int64_t b_group_stride, const float* x_skip, int64_t ld_skip,
                              const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm, float* out,
                              void* stream);
+/* the same on an fp16 hi / lo image (hgt_split_weights_f16) */
+int hgt_linear_update_f16x3(const float* agg, int64_t ld_agg, const int32_t* rows, const int32_t* group_off,
+                            int32_t n_groups, int64_t n_rows, int32_t k, int32_t n_out, const void* w_split,
+                            const float* bias, int64_t b_group_stride, const float* x_skip, int64_t ld_skip,
+                            const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm, float* out,
+                            void* stream);
 /* out[rows[i]][0..d) = 0 for i in [range[0], range[1]) -- range is a DEVICE array of two int32 */
 int hgt_zero_rows(const int32_t* rows, const int32_t* range, int32_t d, float* out, void* stream);
 

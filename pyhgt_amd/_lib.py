@@ -55,7 +55,7 @@ class HgtConvArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 4          # HGT_ABI_VERSION of include/hgt_hip.h this binding was written against
+ABI_VERSION = 5          # HGT_ABI_VERSION of include/hgt_hip.h this binding was written against
 
 _i32, _i64, _u64, _vp = C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
 
@@ -78,6 +78,11 @@ SIGNATURES = {
                                           _i32, _i32, _i32, _vp]),
     "hgt_linear_update_bf16x3": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                                            _i32, _vp, _vp]),
+    "hgt_split_weights_f16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "hgt_typed_linear_f16x3": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp,
+                                         _i32, _i32, _i32, _vp]),
+    "hgt_linear_update_f16x3": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
+                                          _i32, _vp, _vp]),
     "hgt_zero_rows": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "hgt_relation_pack": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "hgt_edge_logits": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

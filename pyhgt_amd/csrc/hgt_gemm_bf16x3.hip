@@ -32,8 +32,10 @@ namespace {
 
 // W [n_groups][n_out][k] fp32 -> [g][pass][kchunk][plane][col tile 8][lane 64][8] bf16 (zero padded): the 8 bf16 of
 // (col tile ct, lane l) are W[pass*256 + ct*32 + (l&31)][kchunk*16 + (l>>5)*8 .. +8] = one lane's B fragment.
+// F16: fp16 hi / lo planes of W[g] * scale[g] (one power-of-two scale per group, k_group_scale; the image's tail holds its inverse)
+template <bool F16>
 __global__ void k_split_weights(const float* __restrict__ W, int64_t wgs, int n_groups, int k, int n_out, int n_pass, int n_kc,
-                                unsigned short* __restrict__ out) {
+                                unsigned short* __restrict__ out, const float* __restrict__ gscale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t per_group = (int64_t)n_pass * n_kc * W_PLANE_ELEMS;
     if (i >= per_group * n_groups) return;
@@ -50,20 +52,74 @@ __global__ void k_split_weights(const float* __restrict__ W, int64_t wgs, int n_
     const int n = pass * BNP + ct * 32 + (l & 31), kidx = kc * KC + (l >> 5) * 8 + e;
     float v = 0.0f;
     if (n < n_out && kidx < k) v = W[(int64_t)g * wgs + (int64_t)n * k + kidx];
-    const unsigned short h = bf16_rne(v);
-    const unsigned short m = bf16_rne(v - bf16_to_f32(h));
+    unsigned short h, m;
+    if constexpr (F16) {
+        v *= gscale[g];
+        const _Float16 hh = (_Float16)v;
+        const _Float16 ll = (_Float16)(v - (float)hh);
+        h = __builtin_bit_cast(unsigned short, hh);
+        m = __builtin_bit_cast(unsigned short, ll);
+    } else {
+        h = bf16_rne(v);
+        m = bf16_rne(v - bf16_to_f32(h));
+    }
     const int64_t tile = (((int64_t)g * n_pass + pass) * n_kc + kc) * 2;
     const int within = (ct * 64 + l) * 8 + e;
     out[(tile + 0) * W_PLANE_ELEMS + within] = h;
     out[(tile + 1) * W_PLANE_ELEMS + within] = m;
 }
 
+// one workgroup per group: max |W[g]| -> tail[g] = inverse scale (read by the GEMM epilogues), tail[n_groups + g] = scale
+__global__ __launch_bounds__(1024) void k_group_scale(const float* __restrict__ W, int64_t wgs, int64_t per_group, float* __restrict__ tail,
+                                                       int n_groups) {
+    __shared__ unsigned s_m[16];
+    const int g = blockIdx.x;
+    unsigned m = 0;
+    for (int64_t i = threadIdx.x; i < per_group; i += 1024) m = max(m, __builtin_bit_cast(unsigned, fabsf(W[(int64_t)g * wgs + i])));
+    m = wave_max_bits(m);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = max(m, s_m[w]);
+        float sc, inv;
+        f16_row_scale(m, sc, inv);
+        tail[g] = inv;
+        tail[n_groups + g] = sc;
+    }
+}
+
+// Row scales of the fp16 split for the kernels that walk K in several LDS panels (k_typed_linear_split): the scale of a row
+// must be the same for all its panels, so the row maximum is taken over the whole row first (one more pass over x; K > 256 only).
+template <int PROLOGUE>
+__device__ __forceinline__ void row_scales_all_panels(int tid, const int* s_rid, const float* __restrict__ x, int64_t ldx, int k,
+                                                      unsigned* s_bits, float* s_scale, float* s_inv) {
+    if (tid < BM) s_bits[tid] = 0u;
+    __syncthreads();
+    for (int kp0 = 0; kp0 < k; kp0 += KP) {
+        for (int f = tid; f < BM * 64; f += 512) {
+            const int kk = kp0 + (f & 63) * 4, rid = s_rid[f >> 6];
+            if (rid < 0 || kk >= k) continue;
+            const float* px = x + (int64_t)rid * ldx + kk;
+            float m = 0.0f;
+            for (int e = 0; e < 4 && kk + e < k; ++e) {
+                float a = px[e];
+                if (PROLOGUE == 1) a = gelu_erf_(a);
+                m = fmaxf(m, fabsf(a));
+            }
+            atomicMax(&s_bits[f >> 6], __builtin_bit_cast(unsigned, m));
+        }
+    }
+    __syncthreads();
+    if (tid < BM) f16_row_scale(s_bits[tid], s_scale[tid], s_inv[tid]);
+    __syncthreads();
+}
+
 // Load one K panel of the 64-row x slab: whole rows, split into bf16 hi/mid planes ONCE, stored to LDS.
 // Done in two halves of 4 float4 per thread to keep the live register set small (the kernel is capped at 128 VGPRs
 // so that two workgroups fit a CU; an 8-deep version spilled ~230 B per lane to scratch = +2.9 GB of HBM traffic at c2).
-template <int PROLOGUE>
+template <int PROLOGUE, bool F16>
 __device__ __forceinline__ void load_a_panel(int kp0, int tid, const int* s_rid, const float* __restrict__ x, int64_t ldx, int k,
-                                             int vec_ok, unsigned char* sA, bool wait_readers) {
+                                             int vec_ok, unsigned char* sA, bool wait_readers, const float* s_scale) {
     if (wait_readers) __syncthreads();   // every wave is done reading the previous panel
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -93,7 +149,7 @@ __device__ __forceinline__ void load_a_panel(int kp0, int tid, const int* s_rid,
             const int f = tid + 512 * (half * 4 + j);
             const int r = f >> 6, cb = (f & 63) * 8;
             uint2 hi, mid;
-            split4(av[j], hi, mid);
+            split4_t<F16>(av[j], F16 ? s_scale[r] : 1.0f, hi, mid);
             *reinterpret_cast<uint2*>(sA + r * A_STRIDE + cb) = hi;
             *reinterpret_cast<uint2*>(sA + A_PLANE + r * A_STRIDE + cb) = mid;
         }
@@ -107,7 +163,8 @@ __device__ __forceinline__ void load_a_panel(int kp0, int tid, const int* s_rid,
 // store (one wave instruction = 8 rows x 128 B) -- 4x fewer store instructions.
 __device__ __forceinline__ void store_pass(f32x16 (&acc)[2], int pass, int wave, int lane, int g, int n_out, int nrows, int row0,
                                            const int* s_rid, const float* __restrict__ bias, int64_t bgs, float* __restrict__ out0,
-                                           float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos) {
+                                           float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos,
+                                           const float* s_inv, float winv) {      // s_inv == nullptr: no operand scales (bf16 split)
     const int col = pass * BNP + wave * 32 + ((lane & 31) >> 2) * 4;      // first of this lane's 4 columns after the transpose
     const bool col_ok = col < n_out;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -124,7 +181,9 @@ __device__ __forceinline__ void store_pass(f32x16 (&acc)[2], int pass, int wave,
             const int rt = j * 32 + (lane & 3) + 8 * q + 4 * (lane >> 5);
             if (col_ok && rt < nrows) {
                 const int64_t orow = by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
-                *reinterpret_cast<float4*>(ob + orow * block_cols + cc) = make_float4(v0 + b4.x, v1 + b4.y, v2 + b4.z, v3 + b4.w);
+                const float sc = s_inv ? s_inv[rt] * winv : 1.0f;
+                *reinterpret_cast<float4*>(ob + orow * block_cols + cc) =
+                    make_float4(v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w);
             }
         }
     }
@@ -148,7 +207,7 @@ struct UpdateArgs {
 // A row's 256 columns live in 8 waves x 8 lanes; partial sums meet in a small LDS table (the A slab is dead by then).
 __device__ __forceinline__ void store_pass_update(f32x16 (&acc)[2], int wave, int lane, int g, int n_out, int nrows, const int* s_rid,
                                                   const float* __restrict__ bias, int64_t bgs, float* __restrict__ out,
-                                                  const UpdateArgs& u, float* s_red) {
+                                                  const UpdateArgs& u, float* s_red, const float* s_inv, float winv) {
     const int col = wave * 32 + ((lane & 31) >> 2) * 4;
     const bool col_ok = col < n_out;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -176,10 +235,11 @@ __device__ __forceinline__ void store_pass_update(f32x16 (&acc)[2], int wave, in
             orow[q] = (rt < nrows) ? (int64_t)s_rid[rt] : -1;
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (col_ok && orow[q] >= 0) xv = *reinterpret_cast<const float4*>(u.xs + orow[q] * u.ldxs + col);
-            y[q][0] = col_ok ? (v0 + b4.x) * alpha + xv.x * (1.0f - alpha) : 0.0f;
-            y[q][1] = col_ok ? (v1 + b4.y) * alpha + xv.y * (1.0f - alpha) : 0.0f;
-            y[q][2] = col_ok ? (v2 + b4.z) * alpha + xv.z * (1.0f - alpha) : 0.0f;
-            y[q][3] = col_ok ? (v3 + b4.w) * alpha + xv.w * (1.0f - alpha) : 0.0f;
+            const float sc = s_inv ? s_inv[rt] * winv : 1.0f;
+            y[q][0] = col_ok ? (v0 * sc + b4.x) * alpha + xv.x * (1.0f - alpha) : 0.0f;
+            y[q][1] = col_ok ? (v1 * sc + b4.y) * alpha + xv.y * (1.0f - alpha) : 0.0f;
+            y[q][2] = col_ok ? (v2 * sc + b4.z) * alpha + xv.z * (1.0f - alpha) : 0.0f;
+            y[q][3] = col_ok ? (v3 * sc + b4.w) * alpha + xv.w * (1.0f - alpha) : 0.0f;
         }
         if (u.use_norm) {
             // pass 1: mean
@@ -226,7 +286,7 @@ __device__ __forceinline__ void store_pass_update(f32x16 (&acc)[2], int wave, in
     }
 }
 
-template <int PROLOGUE, bool UPD>
+template <int PROLOGUE, bool UPD, bool F16>
 __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off,
     int n_groups, int k, int n_out, const unsigned short* __restrict__ wsplit, const float* __restrict__ bias, int64_t bgs,
@@ -234,6 +294,8 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     UpdateArgs upd, int pass_split) {
     __shared__ __attribute__((aligned(16))) unsigned char sA[2 * A_PLANE];        // [plane][64][528]
     __shared__ int s_rid[BM];
+    __shared__ float s_scale[F16 ? BM : 1], s_inv[F16 ? BM : 1];                   // fp16 split: row scales and their inverses
+    __shared__ unsigned s_bits[F16 ? BM : 1];
 
     // pass_split = n_pass (small problems: fewer row tiles than CUs): a workgroup owns ONE 256-column pass of a row tile, so that
     // tiles x passes workgroups share the work (sampled sub-graphs of a few thousand nodes: 50-64 row tiles for 256 CUs);
@@ -264,6 +326,11 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     const int frow = lane & 31, khalf = lane >> 5;
     // this wave's B fragments: plane stride W_PLANE_ELEMS, tile stride 2 * W_PLANE_ELEMS (bf16 elements)
     const unsigned short* __restrict__ wfrag = wsplit + (int64_t)g * total * 2 * W_PLANE_ELEMS + (wave * 64 + lane) * 8;
+    float winv = 1.0f;                               // inverse of the group's weight scale: the image's tail (hgt_split_weights_f16)
+    if constexpr (F16) {
+        winv = reinterpret_cast<const float*>(wsplit + (int64_t)n_groups * total * 2 * W_PLANE_ELEMS)[g];
+        row_scales_all_panels<PROLOGUE>(tid, s_rid, x, ldx, k, s_bits, s_scale, s_inv);
+    }
 
     f32x16 acc[2];
 #pragma unroll
@@ -295,7 +362,7 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     HGT_LOAD_STAGE(3, pass_lo * n_kc + 3)
 #endif
 
-    load_a_panel<PROLOGUE>(0, tid, s_rid, x, ldx, k, vec_ok, sA, false);
+    load_a_panel<PROLOGUE, F16>(0, tid, s_rid, x, ldx, k, vec_ok, sA, false, s_scale);
 
 #define HGT_STEP(S, T, KCP)                                                                                        \
     {                                                                                                              \
@@ -307,17 +374,17 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
         const bf16x8 bh = s##S##h, bm = s##S##m;                                                                   \
         HGT_LOAD_STAGE(S, (T) + HGT_NSTAGE)                                                                        \
         /* small terms first, hi*hi last; the two accumulators alternate */                                        \
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, bh, acc[0], 0, 0, 0);                                \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, bh, acc[1], 0, 0, 0);                                \
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bm, acc[0], 0, 0, 0);                                \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bm, acc[1], 0, 0, 0);                                \
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[0], 0, 0, 0);                                \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1], 0, 0, 0);                                \
+        acc[0] = mfma32_t<F16>(am0, bh, acc[0]);                                \
+        acc[1] = mfma32_t<F16>(am1, bh, acc[1]);                                \
+        acc[0] = mfma32_t<F16>(ah0, bm, acc[0]);                                \
+        acc[1] = mfma32_t<F16>(ah1, bm, acc[1]);                                \
+        acc[0] = mfma32_t<F16>(ah0, bh, acc[0]);                                \
+        acc[1] = mfma32_t<F16>(ah1, bh, acc[1]);                                \
     }
 
     for (int pass = pass_lo; pass < pass_hi; ++pass) {
         for (int panel = 0; panel < n_panel; ++panel) {
-            if (n_panel > 1 && (pass != pass_lo || panel != 0)) load_a_panel<PROLOGUE>(panel * KP, tid, s_rid, x, ldx, k, vec_ok, sA, true);
+            if (n_panel > 1 && (pass != pass_lo || panel != 0)) load_a_panel<PROLOGUE, F16>(panel * KP, tid, s_rid, x, ldx, k, vec_ok, sA, true, s_scale);
             const int nkc_p = min(KP / KC, n_kc - panel * (KP / KC));
             const int tbase = pass * n_kc + panel * (KP / KC);
             for (int kq = 0; kq < nkc_p; kq += 4) {
@@ -336,9 +403,11 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
         }
         if constexpr (UPD) {
             __syncthreads();   // every wave left the MFMA loop: the A slab can be reused as the reduction table
-            store_pass_update(acc, wave, lane, g, n_out, nrows, s_rid, bias, bgs, out0, upd, reinterpret_cast<float*>(sA));
+            store_pass_update(acc, wave, lane, g, n_out, nrows, s_rid, bias, bgs, out0, upd, reinterpret_cast<float*>(sA),
+                              F16 ? s_inv : nullptr, winv);
         } else {
-            store_pass(acc, pass, wave, lane, g, n_out, nrows, row0, s_rid, bias, bgs, out0, out1, out2, block_cols, by_pos);
+            store_pass(acc, pass, wave, lane, g, n_out, nrows, row0, s_rid, bias, bgs, out0, out1, out2, block_cols, by_pos,
+                       F16 ? s_inv : nullptr, winv);
         }
     }
 #undef HGT_STEP
@@ -415,16 +484,23 @@ __device__ __forceinline__ void pc_issue(float4 (&a)[PC_AREGS], int& v_rid, int 
     }
 }
 
-template <int PROLOGUE>
-__device__ __forceinline__ void pc_commit(const float4 (&a)[PC_AREGS], int v_rid, int pw, int lane, unsigned char* slab, int* rid_out) {
+template <int PROLOGUE, bool F16>
+__device__ __forceinline__ void pc_commit(const float4 (&a)[PC_AREGS], int v_rid, int pw, int lane, unsigned char* slab, int* rid_out,
+                                          float* rinv_out) {
     if (lane < PC_AREGS) rid_out[pw + PC_PROD * lane] = v_rid;
 #pragma unroll
     for (int j = 0; j < PC_AREGS; ++j) {
         float4 v = a[j];
         if (__builtin_amdgcn_readlane(v_rid, j) < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);   // row beyond the tile
         if (PROLOGUE == 1) { v.x = gelu_erf_(v.x); v.y = gelu_erf_(v.y); v.z = gelu_erf_(v.z); v.w = gelu_erf_(v.w); }
+        float scale = 1.0f;
+        if constexpr (F16) {      // the wavefront holds the whole row: its maximum is a wave reduction, its scale wave-uniform
+            float inv;
+            f16_row_scale(wave_max_bits(abs_bits4(v)), scale, inv);
+            if (lane == 0) rinv_out[pw + PC_PROD * j] = inv;
+        }
         uint2 hi, mid;
-        split4(v, hi, mid);
+        split4_t<F16>(v, scale, hi, mid);
         unsigned char* p = slab + (pw + PC_PROD * j) * A_STRIDE + lane * 8;
         *reinterpret_cast<uint2*>(p) = hi;
         *reinterpret_cast<uint2*>(p + A_PLANE) = mid;
@@ -463,7 +539,8 @@ struct PendingRows {     // one pass worth of finished output of this lane: 8 x 
 //   y = (acc + b) * sigmoid(skip[t]) + x * (1 - sigmoid(skip[t]));  out = LayerNorm_t(y)  (two-pass mean / variance)
 __device__ __forceinline__ void pc_store_update(f32x16 (&acc)[2], int wave, int lane, int g, int n_out, int nrows, const int* s_rid,
                                                 const float* __restrict__ bias, int64_t bgs, float* __restrict__ out,
-                                                const UpdateArgs& u, float* s_sum, float* s_var, PendingRows& pr) {
+                                                const UpdateArgs& u, float* s_sum, float* s_var, PendingRows& pr,
+                                                const float* s_inv, float winv) {
     const int col = wave * 32 + ((lane & 31) >> 2) * 4;
     const bool col_ok = col < n_out;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -492,10 +569,11 @@ __device__ __forceinline__ void pc_store_update(f32x16 (&acc)[2], int wave, int 
             const int jq = half * 4 + q;
             float v0 = acc[half][4 * q], v1 = acc[half][4 * q + 1], v2 = acc[half][4 * q + 2], v3 = acc[half][4 * q + 3];
             quad_transpose(v0, v1, v2, v3, o1, o2);
-            y[jq][0] = col_ok ? (v0 + b4.x) * alpha + xv[q].x * (1.0f - alpha) : 0.0f;
-            y[jq][1] = col_ok ? (v1 + b4.y) * alpha + xv[q].y * (1.0f - alpha) : 0.0f;
-            y[jq][2] = col_ok ? (v2 + b4.z) * alpha + xv[q].z * (1.0f - alpha) : 0.0f;
-            y[jq][3] = col_ok ? (v3 + b4.w) * alpha + xv[q].w * (1.0f - alpha) : 0.0f;
+            const float sc = s_inv ? s_inv[rt0 + 32 * (jq >> 2) + 8 * (jq & 3)] * winv : 1.0f;
+            y[jq][0] = col_ok ? (v0 * sc + b4.x) * alpha + xv[q].x * (1.0f - alpha) : 0.0f;
+            y[jq][1] = col_ok ? (v1 * sc + b4.y) * alpha + xv[q].y * (1.0f - alpha) : 0.0f;
+            y[jq][2] = col_ok ? (v2 * sc + b4.z) * alpha + xv[q].z * (1.0f - alpha) : 0.0f;
+            y[jq][3] = col_ok ? (v3 * sc + b4.w) * alpha + xv[q].w * (1.0f - alpha) : 0.0f;
         }
     }
     if (!u.use_norm) {
@@ -553,7 +631,7 @@ __device__ __forceinline__ void pc_store_update(f32x16 (&acc)[2], int wave, int 
 __device__ __forceinline__ void pc_stage_pass(f32x16 (&acc)[2], int pass, int wave, int lane, int g, int n_out, int nrows, int row0,
                                               const int* s_rid, const float* __restrict__ bias, int64_t bgs, float* __restrict__ out0,
                                               float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos,
-                                              PendingRows& pr) {
+                                              PendingRows& pr, const float* s_inv, float winv) {
     const int col = pass * BNP + wave * 32 + ((lane & 31) >> 2) * 4;
     const bool col_ok = col < n_out;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -566,7 +644,8 @@ __device__ __forceinline__ void pc_stage_pass(f32x16 (&acc)[2], int pass, int wa
         const int j = jq >> 2, q = jq & 3;
         float v0 = acc[j][4 * q], v1 = acc[j][4 * q + 1], v2 = acc[j][4 * q + 2], v3 = acc[j][4 * q + 3];
         quad_transpose(v0, v1, v2, v3, o1, o2);
-        pr.v[jq] = f32x4{v0 + b4.x, v1 + b4.y, v2 + b4.z, v3 + b4.w};
+        const float sc = s_inv ? s_inv[j * 32 + (lane & 3) + 8 * q + 4 * (lane >> 5)] * winv : 1.0f;
+        pr.v[jq] = f32x4{v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w};
     }
     pr.base = col_ok ? ob + cc : nullptr;
     pr.ld = block_cols;
@@ -576,7 +655,7 @@ __device__ __forceinline__ void pc_stage_pass(f32x16 (&acc)[2], int pass, int wa
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 }
 
-template <int PROLOGUE, bool UPD>
+template <int PROLOGUE, bool UPD, bool F16>
 __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off,
     int n_groups, int k, int n_out, const unsigned short* __restrict__ wsplit, const float* __restrict__ bias, int64_t bgs,
@@ -585,6 +664,7 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
     __shared__ __attribute__((aligned(16))) unsigned char sA[2][2 * A_PLANE];   // [slab][plane][64][528]
     __shared__ int s_rid[3][BM];   // three tables: the parked rows of tile i are written while tile i+2 is being loaded
     __shared__ __attribute__((aligned(16))) float s_red[2][2][BM * 8];          // [parity][sum|var][row][wave]
+    __shared__ float s_rinv[F16 ? 3 : 1][F16 ? BM : 1];                         // fp16 split: inverse row scales, rotating like s_rid
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -607,7 +687,7 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
         int v_rid, g, row0, nrows;
         tile_lookup(first / pass_split, group_off, n_groups, g, row0, nrows);
         pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
-        pc_commit<PROLOGUE>(a, v_rid, pw, lane, sA[0], s_rid[0]);
+        pc_commit<PROLOGUE, F16>(a, v_rid, pw, lane, sA[0], s_rid[0], s_rinv[0]);
         if (n_mine > 1) {
             tile_lookup((first + stride) / pass_split, group_off, n_groups, g, row0, nrows);
             pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
@@ -615,7 +695,7 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
         pc_barrier();                                   // B_0
         for (int i = 0; i < n_mine; ++i) {
             if (i + 1 < n_mine) {
-                pc_commit<PROLOGUE>(a, v_rid, pw, lane, sA[(i + 1) & 1], s_rid[(i + 1) % 3]);
+                pc_commit<PROLOGUE, F16>(a, v_rid, pw, lane, sA[(i + 1) & 1], s_rid[(i + 1) % 3], s_rinv[F16 ? (i + 1) % 3 : 0]);
                 if (i + 2 < n_mine) {
                     tile_lookup((first + (i + 2) * stride) / pass_split, group_off, n_groups, g, row0, nrows);
                     pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
@@ -661,6 +741,8 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
         tile_lookup(vt / pass_split, group_off, n_groups, g, row0, nrows);
         const int pass_lo = (pass_split > 1) ? vt % pass_split : 0, pass_hi = (pass_split > 1) ? pass_lo + 1 : n_pass;
         const unsigned short* __restrict__ wfrag = wsplit + (int64_t)g * total * 2 * W_PLANE_ELEMS + (wave * 64 + lane) * 8;
+        const float winv = F16 ? reinterpret_cast<const float*>(wsplit + (int64_t)n_groups * total * 2 * W_PLANE_ELEMS)[g] : 1.0f;
+        const float* s_inv = F16 ? s_rinv[F16 ? i % 3 : 0] : nullptr;
         bf16x8 s0h, s0m, s1h, s1m, s2h, s2m, s3h, s3m;
 #define PC_LOAD_STAGE(S, T)                                                                           \
     {                                                                                                 \
@@ -695,12 +777,12 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
 #define PC_STEP(S, T, P, PN, KNEXT)                                                                                \
     {                                                                                                              \
         PC_LOAD_A(PN, KNEXT)                                                                                       \
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m0, s##S##h, acc[0], 0, 0, 0);                        \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m1, s##S##h, acc[1], 0, 0, 0);                        \
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##m, acc[0], 0, 0, 0);                        \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##m, acc[1], 0, 0, 0);                        \
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##h, acc[0], 0, 0, 0);                        \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##h, acc[1], 0, 0, 0);                        \
+        acc[0] = mfma32_t<F16>(P##_m0, s##S##h, acc[0]);                        \
+        acc[1] = mfma32_t<F16>(P##_m1, s##S##h, acc[1]);                        \
+        acc[0] = mfma32_t<F16>(P##_h0, s##S##m, acc[0]);                        \
+        acc[1] = mfma32_t<F16>(P##_h1, s##S##m, acc[1]);                        \
+        acc[0] = mfma32_t<F16>(P##_h0, s##S##h, acc[0]);                        \
+        acc[1] = mfma32_t<F16>(P##_h1, s##S##h, acc[1]);                        \
         PC_LOAD_STAGE(S, (T) + NST)                                                             \
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); /* 4 DS reads    */                                     \
         __builtin_amdgcn_sched_group_barrier(0x008, 6, 0); /* 6 MFMAs       */                                     \
@@ -744,13 +826,15 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
             if (n_kc <= 8) { PC_STORE(4) PC_STORE(5) }
             if (n_kc <= 4) { PC_STORE(2) PC_STORE(3) }
             if constexpr (UPD) {
-                pc_store_update(acc, wave, lane, g, n_out, nrows, s_rid[i % 3], bias, bgs, out0, upd, s_red[i & 1][0], s_red[i & 1][1], pr);
+                pc_store_update(acc, wave, lane, g, n_out, nrows, s_rid[i % 3], bias, bgs, out0, upd, s_red[i & 1][0], s_red[i & 1][1], pr,
+                                s_inv, winv);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
             } else {
-                pc_stage_pass(acc, pass, wave, lane, g, n_out, nrows, row0, s_rid[i % 3], bias, bgs, out0, out1, out2, block_cols, by_pos, pr);
+                pc_stage_pass(acc, pass, wave, lane, g, n_out, nrows, row0, s_rid[i % 3], bias, bgs, out0, out1, out2, block_cols, by_pos, pr,
+                              s_inv, winv);
             }
             have_pend = true;
             pr.rid = s_rid[i % 3];
@@ -791,7 +875,8 @@ extern "C" int hgt_split_weights_bytes(int32_t n_groups, int32_t k, int32_t n_ou
     if (!out || n_groups <= 0 || k <= 0 || n_out <= 0) return HGT_ERR_INVALID_ARG;
     int n_pass, n_kstep;
     split_dims(k, n_out, &n_pass, &n_kstep);
-    *out = (uint64_t)n_groups * n_pass * n_kstep * 2 * W_PLANE_ELEMS * 2;
+    // tiles + tail: [n_groups] inverse weight scales, [n_groups] scales (written by hgt_split_weights_f16; unused by the bf16 image)
+    *out = (uint64_t)n_groups * n_pass * n_kstep * 2 * W_PLANE_ELEMS * 2 + hgt_align_up((uint64_t)n_groups * 8, 256);
     return HGT_OK;
 }
 
@@ -801,16 +886,31 @@ extern "C" int hgt_split_weights(const float* W, int64_t w_group_stride, int32_t
     int n_pass, n_kstep;
     split_dims(k, n_out, &n_pass, &n_kstep);
     const int64_t total = (int64_t)n_groups * n_pass * n_kstep * W_PLANE_ELEMS;
-    k_split_weights<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, w_group_stride, n_groups, k, n_out, n_pass, n_kstep,
-                                                                                     (unsigned short*)w_split);
+    k_split_weights<false><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, w_group_stride, n_groups, k, n_out, n_pass,
+                                                                                            n_kstep, (unsigned short*)w_split, nullptr);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }
 
-extern "C" int hgt_typed_linear_bf16x3(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
-                                       int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias,
-                                       int64_t b_group_stride, float* out0, float* out1, float* out2, int32_t block_cols,
-                                       int32_t out_by_position, int32_t prologue, void* stream_) {
+extern "C" int hgt_split_weights_f16(const float* W, int64_t w_group_stride, int32_t n_groups, int32_t k, int32_t n_out, void* w_split,
+                                     void* stream) {
+    if (!W || !w_split || n_groups <= 0 || k <= 0 || n_out <= 0) return HGT_ERR_INVALID_ARG;
+    int n_pass, n_kstep;
+    split_dims(k, n_out, &n_pass, &n_kstep);
+    const int64_t total = (int64_t)n_groups * n_pass * n_kstep * W_PLANE_ELEMS;
+    float* tail = reinterpret_cast<float*>((unsigned short*)w_split + total * 2);
+    k_group_scale<<<(unsigned)n_groups, 1024, 0, (hipStream_t)stream>>>(W, w_group_stride, (int64_t)n_out * k, tail, n_groups);
+    k_split_weights<true><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, w_group_stride, n_groups, k, n_out, n_pass,
+                                                                                           n_kstep, (unsigned short*)w_split, tail + n_groups);
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}
+
+template <bool F16>
+static int typed_linear_split_impl(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
+                                   int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias,
+                                   int64_t b_group_stride, float* out0, float* out1, float* out2, int32_t block_cols,
+                                   int32_t out_by_position, int32_t prologue, void* stream_) {
     if (!x || !rows || !group_off || !w_split || !out0 || n_groups <= 0 || n_rows < 0 || k <= 0 || n_out <= 0 || block_cols <= 0)
         return HGT_ERR_INVALID_ARG;
     const int n_blocks_out = (n_out + block_cols - 1) / block_cols;
@@ -836,11 +936,11 @@ extern "C" int hgt_typed_linear_bf16x3(const float* x, int64_t ldx, const int32_
     if (k <= KP) {   // persistent producer/consumer kernel, one workgroup per CU
         const unsigned grid = (unsigned)std::min<int64_t>(row_tiles * pass_split, pc_grid());
         if (prologue == 0)
-            k_typed_linear_pc<0, false><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
+            k_typed_linear_pc<0, false, F16><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
                                                                          (const unsigned short*)w_split, bias, b_group_stride, out0, out1,
                                                                          out2, block_cols, out_by_position, vec_ok, noupd, pass_split);
         else
-            k_typed_linear_pc<1, false><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
+            k_typed_linear_pc<1, false, F16><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
                                                                          (const unsigned short*)w_split, bias, b_group_stride, out0, out1,
                                                                          out2, block_cols, out_by_position, vec_ok, noupd, pass_split);
         HGT_CHECK_LAUNCH();
@@ -848,22 +948,39 @@ extern "C" int hgt_typed_linear_bf16x3(const float* x, int64_t ldx, const int32_
     }
     const unsigned grid_s = (unsigned)(row_tiles * pass_split);
     if (prologue == 0)
-        k_typed_linear_split<0, false><<<grid_s, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out, (const unsigned short*)w_split,
+        k_typed_linear_split<0, false, F16><<<grid_s, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out, (const unsigned short*)w_split,
                                                                    bias, b_group_stride, out0, out1, out2, block_cols, out_by_position, vec_ok,
                                                                    noupd, pass_split);
     else
-        k_typed_linear_split<1, false><<<grid_s, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out, (const unsigned short*)w_split,
+        k_typed_linear_split<1, false, F16><<<grid_s, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out, (const unsigned short*)w_split,
                                                                    bias, b_group_stride, out0, out1, out2, block_cols, out_by_position, vec_ok,
                                                                    noupd, pass_split);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }
 
+extern "C" int hgt_typed_linear_bf16x3(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
+                                       int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias,
+                                       int64_t b_group_stride, float* out0, float* out1, float* out2, int32_t block_cols,
+                                       int32_t out_by_position, int32_t prologue, void* stream) {
+    return typed_linear_split_impl<false>(x, ldx, rows, group_off, n_groups, n_rows, k, n_out, w_split, bias, b_group_stride, out0, out1, out2,
+                                          block_cols, out_by_position, prologue, stream);
+}
+
+extern "C" int hgt_typed_linear_f16x3(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
+                                      int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias,
+                                      int64_t b_group_stride, float* out0, float* out1, float* out2, int32_t block_cols,
+                                      int32_t out_by_position, int32_t prologue, void* stream) {
+    return typed_linear_split_impl<true>(x, ldx, rows, group_off, n_groups, n_rows, k, n_out, w_split, bias, b_group_stride, out0, out1, out2,
+                                         block_cols, out_by_position, prologue, stream);
+}
+
 // a_linear + gated skip + LayerNorm in one kernel (n_out <= 256, n_out % 4 == 0): see store_pass_update.
-extern "C" int hgt_linear_update_bf16x3(const float* agg, int64_t ld_agg, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
-                                        int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias,
-                                        int64_t b_group_stride, const float* x_skip, int64_t ld_skip, const float* skip,
-                                        const float* ln_w, const float* ln_b, int32_t use_norm, float* out, void* stream_) {
+template <bool F16>
+static int linear_update_split_impl(const float* agg, int64_t ld_agg, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
+                                    int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias,
+                                    int64_t b_group_stride, const float* x_skip, int64_t ld_skip, const float* skip,
+                                    const float* ln_w, const float* ln_b, int32_t use_norm, float* out, void* stream_) {
     if (!agg || !rows || !group_off || !w_split || !x_skip || !skip || !out || n_groups <= 0 || n_rows < 0 || k <= 0 || n_out <= 0)
         return HGT_ERR_INVALID_ARG;
     if (use_norm && (!ln_w || !ln_b)) return HGT_ERR_INVALID_ARG;
@@ -876,15 +993,31 @@ extern "C" int hgt_linear_update_bf16x3(const float* agg, int64_t ld_agg, const 
     UpdateArgs u = {x_skip, ld_skip, skip, ln_w, ln_b, use_norm};
     if (k <= KP) {
         const unsigned grid = (unsigned)std::min<int64_t>(row_tiles, pc_grid());
-        k_typed_linear_pc<0, true><<<grid, PC_THREADS, 0, stream>>>(agg, ld_agg, rows, group_off, n_groups, k, n_out,
+        k_typed_linear_pc<0, true, F16><<<grid, PC_THREADS, 0, stream>>>(agg, ld_agg, rows, group_off, n_groups, k, n_out,
                                                                     (const unsigned short*)w_split, bias, b_group_stride, out, nullptr,
                                                                     nullptr, n_out, 0, vec_ok, u, 1);
         HGT_CHECK_LAUNCH();
         return HGT_OK;
     }
-    k_typed_linear_split<0, true><<<(unsigned)row_tiles, 512, 0, stream>>>(agg, ld_agg, rows, group_off, n_groups, k, n_out,
+    k_typed_linear_split<0, true, F16><<<(unsigned)row_tiles, 512, 0, stream>>>(agg, ld_agg, rows, group_off, n_groups, k, n_out,
                                                                            (const unsigned short*)w_split, bias, b_group_stride, out,
                                                                            nullptr, nullptr, n_out, 0, vec_ok, u, 1);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
+}
+
+extern "C" int hgt_linear_update_bf16x3(const float* agg, int64_t ld_agg, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
+                                        int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias,
+                                        int64_t b_group_stride, const float* x_skip, int64_t ld_skip, const float* skip,
+                                        const float* ln_w, const float* ln_b, int32_t use_norm, float* out, void* stream) {
+    return linear_update_split_impl<false>(agg, ld_agg, rows, group_off, n_groups, n_rows, k, n_out, w_split, bias, b_group_stride, x_skip,
+                                           ld_skip, skip, ln_w, ln_b, use_norm, out, stream);
+}
+
+extern "C" int hgt_linear_update_f16x3(const float* agg, int64_t ld_agg, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
+                                       int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias,
+                                       int64_t b_group_stride, const float* x_skip, int64_t ld_skip, const float* skip,
+                                       const float* ln_w, const float* ln_b, int32_t use_norm, float* out, void* stream) {
+    return linear_update_split_impl<true>(agg, ld_agg, rows, group_off, n_groups, n_rows, k, n_out, w_split, bias, b_group_stride, x_skip,
+                                          ld_skip, skip, ln_w, ln_b, use_norm, out, stream);
 }

@@ -45,6 +45,69 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid) {
     split2(v.z, v.w, hi.y, mid.y);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// fp16 hi / lo split (precision "f16x3", round 3).  The same three products per MFMA step -- lo*hi + hi*lo + hi*hi -- but with
+// 11 + 11 mantissa bits per operand instead of 8 + 8: relative error of a product ~2^-22 instead of ~2^-17 (measured end to end:
+// 2e-7 against 1.4e-5 on the sampled-batch layer, tools/lab/precision_study.py), at the same MFMA count, LDS and register
+// footprint.  fp16 has 5 exponent bits, so every operand ROW is scaled by a power of two (exact) that puts its largest magnitude
+// into [2^14, 2^15): no overflow, and the lo term of every element that matters stays a normal number (gfx950's f16 MFMA honours
+// subnormal inputs -- tools/lab/probe_f16.hip -- so smaller elements degrade gracefully to an absolute error of 2^-25 of the row
+// maximum).  The inverse scales are applied to the fp32 accumulators in the epilogues.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef _Float16 hgt_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hgt_f16x8 __attribute__((ext_vector_type(8)));
+
+// bits of max |x| over a row -> (scale, inverse scale), both exact powers of two: scale * max in [2^14, 2^15)
+__device__ __forceinline__ void f16_row_scale(unsigned max_abs_bits, float& scale, float& inv) {
+    unsigned e = max_abs_bits >> 23;                     // biased exponent of the row maximum (sign bit is 0)
+    e = e < 20u ? 20u : (e > 240u ? 240u : e);           // all-zero / denormal rows and infinities: clamped, results stay finite / propagate
+    scale = __builtin_bit_cast(float, (268u - e) << 23); // 2^(14 - (e - 127))
+    inv = __builtin_bit_cast(float, (e - 14u) << 23);    // 2^((e - 127) - 14)
+}
+
+// fp32 pair (already scaled) -> packed fp16 hi / lo terms: v_cvt_pk_f16_f32 (round to nearest even), 5 instructions per pair
+__device__ __forceinline__ void split2_f16(float a, float b, unsigned& hi, unsigned& lo) {
+    const hgt_f32x2 v = {a, b};
+    const hgt_f16x2 h = __builtin_convertvector(v, hgt_f16x2);
+    const hgt_f32x2 r = v - __builtin_convertvector(h, hgt_f32x2);
+    const hgt_f16x2 l = __builtin_convertvector(r, hgt_f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+// format-generic forms: F16 = false: bf16 hi / mid (scale ignored, pass 1.0f); F16 = true: fp16 hi / lo of v * scale
+template <bool F16>
+__device__ __forceinline__ void split4_t(const float4 v, float scale, uint2& hi, uint2& lo) {
+    if constexpr (F16) {
+        split2_f16(v.x * scale, v.y * scale, hi.x, lo.x);
+        split2_f16(v.z * scale, v.w * scale, hi.y, lo.y);
+    } else {
+        split4(v, hi, lo);
+    }
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32_t(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hgt_f16x8, a), __builtin_bit_cast(hgt_f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// max over the 64 lanes of a wavefront of a NON-NEGATIVE float's bits (compare as unsigned), wave-uniform result:
+// four DPP steps inside the rows of 16 lanes, then the four row results through SGPRs
+__device__ __forceinline__ unsigned wave_max_bits(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ unsigned abs_bits4(const float4 v) {
+    return __builtin_bit_cast(unsigned, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));

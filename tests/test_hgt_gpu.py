@@ -715,7 +715,7 @@ def test_malformed_input_raises_like_the_reference():
 
 
 # ------------------------------------------------------------------ kernels in isolation
-@pytest.mark.parametrize("precision,tol", [(0, 2e-5), (1, 1e-4)])
+@pytest.mark.parametrize("precision,tol", [(0, 2e-5), (1, 1e-4), (2, 4e-6)])      # 2 = fp16 hi / lo split: ~2^-22 per product
 @pytest.mark.parametrize("k,n_out,prologue", [(256, 768, 0), (64, 192, 0), (400, 400, 1), (129, 96, 0), (512, 1536, 1), (256, 256, 0)])
 def test_typed_linear_against_torch_fp32(k, n_out, prologue, precision, tol):
     lib = _lib.load()
@@ -745,9 +745,11 @@ def test_typed_linear_against_torch_fp32(k, n_out, prologue, precision, tol):
         nb = C.c_uint64()
         assert lib.hgt_split_weights_bytes(T, k, n_out, C.byref(nb)) == 0
         ws = torch.empty(nb.value, dtype=torch.uint8, device=DEV)
-        assert lib.hgt_split_weights(Wd.data_ptr(), n_out * k, T, k, n_out, ws.data_ptr(), st) == 0
-        rc = lib.hgt_typed_linear_bf16x3(xd.data_ptr(), k, rd.data_ptr(), od.data_ptr(), T, N, k, n_out, ws.data_ptr(),
-                                         bd.data_ptr(), n_out, optr[0], optr[1], optr[2], bc, 0, prologue, st)
+        split, linear = ((lib.hgt_split_weights, lib.hgt_typed_linear_bf16x3) if precision == 1 else
+                         (lib.hgt_split_weights_f16, lib.hgt_typed_linear_f16x3))
+        assert split(Wd.data_ptr(), n_out * k, T, k, n_out, ws.data_ptr(), st) == 0
+        rc = linear(xd.data_ptr(), k, rd.data_ptr(), od.data_ptr(), T, N, k, n_out, ws.data_ptr(),
+                    bd.data_ptr(), n_out, optr[0], optr[1], optr[2], bc, 0, prologue, st)
         if n_out % 4 != 0:
             assert rc == -2        # documented: odd widths are not supported by the 16-byte-store epilogue
             return
@@ -757,6 +759,46 @@ def test_typed_linear_against_torch_fp32(k, n_out, prologue, precision, tol):
     err = (out.double() - ref).abs().max().item()
     print("typed_linear k=%d n=%d precision=%d err %.2e" % (k, n_out, precision, err))
     assert err < tol
+
+
+def test_f16_split_linear_scales_every_row_and_weight_group():
+    """The fp16 hi / lo split has 5 exponent bits: rows of x between 1e-6 and 1e+8 in magnitude (and an all-zero row, and a row
+    whose elements span twelve decades), weight groups between 1e-4 and 1e+3 -- every output row must be as accurate RELATIVE TO
+    ITS OWN magnitude as a well-scaled one (power-of-two row / group scales, exact), nothing may overflow to inf."""
+    lib = _lib.load()
+    T, N, k, n_out = 3, 3000, 256, 768
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, k, generator=g) * torch.pow(10.0, torch.rand(N, 1, generator=g) * 14 - 6)
+    x[7] = 0.0
+    x[11] = torch.randn(k, generator=g) * torch.pow(10.0, torch.rand(k, generator=g) * 12 - 6)
+    W = torch.randn(T, n_out, k, generator=g) / k ** 0.5 * torch.tensor([1e-4, 1.0, 1e3]).view(T, 1, 1)
+    b = torch.zeros(T, n_out)
+    nt = torch.randint(0, T, (N,), generator=g)
+    rows = torch.argsort(nt, stable=True).int()
+    off = torch.searchsorted(nt.sort().values, torch.arange(T + 1)).int()
+    ref = torch.empty(N, n_out, dtype=torch.float64)
+    mag = torch.empty(N, dtype=torch.float64)
+    for t in range(T):
+        m = nt == t
+        ref[m] = x[m].double() @ W[t].double().T
+        mag[m] = x[m].double().abs().amax(dim=1) * W[t].double().abs().amax() * k ** 0.5     # scale of a row's sums
+    xd, Wd, bd, rd, od = _to_dev(x, W, b, rows, off)
+    out = torch.full((N, n_out), float("nan"), device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = C.c_uint64()
+    assert lib.hgt_split_weights_bytes(T, k, n_out, C.byref(nb)) == 0
+    ws = torch.empty(nb.value, dtype=torch.uint8, device=DEV)
+    assert lib.hgt_split_weights_f16(Wd.data_ptr(), n_out * k, T, k, n_out, ws.data_ptr(), st) == 0
+    assert lib.hgt_typed_linear_f16x3(xd.data_ptr(), k, rd.data_ptr(), od.data_ptr(), T, N, k, n_out, ws.data_ptr(), bd.data_ptr(), n_out,
+                                      out.data_ptr(), 0, 0, n_out, 0, 0, st) == 0
+    torch.cuda.synchronize()
+    o = out.cpu().double()
+    assert torch.isfinite(o).all()
+    assert o[7].abs().max().item() == 0.0
+    rel = ((o - ref).abs().amax(dim=1) / mag.clamp_min(1e-300))
+    rel[7] = 0.0
+    print("f16 split, rows over 14 decades: worst error relative to the row's own scale %.2e" % rel.max().item())
+    assert rel.max().item() < 2e-6
 
 
 def test_gather_rows_bit_exact():
