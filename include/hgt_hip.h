@@ -245,6 +245,17 @@ int hgt_edge_aggregate_slice(const void* plan, int64_t n_nodes, int64_t n_edges,
  * linears).  NULL: exact fp32 mat-vecs on the vector ALU (the round-1 kernel; also taken for a head wider than 256 columns). */
 int hgt_relation_frag_bytes(int32_t n_relations, int32_t n_heads, int32_t dk_pad, uint64_t* out_host);
 int hgt_relation_frag_pack(const float* msg_p, int32_t n_relations, int32_t n_heads, int32_t dk_pad, void* msg_frag, void* stream);
+/* fp16 hi / lo variant (ABI 5, precision "f16x3"; see hgt_split_weights_f16): the fragments hold M * s with ONE power-of-two s for
+ * all relations (everything summed into one accumulator must share it; 1/s sits behind the fragments, hgt_relation_frag_bytes
+ * counts it), the rows  sum att_e v_e  of a target are scaled by one power of two per target, chosen when its first row is
+ * formed (2^7 of headroom, moved with an exact rescale of the accumulator column if a later relation needs more), and both
+ * inverses join the softmax normalisation.  Relative error of a transform ~2^-22.  hgt_edge_aggregate_f16x3 takes the f16 image
+ * (required); slices, hgt_edge_spmm and the hub path (exact fp32) are unchanged. */
+int hgt_relation_frag_pack_f16(const float* msg_p, int32_t n_relations, int32_t n_heads, int32_t dk_pad, void* msg_frag, void* stream);
+int hgt_edge_aggregate_f16x3(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                             int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
+                             const float* msg_p, const void* msg_frag, float* agg, int64_t n_q_rows, int32_t apply_gelu,
+                             void* hub_ws, void* stream);
 /* hub_ws: scratch of hgt_hub_workspace_bytes() bytes for targets with more than 1024 in-edges ("hubs"): their edge
  * ranges are split over many wavefronts (max / sum-exp / weighted sum accumulated with atomics) instead of being
  * walked by the one wavefront that owns their 16-target sub-tile.  NULL = no hub path (correct, slow on hubs). */
@@ -301,6 +312,13 @@ int hgt_edge_aggregate_update(const void* plan, int64_t n_nodes, int64_t n_edges
                               const int64_t* node_type, const void* w_a_split, const float* b_a, const float* x_skip,
                               int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm,
                               int32_t n_out, float* out, void* stream);
+/* the same with the fp16 hi / lo images: msg_frag = hgt_relation_frag_pack_f16, w_a_split = hgt_split_weights_f16 (both required) */
+int hgt_edge_aggregate_update_f16x3(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                                    int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
+                                    const float* msg_p, const void* msg_frag, float* agg, int64_t n_q_rows, void* hub_ws,
+                                    int32_t* pending, const int64_t* node_type, const void* w_a_split, const float* b_a,
+                                    const float* x_skip, int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b,
+                                    int32_t use_norm, int32_t n_out, float* out, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Backward pass (the reference gets it from autograd: OAG/train_paper_field.py:249,
@@ -365,7 +383,9 @@ typedef struct hgt_conv_args {
     /* problem */
     int64_t n_nodes, n_edges;
     int32_t in_dim, out_dim, n_types, n_relations, n_heads;
-    int32_t use_norm, use_rte, precision, want_att;
+    int32_t use_norm, use_rte, precision, want_att;   /* precision: 0 exact fp32 MFMA chain, 1 split-bf16 x3, 2 fp16 hi/lo x3
+                                                       * (every matrix-core product of the layer; stage 0 only: staged calls
+                                                       * return HGT_ERR_UNSUPPORTED) */
     int64_t n_q_rows;            /* nodes [0, n_q_rows) get Q/aggregate/update; others only K,V (halo) */
     /* inputs */
     const float* x;              /* [n_nodes][in_dim]                          */

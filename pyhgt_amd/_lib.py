@@ -91,12 +91,16 @@ SIGNATURES = {
                                            _i32, _i32, _vp, _i32, _i32, _vp]),
     "hgt_edge_softmax": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "hgt_edge_aggregate": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "hgt_edge_aggregate_f16x3": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "hgt_relation_frag_pack_f16": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "hgt_relation_frag_bytes": (C.c_int, [_i32, _i32, _i32, C.POINTER(_u64)]),
     "hgt_relation_frag_pack": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "hgt_hub_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_u64)]),
     "hgt_att_export": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "hgt_edge_aggregate_update": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
                                             _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "hgt_edge_aggregate_update_f16x3": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
+                                                  _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "hgt_edge_spmm": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "hgt_edge_softmax_bwd": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
     "hgt_edge_gather_sorted": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),

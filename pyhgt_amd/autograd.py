@@ -43,7 +43,7 @@ class _Ops:
         self.T, self.R, self.Hreal = T, R, H
         self.H = lay.heads                                   # kernels run with the layout's head count (extra heads: zero)
         self.dk, self.dkp, self.dp = lay.d_k, lay.dk_pad, lay.d_pad
-        self.split = precision == "bf16x3"
+        self.split = precision in ("bf16x3", "f16x3")      # (the differentiable path evaluates "f16x3" layers with the bf16 split)
         self.N, self.E = plan.N, plan.E
         self.dev = plan.device
 
@@ -425,7 +425,7 @@ class TypedLinearFunction(torch.autograd.Function):
         n_out = w.shape[1]
         y = torch.zeros(n, n_out, dtype=torch.float32, device=x.device)
         wc, bc = w.contiguous(), (b.contiguous() if b is not None else None)
-        if precision == "bf16x3" and n_out % 4 == 0:
+        if precision in ("bf16x3", "f16x3") and n_out % 4 == 0:
             nb = C.c_uint64()
             _chk("hgt_split_weights_bytes", lib.hgt_split_weights_bytes(n_groups, k, n_out, C.byref(nb)))
             tiles = torch.empty(int(nb.value), dtype=torch.uint8, device=x.device)
@@ -452,7 +452,7 @@ class TypedLinearFunction(torch.autograd.Function):
         dev = x.device
         dw = torch.zeros(G, n_out, k, dtype=torch.float32, device=dev)
         db = torch.zeros(G, n_out, dtype=torch.float32, device=dev) if ctx.has_bias else None
-        if ctx.precision == "bf16x3":
+        if ctx.precision in ("bf16x3", "f16x3"):
             _chk("hgt_typed_wgrad_bf16x3", lib.hgt_typed_wgrad_bf16x3(_p(gy), n_out, _p(x), k, rows, off, G, n, n_out, k, _p(dw), n_out * k,
                                                                     _p(db), n_out, _st()))
         else:

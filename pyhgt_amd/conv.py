@@ -340,6 +340,9 @@ class RelTemporalEncoding(nn.Module):
         self.lin = nn.Linear(n_hid, n_hid)
 
 
+PRECISIONS = ("fp32", "bf16x3", "f16x3")
+
+
 class HGTConv(nn.Module):
     """Heterogeneous Graph Transformer layer, forward on MI355X.
 
@@ -347,7 +350,11 @@ class HGTConv(nn.Module):
     options: keep_att (export softmax weights into self.att like conv.py:108; off by default
     because nothing in the reference reads it), precision: "bf16x3" (default) evaluates the typed Linear layers as
     3-term split-bf16 MFMA products with fp32 accumulation (max |out - reference| <= 5e-5 over ~1000 tested
-    configurations, bound 1e-4); "fp32" uses the exact fp32 MFMA chain (<= 2e-6, 1.6x slower at c2).
+    configurations, bound 1e-4); "f16x3" runs the same three products on fp16 hi / lo parts with power-of-two row scales
+    (every matrix-core product of the layer: typed Linears, relation transforms of the aggregation, fused a_linear) -- as
+    close to the fp64 result as the reference's own fp32 arithmetic (<= 1e-6), at the speed of "bf16x3"; "fp32" uses the exact
+    fp32 MFMA chain (<= 2e-6, 1.6x slower at c2).  Training (autograd) and the staged multi-GPU calls evaluate an "f16x3"
+    layer with the "bf16x3" kernels.
     """
 
     def __init__(self, in_dim, out_dim, num_types, num_relations, n_heads, dropout=0.2, use_norm=True, use_RTE=True,
@@ -361,8 +368,8 @@ class HGTConv(nn.Module):
         self.sqrt_dk = math.sqrt(self.d_k)
         self.use_norm, self.use_RTE = use_norm, use_RTE
         self.keep_att = keep_att
-        if precision not in ("fp32", "bf16x3"):
-            raise ValueError("precision must be 'fp32' or 'bf16x3'")
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % (PRECISIONS,))
         self.precision = precision
         self.kernel_flags = 0          # hgt_conv_args.flags (HGT_FLAG_*): explicit kernel selection for A/B runs and tests
         self.att = None
@@ -503,10 +510,10 @@ class HGTConv(nn.Module):
         self._prepared_valid = False      # the device-side weight images (hgt_conv_args.prepared) are stale now
         return packed
 
-    def _prepared_buffer(self, device, n_slices=1):
+    def _prepared_buffer(self, device, n_slices=1, prec=None):
         """Per-layer device buffer for the weight-only preprocessing hgt_conv_forward keeps across calls (packed relation
         matrices, split-bf16 weight tiles, temporal tables): valid until a parameter, the precision or the device changes."""
-        key = (str(device), self.precision, n_slices)
+        key = (str(device), prec or self.precision, n_slices)
         if getattr(self, "_prepared", None) is None or self._prepared_tag != key:
             n = C.c_uint64()
             _lib.check(_lib.load().hgt_conv_prepared_bytes(self.in_dim, self.out_dim, self.num_types, self.num_relations * n_slices,
@@ -555,8 +562,10 @@ class HGTConv(nn.Module):
         n_slices = 1 if slices is None else int(slices[1])
         if n_slices < 1 or (stage == 4 and not (0 <= int(slices[0]) < n_slices)):
             raise ValueError("slices must be (index, count) with 0 <= index < count")
-        if n_slices > 1 and (stage == 0 or stage == 3 or self.precision != "bf16x3" or self._UPDATE_MODE != 0):
-            raise ValueError("sliced edge phases run as stages 1 / 2 / 4 of an HGTConv with precision 'bf16x3'")
+        # staged (multi-GPU) calls of an "f16x3" layer run the "bf16x3" kernels (include/hgt_hip.h: precision 2 is whole-layer only)
+        prec = "bf16x3" if (self.precision == "f16x3" and stage != 0) else self.precision
+        if n_slices > 1 and (stage == 0 or stage == 3 or prec != "bf16x3" or self._UPDATE_MODE != 0):
+            raise ValueError("sliced edge phases run as stages 1 / 2 / 4 of an HGTConv with a split precision")
         R_plan = self.num_relations * n_slices
         if plan.N != N or plan.T != self.num_types or plan.R != R_plan:
             raise ValueError("plan was built for a different graph / schema")
@@ -598,7 +607,7 @@ class HGTConv(nn.Module):
         a.n_nodes, a.n_edges = N, E
         a.in_dim, a.out_dim, a.n_types, a.n_relations, a.n_heads = (self.in_dim, self.out_dim, self.num_types, R_plan, self.n_heads)
         a.use_norm, a.use_rte = int(self.use_norm), int(self.use_RTE)
-        a.precision = {"fp32": 0, "bf16x3": 1}[self.precision]
+        a.precision = {"fp32": 0, "bf16x3": 1, "f16x3": 2}[prec]
         a.want_att = int(self.keep_att)
         a.n_q_rows = NQ
         a.x, a.node_type, a.plan = _ptr(x), _ptr(ntype), plan.ptr
@@ -622,7 +631,7 @@ class HGTConv(nn.Module):
             a.slice_index, a.slice_count = int(slices[0]), n_slices
         a.plan_no_hubs = int(plan.no_hubs) | (2 if plan.no_unknown_rows else 0)
         a.flags = int(self.kernel_flags)
-        prep = self._prepared_buffer(x.device, n_slices)          # after _pack_parameters: a re-pack has invalidated it
+        prep = self._prepared_buffer(x.device, n_slices, prec)          # after _pack_parameters: a re-pack has invalidated it
         a.prepared, a.prepared_bytes, a.prepared_valid = _ptr(prep), prep.numel(), int(self._prepared_valid)
         if stage == 2:
             rows, off = proj

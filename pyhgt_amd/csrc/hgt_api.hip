@@ -157,6 +157,11 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     if (a->want_att && E > 0 && !a->att_out) return HGT_ERR_INVALID_ARG;
     const bool dense = (a->update_mode == 1);
     if (a->update_mode != 0 && a->update_mode != 1) return HGT_ERR_INVALID_ARG;
+    if (a->precision < 0 || a->precision > 2) return HGT_ERR_INVALID_ARG;
+    // precision 2 (fp16 hi/lo split, include/hgt_hip.h): whole-layer calls only -- the staged multi-GPU calls share one prepared
+    // image between a sliced edge phase (whose state does not carry the fp16 row scales) and the rest, and stay on precision 1
+    const bool f16 = (a->precision == 2);
+    if (f16 && a->stage != 0) return HGT_ERR_UNSUPPORTED;
     if (dense && (!a->mid_w || !a->mid_b || !a->out_w || !a->out_b || !a->out_ln_w || !a->out_ln_b)) return HGT_ERR_INVALID_ARG;
     hgt_layout lay;
     int rc = hgt_layout_for(dout, Hreal, &lay);
@@ -193,7 +198,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     // relation transforms of the aggregation: matrix cores (split-bf16 x3) with the split precision, exact fp32 mat-vecs otherwise
     uint64_t frag_bytes = 0;
     hgt_relation_frag_bytes(R, H, lay.dk_pad, &frag_bytes);
-    const bool mfma_agg = (a->precision == 1) && frag_bytes > 0 && !(a->flags & HGT_FLAG_VALU_AGGREGATE);
+    const bool mfma_agg = (a->precision >= 1) && frag_bytes > 0 && !(a->flags & HGT_FLAG_VALU_AGGREGATE);
     if (!mfma_agg) msg_f = nullptr;
 
     auto mark = [&](int i) {
@@ -223,13 +228,15 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
         rc = hgt_relation_pack(a->relation_att, a->relation_msg, a->relation_pri, R, Hreal, H, lay.d_k, lay.dk_pad, att_t, msg_p, stream);
         if (rc != HGT_OK) return rc;
         if (mfma_agg) {
-            rc = hgt_relation_frag_pack(msg_p, R, H, lay.dk_pad, msg_f, stream);
+            rc = f16 ? hgt_relation_frag_pack_f16(msg_p, R, H, lay.dk_pad, msg_f, stream)
+                     : hgt_relation_frag_pack(msg_p, R, H, lay.dk_pad, msg_f, stream);
             if (rc != HGT_OK) return rc;
         }
     }
 
     // typed linear dispatch: exact fp32 MFMA, or split-bf16 x3 with weights split+tiled into the workspace
-    const bool split = (a->precision == 1);
+    const bool split = (a->precision >= 1);
+    auto split_weights = f16 ? hgt_split_weights_f16 : hgt_split_weights;
     auto linear = [&](const float* xin, int64_t ldx, const int32_t* rws, const int32_t* goff, int ng, int64_t nrows, int kk, int nout,
                       const float* Wp, int64_t wgs, const float* bp, int64_t bgs, float* o0, float* o1, float* o2, int bcols,
                       int by_pos, void* wsplit, int prologue = 0, bool tiles_ready = false) -> int {
@@ -238,10 +245,12 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
         if (((nout | bcols) & 3) != 0)   // the split kernel stores 16 B per lane: odd widths take the exact fp32 kernel
             return hgt_typed_linear(xin, ldx, rws, goff, ng, nrows, kk, nout, Wp, wgs, bp, bgs, o0, o1, o2, bcols, by_pos, prologue, 0, stream);
         if (!tiles_ready) {
-            int r2 = hgt_split_weights(Wp, wgs, ng, kk, nout, wsplit, stream);
+            int r2 = split_weights(Wp, wgs, ng, kk, nout, wsplit, stream);
             if (r2 != HGT_OK) return r2;
         }
-        return hgt_typed_linear_bf16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos, prologue, stream);
+        return f16 ? hgt_typed_linear_f16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos, prologue, stream)
+                   : hgt_typed_linear_bf16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos, prologue,
+                                             stream);
     };
     void* ws_qkv_scratch = wb + w.off_ws_qkv;                       // K|V-only tiles of the halo branch
     void* ws_qkv = pb ? (void*)(pb + pl.off_ws_qkv) : ws_qkv_scratch; // tiles of the full [Q|K|V] weight
@@ -271,7 +280,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
                     K, V, nullptr, dp, 0, ws_qkv_scratch);
         if (rc != HGT_OK) return rc;
         if (pb && fresh && split) {   // keep the prepared buffer complete: a later call may be a whole-graph or staged one
-            rc = hgt_split_weights(a->w_qkv, wstride, T, din, 3 * dp, ws_qkv, stream);
+            rc = split_weights(a->w_qkv, wstride, T, din, 3 * dp, ws_qkv, stream);
             if (rc != HGT_OK) return rc;
         }
     }
@@ -313,13 +322,14 @@ edge_phase:
     // (graphs below 64k targets take the unfused kernels: hgt_edge_aggregate then runs 4 targets per wavefront, which
     //  matters more in the latency regime than the saved agg round trip)
     const bool fuse_all = split && !dense && dp <= 256 && dout <= dp && (dout & 3) == 0 && (din & 3) == 0 && NQ >= 65536 &&
-                          !(a->flags & HGT_FLAG_NO_FUSED_UPDATE) && !sliced;
+                          !(a->flags & HGT_FLAG_NO_FUSED_UPDATE) && !sliced &&
+                          !(f16 && !mfma_agg);   // the vector-ALU kernel's fused epilogue only reads the bf16 image of W_a
     if (fuse_all) {
         if (fresh || !pb) {
-            rc = hgt_split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
+            rc = split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
             if (rc != HGT_OK) return rc;
         }
-        rc = hgt_edge_aggregate_update(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ,
+        rc = (f16 ? hgt_edge_aggregate_update_f16x3 : hgt_edge_aggregate_update)(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ,
                                        hub_ws, (int32_t*)(wb + w.off_pending), a->node_type,
                                        ws_upd, a->b_a, a->x, din, a->skip, a->ln_w, a->ln_b, a->use_norm, dout, a->out, stream);
         if (rc == HGT_OK) {
@@ -342,8 +352,8 @@ edge_phase:
                                       (float*)(wb + w.off_state), sl_lo > 0, sl_more, stream);
         if (rc != HGT_OK || sl_more) return rc;      // state + un-normalised rows stay in the workspace for the next slice
     } else {
-        rc = hgt_edge_aggregate(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ, dense ? 0 : 1,
-                                hub_ws, stream);
+        rc = (f16 && msg_f ? hgt_edge_aggregate_f16x3 : hgt_edge_aggregate)(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f,
+                                                                            agg, NQ, dense ? 0 : 1, hub_ws, stream);
     }
     if (rc != HGT_OK) return rc;
     if (a->want_att && E > 0) {   // self.att (conv.py:108): normalise the logits in place and un-sort them
@@ -379,10 +389,10 @@ edge_phase:
         rc = hgt_node_update_ex(trans, a->out, dout, a->node_type, nullptr, a->out_ln_w, a->out_ln_b, 1, 1, NQ, dout, T, a->out, stream);
     } else if (fuse_update) {
         if (fresh || !pb) {
-            rc = hgt_split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
+            rc = split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
             if (rc != HGT_OK) return rc;
         }
-        rc = hgt_linear_update_bf16x3(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, ws_upd, a->b_a, dout, a->x, din, a->skip, a->ln_w,
+        rc = (f16 ? hgt_linear_update_f16x3 : hgt_linear_update_bf16x3)(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, ws_upd, a->b_a, dout, a->x, din, a->skip, a->ln_w,
                                       a->ln_b, a->use_norm, a->out, stream);
         if (rc != HGT_OK) return rc;
         mark(5);

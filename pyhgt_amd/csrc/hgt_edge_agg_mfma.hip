@@ -57,7 +57,12 @@ struct MG {   // geometry of one wavefront's slice: DP columns = 64 lanes x VEC 
 // fragments [R][head group][col tile c][k-step s][plane][lane 64][8] bf16 of blockdiag_h(M[r,h]) restricted to the k window
 // of the column tile:  frag[..][l][e] = split( Mfull[kbase(c) + 32 s + (l>>4)*8 + e][16 c + (l&15)] )
 // = the FIRST operand of v_mfma_f32_16x16x32_bf16 (row = output column l&15, k = (l>>4)*8 + e).
-__global__ void k_msg_frag_pack(const float* __restrict__ msgP, int R, int HT, int DKP, int DP, unsigned short* __restrict__ out) {
+// F16: fp16 hi / lo fragments of M * scale, ONE power-of-two scale for all relations and heads (k_msg_scale: it has to be the same
+// for everything that is summed into one accumulator; its inverse sits behind the fragments and is applied when the rows are
+// normalised)
+template <bool F16>
+__global__ void k_msg_frag_pack(const float* __restrict__ msgP, int R, int HT, int DKP, int DP, unsigned short* __restrict__ out,
+                                const float* __restrict__ gscale) {
     const int KW = DKP > 32 ? DKP : 32, NKS = KW / 32, NCT = DP / 16, NY = HT * DKP / DP;
     const int64_t total = (int64_t)R * NY * NCT * NKS * 512;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,11 +79,50 @@ __global__ void k_msg_frag_pack(const float* __restrict__ msgP, int R, int HT, i
     const int hk = kf / DKP, hn = nf / DKP;
     float v = 0.0f;
     if (hk == hn) v = msgP[(((int64_t)rel * HT + hn) * DKP + kf % DKP) * DKP + nf % DKP];
-    const unsigned short hi = bf16_rne(v);
-    const unsigned short mid = bf16_rne(v - bf16_to_f32(hi));
+    unsigned short hi, mid;
+    split1_t<F16>(v, F16 ? gscale[1] : 1.0f, hi, mid);
     const int64_t tile = ((((int64_t)rel * NY + hg) * NCT + c) * NKS + s) * 2;
     out[(tile + 0) * 512 + l * 8 + e] = hi;
     out[(tile + 1) * 512 + l * 8 + e] = mid;
+}
+
+// max |M| over all relations -> tail = {inverse scale, scale} (one workgroup)
+__global__ __launch_bounds__(1024) void k_msg_scale(const float* __restrict__ msgP, int64_t n, float* __restrict__ tail) {
+    __shared__ unsigned s_m[16];
+    unsigned m = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) m = max(m, __builtin_bit_cast(unsigned, fabsf(msgP[i])));
+    m = wave_max_bits(m);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = max(m, s_m[w]);
+        f16_row_scale(m, tail[1], tail[0]);
+    }
+}
+
+// fp16 split of the U rows (F16): every TARGET of a sub-tile has one power-of-two scale sigma_t for all its relations (its rows
+// of all relations are summed into one accumulator column), kept in LDS (s_sig, 0 = not set yet).  It is chosen when the
+// target's first row is parked -- row maximum -> [2^8, 2^9): 2^7 of headroom for the rows of its other relations -- and moved
+// (with a rescale of the target's accumulator column, exactly like a move of the softmax reference) in the rare case that a
+// later row would leave the fp16 range.  1 / sigma_t joins the softmax normalisation at the end.
+template <int VEC>
+__device__ __forceinline__ float f16_target_scale(const float (&U)[VEC], float* s_sig, int dl, float& rescale) {
+    float m = fabsf(U[0]);
+#pragma unroll
+    for (int i = 1; i < VEC; ++i) m = fmaxf(m, fabsf(U[i]));
+    unsigned e = wave_max_bits(__builtin_bit_cast(unsigned, m)) >> 23;       // biased exponent of the row maximum, wave-uniform
+    const unsigned sb = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, s_sig[dl]));
+    const unsigned se = sb >> 23;                                              // biased exponent of sigma_t (0 = unset)
+    rescale = 1.0f;
+    if (e < 40u) return se != 0u ? __builtin_bit_cast(float, sb) : 1.0f;       // an all-zero (or vanishing) row decides nothing
+    e = e > 220u ? 220u : e;
+    // scaled row maximum = 2^((e - 127) + (se - 127)) .. must stay below 2^15
+    if (se != 0u && e + se < 254u + 15u) return __builtin_bit_cast(float, sb);
+    const unsigned ne = 127u + 8u + 127u - e;                                 // sigma = 2^(8 - (e - 127))
+    const float sig = __builtin_bit_cast(float, ne << 23);
+    if (se != 0u) rescale = __builtin_bit_cast(float, (127u + ne - se) << 23);   // sigma_new / sigma_old (< 1)
+    if ((threadIdx.x & 63) == 0) s_sig[dl] = sig;
+    return sig;
 }
 
 template <int VEC>
@@ -87,15 +131,17 @@ constexpr int agg_unroll(bool rte) { return rte ? 4 : 8; }
 // One wavefront: targets [row0, row0 + SUBR) of the destination tile, all relations.  On return acc[c] holds, for target
 // (lane & 15) and columns 16 c + 4 (lane >> 4) .. + 3, the UN-normalised aggregate sum_e exp(s_e - m) v'_e; s_l (LDS) holds
 // the matching exp-sums per (target, head).
-template <int VEC, int LPH, bool RTE, bool HUBS>
+template <int VEC, int LPH, bool RTE, bool HUBS, bool F16>
 __device__ __forceinline__ void agg_mfma_subtile(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
     const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, int R, int rel_lo, int rel_hi, int HT, unsigned hub_mask,
-    int SUBR, int64_t row0, unsigned char* utile, float* s_m, float* s_l, float* s_sc, int raw, f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
+    int SUBR, int64_t row0, unsigned char* utile, float* s_m, float* s_l, float* s_sc, float* s_sig, int raw,
+    f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
     using G = MG<VEC, LPH>;
     constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS;
     constexpr int UN = agg_unroll<VEC>(RTE);
+    if constexpr (F16) { if ((threadIdx.x & 63) < 16) s_sig[threadIdx.x & 63] = 0.0f; }
     const int hg = blockIdx.y;              // head group (head-group split: the wave covers DP of the HT * DKP columns)
     const int64_t ld = (int64_t)HT * DKP;
     const int co = hg * DP;
@@ -156,23 +202,30 @@ __device__ __forceinline__ void agg_mfma_subtile(
                     }
                     if (claimed) {
                         unsigned char* w = utile + dl * ROWB + ((((wb >> 4) ^ (dl & (NS - 1)))) << 4) + (wb & 15);
-                        unsigned short hi[VEC], mid[VEC];
+                        float sig = 1.0f;
+                        if constexpr (F16) {
+                            float resc;
+                            sig = f16_target_scale<VEC>(U, s_sig, dl, resc);
+                            if (resc != 1.0f) {
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) {
-                            hi[i] = bf16_rne(U[i]);
-                            mid[i] = bf16_rne(U[i] - bf16_to_f32(hi[i]));
+                                for (int c = 0; c < NCT; ++c) acc[c] *= (fi == dl) ? resc : 1.0f;
+                            }
                         }
                         if constexpr (VEC == 1) {
-                            *reinterpret_cast<unsigned short*>(w) = hi[0];
-                            *reinterpret_cast<unsigned short*>(w + G::PLANE) = mid[0];
+                            unsigned short hi, mid;
+                            split1_t<F16>(U[0], sig, hi, mid);
+                            *reinterpret_cast<unsigned short*>(w) = hi;
+                            *reinterpret_cast<unsigned short*>(w + G::PLANE) = mid;
                         } else if constexpr (VEC == 2) {
-                            *reinterpret_cast<unsigned*>(w) = (unsigned)hi[0] | ((unsigned)hi[1] << 16);
-                            *reinterpret_cast<unsigned*>(w + G::PLANE) = (unsigned)mid[0] | ((unsigned)mid[1] << 16);
+                            unsigned hi, mid;
+                            split2_t<F16>(U[0], U[1], sig, hi, mid);
+                            *reinterpret_cast<unsigned*>(w) = hi;
+                            *reinterpret_cast<unsigned*>(w + G::PLANE) = mid;
                         } else {
-                            *reinterpret_cast<uint2*>(w) =
-                                make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
-                            *reinterpret_cast<uint2*>(w + G::PLANE) =
-                                make_uint2((unsigned)mid[0] | ((unsigned)mid[1] << 16), (unsigned)mid[2] | ((unsigned)mid[3] << 16));
+                            uint2 hi, mid;
+                            split4_t<F16>(make_float4(U[0], U[1], U[2], U[3]), sig, hi, mid);
+                            *reinterpret_cast<uint2*>(w) = hi;
+                            *reinterpret_cast<uint2*>(w + G::PLANE) = mid;
                         }
                         rowmask |= 1u << dl;
                     }
@@ -300,9 +353,9 @@ __device__ __forceinline__ void agg_mfma_subtile(
                 const unsigned short* t = mf + (int64_t)((c * NKS + s) * 2) * 512;
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(t);
                 const bf16x8 am = *reinterpret_cast<const bf16x8*>(t + 512);
-                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, uh, acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, um, acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, uh, acc[c], 0, 0, 0);
+                acc[c] = mfma16_t<F16>(am, uh, acc[c]);
+                acc[c] = mfma16_t<F16>(ah, um, acc[c]);
+                acc[c] = mfma16_t<F16>(ah, uh, acc[c]);
             }
         }
         __builtin_amdgcn_wave_barrier();   // the tile is rewritten by the next relation only after every lane has read it
@@ -322,14 +375,16 @@ __device__ __forceinline__ void agg_mfma_subtile(
 //   * the relation-end work (zero rows, fragment loads, 48 MFMAs) runs BETWEEN batches, with the next batch's rows already
 //     on their way.
 // ---------------------------------------------------------------------------------------------
-template <int VEC, int LPH, bool RTE>
+template <int VEC, int LPH, bool RTE, bool F16>
 __device__ __forceinline__ void agg_mfma_stream(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
     const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, int R, int rel_lo, int rel_hi, int HT, int SUBR,
-    int64_t row0, unsigned char* utile, float* s_m, float* s_l, float* s_sc, int raw, f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
+    int64_t row0, unsigned char* utile, float* s_m, float* s_l, float* s_sc, float* s_sig, int raw,
+    f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
     using G = MG<VEC, LPH>;
     constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS;
+    if constexpr (F16) { if ((threadIdx.x & 63) < 16) s_sig[threadIdx.x & 63] = 0.0f; }
 #ifndef HGT_AGG_UN
 #define HGT_AGG_UN 4
 #endif
@@ -413,18 +468,28 @@ __device__ __forceinline__ void agg_mfma_stream(
             }
             if (seg_claimed) {
                 unsigned char* w = utile + dl * ROWB + ((((wb >> 4) ^ (dl & (NS - 1)))) << 4) + (wb & 15);
+                float sig = 1.0f;
+                if constexpr (F16) {
+                    float resc;
+                    sig = f16_target_scale<VEC>(U, s_sig, dl, resc);
+                    if (resc != 1.0f) {
+#pragma unroll
+                        for (int c = 0; c < NCT; ++c) acc[c] *= (fi == dl) ? resc : 1.0f;
+                    }
+                }
                 if constexpr (VEC == 1) {
-                    const unsigned short hi = bf16_rne(U[0]);
+                    unsigned short hi, mid;
+                    split1_t<F16>(U[0], sig, hi, mid);
                     *reinterpret_cast<unsigned short*>(w) = hi;
-                    *reinterpret_cast<unsigned short*>(w + G::PLANE) = bf16_rne(U[0] - bf16_to_f32(hi));
+                    *reinterpret_cast<unsigned short*>(w + G::PLANE) = mid;
                 } else if constexpr (VEC == 2) {
                     unsigned hi, mid;
-                    split2(U[0], U[1], hi, mid);
+                    split2_t<F16>(U[0], U[1], sig, hi, mid);
                     *reinterpret_cast<unsigned*>(w) = hi;
                     *reinterpret_cast<unsigned*>(w + G::PLANE) = mid;
                 } else {
                     uint2 hi, mid;
-                    split4(make_float4(U[0], U[1], U[2], U[3]), hi, mid);
+                    split4_t<F16>(make_float4(U[0], U[1], U[2], U[3]), sig, hi, mid);
                     *reinterpret_cast<uint2*>(w) = hi;
                     *reinterpret_cast<uint2*>(w + G::PLANE) = mid;
                 }
@@ -477,9 +542,9 @@ __device__ __forceinline__ void agg_mfma_stream(
         const unsigned char* up = utile + rrow + ((slot ^ (fi & (NS - 1))) << 4);                  \
         const bf16x8 uh = *reinterpret_cast<const bf16x8*>(up);                                    \
         const bf16x8 um = *reinterpret_cast<const bf16x8*>(up + G::PLANE);                         \
-        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FM[j], uh, acc[c], 0, 0, 0);              \
-        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FH[j], um, acc[c], 0, 0, 0);              \
-        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FH[j], uh, acc[c], 0, 0, 0);              \
+        acc[c] = mfma16_t<F16>(FM[j], uh, acc[c]);                                                 \
+        acc[c] = mfma16_t<F16>(FH[j], um, acc[c]);                                                 \
+        acc[c] = mfma16_t<F16>(FH[j], uh, acc[c]);                                                 \
     }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -623,14 +688,21 @@ __device__ __forceinline__ void agg_mfma_stream(
 
 // normalise (PyG softmax denominator, conv.py:108) + optional exact-erf gelu (conv.py:119), in the accumulator layout;
 // apply_gelu: 0 = normalise, 1 = normalise + gelu, 2 = raw weighted sum (no softmax: hgt_edge_spmm)
+// s_sig / minv: the fp16 split's operand scales (1 / sigma_t per target, inverse fragment scale); nullptr / 1 for the bf16 split
 template <int VEC, int LPH>
-__device__ __forceinline__ void agg_mfma_finish(const float* s_l, int apply_gelu, f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
+__device__ __forceinline__ void agg_mfma_finish(const float* s_l, int apply_gelu, f32x4 (&acc)[MG<VEC, LPH>::NCT],
+                                                const float* s_sig = nullptr, float minv = 1.0f) {
     using G = MG<VEC, LPH>;
     const int lane = threadIdx.x & 63;
     const int fi = lane & 15, fg = lane >> 4;
+    float unscale = minv;
+    if (s_sig != nullptr) {
+        const float sg = s_sig[fi];
+        unscale = (sg != 0.0f) ? minv / sg : 0.0f;       // (a target without a claimed edge never set its scale: its column is 0)
+    }
 #pragma unroll
     for (int c = 0; c < G::NCT; ++c) {
-        const float inv = (apply_gelu == 2) ? 1.0f : 1.0f / (s_l[fi * 16 + (16 * c + 4 * fg) / G::DKP] + 1e-16f);
+        const float inv = unscale * ((apply_gelu == 2) ? 1.0f : 1.0f / (s_l[fi * 16 + (16 * c + 4 * fg) / G::DKP] + 1e-16f));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float o = acc[c][r] * inv;
@@ -657,7 +729,14 @@ __device__ __forceinline__ void agg_mfma_store(float* __restrict__ agg, int64_t 
 template <int VEC, int LPH>
 constexpr int agg_mfma_lds_bytes() { return 4 * 2 * MG<VEC, LPH>::PLANE; }
 
-template <int VEC, int LPH, bool RTE>
+// inverse fragment scale of the fp16 image: one float behind the fragments (hgt_relation_frag_pack_f16)
+template <int VEC, int LPH>
+__device__ __forceinline__ float msg_frag_inv_scale(const unsigned short* __restrict__ msgF, int R, int HT) {
+    using G = MG<VEC, LPH>;
+    return reinterpret_cast<const float*>(msgF + (int64_t)R * (HT / G::H) * G::NCT * G::NKS * 2 * 512)[0];
+}
+
+template <int VEC, int LPH, bool RTE, bool F16>
 __global__ __launch_bounds__(256, 2) void k_edge_aggregate_mfma(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
@@ -668,8 +747,10 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_mfma(
     __shared__ __attribute__((aligned(16))) unsigned char s_u[4][2 * G::PLANE];
     __shared__ float s_ml[4][2][16 * 16];   // reference / exp-sum per (target, head); H <= 16
     __shared__ float s_scale[4][16];
+    __shared__ float s_sig[F16 ? 4 : 1][16];          // fp16 split: the targets' row scales
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* my_sig = s_sig[F16 ? wib : 0];
     const int64_t row0 = (int64_t)blockIdx.x * (4 * sub) + wib * sub;
     if (row0 >= NQ) return;
     unsigned hub_mask = 0;
@@ -680,14 +761,14 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_mfma(
     }
     f32x4 acc[G::NCT];
     if (hub_mask == 0 && R < 64)
-        agg_mfma_stream<VEC, LPH, RTE>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, sl.lo, sl.hi, HT, sub, row0, s_u[wib],
-                                       s_ml[wib][0], s_ml[wib][1], s_scale[wib], raw, acc);
+        agg_mfma_stream<VEC, LPH, RTE, F16>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, sl.lo, sl.hi, HT, sub, row0, s_u[wib],
+                                            s_ml[wib][0], s_ml[wib][1], s_scale[wib], my_sig, raw, acc);
     else if (hub_mask == 0)
-        agg_mfma_subtile<VEC, LPH, RTE, false>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, sl.lo, sl.hi, HT, 0u, sub, row0,
-                                               s_u[wib], s_ml[wib][0], s_ml[wib][1], s_scale[wib], raw, acc);
+        agg_mfma_subtile<VEC, LPH, RTE, false, F16>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, sl.lo, sl.hi, HT, 0u, sub, row0,
+                                                    s_u[wib], s_ml[wib][0], s_ml[wib][1], s_scale[wib], my_sig, raw, acc);
     else
-        agg_mfma_subtile<VEC, LPH, RTE, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, sl.lo, sl.hi, HT, hub_mask, sub, row0,
-                                              s_u[wib], s_ml[wib][0], s_ml[wib][1], s_scale[wib], raw, acc);
+        agg_mfma_subtile<VEC, LPH, RTE, true, F16>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, sl.lo, sl.hi, HT, hub_mask, sub, row0,
+                                                   s_u[wib], s_ml[wib][0], s_ml[wib][1], s_scale[wib], my_sig, raw, acc);
     if (sl.state) {
         // Source-bucketed multi-GPU edge phase: this launch covered one slice of the relation buckets.  Merge with what the
         // earlier slices left -- (reference m, exp-sum l) per (target, head) in sl.state, un-normalised rows in agg -- the way
@@ -734,30 +815,34 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_mfma(
             acc[c][3] = acc[c][3] * sb + prev.w * sp;
         }
     }
-    if (!sl.more) agg_mfma_finish<VEC, LPH>(s_ml[wib][1], apply_gelu, acc);
+    if (!sl.more) {
+        if constexpr (F16) agg_mfma_finish<VEC, LPH>(s_ml[wib][1], apply_gelu, acc, my_sig, msg_frag_inv_scale<VEC, LPH>(msgF, R, HT));
+        else agg_mfma_finish<VEC, LPH>(s_ml[wib][1], apply_gelu, acc);
+    }
     agg_mfma_store<VEC, LPH>(agg, row0, sub, NQ, ld_out, (int)blockIdx.y * G::DP, hub_mask, acc);
 }
 
 // The sub-tile walk of a workgroup that contains a hub target, kept OUT OF LINE (a real call, rare path): inlined next to the
 // streaming walk + fused epilogue it costs the common path 22 spilled VGPRs (92 B of scratch per thread = 0.8 GB of extra HBM
 // traffic per launch at c2, rocprofv3 WRITE_SIZE).
-template <int VEC, int LPH, bool RTE>
+template <int VEC, int LPH, bool RTE, bool F16>
 __device__ __attribute__((noinline)) void agg_mfma_hub_workgroup(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
     const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, float* __restrict__ agg, int R, int64_t NQ, int HT,
-    unsigned hub_mask, int64_t wrow0, unsigned char* utile, float* s_m, float* s_l, float* s_sc) {
+    unsigned hub_mask, int64_t wrow0, unsigned char* utile, float* s_m, float* s_l, float* s_sc, float* s_sig) {
     using G = MG<VEC, LPH>;
     f32x4 acc[G::NCT];
-    agg_mfma_subtile<VEC, LPH, RTE, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, 0, R + 1, HT, hub_mask, 16, wrow0, utile, s_m, s_l,
-                                          s_sc, 0, acc);
-    agg_mfma_finish<VEC, LPH>(s_l, 1, acc);
+    agg_mfma_subtile<VEC, LPH, RTE, true, F16>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, 0, R + 1, HT, hub_mask, 16, wrow0, utile,
+                                               s_m, s_l, s_sc, s_sig, 0, acc);
+    if constexpr (F16) agg_mfma_finish<VEC, LPH>(s_l, 1, acc, s_sig, msg_frag_inv_scale<VEC, LPH>(msgF, R, HT));
+    else agg_mfma_finish<VEC, LPH>(s_l, 1, acc);
     agg_mfma_store<VEC, LPH>(agg, wrow0, 16, NQ, (int64_t)HT * G::DKP, 0, hub_mask, acc);
 }
 
 // Aggregation + fused node update (see hgt_fused_update.h).  Workgroups that contain a hub target cannot finish their rows
 // here: they write agg, raise pending[workgroup], and k_update_pending runs the same epilogue from agg after the hub kernels.
-template <int VEC, int LPH, bool RTE>
+template <int VEC, int LPH, bool RTE, bool F16>
 __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
@@ -767,9 +852,10 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
     static_assert(G::DP <= KP, "the fused epilogue keeps the whole K extent in one LDS slab");
     constexpr int TILES = 4 * 2 * G::PLANE;
     constexpr int FRONT = TILES > 2 * A_PLANE ? TILES : 2 * A_PLANE;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[FRONT + 4 * 2 * 256 * 4 + 4 * 16 * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[FRONT + 4 * 2 * 256 * 4 + 4 * 16 * 4 + (F16 ? 4 * 16 * 4 : 0)];
     float* s_ml = reinterpret_cast<float*>(smem + FRONT);                 // [4][2][256]; later: the epilogue's tables
     float* s_scale = reinterpret_cast<float*>(smem + FRONT + 4 * 2 * 256 * 4);
+    float* s_sig = s_scale + (F16 ? 4 * 16 : 0);                           // fp16 split: row scales of the targets, [4][16]
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t row0 = (int64_t)blockIdx.x * 64;
@@ -789,15 +875,16 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
     float* s_l = s_m + 256;
     if (any_hub) {      // (the launcher only takes this kernel for R < 64; hub workgroups walk run by run, all four sub-tiles)
         if (wrow0 < NQ)
-            agg_mfma_hub_workgroup<VEC, LPH, RTE>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, agg, R, NQ, HT, hub_mask, wrow0, utile,
-                                                  s_m, s_l, s_scale + wib * 16);
+            agg_mfma_hub_workgroup<VEC, LPH, RTE, F16>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, agg, R, NQ, HT, hub_mask, wrow0,
+                                                       utile, s_m, s_l, s_scale + wib * 16, s_sig + wib * 16);
         return;
     }
     f32x4 acc[G::NCT];
     if (wrow0 < NQ) {
-        agg_mfma_stream<VEC, LPH, RTE>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, 0, R + 1, HT, 16, wrow0, utile, s_m, s_l,
-                                       s_scale + wib * 16, 0, acc);
-        agg_mfma_finish<VEC, LPH>(s_l, 1, acc);
+        agg_mfma_stream<VEC, LPH, RTE, F16>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, 0, R + 1, HT, 16, wrow0, utile, s_m, s_l,
+                                            s_scale + wib * 16, s_sig + wib * 16, 0, acc);
+        if constexpr (F16) agg_mfma_finish<VEC, LPH>(s_l, 1, acc, s_sig + wib * 16, msg_frag_inv_scale<VEC, LPH>(msgF, R, HT));
+        else agg_mfma_finish<VEC, LPH>(s_l, 1, acc);
     } else {
 #pragma unroll
         for (int c = 0; c < G::NCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};   // rows beyond NQ: gelu(0) = 0
@@ -813,21 +900,35 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
         // accumulator layout -> A slab: target (lane & 15) of this wavefront, columns 16 c + 4 (lane >> 4) .. + 3
         const int fi = lane & 15, fg = lane >> 4;
         unsigned char* prow = smem + (wib * 16 + fi) * A_STRIDE + fg * 8;
+        float scale = 1.0f;
+        if constexpr (F16) {
+            // a row (target fi) lives in the four lanes fi, fi + 16, fi + 32, fi + 48: maximum over the lane's 4 * NCT values,
+            // then over the four lanes; its inverse scale goes into the epilogue's table (FU_RINV_OFF)
+            float m = 0.0f;
+#pragma unroll
+            for (int c = 0; c < G::NCT; ++c) m = fmaxf(fmaxf(m, fmaxf(fabsf(acc[c][0]), fabsf(acc[c][1]))), fmaxf(fabsf(acc[c][2]), fabsf(acc[c][3])));
+            unsigned mb = __builtin_bit_cast(unsigned, m);
+            mb = max(mb, (unsigned)__shfl_xor((int)mb, 16));
+            mb = max(mb, (unsigned)__shfl_xor((int)mb, 32));
+            float inv;
+            f16_row_scale(mb, scale, inv);
+            if (fg == 0) reinterpret_cast<float*>(smem + FRONT + FU_RINV_OFF)[wib * 16 + fi] = inv;
+        }
 #pragma unroll
         for (int c = 0; c < G::NCT; ++c) {
             uint2 hi, mid;
-            split4(make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]), hi, mid);
+            split4_t<F16>(make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]), scale, hi, mid);
             *reinterpret_cast<uint2*>(prow + c * 32) = hi;
             *reinterpret_cast<uint2*>(prow + A_PLANE + c * 32) = mid;
         }
     }
-    fused_update_tail<VEC, HGT_FU_NSTG, true>(smem, smem + FRONT, row0, NQ, fu, type_pre);
+    fused_update_tail<VEC, HGT_FU_NSTG, true, F16>(smem, smem + FRONT, row0, NQ, fu, type_pre);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Launchers.  This file is compiled SEVEN times (csrc/Makefile): once as the main translation unit (C entry points, dispatch) and
-// once per (VEC, RTE) PART, which instantiates the kernels of its five lane layouts -- the 30 x 2 kernel instantiations are then
-// built in parallel instead of in one eight-minute hipcc run.  -DHGT_MFMA_PART_VEC=v -DHGT_MFMA_PART_RTE=r selects a part.
+// Launchers.  This file is compiled THIRTEEN times (csrc/Makefile): once as the main translation unit (C entry points, dispatch) and
+// once per (VEC, RTE, F16) PART, which instantiates the kernels of its five lane layouts -- the 60 x 2 kernel instantiations are then
+// built in parallel instead of in one eight-minute hipcc run.  -DHGT_MFMA_PART_VEC=v -DHGT_MFMA_PART_RTE=r -DHGT_MFMA_PART_F16=f selects a part.
 // ---------------------------------------------------------------------------------------------
 #define HGT_MFMA_AGG_ARGS                                                                                                         \
     const HgtPlanView &pv, const float *logits, const float *V, const float *rteV, const float *msgP, const unsigned short *msgF,  \
@@ -837,8 +938,10 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
         float *agg, int R, int64_t NQ, int HT, HgtHubBuffers hb, int32_t *pending, HgtFusedUpdate fu, hipStream_t stream
 
 #ifdef HGT_MFMA_PART_VEC
-template <int VEC, int LPH, bool RTE>
+template <int VEC, int LPH, bool RTE, bool F16>
 static int launch_agg_mfma(HGT_MFMA_AGG_ARGS) {
+    // fp16 split: the row scales of the targets are not part of the slice state and the backward's spmm keeps bf16
+    if (F16 && (sl.state != nullptr || apply_gelu == 2)) return HGT_ERR_UNSUPPORTED;
     // small graphs (the reference's sampled subgraphs): 4 instead of 16 targets per wavefront -> 4x the wavefronts
     // (round 3: 2 targets per wavefront for sampled-batch sizes when the row is not split over head groups and the schema has
     //  few relations -- c3: 92 -> 82 us per layer; with 33 relations and a head-group split (c5) 4 stays faster: 519 vs 546 us)
@@ -851,26 +954,26 @@ static int launch_agg_mfma(HGT_MFMA_AGG_ARGS) {
     const unsigned ny = (unsigned)(HT / (64 / LPH));
     dim3 grid((unsigned)tiles, ny);
     const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
-    k_edge_aggregate_mfma<VEC, LPH, RTE><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF, agg, R, NQ,
-                                                                  apply_gelu, HT, hub_slot, sub, ld_out, sl);
+    k_edge_aggregate_mfma<VEC, LPH, RTE, F16><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF, agg, R,
+                                                                       NQ, apply_gelu, HT, hub_slot, sub, ld_out, sl);
     if (hb.mx && !sl.more)   // hub targets take all their relations at once, after the last slice
         return hgt_launch_hub(VEC, LPH, pv, logits, V, rteV, msgP, agg, R, NQ, apply_gelu, HT, hb, ny, ld_out, stream);
     return HGT_OK;
 }
 
-template <int VEC, int LPH, bool RTE>
+template <int VEC, int LPH, bool RTE, bool F16>
 static int launch_aggupd_mfma(HGT_MFMA_AGGUPD_ARGS) {
     if (HT != 64 / LPH) return HGT_ERR_UNSUPPORTED;   // a head-group split leaves a workgroup with part of the row
     if (R >= 64) return HGT_ERR_UNSUPPORTED;          // the streaming walk keeps the R + 1 ranges in lane registers
     const int64_t tiles = (NQ + 63) / 64;
     dim3 grid((unsigned)tiles, 1);
     const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
-    k_edge_aggregate_update_mfma<VEC, LPH, RTE><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF, agg, R,
-                                                                         NQ, HT, hub_slot, pending, fu);
+    k_edge_aggregate_update_mfma<VEC, LPH, RTE, F16><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
+                                                                              agg, R, NQ, HT, hub_slot, pending, fu);
     if (hb.mx) {   // hub path + the update of the workgroups that had to wait for it
         int rc = hgt_launch_hub(VEC, LPH, pv, logits, V, rteV, msgP, agg, R, NQ, 1, HT, hb, 1u, (int64_t)HT * (VEC * LPH), stream);
         if (rc != HGT_OK) return rc;
-        k_update_pending<VEC><<<grid, 256, 0, stream>>>(agg, (int64_t)HT * (VEC * LPH), NQ, pending, fu);
+        k_update_pending<VEC, F16><<<grid, 256, 0, stream>>>(agg, (int64_t)HT * (VEC * LPH), NQ, pending, fu);
     }
     return HGT_OK;
 }
@@ -896,16 +999,17 @@ static HgtHubBuffers carve_hub(void* hub_ws, const HgtPlanView& pv, int H, int64
 
 }  // namespace
 
-#define HGT_MFMA_CAT2(a, b, c, d) a##b##c##d
-#define HGT_MFMA_NAME(base, v, r) HGT_MFMA_CAT2(base, v, r_, r)
-// hgt_mfma_agg_v<VEC>r_<RTE>(lph, ...), hgt_mfma_aggupd_v<VEC>r_<RTE>(lph, ...): one pair per part
-#define HGT_MFMA_DECL(v, r)                                             \
-    __attribute__((visibility("hidden"))) int HGT_MFMA_NAME(hgt_mfma_agg_v, v, r)(int lph, HGT_MFMA_AGG_ARGS); \
-    __attribute__((visibility("hidden"))) int HGT_MFMA_NAME(hgt_mfma_aggupd_v, v, r)(int lph, HGT_MFMA_AGGUPD_ARGS);
-HGT_MFMA_DECL(1, 0) HGT_MFMA_DECL(1, 1) HGT_MFMA_DECL(2, 0) HGT_MFMA_DECL(2, 1) HGT_MFMA_DECL(4, 0) HGT_MFMA_DECL(4, 1)
+#define HGT_MFMA_CAT2(a, b, c, d, e, f) a##b##c##d##e##f
+#define HGT_MFMA_NAME(base, v, r, f) HGT_MFMA_CAT2(base, v, r_, r, f_, f)
+// hgt_mfma_agg_v<VEC>r_<RTE>f_<F16>(lph, ...), hgt_mfma_aggupd_v<VEC>r_<RTE>f_<F16>(lph, ...): one pair per part
+#define HGT_MFMA_DECL(v, r, f)                                             \
+    __attribute__((visibility("hidden"))) int HGT_MFMA_NAME(hgt_mfma_agg_v, v, r, f)(int lph, HGT_MFMA_AGG_ARGS); \
+    __attribute__((visibility("hidden"))) int HGT_MFMA_NAME(hgt_mfma_aggupd_v, v, r, f)(int lph, HGT_MFMA_AGGUPD_ARGS);
+#define HGT_MFMA_DECL4(v) HGT_MFMA_DECL(v, 0, 0) HGT_MFMA_DECL(v, 1, 0) HGT_MFMA_DECL(v, 0, 1) HGT_MFMA_DECL(v, 1, 1)
+HGT_MFMA_DECL4(1) HGT_MFMA_DECL4(2) HGT_MFMA_DECL4(4)
 
 #ifdef HGT_MFMA_PART_VEC
-// ------------------------------------------------------------------------------------------------ a (VEC, RTE) part
+// ------------------------------------------------------------------------------------------------ a (VEC, RTE, F16) part
 #ifdef HGT_DEV_LAYOUTS   // development builds: d = 256 / 8 heads and d = 64 / 4 heads only
 #define HGT_MFMA_LPH_CASES(F) \
     if ((HGT_MFMA_PART_VEC == 4 && lph == 8)) return F(8); \
@@ -918,16 +1022,16 @@ HGT_MFMA_DECL(1, 0) HGT_MFMA_DECL(1, 1) HGT_MFMA_DECL(2, 0) HGT_MFMA_DECL(2, 1) 
     if (lph == 32) return F(32); \
     if (lph == 64) return F(64);
 #endif
-int HGT_MFMA_NAME(hgt_mfma_agg_v, HGT_MFMA_PART_VEC, HGT_MFMA_PART_RTE)(int lph, HGT_MFMA_AGG_ARGS) {
+int HGT_MFMA_NAME(hgt_mfma_agg_v, HGT_MFMA_PART_VEC, HGT_MFMA_PART_RTE, HGT_MFMA_PART_F16)(int lph, HGT_MFMA_AGG_ARGS) {
 #define HGT_MFMA_F(L) \
-    launch_agg_mfma<HGT_MFMA_PART_VEC, L, (HGT_MFMA_PART_RTE != 0)>(pv, logits, V, rteV, msgP, msgF, agg, R, NQ, apply_gelu, HT, hb, ld_out, sl, stream)
+    launch_agg_mfma<HGT_MFMA_PART_VEC, L, (HGT_MFMA_PART_RTE != 0), (HGT_MFMA_PART_F16 != 0)>(pv, logits, V, rteV, msgP, msgF, agg, R, NQ, apply_gelu, HT, hb, ld_out, sl, stream)
     HGT_MFMA_LPH_CASES(HGT_MFMA_F)
 #undef HGT_MFMA_F
     return HGT_ERR_UNSUPPORTED;
 }
-int HGT_MFMA_NAME(hgt_mfma_aggupd_v, HGT_MFMA_PART_VEC, HGT_MFMA_PART_RTE)(int lph, HGT_MFMA_AGGUPD_ARGS) {
+int HGT_MFMA_NAME(hgt_mfma_aggupd_v, HGT_MFMA_PART_VEC, HGT_MFMA_PART_RTE, HGT_MFMA_PART_F16)(int lph, HGT_MFMA_AGGUPD_ARGS) {
 #define HGT_MFMA_F(L) \
-    launch_aggupd_mfma<HGT_MFMA_PART_VEC, L, (HGT_MFMA_PART_RTE != 0)>(pv, logits, V, rteV, msgP, msgF, agg, R, NQ, HT, hb, pending, fu, stream)
+    launch_aggupd_mfma<HGT_MFMA_PART_VEC, L, (HGT_MFMA_PART_RTE != 0), (HGT_MFMA_PART_F16 != 0)>(pv, logits, V, rteV, msgP, msgF, agg, R, NQ, HT, hb, pending, fu, stream)
     HGT_MFMA_LPH_CASES(HGT_MFMA_F)
 #undef HGT_MFMA_F
     return HGT_ERR_UNSUPPORTED;
@@ -935,41 +1039,33 @@ int HGT_MFMA_NAME(hgt_mfma_aggupd_v, HGT_MFMA_PART_VEC, HGT_MFMA_PART_RTE)(int l
 #else
 // ------------------------------------------------------------------------------------------------ the main translation unit
 namespace {
-int mfma_agg_dispatch(int vec, int lph, HGT_MFMA_AGG_ARGS) {
-#define HGT_MFMA_CALL(v) \
-    return rteV ? hgt_mfma_agg_v##v##r_1(lph, pv, logits, V, rteV, msgP, msgF, agg, R, NQ, apply_gelu, HT, hb, ld_out, sl, stream) \
-                : hgt_mfma_agg_v##v##r_0(lph, pv, logits, V, rteV, msgP, msgF, agg, R, NQ, apply_gelu, HT, hb, ld_out, sl, stream);
+int mfma_agg_dispatch(int vec, int lph, bool f16, HGT_MFMA_AGG_ARGS) {
+#define HGT_MFMA_ARGS_ lph, pv, logits, V, rteV, msgP, msgF, agg, R, NQ, apply_gelu, HT, hb, ld_out, sl, stream
+#define HGT_MFMA_CALL(v)                                                                                        \
+    return f16 ? (rteV ? hgt_mfma_agg_v##v##r_1f_1(HGT_MFMA_ARGS_) : hgt_mfma_agg_v##v##r_0f_1(HGT_MFMA_ARGS_)) \
+               : (rteV ? hgt_mfma_agg_v##v##r_1f_0(HGT_MFMA_ARGS_) : hgt_mfma_agg_v##v##r_0f_0(HGT_MFMA_ARGS_));
     if (vec == 1) { HGT_MFMA_CALL(1) }
     if (vec == 2) { HGT_MFMA_CALL(2) }
     if (vec == 4) { HGT_MFMA_CALL(4) }
 #undef HGT_MFMA_CALL
+#undef HGT_MFMA_ARGS_
     return HGT_ERR_UNSUPPORTED;      // a wave's slice wider than 256 columns: the vector-ALU kernel
 }
-int mfma_aggupd_dispatch(int vec, int lph, HGT_MFMA_AGGUPD_ARGS) {
-#define HGT_MFMA_CALL(v) \
-    return rteV ? hgt_mfma_aggupd_v##v##r_1(lph, pv, logits, V, rteV, msgP, msgF, agg, R, NQ, HT, hb, pending, fu, stream) \
-                : hgt_mfma_aggupd_v##v##r_0(lph, pv, logits, V, rteV, msgP, msgF, agg, R, NQ, HT, hb, pending, fu, stream);
+int mfma_aggupd_dispatch(int vec, int lph, bool f16, HGT_MFMA_AGGUPD_ARGS) {
+#define HGT_MFMA_ARGS_ lph, pv, logits, V, rteV, msgP, msgF, agg, R, NQ, HT, hb, pending, fu, stream
+#define HGT_MFMA_CALL(v)                                                                                              \
+    return f16 ? (rteV ? hgt_mfma_aggupd_v##v##r_1f_1(HGT_MFMA_ARGS_) : hgt_mfma_aggupd_v##v##r_0f_1(HGT_MFMA_ARGS_)) \
+               : (rteV ? hgt_mfma_aggupd_v##v##r_1f_0(HGT_MFMA_ARGS_) : hgt_mfma_aggupd_v##v##r_0f_0(HGT_MFMA_ARGS_));
     if (vec == 1) { HGT_MFMA_CALL(1) }
     if (vec == 2) { HGT_MFMA_CALL(2) }
     if (vec == 4) { HGT_MFMA_CALL(4) }
 #undef HGT_MFMA_CALL
+#undef HGT_MFMA_ARGS_
     return HGT_ERR_UNSUPPORTED;
 }
-}  // namespace
 
-extern "C" int hgt_relation_frag_bytes(int32_t R, int32_t H, int32_t dk_pad, uint64_t* out) {
-    if (!out || R <= 0 || H <= 0 || dk_pad <= 0 || 64 % H != 0) return HGT_ERR_INVALID_ARG;
-    const int lph = 64 / H;
-    if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
-    const int sp = mfma_split_for(dk_pad / lph, lph);
-    if (sp == 0) { *out = 0; return HGT_OK; }      // layout not covered by the matrix-core kernel: no image needed
-    const int vec = dk_pad / lph / sp, lphs = lph * sp, dkp = vec * lphs, dp = 64 * vec;
-    const int kw = dkp > 32 ? dkp : 32;
-    *out = (uint64_t)R * (H * dk_pad / dp) * (dp / 16) * (kw / 32) * 2 * 512 * 2;
-    return HGT_OK;
-}
-
-extern "C" int hgt_relation_frag_pack(const float* msg_p, int32_t R, int32_t H, int32_t dk_pad, void* msg_frag, void* stream) {
+template <bool F16>
+int relation_frag_pack_impl(const float* msg_p, int32_t R, int32_t H, int32_t dk_pad, void* msg_frag, void* stream) {
     if (!msg_p || !msg_frag || R <= 0 || H <= 0 || dk_pad <= 0 || 64 % H != 0) return HGT_ERR_INVALID_ARG;
     const int lph = 64 / H;
     if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
@@ -981,9 +1077,31 @@ extern "C" int hgt_relation_frag_pack(const float* msg_p, int32_t R, int32_t H, 
     // blockdiag(M) is described by the REAL head width dk_pad
     const int kw = dk_pad > 32 ? dk_pad : 32;
     const int64_t total = (int64_t)R * (H * dk_pad / dp) * (dp / 16) * (kw / 32) * 512;
-    k_msg_frag_pack<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(msg_p, R, H, dk_pad, dp, (unsigned short*)msg_frag);
+    float* tail = reinterpret_cast<float*>((unsigned short*)msg_frag + total * 2);      // [inverse scale, scale]
+    if (F16) k_msg_scale<<<1, 1024, 0, (hipStream_t)stream>>>(msg_p, (int64_t)R * H * dk_pad * dk_pad, tail);
+    k_msg_frag_pack<F16><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(msg_p, R, H, dk_pad, dp, (unsigned short*)msg_frag, tail);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
+}
+}  // namespace
+
+extern "C" int hgt_relation_frag_bytes(int32_t R, int32_t H, int32_t dk_pad, uint64_t* out) {
+    if (!out || R <= 0 || H <= 0 || dk_pad <= 0 || 64 % H != 0) return HGT_ERR_INVALID_ARG;
+    const int lph = 64 / H;
+    if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
+    const int sp = mfma_split_for(dk_pad / lph, lph);
+    if (sp == 0) { *out = 0; return HGT_OK; }      // layout not covered by the matrix-core kernel: no image needed
+    const int vec = dk_pad / lph / sp, lphs = lph * sp, dkp = vec * lphs, dp = 64 * vec;
+    const int kw = dkp > 32 ? dkp : 32;
+    *out = (uint64_t)R * (H * dk_pad / dp) * (dp / 16) * (kw / 32) * 2 * 512 * 2 + 256;   // + the fp16 image's scale pair
+    return HGT_OK;
+}
+
+extern "C" int hgt_relation_frag_pack(const float* msg_p, int32_t R, int32_t H, int32_t dk_pad, void* msg_frag, void* stream) {
+    return relation_frag_pack_impl<false>(msg_p, R, H, dk_pad, msg_frag, stream);
+}
+extern "C" int hgt_relation_frag_pack_f16(const float* msg_p, int32_t R, int32_t H, int32_t dk_pad, void* msg_frag, void* stream) {
+    return relation_frag_pack_impl<true>(msg_p, R, H, dk_pad, msg_frag, stream);
 }
 
 extern "C" int hgt_hub_workspace_bytes(int64_t n_edges, int32_t n_heads, int32_t dk_pad, uint64_t* out) {
@@ -993,9 +1111,10 @@ extern "C" int hgt_hub_workspace_bytes(int64_t n_edges, int32_t n_heads, int32_t
     return HGT_OK;
 }
 
-extern "C" int hgt_edge_aggregate(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
-                                  const float* logits, const float* V, const float* rte_v, const float* msg_p, const void* msg_frag,
-                                  float* agg, int64_t n_q_rows, int32_t apply_gelu, void* hub_ws, void* stream) {
+static int edge_aggregate_impl(bool f16, const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                               const float* logits, const float* V, const float* rte_v, const float* msg_p, const void* msg_frag,
+                               float* agg, int64_t n_q_rows, int32_t apply_gelu, void* hub_ws, void* stream) {
+    if (f16 && !msg_frag) return HGT_ERR_INVALID_ARG;
     if (!plan || !V || !msg_p || !agg || (E > 0 && !logits) || H <= 0 || 64 % H != 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
     const int64_t NQ = (n_q_rows > 0 && n_q_rows <= N) ? n_q_rows : N;
     if (NQ == 0) return HGT_OK;
@@ -1007,7 +1126,7 @@ extern "C" int hgt_edge_aggregate(const void* plan, int64_t N, int64_t E, int32_
     int rc = HGT_ERR_UNSUPPORTED;
     const int sp = msg_frag ? mfma_split_for(dk_pad / lph, lph) : 0;
     if (sp != 0)
-        rc = mfma_agg_dispatch(dk_pad / lph / sp, lph * sp, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
+        rc = mfma_agg_dispatch(dk_pad / lph / sp, lph * sp, f16, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
                                             (int)R, NQ, (int)(apply_gelu ? 1 : 0), (int)H, hb, (int64_t)H * dk_pad, whole,
                                             (hipStream_t)stream);
     if (rc == HGT_ERR_UNSUPPORTED)   // exact-fp32 request (msg_frag == NULL) or a layout only the vector-ALU kernel covers
@@ -1015,6 +1134,18 @@ extern "C" int hgt_edge_aggregate(const void* plan, int64_t N, int64_t E, int32_
     if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();
     return HGT_OK;
+}
+extern "C" int hgt_edge_aggregate(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                  const float* logits, const float* V, const float* rte_v, const float* msg_p, const void* msg_frag,
+                                  float* agg, int64_t n_q_rows, int32_t apply_gelu, void* hub_ws, void* stream) {
+    return edge_aggregate_impl(false, plan, N, E, T, R, H, dk_pad, logits, V, rte_v, msg_p, msg_frag, agg, n_q_rows, apply_gelu, hub_ws, stream);
+}
+// msg_frag = the hgt_relation_frag_pack_f16 image (required); layouts only the vector-ALU kernel covers run in exact fp32
+extern "C" int hgt_edge_aggregate_f16x3(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                        const float* logits, const float* V, const float* rte_v, const float* msg_p,
+                                        const void* msg_frag, float* agg, int64_t n_q_rows, int32_t apply_gelu, void* hub_ws,
+                                        void* stream) {
+    return edge_aggregate_impl(true, plan, N, E, T, R, H, dk_pad, logits, V, rte_v, msg_p, msg_frag, agg, n_q_rows, apply_gelu, hub_ws, stream);
 }
 
 // One slice [rel_lo, rel_hi) of the relation buckets (include/hgt_hip.h): matrix-core kernel only (msg_frag required).
@@ -1034,19 +1165,20 @@ extern "C" int hgt_edge_aggregate_slice(const void* plan, int64_t N, int64_t E, 
     const HgtRelSlice sl = {(int)rel_lo, (int)rel_hi, state, has_prev ? 1 : 0, more ? 1 : 0};
     const int sp = mfma_split_for(dk_pad / lph, lph);
     if (sp == 0) return HGT_ERR_UNSUPPORTED;
-    int rc = mfma_agg_dispatch(dk_pad / lph / sp, lph * sp, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
+    int rc = mfma_agg_dispatch(dk_pad / lph / sp, lph * sp, false, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
                                             (int)R, NQ, (int)(apply_gelu ? 1 : 0), (int)H, hb, (int64_t)H * dk_pad, sl, (hipStream_t)stream);
     if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }
 
-extern "C" int hgt_edge_aggregate_update(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
-                                         const float* logits, const float* V, const float* rte_v, const float* msg_p,
-                                         const void* msg_frag, float* agg, int64_t n_q_rows, void* hub_ws, int32_t* pending,
-                                         const int64_t* node_type, const void* w_a_split, const float* b_a, const float* x_skip,
-                                         int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm,
-                                         int32_t n_out, float* out, void* stream) {
+static int edge_aggregate_update_impl(bool f16, const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                      const float* logits, const float* V, const float* rte_v, const float* msg_p,
+                                      const void* msg_frag, float* agg, int64_t n_q_rows, void* hub_ws, int32_t* pending,
+                                      const int64_t* node_type, const void* w_a_split, const float* b_a, const float* x_skip,
+                                      int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm,
+                                      int32_t n_out, float* out, void* stream) {
+    if (f16 && !msg_frag) return HGT_ERR_INVALID_ARG;
     if (!plan || !V || !msg_p || !agg || !pending || !node_type || !w_a_split || !b_a || !x_skip || !skip || !out || H <= 0 ||
         64 % H != 0 || dk_pad <= 0 || n_out <= 0)
         return HGT_ERR_INVALID_ARG;
@@ -1063,7 +1195,7 @@ extern "C" int hgt_edge_aggregate_update(const void* plan, int64_t N, int64_t E,
     HgtFusedUpdate fu = {node_type, (const unsigned short*)w_a_split, b_a, x_skip, ld_skip, skip, ln_w, ln_b, use_norm, T, n_out, out};
     int rc = HGT_ERR_UNSUPPORTED;
     if (msg_frag && mfma_split_for(dk_pad / lph, lph) == 1)
-        rc = mfma_aggupd_dispatch(dk_pad / lph, lph, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
+        rc = mfma_aggupd_dispatch(dk_pad / lph, lph, f16, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
                                                   (int)R, NQ, (int)H, hb, pending, fu, (hipStream_t)stream);
     if (rc == HGT_ERR_UNSUPPORTED && !msg_frag)
         rc = hgt_valu_aggregate_update(pv, dk_pad, logits, V, rte_v, msg_p, agg, (int)R, NQ, (int)H, hb, pending, fu, (hipStream_t)stream);
@@ -1071,6 +1203,17 @@ extern "C" int hgt_edge_aggregate_update(const void* plan, int64_t N, int64_t E,
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }
+#define HGT_AGGUPD_PARAMS                                                                                                            \
+    const void *plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad, const float *logits, const float *V,     \
+        const float *rte_v, const float *msg_p, const void *msg_frag, float *agg, int64_t n_q_rows, void *hub_ws, int32_t *pending,   \
+        const int64_t *node_type, const void *w_a_split, const float *b_a, const float *x_skip, int64_t ld_skip, const float *skip,   \
+        const float *ln_w, const float *ln_b, int32_t use_norm, int32_t n_out, float *out, void *stream
+#define HGT_AGGUPD_PASS                                                                                                              \
+    plan, N, E, T, R, H, dk_pad, logits, V, rte_v, msg_p, msg_frag, agg, n_q_rows, hub_ws, pending, node_type, w_a_split, b_a, x_skip, \
+        ld_skip, skip, ln_w, ln_b, use_norm, n_out, out, stream
+extern "C" int hgt_edge_aggregate_update(HGT_AGGUPD_PARAMS) { return edge_aggregate_update_impl(false, HGT_AGGUPD_PASS); }
+// msg_frag = hgt_relation_frag_pack_f16 image, w_a_split = hgt_split_weights_f16 image (both required)
+extern "C" int hgt_edge_aggregate_update_f16x3(HGT_AGGUPD_PARAMS) { return edge_aggregate_update_impl(true, HGT_AGGUPD_PASS); }
 
 // out[i][ld_out] = sum_rel ( sum_{e in (i,rel)} w_e rows[src_e] ) F[rel]  -- the aggregation kernel without the softmax: the edge
 // weights are given.  The backward pass is three of these (include/hgt_hip.h).
@@ -1086,7 +1229,7 @@ extern "C" int hgt_edge_spmm(const void* plan, int64_t N, int64_t E, int32_t T, 
     HgtHubBuffers hb = carve_hub(hub_ws, pv, H, E);
     const int sp = mfma_split_for(dk_pad / lph, lph);
     if (sp == 0) return HGT_ERR_UNSUPPORTED;
-    int rc = mfma_agg_dispatch(dk_pad / lph / sp, lph * sp, pv, weights, rows, rte_rows, f_p, (const unsigned short*)f_frag, out,
+    int rc = mfma_agg_dispatch(dk_pad / lph / sp, lph * sp, false, pv, weights, rows, rte_rows, f_p, (const unsigned short*)f_frag, out,
                                             (int)R, NQ, 2, (int)H, hb, ld_out, HgtRelSlice{0, (int)R + 1, nullptr, 0, 0}, (hipStream_t)stream);
     if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();

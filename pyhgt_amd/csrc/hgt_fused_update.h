@@ -20,19 +20,26 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // A operand of the epilogue: hi/mid bf16 planes of this wavefront's 16 finished rows (gather layout: lane = VEC consecutive
 // columns of a row), [plane][row][k], 528 B row stride
-template <int VEC>
-__device__ __forceinline__ void fused_slab_from_rows(const float (&vals)[16][VEC], unsigned char* slab) {
+constexpr int FU_RINV_OFF = 2560;      // byte offset of the fp16 split's inverse row scales ([64] floats) inside `tables`
+template <int VEC, bool F16 = false>
+__device__ __forceinline__ void fused_slab_from_rows(const float (&vals)[16][VEC], unsigned char* slab, float* s_rinv = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         unsigned char* prow = slab + (wave * 16 + r) * A_STRIDE + lane * VEC * 2;
         unsigned short hi[VEC], mid[VEC];
+        float scale = 1.0f;
+        if constexpr (F16) {      // the wavefront holds the whole row (gather layout)
+            float m = fabsf(vals[r][0]);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            hi[i] = bf16_rne(vals[r][i]);
-            mid[i] = bf16_rne(vals[r][i] - bf16_to_f32(hi[i]));
+            for (int i = 1; i < VEC; ++i) m = fmaxf(m, fabsf(vals[r][i]));
+            float inv;
+            f16_row_scale(wave_max_bits(__builtin_bit_cast(unsigned, m)), scale, inv);
+            if (lane == 0) s_rinv[wave * 16 + r] = inv;
         }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) split1_t<F16>(vals[r][i], scale, hi[i], mid[i]);
         if constexpr (VEC == 1) {
             *reinterpret_cast<unsigned short*>(prow) = hi[0];
             *reinterpret_cast<unsigned short*>(prow + A_PLANE) = mid[0];
@@ -56,7 +63,7 @@ __device__ __forceinline__ void fused_slab_from_rows(const float (&vals)[16][VEC
 // right before its use: 16 dependent HBM round trips per tile, ~30 us of a workgroup's ~125 us at c2 (measured by removing the
 // epilogue: 3.61 -> 2.66 ms) -- the whole cost of the fused epilogue.  Unconditional (clamped) loads ahead of the MFMA loop take one.
 constexpr int FU_NO_TYPE = -0x7fffffff;
-template <int VEC, int NSTG = 4, bool XPRE = false>
+template <int VEC, int NSTG = 4, bool XPRE = false, bool F16 = false>
 __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned char* tables, int64_t row0, int64_t NQ,
                                                   const HgtFusedUpdate& fu, int type_pre = FU_NO_TYPE) {
     constexpr int DP = 64 * VEC;
@@ -65,6 +72,7 @@ __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned 
     int* s_type = reinterpret_cast<int*>(tables);                // [64]
     float* s_sum = reinterpret_cast<float*>(tables + 256);         // [64][4]
     float* s_var = s_sum + 256;                                    // [64][4]
+    const float* s_rinv = reinterpret_cast<const float*>(tables + FU_RINV_OFF);   // [64], fp16 split only (written by the caller)
     if (tid < 64) {
         // type_pre: the caller requested node_type[row0 + lane] before its own barrier (one round trip off the critical path)
         int64_t t = type_pre;
@@ -157,18 +165,18 @@ __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned 
 #define FU_STEP(S, KCI, P, PN)                                                                                     \
     {                                                                                                              \
         FU_LOAD_A(PN, (KCI) + 1)                                                                                   \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m0, s##S##h0, acc[0][0], 0, 0, 0);                 \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m1, s##S##h0, acc[0][1], 0, 0, 0);                 \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m0, s##S##h1, acc[1][0], 0, 0, 0);                 \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_m1, s##S##h1, acc[1][1], 0, 0, 0);                 \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##m0, acc[0][0], 0, 0, 0);                 \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##m0, acc[0][1], 0, 0, 0);                 \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##m1, acc[1][0], 0, 0, 0);                 \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##m1, acc[1][1], 0, 0, 0);                 \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##h0, acc[0][0], 0, 0, 0);                 \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##h0, acc[0][1], 0, 0, 0);                 \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h0, s##S##h1, acc[1][0], 0, 0, 0);                 \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P##_h1, s##S##h1, acc[1][1], 0, 0, 0);                 \
+        acc[0][0] = mfma32_t<F16>(P##_m0, s##S##h0, acc[0][0]);                 \
+        acc[0][1] = mfma32_t<F16>(P##_m1, s##S##h0, acc[0][1]);                 \
+        acc[1][0] = mfma32_t<F16>(P##_m0, s##S##h1, acc[1][0]);                 \
+        acc[1][1] = mfma32_t<F16>(P##_m1, s##S##h1, acc[1][1]);                 \
+        acc[0][0] = mfma32_t<F16>(P##_h0, s##S##m0, acc[0][0]);                 \
+        acc[0][1] = mfma32_t<F16>(P##_h1, s##S##m0, acc[0][1]);                 \
+        acc[1][0] = mfma32_t<F16>(P##_h0, s##S##m1, acc[1][0]);                 \
+        acc[1][1] = mfma32_t<F16>(P##_h1, s##S##m1, acc[1][1]);                 \
+        acc[0][0] = mfma32_t<F16>(P##_h0, s##S##h0, acc[0][0]);                 \
+        acc[0][1] = mfma32_t<F16>(P##_h1, s##S##h0, acc[0][1]);                 \
+        acc[1][0] = mfma32_t<F16>(P##_h0, s##S##h1, acc[1][0]);                 \
+        acc[1][1] = mfma32_t<F16>(P##_h1, s##S##h1, acc[1][1]);                 \
         FU_LOAD_B(S, (KCI) + NST)                                                                                  \
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  /* 4 DS reads   */                                     \
         __builtin_amdgcn_sched_group_barrier(0x008, 12, 0); /* 12 MFMAs     */                                     \
@@ -222,6 +230,8 @@ __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned 
         asm volatile("" : "+v"(lane_e));
         const int rt0e = (lane_e & 3) + 4 * (lane_e >> 5);
         const float alpha = 1.0f / (1.0f + expf(-(XPRE ? skip_pre : fu.skip[g])));
+        // fp16 split: inverse scale of the group's W_a image (tail of the image, hgt_split_weights_f16) x the rows' inverse scales
+        const float winv = F16 ? reinterpret_cast<const float*>(fu.w_split + (int64_t)fu.n_types * NKC * 2 * W_PLANE_ELEMS)[g] : 1.0f;
         float y[16][4];                                // [c*8 + j*4 + q][4 consecutive columns]
         int orow[8];                                   // row of group (j, q); -1 = not a row of this type
 #pragma unroll
@@ -252,10 +262,11 @@ __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned 
                 } else {
                     if (col_ok && orow[jq] >= 0) xv = *reinterpret_cast<const float4*>(fu.xs + (row0 + orow[jq]) * fu.ldxs + col);
                 }
-                y[c * 8 + jq][0] = col_ok ? (v0 + b4.x) * alpha + xv.x * (1.0f - alpha) : 0.0f;
-                y[c * 8 + jq][1] = col_ok ? (v1 + b4.y) * alpha + xv.y * (1.0f - alpha) : 0.0f;
-                y[c * 8 + jq][2] = col_ok ? (v2 + b4.z) * alpha + xv.z * (1.0f - alpha) : 0.0f;
-                y[c * 8 + jq][3] = col_ok ? (v3 + b4.w) * alpha + xv.w * (1.0f - alpha) : 0.0f;
+                const float sc = F16 ? s_rinv[rt0e + 32 * (jq >> 2) + 8 * (jq & 3)] * winv : 1.0f;
+                y[c * 8 + jq][0] = col_ok ? (v0 * sc + b4.x) * alpha + xv.x * (1.0f - alpha) : 0.0f;
+                y[c * 8 + jq][1] = col_ok ? (v1 * sc + b4.y) * alpha + xv.y * (1.0f - alpha) : 0.0f;
+                y[c * 8 + jq][2] = col_ok ? (v2 * sc + b4.z) * alpha + xv.z * (1.0f - alpha) : 0.0f;
+                y[c * 8 + jq][3] = col_ok ? (v3 * sc + b4.w) * alpha + xv.w * (1.0f - alpha) : 0.0f;
             }
         }
         if (fu.use_norm) {
@@ -323,18 +334,18 @@ __device__ __forceinline__ void fused_update_tail(unsigned char* slab, unsigned 
 }
 
 // `vals` = this wavefront's 16 finished rows (gelu applied) in the gather layout
-template <int VEC>
+template <int VEC, bool F16 = false>
 __device__ __forceinline__ void fused_update_epilogue(const float (&vals)[16][VEC], unsigned char* slab, unsigned char* tables,
                                                       int64_t row0, int64_t NQ, const HgtFusedUpdate& fu) {
-    fused_slab_from_rows<VEC>(vals, slab);
-    fused_update_tail<VEC>(slab, tables, row0, NQ, fu);
+    fused_slab_from_rows<VEC, F16>(vals, slab, reinterpret_cast<float*>(tables + FU_RINV_OFF));
+    fused_update_tail<VEC, 4, false, F16>(slab, tables, row0, NQ, fu);
 }
 
 // Workgroups that contain a hub target cannot finish their rows here (the hub kernels write those rows of agg later):
 
 
 // the node update of the workgroups k_edge_aggregate_update left pending (their agg rows are complete by now)
-template <int VEC>
+template <int VEC, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void k_update_pending(const float* __restrict__ agg, int64_t ld_agg, int64_t NQ,
                                                            const int32_t* __restrict__ pending, HgtFusedUpdate fu) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_PLANE + 4096];
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void k_update_pending(const float* __restri
         for (int i = 0; i < VEC; ++i) vals[r][i] = 0.0f;
         if (row < NQ) load_vec<VEC>(agg + row * ld_agg + lane * VEC, vals[r]);
     }
-    fused_update_epilogue<VEC>(vals, smem, smem + 2 * A_PLANE, row0, NQ, fu);
+    fused_update_epilogue<VEC, F16>(vals, smem, smem + 2 * A_PLANE, row0, NQ, fu);
 }
 
 }  // namespace

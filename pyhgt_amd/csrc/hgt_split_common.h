@@ -93,6 +93,32 @@ __device__ __forceinline__ f32x16 mfma32_t(bf16x8 a, bf16x8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+typedef float hgt_f32x4v __attribute__((ext_vector_type(4)));
+template <bool F16>
+__device__ __forceinline__ hgt_f32x4v mfma16_t(bf16x8 a, bf16x8 b, hgt_f32x4v c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hgt_f16x8, a), __builtin_bit_cast(hgt_f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ void split2_t(float a, float b, float scale, unsigned& hi, unsigned& lo) {
+    if constexpr (F16) split2_f16(a * scale, b * scale, hi, lo);
+    else split2(a, b, hi, lo);
+}
+template <bool F16>
+__device__ __forceinline__ void split1_t(float a, float scale, unsigned short& hi, unsigned short& lo) {
+    if constexpr (F16) {
+        const _Float16 h = (_Float16)(a * scale);
+        const _Float16 l = (_Float16)(a * scale - (float)h);
+        hi = __builtin_bit_cast(unsigned short, h);
+        lo = __builtin_bit_cast(unsigned short, l);
+    } else {
+        hi = bf16_rne(a);
+        lo = bf16_rne(a - bf16_to_f32(hi));
+    }
+}
+
 // max over the 64 lanes of a wavefront of a NON-NEGATIVE float's bits (compare as unsigned), wave-uniform result:
 // four DPP steps inside the rows of 16 lanes, then the four row results through SGPRs
 __device__ __forceinline__ unsigned wave_max_bits(unsigned v) {

@@ -274,7 +274,7 @@ class PartitionedGraph:
 
     def forward(self, layer, x_own, phase_events=None):
         d = x_own.size(1)
-        bucketed = self.bucketed and getattr(layer, "precision", None) == "bf16x3" and getattr(layer, "_UPDATE_MODE", 0) == 0
+        bucketed = self.bucketed and getattr(layer, "precision", None) in ("bf16x3", "f16x3") and getattr(layer, "_UPDATE_MODE", 0) == 0
         need = layer.workspace_bytes(self.n_local, self.plan.E, self.n_buckets if bucketed else 1)
         if self.workspace is None or self.workspace.numel() < need or self.workspace.device != x_own.device:
             self.workspace = torch.empty(need, dtype=torch.uint8, device=x_own.device)

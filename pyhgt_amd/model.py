@@ -86,16 +86,16 @@ class GNN(nn.Module):
             self._packed, self._packed_key = (w, b), key
         return self._packed
 
-    def _adapter_tiles(self, w, in_dim, n_hid, st):
-        """Split-bf16 MFMA tiles of the adapter weights (hgt_split_weights), kept until the weights change."""
-        key = (w.data_ptr(), self._packed_key)
+    def _adapter_tiles(self, w, in_dim, n_hid, st, f16=False):
+        """Split MFMA tiles of the adapter weights (hgt_split_weights[_f16]), kept until the weights change."""
+        key = (w.data_ptr(), self._packed_key, f16)
         if getattr(self, "_tiles_key", None) != key:
             lib = _lib.load()
             nb = C.c_uint64()
             _lib.check(lib.hgt_split_weights_bytes(self.num_types, in_dim, n_hid, C.byref(nb)), "hgt_split_weights_bytes")
             self._tiles = torch.empty(int(nb.value), dtype=torch.uint8, device=w.device)
-            _lib.check(lib.hgt_split_weights(_ptr(w), n_hid * in_dim, self.num_types, in_dim, n_hid, _ptr(self._tiles), st),
-                       "hgt_split_weights(adapter)")
+            _lib.check((lib.hgt_split_weights_f16 if f16 else lib.hgt_split_weights)(_ptr(w), n_hid * in_dim, self.num_types, in_dim, n_hid,
+                                                                                      _ptr(self._tiles), st), "hgt_split_weights(adapter)")
             self._tiles_key = key
         return self._tiles
 
@@ -128,9 +128,10 @@ class GNN(nn.Module):
         st = _stream()
         # typed adapter (in_dim is arbitrary, e.g. 129 or 1169): the precision of the layers -- split-bf16 x3 MFMA (its row loader
         # takes any K) or the exact fp32 MFMA kernel
-        if conv0.precision == "bf16x3" and n_hid % 4 == 0:
-            tiles = self._adapter_tiles(w, in_dim, n_hid, st)
-            _lib.check(lib.hgt_typed_linear_bf16x3(_ptr(x), in_dim, rows.rows_all, rows.off_all, T, N, in_dim, n_hid, _ptr(tiles),
+        if conv0.precision in ("bf16x3", "f16x3") and n_hid % 4 == 0:
+            f16 = conv0.precision == "f16x3"
+            tiles = self._adapter_tiles(w, in_dim, n_hid, st, f16)
+            _lib.check((lib.hgt_typed_linear_f16x3 if f16 else lib.hgt_typed_linear_bf16x3)(_ptr(x), in_dim, rows.rows_all, rows.off_all, T, N, in_dim, n_hid, _ptr(tiles),
                                                    _ptr(b), n_hid, _ptr(h), 0, 0, n_hid, 0, 0, st), "hgt_typed_linear_bf16x3(adapter)")
         else:
             _lib.check(lib.hgt_typed_linear(_ptr(x), in_dim, rows.rows_all, rows.off_all, T, N, in_dim, n_hid, _ptr(w), n_hid * in_dim,

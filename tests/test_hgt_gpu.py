@@ -56,7 +56,21 @@ def test_split_bf16_precision_matches_reference_golden(golden):
     assert (att - g["att"]).abs().max().item() < 1e-5
 
 
+def test_split_f16_precision_matches_reference_golden(golden):
+    """precision="f16x3" (fp16 hi / lo split with power-of-two row scales) against the verbatim reference's outputs: the
+    difference is the reference's own fp32 rounding, an order of magnitude inside the 1e-4 bound."""
+    g = golden
+    layer = _layer_from(g["sd"], g["d"], g["T"], g["R"], g["H"], g["use_norm"], g["use_RTE"], precision="f16x3", dense=g["dense"])
+    out, att = _run(layer, g["x"], g["node_type"], g["edge_index"], g["edge_type"], g["edge_time"])
+    err = (out - g["out"]).abs().max().item()
+    print("golden %s f16x3: max|err| %.2e" % (g["name"], err))
+    assert err < F16_TOL
+    assert (att - g["att"]).abs().max().item() < 1e-5
+
+
 # ------------------------------------------------------------------ (b) oracle on seeded inputs
+F16_TOL = 1e-5          # "f16x3" against the fp64 closed form / the reference's fp32 outputs (measured <= 2e-6)
+PREC_TOL = {"fp32": TOL, "bf16x3": TOL, "f16x3": F16_TOL}
 CASES = [
     # N, E, d, H, T, R, use_norm, use_RTE, graph kwargs
     (3000, 30000, 256, 8, 4, 8, True, False, {}),                     # c2 shape, small
@@ -71,7 +85,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x3"])
 @pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
 def test_matches_oracle(case, precision):
     N, E, d, H, T, R, use_norm, use_RTE, gk = case
@@ -83,7 +97,7 @@ def test_matches_oracle(case, precision):
     out, att = _run(layer, x, nt, ei, et, tm if use_RTE else None)
     err, err_att = (out.double() - ref).abs().max().item(), (att.double() - att_ref).abs().max().item()
     print("case N=%d E=%d d=%d H=%d %s: max|out| err %.2e, att err %.2e" % (N, E, d, H, precision, err, err_att))
-    assert err < TOL
+    assert err < PREC_TOL[precision]
     assert err_att < 1e-5
 
 
@@ -96,7 +110,7 @@ DENSE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x3"])
 @pytest.mark.parametrize("case", DENSE_CASES, ids=[str(i) for i in range(len(DENSE_CASES))])
 def test_dense_hgt_conv_matches_oracle(case, precision):
     """DenseHGTConv (conv.py:143-280): HGTConv's message() + the dense update; unknown node types and unclaimed
@@ -113,12 +127,12 @@ def test_dense_hgt_conv_matches_oracle(case, precision):
     out, att = _run(layer, x, nt, ei, et, tm if use_RTE else None)
     err = (out.double() - ref).abs().max().item()
     print("dense case N=%d E=%d d=%d H=%d %s: max|out| err %.2e" % (N, E, d, H, precision, err))
-    assert err < TOL
+    assert err < PREC_TOL[precision]
     assert (att.double() - att_ref).abs().max().item() < 1e-5
     assert out[nt == T + 1].abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x3"])
 def test_prepared_weight_images_follow_parameter_updates(precision):
     """hgt_conv_args.prepared keeps the weight-only preprocessing (packed relation matrices, split weight tiles, temporal
     tables) across calls; it must be rebuilt when any parameter changes in place and reused (bit-identical output) when
@@ -218,7 +232,7 @@ def test_hub_targets_with_extreme_logits(scale):
     assert (att.double() - att_ref).abs().max().item() < (1e-4 if abs(scale) <= 60 else 2e-3)   # logits ~ 1e2..1e3 in fp32
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x3"])
 @pytest.mark.parametrize("d,H", [(96, 3), (80, 5), (96, 6), (192, 12)])
 def test_head_counts_that_do_not_divide_64(d, H, precision):
     """conv.py:21 only needs d % n_heads == 0.  3 / 5 / 6 / 12 heads run in the layout of the next power of two; the padding
@@ -424,7 +438,7 @@ def test_gnn_wrapper_matches_oracle(precision):
 
 
 @pytest.mark.parametrize("handoff", [False, True], ids=["to_torch", "to_device_graph"])
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3", "fp32"])
 @pytest.mark.parametrize("name", ["gnn_oag2", "gnn_mag4"])
 def test_gnn_matches_reference_gnn_goldens(name, precision, handoff):
     """The HIP GNN against rows of the VERBATIM reference GNN's outputs (oracle/gen_golden_gnn.py) at the exact shapes of
@@ -478,7 +492,7 @@ def test_single_layer_at_the_exact_configs2_shape():
     T, R, d, H = 4, len(edge_dict), 256, 8
     sd = O.make_state_dict(d, d, T, R, H, True, True, seed=77)
     ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, use_norm=True, use_RTE=True, dtype=torch.float64)
-    for precision in ("bf16x3", "fp32"):
+    for precision in ("bf16x3", "f16x3", "fp32"):
         layer = HGTConv(d, d, T, R, H, 0.2, True, True, precision=precision).eval()
         layer.load_state_dict(sd)
         layer = layer.to(DEV)
@@ -843,7 +857,8 @@ def test_properties_at_scale():
     assert (out - ref).abs().max().item() < TOL
 
 
-@pytest.mark.parametrize("variant,precision", [("plain", "bf16x3"), ("plain", "fp32"), ("rte", "bf16x3"), ("zipf", "bf16x3")])
+@pytest.mark.parametrize("variant,precision", [("plain", "bf16x3"), ("plain", "fp32"), ("rte", "bf16x3"), ("zipf", "bf16x3"),
+                                               ("plain", "f16x3"), ("rte", "f16x3"), ("zipf", "f16x3")])
 def test_benchmark_configuration_sampled_parity(variant, precision):
     """BASELINE.json configs[1] AT ITS OWN SIZE (T4 R8, 1M nodes / 10M edges, d=256, H=8; bench.py's recipe): the 512-edge work
     items, full-occupancy fused workgroups and the 10M-edge plan that produce the headline number.  ~2000 sampled target rows
@@ -876,7 +891,7 @@ def test_benchmark_configuration_sampled_parity(variant, precision):
     print("c2 full size (%s, %s): %d rows, %d edges, max in-degree %d, max|err| %.2e" % (
         variant, precision, tg.numel(), eis.size(1), int(torch.bincount(eis[1]).max()), err))
     assert torch.isfinite(out).all()
-    assert err < TOL
+    assert err < PREC_TOL[precision]
     del out, x
     GraphPlan.clear_cache()
     torch.cuda.empty_cache()
@@ -891,8 +906,9 @@ FUSED_CASES = [
 ]
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
 @pytest.mark.parametrize("case", FUSED_CASES, ids=[str(i) for i in range(len(FUSED_CASES))])
-def test_fused_aggregate_update_matches_oracle(case):
+def test_fused_aggregate_update_matches_oracle(case, precision):
     """hgt_edge_aggregate_update only runs for >= 65536 targets with the split-bf16 precision: the small oracle cases do
     not reach it.  Unknown node types (rows must be 0) and unclaimed relations included."""
     N, E, d, H, T, R, use_norm, use_RTE, gk = case
@@ -906,12 +922,41 @@ def test_fused_aggregate_update_matches_oracle(case):
         ei[1, :3000] = 12_345
         ei[1, 3000:5000] = 70_001
     ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, use_norm=use_norm, use_RTE=use_RTE, dtype=torch.float64)
-    layer = _layer_from(sd, d, T, R, H, use_norm, use_RTE, keep_att=False, precision="bf16x3")
+    layer = _layer_from(sd, d, T, R, H, use_norm, use_RTE, keep_att=False, precision=precision)
     out, _ = _run(layer, x, nt, ei, et, tm if use_RTE else None)
     err = (out.double() - ref).abs().max().item()
-    print("fused case N=%d E=%d d=%d H=%d: max|out| err %.2e" % (N, E, d, H, err))
-    assert err < TOL
+    print("fused case N=%d E=%d d=%d H=%d %s: max|out| err %.2e" % (N, E, d, H, precision, err))
+    assert err < PREC_TOL[precision]
     assert out[nt == T + 3].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("order", ["small_first", "large_first"])
+@pytest.mark.parametrize("N", [3000, 70_000])        # unfused (4 targets per wavefront) and fused (streaming walk) aggregation
+def test_f16_split_rows_of_very_different_size_per_relation(N, order):
+    """fp16 has 5 exponent bits: the aggregation scales the relation rows of a target by ONE power of two, chosen at the target's
+    first relation with 2^7 of headroom.  Here the sources of relation 0 are 10^6 times smaller (or larger) than those of the
+    other relations, so the scale has to move mid-target (with the accumulator rescale) -- and the tiny rows must neither flush the
+    result nor overflow it.  No LayerNorm: the output keeps the raw magnitudes; the error is measured relative to each row."""
+    d, H, T, R = 64, 4, 2, 4
+    E = 6 * N
+    sd = O.make_state_dict(d, d, T, R, H, False, False, seed=31)
+    for t in range(T):
+        sd["v_linears.%d.bias" % t].zero_()          # V = x W_v: the rows inherit the scale of the source features
+        sd["q_linears.%d.weight" % t].zero_()        # Q, K = their biases: logits of size 10^6 would make the fp32 softmax itself
+        sd["k_linears.%d.weight" % t].zero_()        # (in the reference too) the dominant error
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=77)
+    et = torch.where(ei[0] < N // 2, torch.zeros_like(et), 1 + et % (R - 1))
+    lo, hi = (slice(0, N // 2), slice(N // 2, N)) if order == "small_first" else (slice(N // 2, N), slice(0, N // 2))
+    x = x.clone()
+    x[lo] *= 1e-3
+    x[hi] *= 1e3
+    ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, None, use_norm=False, use_RTE=False, dtype=torch.float64)
+    layer = _layer_from(sd, d, T, R, H, False, False, keep_att=False, precision="f16x3")
+    out, _ = _run(layer, x, nt, ei, et, None)
+    assert torch.isfinite(out).all()
+    rel = ((out.double() - ref).abs().amax(dim=1) / ref.abs().amax(dim=1).clamp_min(1e-30)).max().item()
+    print("f16x3 rows 1e-3 / 1e+3 (%s, N=%d): max row-relative err %.2e" % (order, N, rel))
+    assert rel < 1e-5
 
 
 def test_classifier_and_matcher_heads():
