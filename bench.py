@@ -211,7 +211,7 @@ def small_regime(dev):
     ref = torch.from_numpy(z["out"])
     res["c1"] = {"workload": "BASELINE.json configs[0]: T=%d R=%d N=%d E=%d d=%d H=%d use_RTE=%s (tests/golden/c1_full.npz: the reference's "
                              "own output is the checker)" % (T, R, N, E, d, H, bool(use_rte))}
-    for prec in ("bf16x3", "fp32"):
+    for prec in ("bf16x3", "f16x3", "fp32"):
         layer = HGTConv(d, d, T, R, H, 0.2, bool(use_norm), bool(use_rte), precision=prec).eval()
         layer.load_state_dict(sd)
         layer = layer.to(dev)
@@ -240,7 +240,7 @@ def small_regime(dev):
                  "plan_from_sorted_us": wall_us(lambda: GraphPlan.from_sorted(dg[1], dg[3], dg[4], dg[2], src32, dst32, time32, rel_ptr,
                                                                               type_off, T, R), 50, 5)}
     alg = algorithmic_bytes(N, E, d, True)["layer"]
-    for prec in ("bf16x3", "fp32"):
+    for prec in ("bf16x3", "f16x3", "fp32"):
         layer = HGTConv(d, d, T, R, H, 0.2, True, True, precision=prec).eval()
         layer.load_state_dict(sd)
         layer = layer.to(dev)
@@ -265,7 +265,7 @@ def small_regime(dev):
                                 "(tests/golden/%s.npz: rows of the verbatim reference GNN's output are the checker)" % (
                                     "BASELINE.json configs[4] surrogate" if key == "c5" else "published ogbn-mag model on a configs[2]-sized batch",
                                     c["schema"], ntc.numel(), etc_.numel(), c["in_dim"], c["n_hid"], c["T"], c["R"], c["H"], c["n_layers"], name)}
-        for prec in ("bf16x3", "fp32"):
+        for prec in ("bf16x3", "f16x3", "fp32"):
             gnn = GNN(c["in_dim"], c["n_hid"], c["T"], c["R"], c["H"], c["n_layers"], 0.2, "hgt", c["prev_norm"], c["last_norm"],
                       c["use_RTE"]).eval()
             gnn.load_state_dict(sd)
@@ -353,7 +353,8 @@ def replicas_c5(args, world, rank, dev, backend_name):
         line = {"metric": "GNN forward edges/sec (independent sampled batches)", "value": all_edges / elapsed, "unit": "edges/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32 (typed linears and relation transforms as 3-term split-bf16 MFMA, fp32 accumulate)" if args.precision == "bf16x3" else "f32",
+                "dtype": {"bf16x3": "f32 (typed linears and relation transforms as 3-term split-bf16 MFMA, fp32 accumulate)",
+                          "f16x3": "f32 (typed linears and relation transforms as 3-term fp16 hi/lo MFMA, fp32 accumulate)"}.get(args.precision, "f32"),
                 "data": "synthetic",
                 "config": {"workload": "BASELINE.json configs[4] surrogate, replicas only: sampler-shaped OAG batches (T=5, R=33, ~4.1k nodes / "
                                        "~41k edges), 2-layer GNN in_dim 1169 -> n_hid 400, 8 heads, use_RTE=True, device-side hand-off, plans cached; "
@@ -392,7 +393,7 @@ def main():
     ap.add_argument("--halo-c24", action="store_true", help="multi-GPU: ship halo rows in the 24-bit transport format in the JUDGED run "
                     "(default: exact fp32 rows; the 24-bit variant is then reported as a secondary figure)")
     ap.add_argument("--halo-fp32", action="store_true", help=argparse.SUPPRESS)   # the default now; kept for old command lines
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f16x3", "fp32"],
                     help="typed linears / relation transforms: 3-term split-bf16 MFMA with fp32 accumulation (default; parity-tested "
                          "at 1e-4) or exact fp32")
     ap.add_argument("--kernel-flags", type=int, default=0, help="hgt_conv_args.flags (HGT_FLAG_*), A/B runs")
@@ -588,18 +589,18 @@ def main():
     secondary = {}
     if not args.no_secondary:
         if world == 1:
-            other = "fp32" if args.precision == "bf16x3" else "bf16x3"
-            lay2 = make_layer(other)
-            sd2 = {k: v.detach().cpu() for k, v in lay2.state_dict().items()}
-            out2, el2, ph2, med2 = timed(make_step(lay2), args.steps, 2)
-            ms2 = el2 / args.steps * 1e3
-            par2 = check(out2, sd2)
-            secondary["precision_" + other] = {
-                "ms_per_step": ms2, "median_ms_per_step": med2, "edges_per_s": El / (ms2 * 1e-3),
-                "layer_frac": round(alg["layer"] / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "phase_ms": {p: round(v, 4) for p, v in ph2.items()},
-                "parity_max_abs_err": None if par2 is None else par2["max_abs_err"]}
-            del out2, lay2
+            for other in [p for p in ("bf16x3", "f16x3", "fp32") if p != args.precision]:
+                lay2 = make_layer(other)
+                sd2 = {k: v.detach().cpu() for k, v in lay2.state_dict().items()}
+                out2, el2, ph2, med2 = timed(make_step(lay2), args.steps, 2)
+                ms2 = el2 / args.steps * 1e3
+                par2 = check(out2, sd2)
+                secondary["precision_" + other] = {
+                    "ms_per_step": ms2, "median_ms_per_step": med2, "edges_per_s": El / (ms2 * 1e-3),
+                    "layer_frac": round(alg["layer"] / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "phase_ms": {p: round(v, 4) for p, v in ph2.items()},
+                    "parity_max_abs_err": None if par2 is None else par2["max_abs_err"]}
+                del out2, lay2
         else:
             out2, el2, ph2, med2 = timed(make_step(layer, compress=not args.halo_c24), args.steps, 2)
             ms2 = el2 / args.steps * 1e3
@@ -669,7 +670,9 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(d, H, T, R)
-        prec_note = {"fp32": "f32", "bf16x3": "f32 (typed linears and relation transforms as 3-term split-bf16 MFMA, fp32 accumulate)"}
+        prec_note = {"fp32": "f32", "bf16x3": "f32 (typed linears and relation transforms as 3-term split-bf16 MFMA, fp32 accumulate)",
+                     "f16x3": "f32 (typed linears and relation transforms as 3-term fp16 hi/lo MFMA with power-of-two row scales, "
+                              "fp32 accumulate)"}
         line = {
             "metric": "HGTConv forward edges/sec", "value": value, "unit": "edges/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "median_ms_per_step": median_ms,
@@ -687,7 +690,7 @@ def main():
                        "halo_format": None if world == 1 else ("24-bit (sign, 8 exp, 15 mantissa; fp32 arithmetic)" if pg.compress else "fp32"),
                        "halo_chunks": 0 if world == 1 else int(pg.halo.n_chunks),
                        "edge_phase": None if world == 1 else ("source-bucketed, overlaps the exchange (hgt_conv_forward stages 1/2/4)"
-                                                              if pg.bucketed and args.precision == "bf16x3" else
+                                                              if pg.bucketed and args.precision != "fp32" else
                                                               "after the last halo chunk (stages 1/2/3)"),
                        "parallelism": "single" if world == 1 else "dst-partition x%d + RCCL all-to-all halo" % world,
                        "backend": backend_name + (" (RCCL)" if backend_name == "nccl" else ""),

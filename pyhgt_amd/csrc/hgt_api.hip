@@ -398,8 +398,9 @@ edge_phase:
         mark(5);
         if (!no_unknown_rows) rc = hgt_zero_rows(pr.rows_q, pr.off_q + T, dout, a->out, stream);   // nodes of unknown type -> 0 (conv.py:120)
     } else {
+        // (rows wider than 256 columns, e.g. n_hid = 400: the image of W_a is kept with the prepared weights like the fused forms')
         rc = linear(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, a->w_a, (int64_t)dout * dp, a->b_a, dout, trans, nullptr, nullptr, dout,
-                    0, ws_a);
+                    0, ws_upd, 0, pb && !fresh);
         if (rc != HGT_OK) return rc;
         mark(5);
         rc = hgt_node_update(trans, a->x, din, a->node_type, a->skip, a->ln_w, a->ln_b, a->use_norm, NQ, dout, T, a->out, stream);

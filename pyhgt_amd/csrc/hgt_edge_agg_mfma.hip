@@ -101,28 +101,56 @@ __global__ __launch_bounds__(1024) void k_msg_scale(const float* __restrict__ ms
 }
 
 // fp16 split of the U rows (F16): every TARGET of a sub-tile has one power-of-two scale sigma_t for all its relations (its rows
-// of all relations are summed into one accumulator column), kept in LDS (s_sig, 0 = not set yet).  It is chosen when the
-// target's first row is parked -- row maximum -> [2^8, 2^9): 2^7 of headroom for the rows of its other relations -- and moved
-// (with a rescale of the target's accumulator column, exactly like a move of the softmax reference) in the rare case that a
-// later row would leave the fp16 range.  1 / sigma_t joins the softmax normalisation at the end.
+// of all relations are summed into one accumulator column).  The wavefront keeps the 16 scales in ONE register, lane i = target
+// i (sigv; thrv = 2^15 / sigma_t, 0 = not set yet), read with v_readlane -- an LDS table cost a dependent LDS round trip per
+// parked row, +0.55 ms at the benchmark size.  sigma_t is chosen when the target's first row is parked -- row maximum ->
+// [2^8, 2^9): 2^7 of headroom for the rows of its other relations -- and the common case afterwards is ONE compare of the lane's
+// own maximum with the threshold (no cross-lane reduction); only a row that would leave the fp16 range takes the slow path
+// again, which moves sigma_t and rescales the target's accumulator column (exactly like a move of the softmax reference).
+// 1 / sigma_t joins the softmax normalisation at the end.
 template <int VEC>
-__device__ __forceinline__ float f16_target_scale(const float (&U)[VEC], float* s_sig, int dl, float& rescale) {
-    float m = fabsf(U[0]);
+__device__ __forceinline__ float f16_target_scale(const float (&U)[VEC], float& sigv, float& thrv, float& rescv, int& resc_any, int dl_) {
+    const int dl = __builtin_amdgcn_readfirstlane(dl_);
+    float m;
+    if constexpr (VEC == 4) {     // two instructions (fmaxf(fabsf()) chains cost four: hipcc canonicalises every operand)
+        asm("v_max3_f32 %0, |%1|, |%2|, |%3|\n\tv_max_f32 %0, %0, |%4|" : "=&v"(m) : "v"(U[0]), "v"(U[1]), "v"(U[2]), "v"(U[3]));
+    } else {
+        m = fabsf(U[0]);
 #pragma unroll
-    for (int i = 1; i < VEC; ++i) m = fmaxf(m, fabsf(U[i]));
+        for (int i = 1; i < VEC; ++i) m = fmaxf(m, fabsf(U[i]));
+    }
+    const float thr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thrv), dl));
+    const unsigned sb = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, sigv), dl);
+    if (__builtin_amdgcn_ballot_w64(m >= thr) == 0) return __builtin_bit_cast(float, sb);      // fits under the target's scale
     unsigned e = wave_max_bits(__builtin_bit_cast(unsigned, m)) >> 23;       // biased exponent of the row maximum, wave-uniform
-    const unsigned sb = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, s_sig[dl]));
     const unsigned se = sb >> 23;                                              // biased exponent of sigma_t (0 = unset)
-    rescale = 1.0f;
     if (e < 40u) return se != 0u ? __builtin_bit_cast(float, sb) : 1.0f;       // an all-zero (or vanishing) row decides nothing
     e = e > 220u ? 220u : e;
-    // scaled row maximum = 2^((e - 127) + (se - 127)) .. must stay below 2^15
-    if (se != 0u && e + se < 254u + 15u) return __builtin_bit_cast(float, sb);
     const unsigned ne = 127u + 8u + 127u - e;                                 // sigma = 2^(8 - (e - 127))
     const float sig = __builtin_bit_cast(float, ne << 23);
-    if (se != 0u) rescale = __builtin_bit_cast(float, (127u + ne - se) << 23);   // sigma_new / sigma_old (< 1)
-    if ((threadIdx.x & 63) == 0) s_sig[dl] = sig;
+    const bool mine = (int)(threadIdx.x & 63) == dl;
+    if (se != 0u) {      // sigma moves: the target's accumulator column follows at the relation's end (f16_apply_rescale) -- done
+                         // here, the structurizer merged this rare branch into the common paths through 64 accumulator copies
+        const int de = 127 + (int)ne - (int)se;                                    // sigma_new / sigma_old (< 1) = 2^(ne - se)
+        const float rescale = de > 0 ? __builtin_bit_cast(float, (unsigned)de << 23) : 0.0f;   // (below 2^-126: what was summed is nothing)
+        rescv = mine ? rescv * rescale : rescv;
+        resc_any = 1;
+    }
+    sigv = mine ? sig : sigv;
+    thrv = mine ? __builtin_bit_cast(float, (127u + 15u + 127u - ne) << 23) : thrv;      // 2^15 / sigma
     return sig;
+}
+
+// the pending moves of sigma_t (f16_target_scale) applied to the accumulator columns, before the relation's products are added
+template <int NCT>
+__device__ __forceinline__ void f16_apply_rescale(float& rescv, int& resc_any, f32x4 (&acc)[NCT]) {
+    if (resc_any) {
+        const float f = __shfl(rescv, (int)(threadIdx.x & 15));
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[c] *= f;
+        rescv = 1.0f;
+        resc_any = 0;
+    }
 }
 
 template <int VEC>
@@ -141,6 +169,8 @@ __device__ __forceinline__ void agg_mfma_subtile(
     using G = MG<VEC, LPH>;
     constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS;
     constexpr int UN = agg_unroll<VEC>(RTE);
+    float sigv = 0.0f, thrv = 0.0f, rescv = 1.0f;   // fp16 split: the targets' scales / thresholds / pending moves, lane i = target i
+    int resc_any = 0;
     if constexpr (F16) { if ((threadIdx.x & 63) < 16) s_sig[threadIdx.x & 63] = 0.0f; }
     const int hg = blockIdx.y;              // head group (head-group split: the wave covers DP of the HT * DKP columns)
     const int64_t ld = (int64_t)HT * DKP;
@@ -204,12 +234,7 @@ __device__ __forceinline__ void agg_mfma_subtile(
                         unsigned char* w = utile + dl * ROWB + ((((wb >> 4) ^ (dl & (NS - 1)))) << 4) + (wb & 15);
                         float sig = 1.0f;
                         if constexpr (F16) {
-                            float resc;
-                            sig = f16_target_scale<VEC>(U, s_sig, dl, resc);
-                            if (resc != 1.0f) {
-#pragma unroll
-                                for (int c = 0; c < NCT; ++c) acc[c] *= (fi == dl) ? resc : 1.0f;
-                            }
+                            sig = f16_target_scale<VEC>(U, sigv, thrv, rescv, resc_any, dl);
                         }
                         if constexpr (VEC == 1) {
                             unsigned short hi, mid;
@@ -318,6 +343,7 @@ __device__ __forceinline__ void agg_mfma_subtile(
             flush();
         }
         if (rowmask == 0) continue;   // no claimed edge in this relation: nothing to transform
+        if constexpr (F16) f16_apply_rescale<NCT>(rescv, resc_any, acc);
 
         // rows without an edge in this relation contribute nothing: zero them (rows >= SUBR are never read back: every
         // column of the transposed product depends on its own row only)
@@ -360,6 +386,7 @@ __device__ __forceinline__ void agg_mfma_subtile(
         }
         __builtin_amdgcn_wave_barrier();   // the tile is rewritten by the next relation only after every lane has read it
     }
+    if constexpr (F16) { if ((threadIdx.x & 63) < 16) s_sig[threadIdx.x & 63] = sigv; }      // for agg_mfma_finish
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -384,6 +411,8 @@ __device__ __forceinline__ void agg_mfma_stream(
     f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
     using G = MG<VEC, LPH>;
     constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS;
+    float sigv = 0.0f, thrv = 0.0f, rescv = 1.0f;   // fp16 split: the targets' scales / thresholds / pending moves, lane i = target i
+    int resc_any = 0;
     if constexpr (F16) { if ((threadIdx.x & 63) < 16) s_sig[threadIdx.x & 63] = 0.0f; }
 #ifndef HGT_AGG_UN
 #define HGT_AGG_UN 4
@@ -470,12 +499,7 @@ __device__ __forceinline__ void agg_mfma_stream(
                 unsigned char* w = utile + dl * ROWB + ((((wb >> 4) ^ (dl & (NS - 1)))) << 4) + (wb & 15);
                 float sig = 1.0f;
                 if constexpr (F16) {
-                    float resc;
-                    sig = f16_target_scale<VEC>(U, s_sig, dl, resc);
-                    if (resc != 1.0f) {
-#pragma unroll
-                        for (int c = 0; c < NCT; ++c) acc[c] *= (fi == dl) ? resc : 1.0f;
-                    }
+                    sig = f16_target_scale<VEC>(U, sigv, thrv, rescv, resc_any, dl);
                 }
                 if constexpr (VEC == 1) {
                     unsigned short hi, mid;
@@ -507,6 +531,7 @@ __device__ __forceinline__ void agg_mfma_stream(
     static_assert(STEPS % GS == 0, "column-tile steps come in multiples of 4 (DP is a multiple of 64)");
     auto relation_end = [&](int rel) {
         if (rowmask == 0) return;
+        if constexpr (F16) f16_apply_rescale<NCT>(rescv, resc_any, acc);
         for (int r = 0; r < SUBR; ++r) {
             if ((rowmask >> r) & 1u) continue;
             unsigned char* w = utile + r * ROWB + ((((wb >> 4) ^ (r & (NS - 1)))) << 4) + (wb & 15);
@@ -677,6 +702,7 @@ __device__ __forceinline__ void agg_mfma_stream(
     }
     flush();
     relation_end(cur_rel);
+    if constexpr (F16) { if ((threadIdx.x & 63) < 16) s_sig[threadIdx.x & 63] = sigv; }      // for agg_mfma_finish
 #undef AGG_ISSUE
 #undef AGG_LOAD
 #undef AGG_WAIT

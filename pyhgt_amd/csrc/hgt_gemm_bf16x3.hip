@@ -92,25 +92,33 @@ __global__ __launch_bounds__(1024) void k_group_scale(const float* __restrict__ 
 // must be the same for all its panels, so the row maximum is taken over the whole row first (one more pass over x; K > 256 only).
 template <int PROLOGUE>
 __device__ __forceinline__ void row_scales_all_panels(int tid, const int* s_rid, const float* __restrict__ x, int64_t ldx, int k,
-                                                      unsigned* s_bits, float* s_scale, float* s_inv) {
-    if (tid < BM) s_bits[tid] = 0u;
-    __syncthreads();
-    for (int kp0 = 0; kp0 < k; kp0 += KP) {
-        for (int f = tid; f < BM * 64; f += 512) {
-            const int kk = kp0 + (f & 63) * 4, rid = s_rid[f >> 6];
-            if (rid < 0 || kk >= k) continue;
-            const float* px = x + (int64_t)rid * ldx + kk;
-            float m = 0.0f;
-            for (int e = 0; e < 4 && kk + e < k; ++e) {
-                float a = px[e];
-                if (PROLOGUE == 1) a = gelu_erf_(a);
-                m = fmaxf(m, fabsf(a));
+                                                      int vec_ok, float* s_scale, float* s_inv) {
+    // wave w owns rows w, w + 8, ... (the mapping of load_a_panel): the 64 lanes walk the row 16 B each, one wave reduction
+    // per row (the first version: scalar loads + an LDS atomicMax per lane -- 22 us on a 3000-row sampled batch)
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < BM / 8; ++j) {
+        const int r = wave + 8 * j, rid = s_rid[r];
+        unsigned mb = 0u;
+        if (rid >= 0) {
+            for (int kk = lane * 4; kk < k; kk += 256) {
+                const float* px = x + (int64_t)rid * ldx + kk;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (vec_ok && kk + 3 < k) {
+                    a = *reinterpret_cast<const float4*>(px);
+                } else {
+                    a.x = px[0];
+                    if (kk + 1 < k) a.y = px[1];
+                    if (kk + 2 < k) a.z = px[2];
+                    if (kk + 3 < k) a.w = px[3];
+                }
+                if (PROLOGUE == 1) { a.x = gelu_erf_(a.x); a.y = gelu_erf_(a.y); a.z = gelu_erf_(a.z); a.w = gelu_erf_(a.w); }
+                mb = max(mb, abs_bits4(a));
             }
-            atomicMax(&s_bits[f >> 6], __builtin_bit_cast(unsigned, m));
         }
+        mb = wave_max_bits(mb);
+        if (lane == 0) f16_row_scale(mb, s_scale[r], s_inv[r]);
     }
-    __syncthreads();
-    if (tid < BM) f16_row_scale(s_bits[tid], s_scale[tid], s_inv[tid]);
     __syncthreads();
 }
 
@@ -119,7 +127,8 @@ __device__ __forceinline__ void row_scales_all_panels(int tid, const int* s_rid,
 // so that two workgroups fit a CU; an 8-deep version spilled ~230 B per lane to scratch = +2.9 GB of HBM traffic at c2).
 template <int PROLOGUE, bool F16>
 __device__ __forceinline__ void load_a_panel(int kp0, int tid, const int* s_rid, const float* __restrict__ x, int64_t ldx, int k,
-                                             int vec_ok, unsigned char* sA, bool wait_readers, const float* s_scale) {
+                                             int vec_ok, unsigned char* sA, bool wait_readers, float* s_scale, float* s_inv,
+                                             bool single) {      // single (F16): K fits one panel, the row scales are found here
     if (wait_readers) __syncthreads();   // every wave is done reading the previous panel
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -149,7 +158,17 @@ __device__ __forceinline__ void load_a_panel(int kp0, int tid, const int* s_rid,
             const int f = tid + 512 * (half * 4 + j);
             const int r = f >> 6, cb = (f & 63) * 8;
             uint2 hi, mid;
-            split4_t<F16>(av[j], F16 ? s_scale[r] : 1.0f, hi, mid);
+            float scale = 1.0f;
+            if constexpr (F16) {
+                if (single) {      // the wavefront holds the whole row (64 lanes x 4 columns)
+                    float inv;
+                    f16_row_scale(wave_max_bits(abs_bits4(av[j])), scale, inv);
+                    if ((tid & 63) == 0) s_inv[r] = inv;
+                } else {
+                    scale = s_scale[r];
+                }
+            }
+            split4_t<F16>(av[j], scale, hi, mid);
             *reinterpret_cast<uint2*>(sA + r * A_STRIDE + cb) = hi;
             *reinterpret_cast<uint2*>(sA + A_PLANE + r * A_STRIDE + cb) = mid;
         }
@@ -295,7 +314,6 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     __shared__ __attribute__((aligned(16))) unsigned char sA[2 * A_PLANE];        // [plane][64][528]
     __shared__ int s_rid[BM];
     __shared__ float s_scale[F16 ? BM : 1], s_inv[F16 ? BM : 1];                   // fp16 split: row scales and their inverses
-    __shared__ unsigned s_bits[F16 ? BM : 1];
 
     // pass_split = n_pass (small problems: fewer row tiles than CUs): a workgroup owns ONE 256-column pass of a row tile, so that
     // tiles x passes workgroups share the work (sampled sub-graphs of a few thousand nodes: 50-64 row tiles for 256 CUs);
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     float winv = 1.0f;                               // inverse of the group's weight scale: the image's tail (hgt_split_weights_f16)
     if constexpr (F16) {
         winv = reinterpret_cast<const float*>(wsplit + (int64_t)n_groups * total * 2 * W_PLANE_ELEMS)[g];
-        row_scales_all_panels<PROLOGUE>(tid, s_rid, x, ldx, k, s_bits, s_scale, s_inv);
+        if (n_panel > 1) row_scales_all_panels<PROLOGUE>(tid, s_rid, x, ldx, k, vec_ok, s_scale, s_inv);
     }
 
     f32x16 acc[2];
@@ -362,7 +380,7 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     HGT_LOAD_STAGE(3, pass_lo * n_kc + 3)
 #endif
 
-    load_a_panel<PROLOGUE, F16>(0, tid, s_rid, x, ldx, k, vec_ok, sA, false, s_scale);
+    load_a_panel<PROLOGUE, F16>(0, tid, s_rid, x, ldx, k, vec_ok, sA, false, s_scale, s_inv, n_panel == 1);
 
 #define HGT_STEP(S, T, KCP)                                                                                        \
     {                                                                                                              \
@@ -384,7 +402,7 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
 
     for (int pass = pass_lo; pass < pass_hi; ++pass) {
         for (int panel = 0; panel < n_panel; ++panel) {
-            if (n_panel > 1 && (pass != pass_lo || panel != 0)) load_a_panel<PROLOGUE, F16>(panel * KP, tid, s_rid, x, ldx, k, vec_ok, sA, true, s_scale);
+            if (n_panel > 1 && (pass != pass_lo || panel != 0)) load_a_panel<PROLOGUE, F16>(panel * KP, tid, s_rid, x, ldx, k, vec_ok, sA, true, s_scale, s_inv, false);
             const int nkc_p = min(KP / KC, n_kc - panel * (KP / KC));
             const int tbase = pass * n_kc + panel * (KP / KC);
             for (int kq = 0; kq < nkc_p; kq += 4) {

@@ -27,6 +27,9 @@ def timeit(fn, iters=200, warm=20):
     return (time.perf_counter() - t0) / iters * 1e6
 
 
+PRECS = tuple(os.environ.get("HGT_SMALL_PRECS", "bf16x3,f16x3,fp32").split(","))      # e.g. HGT_SMALL_PRECS=f16x3 under rocprofv3
+
+
 def main():
     dev = "cuda:0"
     res = {}
@@ -44,7 +47,7 @@ def main():
     us_sorted = timeit(lambda: GraphPlan.from_sorted(dg[1], dg[3], dg[4], dg[2], src32, dst32, time32, rel_ptr, type_off, T, R),
                        iters=100, warm=10)
     res["c3"] = {"N": N, "E": E, "plan_build_us": us_build, "plan_from_sorted_us": us_sorted}
-    for prec in ("bf16x3", "fp32"):
+    for prec in PRECS:
         layer = HGTConv(d, d, T, R, H, 0.2, True, True, precision=prec).eval().to(dev)
         plan = GraphPlan(nt, ei, et, tm, T, R)
         with torch.no_grad():
@@ -58,7 +61,7 @@ def main():
     T, R, d, H, din = 5, len(edge_dict), 400, 8, 1169
     N, E = nt.numel(), et.numel()
     res["c5"] = {"N": N, "E": E}
-    for prec in ("bf16x3", "fp32"):
+    for prec in PRECS:
         gnn = GNN(din, d, T, R, H, 2, prev_norm=True, last_norm=True, use_RTE=True).eval().to(dev)
         for gc in gnn.gcs:
             gc.base_conv.precision = prec
