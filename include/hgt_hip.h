@@ -218,6 +218,14 @@ int hgt_relation_pack(const float* relation_att, const float* relation_msg, cons
 int hgt_edge_logits(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                     int32_t n_heads, int32_t dk_pad, const float* Q, const float* K, const float* rte_k,
                     const float* att_t, float* logits, void* stream);
+/* ABI 5: the same logits with the target-side transform  q~ = q A'[r]  on the matrix cores: att_frag = hgt_relation_frag_pack(att_t)
+ * (frag_f16 = 0) or hgt_relation_frag_pack_f16(att_t) (frag_f16 = 1), 16 distinct targets of a work item at a time, 3-term split
+ * products like the aggregation's.  The form for d_k >= 64 (the reference's own widths: n_hid 400 / 512 with 8 heads), where the
+ * vector-ALU kernel needs a 4-way head-group split and is instruction-bound; layouts it does not cover fall through to
+ * hgt_edge_logits (att_t is required for that). */
+int hgt_edge_logits_mfma(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                         int32_t n_heads, int32_t dk_pad, const float* Q, const float* K, const float* rte_k,
+                         const float* att_t, const void* att_frag, int32_t frag_f16, float* logits, void* stream);
 int hgt_edge_softmax(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                      int32_t n_heads, float* logits_att, void* stream);
 int hgt_edge_aggregate(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
@@ -463,6 +471,8 @@ typedef struct hgt_conv_args {
 /* hgt_conv_args.flags: explicit kernel-selection switches (A/B measurements, tests); never read from the environment */
 #define HGT_FLAG_NO_FUSED_UPDATE 1   /* aggregation writes agg, the node update runs as its own kernel(s) */
 #define HGT_FLAG_VALU_AGGREGATE  2   /* relation transforms of the aggregation on the vector ALU (round-1 kernel) instead of MFMA */
+#define HGT_FLAG_MFMA_LOGITS     4   /* hgt_edge_logits_mfma for every layout it covers (default: d_k >= 64 only) */
+#define HGT_FLAG_VALU_LOGITS     8   /* never hgt_edge_logits_mfma */
 
 /* phase boundaries at which hgt_conv_forward records phase_events[i]:
  *   0 start | 1 relation pack + Q/K/V (+ temporal tables) done | 2 logits done | 3 softmax done |

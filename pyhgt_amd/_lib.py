@@ -86,6 +86,7 @@ SIGNATURES = {
     "hgt_zero_rows": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "hgt_relation_pack": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "hgt_edge_logits": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hgt_edge_logits_mfma": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "hgt_edge_logits_slice": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "hgt_edge_aggregate_slice": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp,
                                            _i32, _i32, _vp, _i32, _i32, _vp]),

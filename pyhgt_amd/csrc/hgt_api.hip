@@ -5,7 +5,7 @@
 namespace {
 
 struct ConvWorkspace {
-    uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p, off_msg_f, off_hub;
+    uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p, off_msg_f, off_att_f, off_hub;
     uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, off_ws_qkv, off_ws_a, off_ws_rte, off_off2, off_pending, off_state, total;
 };
 
@@ -27,6 +27,7 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
     uint64_t fb = 0;
     hgt_relation_frag_bytes(R, H, lay.dk_pad, &fb);
     w.off_msg_f = take(fb);
+    w.off_att_f = take(fb);
     uint64_t hb = 0;
     hgt_hub_workspace_bytes(E, H, lay.dk_pad, &hb);
     w.off_hub = take(hb);
@@ -64,7 +65,7 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
 }
 
 struct PreparedLayout {
-    uint64_t off_att_t, off_msg_p, off_msg_f, off_ws_qkv, off_ws_upd, off_rte_k, off_rte_v, total;
+    uint64_t off_att_t, off_msg_p, off_msg_f, off_att_f, off_ws_qkv, off_ws_upd, off_rte_k, off_rte_v, total;
 };
 
 static PreparedLayout prepared_layout(int in_dim, int out_dim, int T, int R, int /*n_heads*/, int use_rte, const hgt_layout& lay) {
@@ -76,6 +77,7 @@ static PreparedLayout prepared_layout(int in_dim, int out_dim, int T, int R, int
     p.off_msg_p = take((uint64_t)R * H * lay.dk_pad * lay.dk_pad * 4);
     hgt_relation_frag_bytes(R, H, lay.dk_pad, &b);
     p.off_msg_f = take(b);
+    p.off_att_f = take(b);
     hgt_split_weights_bytes(T, in_dim, 3 * lay.d_pad, &b);
     p.off_ws_qkv = take(b);
     hgt_split_weights_bytes(T, lay.d_pad, out_dim, &b);
@@ -190,16 +192,21 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     void* hub_ws = (a->plan_no_hubs & 1) ? nullptr : (void*)(wb + w.off_hub);
     const bool no_unknown_rows = (a->plan_no_hubs & 2) != 0;     // the caller knows that every target row has a valid type
     void* msg_f = wb + w.off_msg_f;
+    void* att_f = wb + w.off_att_f;
     if (pb) {
         att_t = (float*)(pb + pl.off_att_t);
         msg_p = (float*)(pb + pl.off_msg_p);
         msg_f = pb + pl.off_msg_f;
+        att_f = pb + pl.off_att_f;
     }
     // relation transforms of the aggregation: matrix cores (split-bf16 x3) with the split precision, exact fp32 mat-vecs otherwise
     uint64_t frag_bytes = 0;
     hgt_relation_frag_bytes(R, H, lay.dk_pad, &frag_bytes);
     const bool mfma_agg = (a->precision >= 1) && frag_bytes > 0 && !(a->flags & HGT_FLAG_VALU_AGGREGATE);
     if (!mfma_agg) msg_f = nullptr;
+    // logits: the target-side transforms on the matrix cores where the vector-ALU kernel is instruction-bound (d_k >= 64)
+    const bool mfma_logits = (a->precision >= 1) && frag_bytes > 0 && !(a->flags & HGT_FLAG_VALU_LOGITS) && a->stage != 4 &&
+                             (lay.dk_pad >= 64 || (a->flags & HGT_FLAG_MFMA_LOGITS));
 
     auto mark = [&](int i) {
         if (a->phase_events && a->phase_events[i]) (void)hipEventRecord((hipEvent_t)a->phase_events[i], stream);
@@ -230,6 +237,11 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
         if (mfma_agg) {
             rc = f16 ? hgt_relation_frag_pack_f16(msg_p, R, H, lay.dk_pad, msg_f, stream)
                      : hgt_relation_frag_pack(msg_p, R, H, lay.dk_pad, msg_f, stream);
+            if (rc != HGT_OK) return rc;
+        }
+        if (mfma_logits) {
+            rc = f16 ? hgt_relation_frag_pack_f16(att_t, R, H, lay.dk_pad, att_f, stream)
+                     : hgt_relation_frag_pack(att_t, R, H, lay.dk_pad, att_f, stream);
             if (rc != HGT_OK) return rc;
         }
     }
@@ -313,7 +325,8 @@ edge_phase:
     // (4) edge phase: logits, then softmax fused into the aggregation (online, per target sub-tile)
     if (E > 0) {
         rc = sliced ? hgt_edge_logits_slice(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, sl_lo, sl_hi, stream)
-                    : hgt_edge_logits(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, stream);
+             : mfma_logits ? hgt_edge_logits_mfma(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, att_f, f16 ? 1 : 0, logits, stream)
+                           : hgt_edge_logits(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, stream);
         if (rc != HGT_OK) return rc;
     }
     mark(2);

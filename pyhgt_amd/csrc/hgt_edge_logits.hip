@@ -17,6 +17,10 @@
 // lanes with DPP.  Rows for the next UN edges are requested before the current ones are consumed.
 #include "hgt_edge_common.h"
 
+#ifndef HGT_LOGITS_XCD
+#define HGT_LOGITS_XCD 1
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -41,8 +45,20 @@ __global__ __launch_bounds__(256) void k_edge_logits(
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = blockIdx.x * 4 + wib;
-    if (item >= hdr->n_items) return;
+    // XCD-aware item order: workgroups are dealt to the 8 XCDs round-robin (linear id % 8), and the R + 1 items of a target tile
+    // (adjacent in the item list) all read the tile's Q rows.  XCD x takes the x-th CONTIGUOUS eighth of the item groups, so a
+    // tile's items meet in one L2 at about the same time instead of pulling the tile through eight of them (HGT_LOGITS_XCD=0:
+    // the plain order; gridDim.x is a multiple of 8)
+    const int n_items = hdr->n_items;
+#if HGT_LOGITS_XCD
+    const int n_groups = (n_items + 3) >> 2, per_xcd = (n_groups + 7) >> 3;
+    const int vblock = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd) return;
+#else
+    const int vblock = blockIdx.x;
+#endif
+    const int item = vblock * 4 + wib;
+    if (item >= n_items) return;
     const HgtItem it = items[item];
     const int beg = __builtin_amdgcn_readfirstlane(it.beg), end = __builtin_amdgcn_readfirstlane(it.end);
     const int rel = __builtin_amdgcn_readfirstlane(it.rel);
@@ -188,7 +204,7 @@ template <int VEC, int LPH>
 struct LaunchLogits {
     static int run(const HgtPlanView& pv, const float* Q, const float* K, const float* rteK, const float* attT, float* logits,
                    int R, int HT, int rel_lo, int rel_hi, hipStream_t stream) {
-        const unsigned blocks = (unsigned)((pv.L.max_items + 3) / 4);
+        const unsigned blocks = ((unsigned)((pv.L.max_items + 3) / 4) + 7u) & ~7u;      // (a multiple of 8: XCD-aware item order)
         dim3 grid(blocks, (unsigned)(HT / (64 / LPH)));
         if (rteK)
             k_edge_logits<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi);
@@ -211,14 +227,35 @@ extern "C" int hgt_relation_pack(const float* relation_att, const float* relatio
     return HGT_OK;
 }
 
+// hgt_edge_logits_mfma.hip
+int hgt_launch_logits_mfma(int vec, int lph, bool f16, const HgtPlanView& pv, const float* Q, const float* K, const float* rteK,
+                           const unsigned short* attF, float* logits, int R, int HT, int rel_lo, int rel_hi, hipStream_t stream);
+
+// head-group split of the matrix-core kernels (hgt_edge_agg_mfma.hip): the wave's slice must be <= 256 columns
+static int mfma_logits_split_for(int vec_full, int lph_full) {
+    int s = 1;
+    while (vec_full / s > 4 && lph_full * s * 2 <= 64) s *= 2;
+    return (vec_full / s <= 4) ? s : 0;
+}
+
 static int edge_logits_impl(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad, const float* Q,
-                            const float* K, const float* rte_k, const float* att_t, float* logits, int rel_lo, int rel_hi, void* stream) {
+                            const float* K, const float* rte_k, const float* att_t, float* logits, int rel_lo, int rel_hi, void* stream,
+                            const void* att_frag = nullptr, int frag_f16 = 0) {
     if (!plan || !Q || !K || !att_t || !logits || H <= 0 || 64 % H != 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
     if (rel_lo < 0 || rel_hi > R + 1 || rel_lo > rel_hi) return HGT_ERR_INVALID_ARG;
     if (E == 0) return HGT_OK;
     const int lph = 64 / H;
     if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
     HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
+    if (att_frag) {      // target-side transforms on the matrix cores; layouts it does not cover take the vector-ALU kernel below
+        const int spm = mfma_logits_split_for(dk_pad / lph, lph);
+        if (spm != 0) {
+            int rc = hgt_launch_logits_mfma(dk_pad / lph / spm, lph * spm, frag_f16 != 0, pv, Q, K, rte_k, (const unsigned short*)att_frag,
+                                            logits, (int)R, (int)H, rel_lo, rel_hi, (hipStream_t)stream);
+            if (rc == HGT_OK) HGT_CHECK_LAUNCH();
+            if (rc != HGT_ERR_UNSUPPORTED) return rc;
+        }
+    }
     const int sp = head_split_for(dk_pad / lph, lph, dk_pad);
     int rc = dispatch_layout<LaunchLogits>(dk_pad / lph / sp, lph * sp, pv, Q, K, rte_k, att_t, logits, (int)R, (int)H, rel_lo, rel_hi,
                                            (hipStream_t)stream);
@@ -230,6 +267,13 @@ static int edge_logits_impl(const void* plan, int64_t N, int64_t E, int32_t T, i
 extern "C" int hgt_edge_logits(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
                                const float* Q, const float* K, const float* rte_k, const float* att_t, float* logits, void* stream) {
     return edge_logits_impl(plan, N, E, T, R, H, dk_pad, Q, K, rte_k, att_t, logits, 0, R + 1, stream);
+}
+
+extern "C" int hgt_edge_logits_mfma(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                    const float* Q, const float* K, const float* rte_k, const float* att_t, const void* att_frag,
+                                    int32_t frag_f16, float* logits, void* stream) {
+    if (!att_frag) return HGT_ERR_INVALID_ARG;
+    return edge_logits_impl(plan, N, E, T, R, H, dk_pad, Q, K, rte_k, att_t, logits, 0, R + 1, stream, att_frag, frag_f16);
 }
 
 extern "C" int hgt_edge_logits_slice(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,

@@ -1,0 +1,288 @@
+// Attention logits (conv.py:98-99,104) with the target-side relation transform on the matrix cores.
+//
+//     s_e,h = < q~_(i,r),h , k_j,h >,   q~_(i,r) = q_i blockdiag_h(A'[r,h])        (hgt_edge_logits.hip: algebra, A' = att_t)
+//
+// k_edge_logits evaluates q~ once per (target, relation) segment as a d_k x d_k mat-vec on the vector ALU with the relation's
+// matrix held in registers.  That is the right form for d_k <= 32 (128 floats per lane: at the benchmark size the kernel runs at
+// the gather rate of the K rows), but for d_k = 64 -- the width of the reference's own training configurations (n_hid 400 or 512
+// with 8 heads) -- the matrix only fits after a 4-way head-group split (512-byte row slices per wavefront) and the mat-vecs cost
+// 4x the vector instructions per edge: the kernel is instruction-bound at half the gather rate.
+//
+// Here a wavefront takes the same work item (<= 256 edges of one (target tile, relation), sorted by target), numbers the
+// distinct targets it meets ("slots", in order of appearance: the items are target-sorted, so a slot is a run of edges) and
+// processes them 16 at a time, like a relation end of the aggregation kernel (hgt_edge_agg_mfma.hip) run backwards:
+//   A. the 16 Q rows -> split hi/mid (bf16, or fp16 with a power-of-two row scale) -> wave-private LDS tile
+//   B. q~^T = A'^T-fragments x Q^T on v_mfma_f32_16x16x32 (3 products per step, fragments of hgt_relation_frag_pack(att_t)
+//      streamed from L2), accumulators -> the same LDS bytes as an fp32 [16][DP + 4] tile
+//   C. the edges of the 16 slots: gather K (+ temporal row), read q~ of the edge's slot from LDS, dot, reduce over the head's
+//      lanes, store -- the per-edge part of k_edge_logits without the per-edge Q row.
+// The wavefront covers DP = 64 * VEC <= 256 columns (1 KB row slices); wider rows use blockIdx.y head groups.
+#include "hgt_edge_common.h"
+#include "hgt_split_common.h"
+
+#ifndef HGT_LOGITS_XCD
+#define HGT_LOGITS_XCD 1
+#endif
+#ifndef HGT_LGM_GS
+#define HGT_LGM_GS 8      // column-tile steps whose fragments are requested together (16 loads in flight)
+#endif
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int VEC, int LPH>
+struct LG {   // geometry of one wavefront's slice (same tile layout as MG in hgt_edge_agg_mfma.hip)
+    static constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH;
+    static constexpr int NCT = DP / 16;                 // 16-column output tiles
+    static constexpr int KW = DKP > 32 ? DKP : 32;      // k window of a column tile
+    static constexpr int NKS = KW / 32;                 // MFMA k-steps per column tile
+    static constexpr int ROWB = DP * 2;                 // bytes of one 16-bit row of the Q tile
+    static constexpr int NS = DP / 8;                   // 16-byte slots per row
+    static constexpr int PLANE = 16 * ROWB;             // one 16-bit plane of the tile (16 targets)
+    static constexpr int QS = DP + 4;                   // floats per row of the fp32 q~ tile (+4: the 16 rows start on different banks)
+    static constexpr int WAVE_LDS = 16 * QS * 4;        // bytes per wavefront (>= 2 * PLANE)
+};
+
+template <int VEC>
+__device__ __forceinline__ unsigned abs_bits_vec(const float (&v)[VEC]) {
+    float m = fabsf(v[0]);
+#pragma unroll
+    for (int i = 1; i < VEC; ++i) m = fmaxf(m, fabsf(v[i]));
+    return __builtin_bit_cast(unsigned, m);
+}
+
+template <int VEC, int LPH, bool RTE, bool F16>
+__global__ __launch_bounds__(256, 2) void k_edge_logits_mfma(
+    const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
+    const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ Q,
+    const float* __restrict__ K, const float* __restrict__ rteK, const unsigned short* __restrict__ attF, float* __restrict__ logits,
+    int R, int HT, int rel_lo, int rel_hi) {
+    using G = LG<VEC, LPH>;
+    constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS, QS = G::QS;
+    constexpr int UN = RTE ? (unroll_for<VEC>() * 3) / 4 : unroll_for<VEC>(), HB = UN / 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4][G::WAVE_LDS];
+
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_items = hdr->n_items;
+#if HGT_LOGITS_XCD     // XCD-aware item order, see k_edge_logits
+    const int n_groups = (n_items + 3) >> 2, per_xcd = (n_groups + 7) >> 3;
+    const int vblock = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd) return;
+#else
+    const int vblock = blockIdx.x;
+#endif
+    const int item = vblock * 4 + wib;
+    if (item >= n_items) return;
+    const HgtItem it = items[item];
+    const int beg = __builtin_amdgcn_readfirstlane(it.beg), end = __builtin_amdgcn_readfirstlane(it.end);
+    const int rel = __builtin_amdgcn_readfirstlane(it.rel);
+    if (rel < rel_lo || rel >= rel_hi) return;
+    const int hg = blockIdx.y;
+    const int64_t ld = (int64_t)HT * DKP;
+    const int co = hg * DP, NY = HT / H;
+    const int h = lane / LPH, p = lane % LPH;
+    if (rel >= R) {   // edges no meta relation claims: logit 0 (conv.py:68)
+        for (int64_t i = (int64_t)beg * H + lane; i < (int64_t)end * H; i += 64) logits[(i / H) * HT + hg * H + (i % H)] = 0.0f;
+        return;
+    }
+
+    unsigned char* tile = smem[wib];
+    float* qtile = reinterpret_cast<float*>(tile);
+    const int fi = lane & 15, fg = lane >> 4;
+    const int wb = lane * VEC * 2;            // byte offset of this lane's 16-bit elements inside a tile row
+    const int rrow = fi * ROWB;
+    const unsigned short* __restrict__ mf = attF + (((int64_t)rel * NY + hg) * NCT) * NKS * 2 * 512 + lane * 8;
+    float ainv = 1.0f;                         // inverse scale of the fp16 fragment image (behind the fragments)
+    if constexpr (F16) ainv = reinterpret_cast<const float*>(attF + (int64_t)R * NY * NCT * NKS * 2 * 512)[0];
+
+    constexpr int STEPS = NCT * NKS, GS = HGT_LGM_GS < STEPS ? HGT_LGM_GS : STEPS, NG = STEPS / GS;
+    static_assert(STEPS % GS == 0, "column-tile steps come in multiples of 4");
+
+    for (int base = beg; base < end; base += 64) {
+        const int nb = min(64, end - base);
+        const int li = base + min(lane, nb - 1);
+        const int my_src = esrc[li], my_dst = edst[li];
+        const int my_rte = RTE ? (int)ertei[li] : 0;
+        // slots: distinct targets of the chunk in order of appearance (lanes beyond the chunk replicate its last edge)
+        const int prev_dst = __shfl_up(my_dst, 1);
+        const bool lead = (lane == 0) || (my_dst != prev_dst);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(lead);
+        const int my_slot = __builtin_popcountll(mask & (~0ull >> (63 - lane))) - 1;
+        const int nd = __builtin_popcountll(mask);
+        unsigned long long mrem = mask;       // leaders of the slots not yet loaded
+        int lead_idx = 0;
+
+        for (int t0 = 0; t0 < nd; t0 += 16) {
+            // ---- A. Q rows of slots [t0, t0 + 16) (slots beyond the chunk's last re-read its last leader: rows nobody reads)
+            float qrow[16][VEC];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (mrem != 0ull) {
+                    lead_idx = __builtin_ctzll(mrem);
+                    mrem &= mrem - 1ull;
+                }
+                const int d_ = __builtin_amdgcn_readlane(my_dst, lead_idx);
+                load_vec<VEC>(Q + (int64_t)d_ * ld + co + lane * VEC, qrow[r]);
+            }
+            // the edges of the group: lanes [e_lo, e_lo + e_cnt)
+            const unsigned long long in_g = __builtin_amdgcn_ballot_w64(my_slot >= t0 && my_slot < t0 + 16 && lane < nb);
+            const int e_lo = __builtin_ctzll(in_g), e_end = e_lo + __builtin_popcountll(in_g);
+
+            float qinv = 1.0f;                 // fp16 split: lane r = inverse scale of row r
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float scale = 1.0f;
+                if constexpr (F16) {
+                    float inv;
+                    f16_row_scale(wave_max_bits(abs_bits_vec<VEC>(qrow[r])), scale, inv);
+                    qinv = (lane == r) ? inv : qinv;
+                }
+                unsigned char* w = tile + r * ROWB + ((((wb >> 4) ^ (r & (NS - 1)))) << 4) + (wb & 15);
+                if constexpr (VEC == 1) {
+                    unsigned short hi, mid;
+                    split1_t<F16>(qrow[r][0], scale, hi, mid);
+                    *reinterpret_cast<unsigned short*>(w) = hi;
+                    *reinterpret_cast<unsigned short*>(w + G::PLANE) = mid;
+                } else if constexpr (VEC == 2) {
+                    unsigned hi, mid;
+                    split2_t<F16>(qrow[r][0], qrow[r][1], scale, hi, mid);
+                    *reinterpret_cast<unsigned*>(w) = hi;
+                    *reinterpret_cast<unsigned*>(w + G::PLANE) = mid;
+                } else {
+                    uint2 hi, mid;
+                    split4_t<F16>(make_float4(qrow[r][0], qrow[r][1], qrow[r][2], qrow[r][3]), scale, hi, mid);
+                    *reinterpret_cast<uint2*>(w) = hi;
+                    *reinterpret_cast<uint2*>(w + G::PLANE) = mid;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // ---- B. q~^T = fragments x Q^T
+            f32x4 acc[NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 fh[GS], fm[GS];
+            // the fragments do not depend on the group: left visible, hipcc hoists all 2 * STEPS loads out of both loops (256
+            // registers for d_k = 64 -> 245 spilled).  They are meant to be re-read from L2 per group, like a relation end of
+            // the aggregation kernel.
+            const unsigned short* mfg = mf;
+            asm volatile("" : "+v"(mfg));
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                for (int j = 0; j < GS; ++j) {
+                    const unsigned short* t_ = mfg + (int64_t)((g * GS + j) * 2) * 512;
+                    fh[j] = *reinterpret_cast<const bf16x8*>(t_);
+                    fm[j] = *reinterpret_cast<const bf16x8*>(t_ + 512);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // all 2 GS loads of the group are issued before the first MFMA waits
+#pragma unroll
+                for (int j = 0; j < GS; ++j) {
+                    const int step = g * GS + j, c = step / NKS, ks = step % NKS;
+                    const int kbase = (16 * c / KW) * KW;
+                    const int slot = (kbase + 32 * ks) / 8 + fg;
+                    const unsigned char* up = tile + rrow + ((slot ^ (fi & (NS - 1))) << 4);
+                    const bf16x8 uh = *reinterpret_cast<const bf16x8*>(up);
+                    const bf16x8 um = *reinterpret_cast<const bf16x8*>(up + G::PLANE);
+                    acc[c] = mfma16_t<F16>(fm[j], uh, acc[c]);
+                    acc[c] = mfma16_t<F16>(fh[j], um, acc[c]);
+                    acc[c] = mfma16_t<F16>(fh[j], uh, acc[c]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();         // every lane has read the 16-bit tile: its bytes become the fp32 q~ tile
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {
+                float sc = 1.0f;
+                if constexpr (F16) sc = __shfl(qinv, fi) * ainv;
+                // accumulator layout: lane = (target fi, row group fg): columns 16 c + 4 fg .. + 3 of target fi
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    *reinterpret_cast<float4*>(qtile + fi * QS + 16 * c + 4 * fg) =
+                        make_float4(acc[c][0] * sc, acc[c][1] * sc, acc[c][2] * sc, acc[c][3] * sc);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // ---- C. the edges of the group, two half-batches in flight (fixed-size unconditional issues: counted vmcnt)
+            float krA[HB][VEC], trA[RTE ? HB : 1][VEC], krB[HB][VEC], trB[RTE ? HB : 1][VEC];
+#define LGM_ISSUE(KR, TR, I0)                                                                      \
+    _Pragma("unroll") for (int u = 0; u < HB; ++u) {                                               \
+        const int idx = min((I0) + u, e_end - 1);                                                  \
+        const int s_ = __builtin_amdgcn_readlane(my_src, idx);                                     \
+        load_vec<VEC>(K + (int64_t)s_ * ld + co + lane * VEC, KR[u]);                              \
+        if constexpr (RTE) {                                                                       \
+            const int ri = __builtin_amdgcn_readlane(my_rte, idx);                                 \
+            load_vec<VEC>(rteK + (int64_t)ri * ld + co + lane * VEC, TR[u]);                       \
+        }                                                                                          \
+    }
+#define LGM_PROCESS(KR, TR, I0)                                                                    \
+    _Pragma("unroll") for (int u = 0; u < HB; ++u) {                                               \
+        if ((I0) + u < e_end) {                                                                    \
+            const int r_ = __builtin_amdgcn_readlane(my_slot, (I0) + u) - t0;                      \
+            float qt[VEC];                                                                         \
+            load_vec<VEC>(qtile + r_ * QS + lane * VEC, qt);                                       \
+            float part = 0.0f;                                                                     \
+            _Pragma("unroll") for (int i = 0; i < VEC; ++i) {                                      \
+                float kv = KR[u][i];                                                               \
+                if constexpr (RTE) kv += TR[u][i];                                                 \
+                part = fmaf(qt[i], kv, part);                                                      \
+            }                                                                                      \
+            part = head_allreduce<LPH>(part);                                                      \
+            if (p == 0) logits[(int64_t)(base + (I0) + u) * HT + hg * H + h] = part;               \
+        }                                                                                          \
+    }
+            LGM_ISSUE(krA, trA, e_lo)
+            for (int i0 = e_lo; i0 < e_end; i0 += 2 * HB) {
+                LGM_ISSUE(krB, trB, i0 + HB)
+                LGM_PROCESS(krA, trA, i0)
+                LGM_ISSUE(krA, trA, i0 + 2 * HB)
+                LGM_PROCESS(krB, trB, i0 + HB)
+            }
+#undef LGM_ISSUE
+#undef LGM_PROCESS
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();         // the q~ tile is rewritten by the next group only after every lane has read it
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+template <int VEC, int LPH>
+static int launch_logits_mfma(bool f16, const HgtPlanView& pv, const float* Q, const float* K, const float* rteK, const unsigned short* attF,
+                              float* logits, int R, int HT, int rel_lo, int rel_hi, hipStream_t stream) {
+    const unsigned blocks = ((unsigned)((pv.L.max_items + 3) / 4) + 7u) & ~7u;      // (a multiple of 8: XCD-aware item order)
+    dim3 grid(blocks, (unsigned)(HT / (64 / LPH)));
+#define LGM_LAUNCH(RTE_, F16_)                                                                                                   \
+    k_edge_logits_mfma<VEC, LPH, RTE_, F16_><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attF, \
+                                                                       logits, R, HT, rel_lo, rel_hi)
+    if (rteK) { if (f16) LGM_LAUNCH(true, true); else LGM_LAUNCH(true, false); }
+    else      { if (f16) LGM_LAUNCH(false, true); else LGM_LAUNCH(false, false); }
+#undef LGM_LAUNCH
+    return HGT_OK;
+}
+
+}  // namespace
+
+// vec / lph: the wavefront's layout after the head-group split of the matrix-core kernels (<= 256 columns per wavefront)
+__attribute__((visibility("hidden"))) int hgt_launch_logits_mfma(int vec, int lph, bool f16, const HgtPlanView& pv, const float* Q,
+                                                                 const float* K, const float* rteK, const unsigned short* attF,
+                                                                 float* logits, int R, int HT, int rel_lo, int rel_hi,
+                                                                 hipStream_t stream) {
+#define LGM_CASE(V, L) \
+    if (vec == V && lph == L) return launch_logits_mfma<V, L>(f16, pv, Q, K, rteK, attF, logits, R, HT, rel_lo, rel_hi, stream);
+#ifdef HGT_DEV_LAYOUTS
+    LGM_CASE(4, 8) LGM_CASE(4, 16)
+#else
+    // d_k >= 64 (the layouts the vector-ALU kernel has to split into narrow head groups) + the benchmark layout for A/B runs
+    LGM_CASE(4, 8) LGM_CASE(4, 16) LGM_CASE(4, 32) LGM_CASE(4, 64) LGM_CASE(2, 32) LGM_CASE(2, 64) LGM_CASE(1, 64)
+#endif
+#undef LGM_CASE
+    return HGT_ERR_UNSUPPORTED;
+}

@@ -101,6 +101,46 @@ def test_matches_oracle(case, precision):
     assert err_att < 1e-5
 
 
+MFMA_LOGITS_CASES = [
+    # N, E, d, H, T, R, use_RTE: wavefront layouts (VEC, LPH) of hgt_edge_logits_mfma
+    (3000, 30000, 256, 8, 4, 8, True),        # (4, 8): the benchmark layout (vector-ALU kernel by default; forced here)
+    (1500, 12000, 512, 8, 3, 9, True),        # (4, 16) x 2 head groups: ogbn-mag width
+    (1500, 12000, 256, 4, 3, 5, False),       # (4, 16)
+    (1200, 9000, 128, 2, 2, 4, True),         # (2, 32)
+    (1200, 9000, 256, 2, 2, 4, False),        # (4, 32)
+    (900, 7000, 64, 1, 2, 3, True),           # (1, 64)
+    (900, 7000, 128, 1, 2, 3, False),         # (2, 64)
+    (900, 7000, 256, 1, 2, 3, True),          # (4, 64)
+    (5000, 60000, 256, 4, 3, 4, True),        # (4, 16) with hub targets (dst_skew below): many chunks with one slot
+]
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("case", MFMA_LOGITS_CASES, ids=[str(i) for i in range(len(MFMA_LOGITS_CASES))])
+def test_logits_with_matrix_core_transforms(case, precision):
+    """hgt_edge_logits_mfma (target-side relation transform of 16 distinct targets at a time on the matrix cores) on every
+    wavefront layout it is instantiated for: the attention weights (softmax of the logits) and the layer output against the
+    fp64 closed form; unclaimed relations (logit 0) included."""
+    N, E, d, H, T, R, use_RTE = case
+    gk = dict(dst_skew=1.1) if N == 5000 else {}
+    sd = O.make_state_dict(d, d, T, R, H, True, use_RTE, seed=N + E + d)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=E + 7, **gk)
+    et = et.clone()
+    et[::41] = R
+    ref, att_ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, use_norm=True, use_RTE=use_RTE,
+                                         dtype=torch.float64, return_att=True)
+    layer = _layer_from(sd, d, T, R, H, True, use_RTE, precision=precision)
+    layer.kernel_flags = 4          # HGT_FLAG_MFMA_LOGITS
+    out, att = _run(layer, x, nt, ei, et, tm if use_RTE else None)
+    err, err_att = (out.double() - ref).abs().max().item(), (att.double() - att_ref).abs().max().item()
+    print("mfma logits N=%d E=%d d=%d H=%d %s: max|out| err %.2e, att err %.2e" % (N, E, d, H, precision, err, err_att))
+    assert err < PREC_TOL[precision]
+    assert err_att < (1e-5 if precision == "bf16x3" else 2e-6)
+    layer.kernel_flags = 8          # HGT_FLAG_VALU_LOGITS: the two kernels agree on the attention weights
+    out2, att2 = _run(layer, x, nt, ei, et, tm if use_RTE else None)
+    assert (att2 - att).abs().max().item() < 1e-5
+
+
 DENSE_CASES = [
     # N, E, d, H, T, R, use_norm, use_RTE
     (2500, 25000, 256, 8, 4, 8, True, False),      # c2 shape
