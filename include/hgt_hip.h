@@ -232,6 +232,16 @@ int hgt_edge_aggregate(const void* plan, int64_t n_nodes, int64_t n_edges, int32
                        int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
                        const float* msg_p, const void* msg_frag, float* agg, int64_t n_q_rows, int32_t apply_gelu,
                        void* hub_ws, void* stream);
+/* ABI 5, latency regime (sampled sub-graphs): the same aggregate (after it agg equals hgt_edge_aggregate's up to fp32 rounding), item-
+ * parallel: one wavefront per logits work item sums the runs of consecutive same-target edges, transforms 16 runs per matrix-core
+ * round and writes them to `scratch` (hgt_edge_aggregate_items_bytes); a second kernel combines every target's runs in (relation,
+ * position) order like softmax partials.  No atomics, fixed order: bit-reproducible; hub targets need no hub_ws.  msg_frag is
+ * required (frag_f16: which of hgt_relation_frag_pack / _f16 made it); apply_gelu 0 / 1; n_relations < 64. */
+int hgt_edge_aggregate_items_bytes(int64_t n_edges, int32_t n_heads, int32_t dk_pad, uint64_t* out_host);
+int hgt_edge_aggregate_items(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                             int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
+                             const void* msg_frag, int32_t frag_f16, float* agg, int64_t n_q_rows, int32_t apply_gelu,
+                             void* scratch, uint64_t scratch_bytes, void* stream);
 /* ABI 4: one slice [rel_lo, rel_hi) of the plan's n_relations + 1 relation buckets (bucket n_relations = unclaimed edges).
  * hgt_edge_logits_slice writes the logits of the slice's edges only.  hgt_edge_aggregate_slice (matrix-core kernel: msg_frag
  * required) aggregates the slice and combines it with what earlier slices left: state = f32[n_q_rows][n_heads][2] (softmax
@@ -473,6 +483,8 @@ typedef struct hgt_conv_args {
 #define HGT_FLAG_VALU_AGGREGATE  2   /* relation transforms of the aggregation on the vector ALU (round-1 kernel) instead of MFMA */
 #define HGT_FLAG_MFMA_LOGITS     4   /* hgt_edge_logits_mfma for every layout it covers (default: d_k >= 64 only) */
 #define HGT_FLAG_VALU_LOGITS     8   /* never hgt_edge_logits_mfma */
+#define HGT_FLAG_ITEM_AGGREGATE 16   /* hgt_edge_aggregate_items wherever it applies (default: < 16384 nodes and d_k >= 64 or > 16 relations) */
+#define HGT_FLAG_NO_ITEM_AGGREGATE 32 /* never hgt_edge_aggregate_items */
 
 /* phase boundaries at which hgt_conv_forward records phase_events[i]:
  *   0 start | 1 relation pack + Q/K/V (+ temporal tables) done | 2 logits done | 3 softmax done |

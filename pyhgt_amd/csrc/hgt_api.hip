@@ -2,11 +2,15 @@
 // kernel of one HGTConv.forward (conv.py:56-134, eval mode) on the caller's stream.
 #include "hgt_common.h"
 
+#ifndef HGT_ITEM_AGG_MAX_NODES
+#define HGT_ITEM_AGG_MAX_NODES 16384      // graphs below this take the item-parallel aggregation where it pays (hgt_edge_agg_items.hip)
+#endif
+
 namespace {
 
 struct ConvWorkspace {
     uint64_t off_q, off_k, off_v, off_logits, off_agg, off_trans, off_att_t, off_msg_p, off_msg_f, off_att_f, off_hub;
-    uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, off_ws_qkv, off_ws_a, off_ws_rte, off_off2, off_pending, off_state, total;
+    uint64_t off_rte_lin, off_rte_k, off_rte_v, off_rte_rows, off_rte_off, off_ws_qkv, off_ws_a, off_ws_rte, off_off2, off_pending, off_state, off_zitems, zitems_bytes, total;
 };
 
 static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim, int out_dim, int T, int R, int /*n_heads*/, int use_rte,
@@ -60,6 +64,14 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
     w.off_off2 = take(256);
     w.off_pending = take((uint64_t)(NQ / 64 + 1) * 4);
     w.off_state = take((uint64_t)NQ * H * 2 * 4);   // softmax state carried between relation slices (stage 4)
+    // scratch of the item-parallel aggregation (hgt_edge_aggregate_items): only for graphs in the latency regime
+    w.zitems_bytes = 0;
+    if (N < HGT_ITEM_AGG_MAX_NODES) {
+        uint64_t zb = 0;
+        hgt_edge_aggregate_items_bytes(E, H, lay.dk_pad, &zb);
+        if (zb <= ((uint64_t)1 << 30)) w.zitems_bytes = zb;
+    }
+    w.off_zitems = take(w.zitems_bytes);
     w.total = o;
     return w;
 }
@@ -360,7 +372,18 @@ edge_phase:
         if (rc != HGT_ERR_UNSUPPORTED) return rc;   // unsupported layout (head-group split): the unfused kernels below
     }
     // runs for E == 0 too: it writes the zero rows of isolated targets; HGTConv stores gelu(agg) (conv.py:119), DenseHGTConv agg
-    if (sliced) {
+    // latency regime: the item-parallel form (hgt_edge_agg_items.hip) where a sub-tile wavefront's chain of relation ends is the
+    // kernel time -- many relations or a head-group split (d_k >= 64); flags force / forbid it
+    const bool items_agg = mfma_agg && !sliced && w.zitems_bytes > 0 && NQ < HGT_ITEM_AGG_MAX_NODES && R < 64 &&
+                           !(a->flags & HGT_FLAG_NO_ITEM_AGGREGATE) &&
+                           (lay.dk_pad >= 64 || R > 16 || (a->flags & HGT_FLAG_ITEM_AGGREGATE));
+    rc = HGT_ERR_UNSUPPORTED;
+    if (items_agg)
+        rc = hgt_edge_aggregate_items(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_f, f16 ? 1 : 0, agg, NQ, dense ? 0 : 1,
+                                      wb + w.off_zitems, w.zitems_bytes, stream);
+    if (rc != HGT_ERR_UNSUPPORTED) {
+        // (done, or a real error)
+    } else if (sliced) {
         rc = hgt_edge_aggregate_slice(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ, 1, hub_ws, sl_lo, sl_hi,
                                       (float*)(wb + w.off_state), sl_lo > 0, sl_more, stream);
         if (rc != HGT_OK || sl_more) return rc;      // state + un-normalised rows stay in the workspace for the next slice

@@ -1,0 +1,411 @@
+// Aggregation for the latency regime (sampled sub-graphs: a few thousand targets), item-parallel and deterministic.
+//
+// The sub-tile kernels (hgt_edge_agg_mfma.hip) give a wavefront a few targets and ALL their relations: one dependent chain of
+// edge batches (~2.5 us per 6-8 edges under load) and relation ends (fragment loads from L2 + MFMAs, ~3.5 us each).  That chain
+// is hidden behind 2 000 other wavefronts on a million-node graph, but it IS the kernel time on a 4 000-node batch: with the 33
+// relations of the OAG schema a wavefront runs ~25 relation ends for ~40 edges (102 us per layer at c5, its largest kernel).
+//
+// Here the parallelism is the logits kernels': one wavefront per work item = <= 256 target-sorted edges of ONE (target tile,
+// relation).  A "run" is the maximal stretch of consecutive edges of one target inside a 64-edge chunk of an item; the
+// wavefront sums  u = sum_e e^(s_e - m_run) v_e  per run (online softmax with the run's own reference), parks the u rows of up
+// to 16 runs in a wave-private LDS tile, transforms them with the relation's message fragments on the matrix cores (ONE
+// round per 16 runs) and writes every transformed row, with the run's (m_run, l_run) per head, at the position of the run's
+// first edge in a scratch [E][d] (k_edge_runs_mfma).  A second kernel (k_merge_runs) owns one target per wavefront, walks the
+// target's segments in (relation, position) order and combines the runs exactly like two softmax partials combine
+// (m = max, x = sum x_run e^(m_run - m)), adds the edges no meta relation claims (logit 0, no message), normalises, applies
+// gelu and stores the row -- fixed order, no atomics: a forward is bit-reproducible.  Hub targets need no separate path.
+#include "hgt_edge_common.h"
+#include "hgt_split_common.h"
+
+#ifndef HGT_LOGITS_XCD
+#define HGT_LOGITS_XCD 1
+#endif
+#ifndef HGT_AGI_GS
+#define HGT_AGI_GS 8      // column-tile steps whose fragments are requested together (16 loads in flight)
+#endif
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int VEC, int LPH>
+struct AG {   // geometry of one wavefront's slice (tile layout of MG in hgt_edge_agg_mfma.hip)
+    static constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH;
+    static constexpr int NCT = DP / 16, KW = DKP > 32 ? DKP : 32, NKS = KW / 32;
+    static constexpr int ROWB = DP * 2, NS = DP / 8, PLANE = 16 * ROWB;
+};
+
+template <int VEC>
+__device__ __forceinline__ unsigned abs_bits_v(const float (&v)[VEC]) {
+    float m = fabsf(v[0]);
+#pragma unroll
+    for (int i = 1; i < VEC; ++i) m = fmaxf(m, fabsf(v[i]));
+    return __builtin_bit_cast(unsigned, m);
+}
+
+template <int VEC, int LPH, bool RTE, bool F16>
+__global__ __launch_bounds__(256, 2) void k_edge_runs_mfma(
+    const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
+    const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ logits,
+    const float* __restrict__ V, const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, float* __restrict__ zrows,
+    float* __restrict__ zstat, unsigned char* __restrict__ zflag, int R, int HT) {
+    using G = AG<VEC, LPH>;
+    constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS;
+    constexpr int UN = RTE ? (unroll_for<VEC>() * 3) / 4 : unroll_for<VEC>(), HB = UN / 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4][2 * G::PLANE];
+    __shared__ int s_pos[4][16];
+    __shared__ float s_rinv[F16 ? 4 : 1][16];
+
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_items = hdr->n_items;
+#if HGT_LOGITS_XCD     // XCD-aware item order, see k_edge_logits
+    constexpr int XC = 16;
+    const int q8 = (int)(blockIdx.x >> 3), vblock = (q8 / XC) * (8 * XC) + (int)(blockIdx.x & 7u) * XC + (q8 % XC);
+#else
+    const int vblock = blockIdx.x;
+#endif
+    const int item = vblock * 4 + wib;
+    if (item >= n_items) return;
+    const HgtItem it = items[item];
+    const int beg = __builtin_amdgcn_readfirstlane(it.beg), end = __builtin_amdgcn_readfirstlane(it.end);
+    const int rel = __builtin_amdgcn_readfirstlane(it.rel);
+    if (rel >= R) return;                      // edges no meta relation claims carry no message: k_merge_runs counts them
+    const int hg = blockIdx.y;
+    const int64_t ld = (int64_t)HT * DKP;
+    const int co = hg * DP, NY = HT / H;
+    const int h = lane / LPH, p = lane % LPH;
+
+    unsigned char* tile = smem[wib];
+    const int fi = lane & 15, fg = lane >> 4;
+    const int wb = lane * VEC * 2;
+    const int rrow = fi * ROWB;
+    const unsigned short* __restrict__ mf = msgF + (((int64_t)rel * NY + hg) * NCT) * NKS * 2 * 512 + lane * 8;
+    float minv = 1.0f;
+    if constexpr (F16) minv = reinterpret_cast<const float*>(msgF + (int64_t)R * NY * NCT * NKS * 2 * 512)[0];
+
+    constexpr int STEPS = NCT * NKS, GS = HGT_AGI_GS < STEPS ? HGT_AGI_GS : STEPS, NG = STEPS / GS;
+    static_assert(STEPS % GS == 0, "column-tile steps come in multiples of 4");
+
+    for (int base = beg; base < end; base += 64) {
+        const int nb = min(64, end - base);
+        const int li = base + min(lane, nb - 1);
+        const int my_src = esrc[li], my_dst = edst[li];
+        const int my_rte = RTE ? (int)ertei[li] : 0;
+        const int prev_dst = __shfl_up(my_dst, 1);
+        const bool lead = (lane == 0) || (my_dst != prev_dst);      // (lanes beyond the chunk replicate its last edge: never leaders)
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(lead);
+        const int my_slot = __builtin_popcountll(mask & (~0ull >> (63 - lane))) - 1;
+        const int nd = __builtin_popcountll(mask);
+        if (hg == 0 && lane < nb) zflag[base + lane] = lead ? 1 : 0;
+
+        for (int t0 = 0; t0 < nd; t0 += 16) {
+            const unsigned long long in_g = __builtin_amdgcn_ballot_w64(my_slot >= t0 && my_slot < t0 + 16 && lane < nb);
+            const int e_lo = __builtin_ctzll(in_g), e_end = e_lo + __builtin_popcountll(in_g);
+            const int nrows = min(16, nd - t0);
+            if (lead && my_slot >= t0 && my_slot < t0 + 16) s_pos[wib][my_slot - t0] = base + lane;
+
+            // ---- runs of the group: u = sum e^(s - m_run) v, parked in the tile (split hi / mid)
+            int cur_r = -1, cur_pos = 0;
+            float U[VEC], m_run = HGT_NEG, l_run = 0.0f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
+            auto flush = [&]() {
+                if (cur_r < 0) return;
+                float scale = 1.0f;
+                if constexpr (F16) {
+                    float inv;
+                    f16_row_scale(wave_max_bits(abs_bits_v<VEC>(U)), scale, inv);
+                    if (lane == 0) s_rinv[wib][cur_r] = inv;
+                }
+                unsigned char* w = tile + cur_r * ROWB + ((((wb >> 4) ^ (cur_r & (NS - 1)))) << 4) + (wb & 15);
+                if constexpr (VEC == 1) {
+                    unsigned short hi, mid;
+                    split1_t<F16>(U[0], scale, hi, mid);
+                    *reinterpret_cast<unsigned short*>(w) = hi;
+                    *reinterpret_cast<unsigned short*>(w + G::PLANE) = mid;
+                } else if constexpr (VEC == 2) {
+                    unsigned hi, mid;
+                    split2_t<F16>(U[0], U[1], scale, hi, mid);
+                    *reinterpret_cast<unsigned*>(w) = hi;
+                    *reinterpret_cast<unsigned*>(w + G::PLANE) = mid;
+                } else {
+                    uint2 hi, mid;
+                    split4_t<F16>(make_float4(U[0], U[1], U[2], U[3]), scale, hi, mid);
+                    *reinterpret_cast<uint2*>(w) = hi;
+                    *reinterpret_cast<uint2*>(w + G::PLANE) = mid;
+                }
+                if (p == 0) *reinterpret_cast<float2*>(zstat + ((int64_t)cur_pos * HT + hg * H + h) * 2) = make_float2(m_run, l_run);
+            };
+            float vrA[HB][VEC], trA[RTE ? HB : 1][VEC], slA[HB], vrB[HB][VEC], trB[RTE ? HB : 1][VEC], slB[HB];
+#define AGI_ISSUE(VR, TR, SL, I0)                                                                  \
+    _Pragma("unroll") for (int u = 0; u < HB; ++u) {                                               \
+        const int idx = min((I0) + u, e_end - 1);                                                  \
+        const int s_ = __builtin_amdgcn_readlane(my_src, idx);                                     \
+        load_vec<VEC>(V + (int64_t)s_ * ld + co + lane * VEC, VR[u]);                              \
+        SL[u] = logits[(int64_t)(base + idx) * HT + hg * H + h];                                   \
+        if constexpr (RTE) {                                                                       \
+            const int ri = __builtin_amdgcn_readlane(my_rte, idx);                                 \
+            load_vec<VEC>(rteV + (int64_t)ri * ld + co + lane * VEC, TR[u]);                       \
+        }                                                                                          \
+    }
+#define AGI_PROCESS(VR, TR, SL, I0)                                                                \
+    _Pragma("unroll") for (int u = 0; u < HB; ++u) {                                               \
+        if ((I0) + u < e_end) {                                                                    \
+            const int r_ = __builtin_amdgcn_readlane(my_slot, (I0) + u) - t0;                      \
+            if (r_ != cur_r) {                                                                     \
+                flush();                                                                           \
+                cur_r = r_;                                                                        \
+                cur_pos = base + (I0) + u;                                                         \
+                m_run = HGT_NEG;                                                                   \
+                l_run = 0.0f;                                                                      \
+                _Pragma("unroll") for (int i = 0; i < VEC; ++i) U[i] = 0.0f;                       \
+            }                                                                                      \
+            const float m_new = fmaxf(m_run, SL[u]);                                               \
+            const float sc = __expf(m_run - m_new), pe = __expf(SL[u] - m_new);                    \
+            _Pragma("unroll") for (int i = 0; i < VEC; ++i) {                                      \
+                float vv = VR[u][i];                                                               \
+                if constexpr (RTE) vv += TR[u][i];                                                 \
+                U[i] = fmaf(pe, vv, U[i] * sc);                                                    \
+            }                                                                                      \
+            l_run = fmaf(l_run, sc, pe);                                                           \
+            m_run = m_new;                                                                         \
+        }                                                                                          \
+    }
+            AGI_ISSUE(vrA, trA, slA, e_lo)
+            for (int i0 = e_lo; i0 < e_end; i0 += 2 * HB) {
+                AGI_ISSUE(vrB, trB, slB, i0 + HB)
+                AGI_PROCESS(vrA, trA, slA, i0)
+                AGI_ISSUE(vrA, trA, slA, i0 + 2 * HB)
+                AGI_PROCESS(vrB, trB, slB, i0 + HB)
+            }
+#undef AGI_ISSUE
+#undef AGI_PROCESS
+            flush();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // ---- z^T = message fragments x u^T (rows the group does not use hold stale bytes: every column of the transposed
+            //      product depends on its own row only, and those columns are not stored)
+            f32x4 acc[NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 fh[GS], fm[GS];
+            const unsigned short* mfg = mf;
+            asm volatile("" : "+v"(mfg));          // (keeps hipcc from hoisting all 2 * STEPS fragment loads out of the loops)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                for (int j = 0; j < GS; ++j) {
+                    const unsigned short* t_ = mfg + (int64_t)((g * GS + j) * 2) * 512;
+                    fh[j] = *reinterpret_cast<const bf16x8*>(t_);
+                    fm[j] = *reinterpret_cast<const bf16x8*>(t_ + 512);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < GS; ++j) {
+                    const int step = g * GS + j, c = step / NKS, ks = step % NKS;
+                    const int kbase = (16 * c / KW) * KW;
+                    const int slot = (kbase + 32 * ks) / 8 + fg;
+                    const unsigned char* up = tile + rrow + ((slot ^ (fi & (NS - 1))) << 4);
+                    const bf16x8 uh = *reinterpret_cast<const bf16x8*>(up);
+                    const bf16x8 um = *reinterpret_cast<const bf16x8*>(up + G::PLANE);
+                    acc[c] = mfma16_t<F16>(fm[j], uh, acc[c]);
+                    acc[c] = mfma16_t<F16>(fh[j], um, acc[c]);
+                    acc[c] = mfma16_t<F16>(fh[j], uh, acc[c]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- transformed rows -> scratch, at the position of the run's first edge
+            if (fi < nrows) {
+                float sc = 1.0f;
+                if constexpr (F16) sc = s_rinv[wib][fi] * minv;
+                float* zr = zrows + (int64_t)s_pos[wib][fi] * ld + co + 4 * fg;
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    *reinterpret_cast<float4*>(zr + 16 * c) = make_float4(acc[c][0] * sc, acc[c][1] * sc, acc[c][2] * sc, acc[c][3] * sc);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();         // the tile / position table are rewritten by the next group
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+// One wavefront per target: the runs of all its segments, in (relation, position) order.  Lane l holds VECF consecutive columns
+// of the full row (d = 64 * VECF); DKP >= VECF, so a lane's columns belong to one head.
+template <int VECF>
+__global__ __launch_bounds__(256) void k_merge_runs(const int32_t* __restrict__ segptr, const float* __restrict__ zrows,
+                                                    const float* __restrict__ zstat, const unsigned char* __restrict__ zflag,
+                                                    float* __restrict__ agg, int R, int64_t NQ, int HT, int DKP, int apply_gelu,
+                                                    int64_t ld_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= NQ) return;
+    const int64_t ld = (int64_t)HT * DKP;
+    const int hd = (lane * VECF) / DKP;
+    const int64_t tile = i / HGT_TD;
+    const int dl = (int)(i % HGT_TD);
+    int e0 = 0, len = 0;
+    if (lane <= R) {
+        const int64_t b = (tile * (R + 1) + lane) * HGT_TD + dl;
+        e0 = segptr[b];
+        len = segptr[b + 1] - e0;
+    }
+    const int n_unclaimed = __builtin_amdgcn_readlane(len, R);      // R < 64 (checked by the launcher)
+    if (lane >= R) len = 0;
+    int incl = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    float M = HGT_NEG, L = 0.0f, X[VECF];
+#pragma unroll
+    for (int k = 0; k < VECF; ++k) X[k] = 0.0f;
+
+    for (int j0 = 0; j0 < total; j0 += 64) {
+        // edge j0 + lane of the target's concatenated segments -> (relation, position)
+        const int j = j0 + lane;
+        int rsel = 0;
+        for (int r = 0; r < R; ++r) rsel += (j >= __builtin_amdgcn_readlane(incl, r)) ? 1 : 0;
+        rsel = min(rsel, R - 1);
+        const int pos = __shfl(e0, rsel) + (j - (__shfl(incl, rsel) - __shfl(len, rsel)));
+        const bool live = j < total;
+        const bool start = live && zflag[live ? pos : 0] != 0;
+        unsigned long long runs = __builtin_amdgcn_ballot_w64(start);
+        while (runs != 0ull) {
+            // up to four runs per round: their rows and statistics are requested together
+            int pz[4];
+            int nr = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (runs != 0ull) {
+                    const int k = __builtin_ctzll(runs);
+                    runs &= runs - 1ull;
+                    pz[u] = __builtin_amdgcn_readlane(pos, k);
+                    nr = u + 1;
+                } else {
+                    pz[u] = pz[u > 0 ? u - 1 : 0];
+                }
+            }
+            float rows[4][VECF];
+            float2 st[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                load_vec<VECF>(zrows + (int64_t)pz[u] * ld + lane * VECF, rows[u]);
+                st[u] = *reinterpret_cast<const float2*>(zstat + ((int64_t)pz[u] * HT + hd) * 2);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u < nr) {
+                    const float m_new = fmaxf(M, st[u].x);
+                    const float sa = __expf(M - m_new), sb = __expf(st[u].x - m_new);
+#pragma unroll
+                    for (int k = 0; k < VECF; ++k) X[k] = fmaf(rows[u][k], sb, X[k] * sa);
+                    L = fmaf(L, sa, st[u].y * sb);
+                    M = m_new;
+                }
+            }
+        }
+    }
+    if (n_unclaimed > 0) {                       // logit 0, no message (conv.py:68)
+        const float m_new = fmaxf(M, 0.0f);
+        const float sa = __expf(M - m_new), sb = __expf(0.0f - m_new);
+#pragma unroll
+        for (int k = 0; k < VECF; ++k) X[k] *= sa;
+        L = fmaf(L, sa, (float)n_unclaimed * sb);
+    }
+    const float inv = 1.0f / (L + 1e-16f);
+    float o[VECF];
+#pragma unroll
+    for (int k = 0; k < VECF; ++k) {
+        float v = X[k] * inv;
+        if (apply_gelu == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        o[k] = v;
+    }
+    float* g = agg + i * ld_out + lane * VECF;
+    if constexpr (VECF == 1) {
+        g[0] = o[0];
+    } else if constexpr (VECF == 2) {
+        *reinterpret_cast<float2*>(g) = make_float2(o[0], o[1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < VECF / 4; ++k) *reinterpret_cast<float4*>(g + 4 * k) = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    }
+}
+
+template <int VEC, int LPH>
+static int launch_runs(bool f16, const HgtPlanView& pv, const float* logits, const float* V, const float* rteV, const unsigned short* msgF,
+                       float* zrows, float* zstat, unsigned char* zflag, int R, int HT, hipStream_t stream) {
+    const unsigned blocks = ((unsigned)((pv.L.max_items + 3) / 4) + 127u) & ~127u;
+    dim3 grid(blocks, (unsigned)(HT / (64 / LPH)));
+#define AGI_LAUNCH(RTE_, F16_)                                                                                                     \
+    k_edge_runs_mfma<VEC, LPH, RTE_, F16_><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF, \
+                                                                     zrows, zstat, zflag, R, HT)
+    if (rteV) { if (f16) AGI_LAUNCH(true, true); else AGI_LAUNCH(true, false); }
+    else      { if (f16) AGI_LAUNCH(false, true); else AGI_LAUNCH(false, false); }
+#undef AGI_LAUNCH
+    return HGT_OK;
+}
+
+}  // namespace
+
+// scratch: [E][d] transformed rows | [E][H][2] run statistics | [E] run-start flags
+extern "C" int hgt_edge_aggregate_items_bytes(int64_t n_edges, int32_t n_heads, int32_t dk_pad, uint64_t* out) {
+    if (!out || n_edges < 0 || n_heads <= 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
+    const uint64_t E = (uint64_t)n_edges, d = (uint64_t)n_heads * dk_pad;
+    *out = hgt_align_up(E * d * 4, 256) + hgt_align_up(E * n_heads * 8, 256) + hgt_align_up(E, 256);
+    return HGT_OK;
+}
+
+extern "C" int hgt_edge_aggregate_items(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                        const float* logits, const float* V, const float* rte_v, const void* msg_frag, int32_t frag_f16,
+                                        float* agg, int64_t n_q_rows, int32_t apply_gelu, void* scratch, uint64_t scratch_bytes,
+                                        void* stream_) {
+    if (!plan || !V || !msg_frag || !agg || (E > 0 && (!logits || !scratch)) || H <= 0 || 64 % H != 0 || dk_pad <= 0)
+        return HGT_ERR_INVALID_ARG;
+    if (apply_gelu != 0 && apply_gelu != 1) return HGT_ERR_INVALID_ARG;
+    const int64_t NQ = (n_q_rows > 0 && n_q_rows <= N) ? n_q_rows : N;
+    if (NQ == 0) return HGT_OK;
+    const int lph = 64 / H;
+    const int64_t d = (int64_t)H * dk_pad;
+    if (dk_pad % lph != 0 || R >= 64 || d % 64 != 0 || d / 64 > 8) return HGT_ERR_UNSUPPORTED;
+    uint64_t need = 0;
+    hgt_edge_aggregate_items_bytes(E, H, dk_pad, &need);
+    if (E > 0 && scratch_bytes < need) return HGT_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
+    float* zrows = (float*)scratch;
+    float* zstat = (float*)((char*)scratch + hgt_align_up((uint64_t)E * d * 4, 256));
+    unsigned char* zflag = (unsigned char*)zstat + hgt_align_up((uint64_t)E * H * 8, 256);
+    // the wavefront's layout after the head-group split of the matrix-core kernels (<= 256 columns per wavefront)
+    int sp = 1;
+    const int vec_full = dk_pad / lph;
+    while (vec_full / sp > 4 && lph * sp * 2 <= 64) sp *= 2;
+    if (vec_full / sp > 4) return HGT_ERR_UNSUPPORTED;
+    const int vec = vec_full / sp, lphs = lph * sp;
+    if (E > 0) {
+        int rc = HGT_ERR_UNSUPPORTED;
+#define AGI_CASE(V_, L_) \
+        if (vec == V_ && lphs == L_) rc = launch_runs<V_, L_>(frag_f16 != 0, pv, logits, V, rte_v, (const unsigned short*)msg_frag, zrows, zstat, zflag, (int)R, (int)H, stream);
+#ifdef HGT_DEV_LAYOUTS
+        AGI_CASE(4, 8) AGI_CASE(4, 16) AGI_CASE(1, 16)
+#else
+        AGI_CASE(1, 4) AGI_CASE(2, 4) AGI_CASE(4, 4) AGI_CASE(1, 8) AGI_CASE(2, 8) AGI_CASE(4, 8) AGI_CASE(1, 16) AGI_CASE(2, 16) AGI_CASE(4, 16)
+        AGI_CASE(1, 32) AGI_CASE(2, 32) AGI_CASE(4, 32) AGI_CASE(1, 64) AGI_CASE(2, 64) AGI_CASE(4, 64)
+#endif
+#undef AGI_CASE
+        if (rc != HGT_OK) return rc;
+    }
+    const unsigned mgrid = (unsigned)((NQ + 3) / 4);
+    const int vf = (int)(d / 64);
+#define AGI_MERGE(VF) \
+    k_merge_runs<VF><<<mgrid, 256, 0, stream>>>(pv.segptr, zrows, zstat, zflag, agg, (int)R, NQ, (int)H, (int)dk_pad, (int)apply_gelu, d)
+    if (vf == 1) AGI_MERGE(1); else if (vf == 2) AGI_MERGE(2); else if (vf == 4) AGI_MERGE(4); else AGI_MERGE(8);
+#undef AGI_MERGE
+    HGT_CHECK_LAUNCH();
+    return HGT_OK;
+}

@@ -141,6 +141,46 @@ def test_logits_with_matrix_core_transforms(case, precision):
     assert (att2 - att).abs().max().item() < 1e-5
 
 
+ITEM_AGG_CASES = [
+    # N, E, d, H, T, R, use_RTE, graph kwargs: hgt_edge_aggregate_items on every kind of wavefront layout
+    (3000, 30000, 256, 8, 4, 8, True, {}),                       # (4, 8): the benchmark layout (sub-tile kernel by default; forced here)
+    (1500, 12000, 512, 8, 3, 9, True, {}),                       # (4, 16) x 2 head groups
+    (600, 5000, 400, 8, 5, 33, True, dict(schema=True)),          # OAG shape: 33 relations, d_k = 50 padded to 64
+    (2000, 20000, 128, 16, 3, 5, False, {}),                      # (2, 4): 16 heads
+    (2000, 20000, 64, 1, 2, 3, True, {}),                         # (1, 64): one head
+    (5000, 60000, 64, 4, 3, 4, True, dict(dst_skew=1.1)),         # hub targets: runs of thousands of edges across items and chunks
+    (700, 3000, 32, 2, 3, 2, False, dict(sorted_types=False)),    # (1, 32)... half-empty rows
+    (129, 1, 64, 4, 2, 2, True, {}),                              # a single edge
+]
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("case", ITEM_AGG_CASES, ids=[str(i) for i in range(len(ITEM_AGG_CASES))])
+def test_item_parallel_aggregation(case, precision):
+    """hgt_edge_aggregate_items (latency regime: runs per work item on the matrix cores + an ordered merge per target) forced on
+    every layout: output against the fp64 closed form, unclaimed relations and unknown node types included; two forwards are
+    bit-identical (no atomics), and the sub-tile kernels (flag 32) agree."""
+    N, E, d, H, T, R, use_RTE, gk = case
+    sd = O.make_state_dict(d, d, T, R, H, True, use_RTE, seed=N + E + 3)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=E + 11, **gk)
+    nt, et = nt.clone(), et.clone()
+    if N > 200:
+        nt[::131] = T + 2
+        et[::37] = R
+    ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, use_norm=True, use_RTE=use_RTE, dtype=torch.float64)
+    layer = _layer_from(sd, d, T, R, H, True, use_RTE, keep_att=False, precision=precision)
+    layer.kernel_flags = 16         # HGT_FLAG_ITEM_AGGREGATE
+    out, _ = _run(layer, x, nt, ei, et, tm if use_RTE else None)
+    out_b, _ = _run(layer, x, nt, ei, et, tm if use_RTE else None)
+    err = (out.double() - ref).abs().max().item()
+    print("item aggregation N=%d E=%d d=%d H=%d R=%d %s: max|out| err %.2e" % (N, E, d, H, R, precision, err))
+    assert err < PREC_TOL[precision]
+    assert torch.equal(out, out_b)
+    layer.kernel_flags = 32         # HGT_FLAG_NO_ITEM_AGGREGATE
+    out2, _ = _run(layer, x, nt, ei, et, tm if use_RTE else None)
+    assert (out2 - out).abs().max().item() < (1e-4 if precision == "bf16x3" else 1e-5)
+
+
 DENSE_CASES = [
     # N, E, d, H, T, R, use_norm, use_RTE
     (2500, 25000, 256, 8, 4, 8, True, False),      # c2 shape
