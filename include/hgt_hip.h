@@ -483,7 +483,7 @@ typedef struct hgt_conv_args {
 #define HGT_FLAG_VALU_AGGREGATE  2   /* relation transforms of the aggregation on the vector ALU (round-1 kernel) instead of MFMA */
 #define HGT_FLAG_MFMA_LOGITS     4   /* hgt_edge_logits_mfma for every layout it covers (default: d_k >= 64 only) */
 #define HGT_FLAG_VALU_LOGITS     8   /* never hgt_edge_logits_mfma */
-#define HGT_FLAG_ITEM_AGGREGATE 16   /* hgt_edge_aggregate_items wherever it applies (default: < 16384 nodes and d_k >= 64 or > 16 relations) */
+#define HGT_FLAG_ITEM_AGGREGATE 16   /* hgt_edge_aggregate_items wherever it applies (the default below 65536 nodes when its scratch is at most 1 GB) */
 #define HGT_FLAG_NO_ITEM_AGGREGATE 32 /* never hgt_edge_aggregate_items */
 
 /* phase boundaries at which hgt_conv_forward records phase_events[i]:

@@ -3,7 +3,12 @@
 #include "hgt_common.h"
 
 #ifndef HGT_ITEM_AGG_MAX_NODES
-#define HGT_ITEM_AGG_MAX_NODES 16384      // graphs below this take the item-parallel aggregation where it pays (hgt_edge_agg_items.hip)
+#define HGT_ITEM_AGG_MAX_NODES 65536      // graphs below this CAN take the item-parallel aggregation (its scratch is part of the workspace)
+#endif
+#ifndef HGT_ITEM_AGG_DEFAULT_NODES
+#define HGT_ITEM_AGG_DEFAULT_NODES 65536  // ... and below this they do by default (hgt_edge_agg_items.hip; measured with 10 edges per
+                                          // node: 127 vs 173 us at 8k nodes, 196 vs 937 at 16k, 369 vs 383 at 32k, 708 vs 745 at 64k, d = 256;
+                                          // 330 vs 356 at 8k ... 1409 vs 1501 at 48k, d = 512)
 #endif
 
 namespace {
@@ -372,11 +377,11 @@ edge_phase:
         if (rc != HGT_ERR_UNSUPPORTED) return rc;   // unsupported layout (head-group split): the unfused kernels below
     }
     // runs for E == 0 too: it writes the zero rows of isolated targets; HGTConv stores gelu(agg) (conv.py:119), DenseHGTConv agg
-    // latency regime: the item-parallel form (hgt_edge_agg_items.hip) where a sub-tile wavefront's chain of relation ends is the
-    // kernel time -- many relations or a head-group split (d_k >= 64); flags force / forbid it
+    // latency regime: the item-parallel form (hgt_edge_agg_items.hip), where a sub-tile wavefront's chain of edge batches and
+    // relation ends is the kernel time (c3: 80 -> 66 us per layer, c5: 195 -> 147 us); flags force / forbid it
     const bool items_agg = mfma_agg && !sliced && w.zitems_bytes > 0 && NQ < HGT_ITEM_AGG_MAX_NODES && R < 64 &&
                            !(a->flags & HGT_FLAG_NO_ITEM_AGGREGATE) &&
-                           (lay.dk_pad >= 64 || R > 16 || (a->flags & HGT_FLAG_ITEM_AGGREGATE));
+                           (NQ < HGT_ITEM_AGG_DEFAULT_NODES || (a->flags & HGT_FLAG_ITEM_AGGREGATE));
     rc = HGT_ERR_UNSUPPORTED;
     if (items_agg)
         rc = hgt_edge_aggregate_items(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_f, f16 ? 1 : 0, agg, NQ, dense ? 0 : 1,

@@ -975,7 +975,9 @@ static int launch_agg_mfma(HGT_MFMA_AGG_ARGS) {
 #define HGT_SMALL_SUB 2
 #endif
     const unsigned ny_ = (unsigned)(HT / (64 / LPH));
-    const int sub = (NQ < 65536) ? ((NQ < 16384 && ny_ == 1 && R <= 16) ? HGT_SMALL_SUB : 4) : HGT_SUB;
+    // (2 targets per wavefront only up to a few thousand targets: at 16 000 the 8 000 wavefronts re-read 2 GB of fragments -- 937 us
+    //  per layer against 320 us with 4; since round 3 these sizes take hgt_edge_aggregate_items unless it is switched off)
+    const int sub = (NQ < 65536) ? ((NQ < 6144 && ny_ == 1 && R <= 16) ? HGT_SMALL_SUB : 4) : HGT_SUB;
     const int64_t tiles = (NQ + 4 * sub - 1) / (4 * sub);
     const unsigned ny = (unsigned)(HT / (64 / LPH));
     dim3 grid((unsigned)tiles, ny);

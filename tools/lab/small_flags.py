@@ -26,7 +26,7 @@ for name, schema, kw, d, H in (("c3", "mag", dict(n_seed=128, width=128, depth=6
     T, R = int(nt.max()) + 1, len(edge_dict)
     plan = GraphPlan(nt, ei, et, tm, T, R)
     for prec in ("bf16x3", "f16x3"):
-        for flags in (0, 2, 1, 3):
+        for flags in (0, 16, 32):
             layer = HGTConv(d, d, T, R, H, 0.2, True, True, precision=prec).eval().to(dev)
             layer.kernel_flags = flags
             with torch.no_grad():
