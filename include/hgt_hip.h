@@ -485,6 +485,7 @@ typedef struct hgt_conv_args {
 #define HGT_FLAG_VALU_LOGITS     8   /* never hgt_edge_logits_mfma */
 #define HGT_FLAG_ITEM_AGGREGATE 16   /* hgt_edge_aggregate_items wherever it applies (the default below 65536 nodes when its scratch is at most 1 GB) */
 #define HGT_FLAG_NO_ITEM_AGGREGATE 32 /* never hgt_edge_aggregate_items */
+#define HGT_FLAG_FUSED_ANY_SIZE 64   /* hgt_edge_aggregate_update below its default size too (>= 16384 targets) */
 
 /* phase boundaries at which hgt_conv_forward records phase_events[i]:
  *   0 start | 1 relation pack + Q/K/V (+ temporal tables) done | 2 logits done | 3 softmax done |

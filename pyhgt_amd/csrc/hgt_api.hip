@@ -2,12 +2,17 @@
 // kernel of one HGTConv.forward (conv.py:56-134, eval mode) on the caller's stream.
 #include "hgt_common.h"
 
+#ifndef HGT_FUSED_MIN_NODES
+#define HGT_FUSED_MIN_NODES 16384         // targets from which the aggregation + update run as ONE kernel (hgt_edge_aggregate_update):
+                                          // 10 edges per node, d = 256: 154 vs 125 us (item-parallel + update kernel) at 8k nodes, 181 vs
+                                          // 191 at 16k, 229 vs 285 at 24k, 252 vs 365 at 32k, 474 vs 677 at 60k
+#endif
 #ifndef HGT_ITEM_AGG_MAX_NODES
 #define HGT_ITEM_AGG_MAX_NODES 65536      // graphs below this CAN take the item-parallel aggregation (its scratch is part of the workspace)
 #endif
 #ifndef HGT_ITEM_AGG_DEFAULT_NODES
 #define HGT_ITEM_AGG_DEFAULT_NODES 65536  // ... and below this they do by default (hgt_edge_agg_items.hip; measured with 10 edges per
-                                          // node: 127 vs 173 us at 8k nodes, 196 vs 937 at 16k, 369 vs 383 at 32k, 708 vs 745 at 64k, d = 256;
+                                          // node: 127 vs 173 us at 8k nodes, 191 vs 194 at 16k, 369 vs 383 at 32k, 708 vs 745 at 64k, d = 256 (unfused);
                                           // 330 vs 356 at 8k ... 1409 vs 1501 at 48k, d = 512)
 #endif
 
@@ -349,9 +354,9 @@ edge_phase:
     mark(2);
     mark(3);
     // (5) aggregation + update.  Preferred form: one kernel that never writes agg (hgt_edge_aggregate_update).
-    // (graphs below 64k targets take the unfused kernels: hgt_edge_aggregate then runs 4 targets per wavefront, which
-    //  matters more in the latency regime than the saved agg round trip)
-    const bool fuse_all = split && !dense && dp <= 256 && dout <= dp && (dout & 3) == 0 && (din & 3) == 0 && NQ >= 65536 &&
+    // (graphs below HGT_FUSED_MIN_NODES targets take the unfused kernels: the latency regime, see items_agg below)
+    const bool fuse_all = split && !dense && dp <= 256 && dout <= dp && (dout & 3) == 0 && (din & 3) == 0 &&
+                          (NQ >= HGT_FUSED_MIN_NODES || (a->flags & HGT_FLAG_FUSED_ANY_SIZE)) &&
                           !(a->flags & HGT_FLAG_NO_FUSED_UPDATE) && !sliced &&
                           !(f16 && !mfma_agg);   // the vector-ALU kernel's fused epilogue only reads the bf16 image of W_a
     if (fuse_all) {

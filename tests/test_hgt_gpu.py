@@ -978,7 +978,7 @@ def test_benchmark_configuration_sampled_parity(variant, precision):
 
 
 FUSED_CASES = [
-    # N (>= 65536: the fused aggregate + update kernel), E, d, H, T, R, use_norm, use_RTE, graph kwargs
+    # N (>= 16384: the fused aggregate + update kernel), E, d, H, T, R, use_norm, use_RTE, graph kwargs
     (70_000, 350_000, 64, 4, 3, 4, True, True, dict(sorted_types=False)),              # mixed-type tiles everywhere
     (66_000, 300_000, 256, 8, 4, 8, True, False, {}),                                   # c2 layout, type-sorted
     (80_000, 400_000, 128, 8, 2, 5, False, False, dict(dst_skew=1.05)),                 # hubs -> pending workgroups
@@ -989,7 +989,7 @@ FUSED_CASES = [
 @pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
 @pytest.mark.parametrize("case", FUSED_CASES, ids=[str(i) for i in range(len(FUSED_CASES))])
 def test_fused_aggregate_update_matches_oracle(case, precision):
-    """hgt_edge_aggregate_update only runs for >= 65536 targets with the split-bf16 precision: the small oracle cases do
+    """hgt_edge_aggregate_update only runs for >= 16384 targets with a split precision: the small oracle cases do
     not reach it.  Unknown node types (rows must be 0) and unclaimed relations included."""
     N, E, d, H, T, R, use_norm, use_RTE, gk = case
     sd = O.make_state_dict(d, d, T, R, H, use_norm, use_RTE, seed=N % 1000 + E % 77)

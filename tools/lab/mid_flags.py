@@ -19,15 +19,17 @@ def timeit(fn, iters=100, warm=10):
 
 
 dev = "cuda:0"
+SIZES = [int(v) for v in os.environ.get("MID_SIZES", "8000,16000,24000,32000,48000,64000").split(",")]
+FLAGS = [int(v) for v in os.environ.get("MID_FLAGS", "16,32").split(",")]
 for d, H, T, R in ((256, 8, 4, 8), (512, 8, 4, 9)):
-    for N in (8000, 16000, 24000, 32000, 48000, 64000):
+    for N in SIZES:
         E = 10 * N
         x, nt, ei, et, tm = [t.to(dev) for t in synthetic_typed_graph(N, E, d, T, R, seed=N)]
         plan = GraphPlan(nt, ei, et, tm, T, R)
         res = []
-        for flags in (16, 32):
+        for flags in FLAGS:
             layer = HGTConv(d, d, T, R, H, 0.2, True, True).eval().to(dev)
             layer.kernel_flags = flags
             with torch.no_grad():
                 res.append(timeit(lambda: layer(x, nt, ei, et, tm, plan=plan)))
-        print("d=%d N=%d E=%d: items %.1f us, sub-tile %.1f us" % (d, N, E, res[0], res[1]))
+        print("d=%d N=%d E=%d:" % (d, N, E), ", ".join("flags %d: %.1f us" % (f, r) for f, r in zip(FLAGS, res)))
