@@ -14,10 +14,10 @@ from pyhgt_amd.synth import synthetic_typed_graph  # noqa: E402
 
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    big = len(sys.argv) > 2 and sys.argv[2] == "big"      # around the 65536-target switch to the fused kernel
+    big = len(sys.argv) > 2 and sys.argv[2] == "big"      # around the 16384-target switch to the fused kernel
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else (4321 if big else 1234)
     rng = random.Random(seed)
-    worst = 0.0
+    worst, fails = 0.0, 0
     for case in range(n_cases):
         H = rng.choice([1, 2, 4, 8, 16])
         dk = rng.choice([4, 8, 16, 25, 32, 50, 64]) if H <= 8 else rng.choice([4, 8, 16])
@@ -27,13 +27,14 @@ def main():
         T, R = rng.randint(1, 5), rng.randint(1, 12)
         N, E = rng.randint(1, 3000), rng.randint(0, 20000)
         if big:
-            N, E = rng.randint(60000, 80000), rng.randint(0, 300000)
+            N, E = rng.randint(12000, 24000), rng.randint(0, 150000)
             if d > 128:
                 continue
         use_norm, use_rte, dense = rng.random() < 0.7, rng.random() < 0.5, rng.random() < 0.3
         if d % 2:
             use_rte = False          # the reference's sinusoid table needs an even width (conv.py:289-294)
-        prec = rng.choice(["fp32", "bf16x3"])
+        prec = rng.choice(["fp32", "bf16x3", "f16x3"])
+        flags = rng.choice([0, 0, 0, 4, 8, 16, 32, 64, 4 | 16, 2])      # explicit kernel selections (include/hgt_hip.h HGT_FLAG_*)
         gk = dict(sorted_types=rng.random() < 0.5)
         if gk["sorted_types"] and rng.random() < 0.4:
             gk["schema"] = True
@@ -56,12 +57,13 @@ def main():
         layer = cls(d, d, T, R, H, 0.2, use_norm, use_rte, precision=prec, keep_att=keep_att).eval()
         layer.load_state_dict(sd)
         layer = layer.to("cuda:0")
+        layer.kernel_flags = flags
         GraphPlan.clear_cache()
         with torch.no_grad():
             out = layer(x.cuda(), nt.cuda(), ei.cuda(), et.cuda(), tm.cuda() if use_rte else None, n_q_rows=nq if nq < N else None)
         torch.cuda.synchronize()
         err = (out.cpu().double() - ref[:nq]).abs().max().item() if out.numel() else 0.0
-        if nq < N and rng.random() < 0.7:
+        if nq < N and rng.random() < 0.7 and prec != "f16x3":      # (staged calls of an f16x3 layer run the bf16 kernels)
             # staged execution (the pipelined multi-GPU step): own rows, then the source-only rows in 1-3 typed chunks
             xd, ntd, eid, etd = x.cuda(), nt.cuda(), ei.cuda(), et.cuda()
             tmd = tm.cuda() if use_rte else None
@@ -85,10 +87,12 @@ def main():
                 err = max(err, 1.0)
                 print("   staged forward differs from the one-call layer: max diff %.3e" % (staged - out).abs().max().item())
         worst = max(worst, err)
-        flag = "" if err < 1e-4 else "   <<<<<< FAIL"
-        print("case %3d N=%5d NQ=%5d E=%6d d=%3d H=%2d T=%d R=%2d norm=%d rte=%d dense=%d %-6s %s err=%.2e%s" % (
-            case, N, nq, E, d, H, T, R, use_norm, use_rte, dense, prec, sorted(gk.items()), err, flag), flush=True)
-    print("worst error %.3e" % worst)
+        tol = 1e-5 if prec == "f16x3" and not (flags & 2) else 1e-4
+        flag = "" if err < tol else "   <<<<<< FAIL"
+        fails += err >= tol
+        print("case %3d N=%5d NQ=%5d E=%6d d=%3d H=%2d T=%d R=%2d norm=%d rte=%d dense=%d %-6s flags=%2d %s err=%.2e%s" % (
+            case, N, nq, E, d, H, T, R, use_norm, use_rte, dense, prec, flags, sorted(gk.items()), err, flag), flush=True)
+    print("worst error %.3e, %d failures" % (worst, fails))
 
 
 if __name__ == "__main__":
