@@ -305,8 +305,8 @@ __device__ __forceinline__ void store_pass_update(f32x16 (&acc)[2], int wave, in
     }
 }
 
-template <int PROLOGUE, bool UPD, bool F16>
-__global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
+template <int PROLOGUE, bool UPD, bool F16, int NSTG = 2>
+__global__ __launch_bounds__(512, (UPD || NSTG == 4) ? 2 : 4) void k_typed_linear_split(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off,
     int n_groups, int k, int n_out, const unsigned short* __restrict__ wsplit, const float* __restrict__ bias, int64_t bgs,
     float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos, int vec_ok,
@@ -359,13 +359,10 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     // B fragment stream: k-chunk T of the flattened (pass, k-chunk) sequence, prefetched HGT_NSTAGE ahead in named register stages.
     // n_kc is a multiple of 4 (hgt_split_weights zero-pads K to a multiple of 64, the A slab is zero-filled
     // beyond k), so the 4-step body needs no guards and a pass boundary always falls between bodies.
-#ifndef HGT_NSTAGE
-#define HGT_NSTAGE 2   // measured: 2 stages (1.83 ms at c2) beat 4 (1.88 ms): fewer live registers -> fewer spills at the 128-VGPR cap
-#endif
-    bf16x8 s0h, s0m, s1h, s1m;
-#if HGT_NSTAGE == 4
-    bf16x8 s2h, s2m, s3h, s3m;
-#endif
+    // NSTG = 2: measured at c2 (1.83 ms) against 4 (1.88 ms): fewer live registers -> no spills at the 128-VGPR cap.
+    // NSTG = 4 (latency regime, launched when the grid is smaller than the chip: one workgroup = one dependent chain of B-fragment
+    // round trips to L2, registers are not what limits it): four k-chunks in flight, 256-VGPR budget.
+    bf16x8 s0h, s0m, s1h, s1m, s2h, s2m, s3h, s3m;
 #define HGT_LOAD_STAGE(S, T)                                                                          \
     {                                                                                                 \
         const unsigned short* t_ = wfrag + (int64_t)min((T), total - 1) * 2 * W_PLANE_ELEMS;          \
@@ -375,10 +372,10 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     const int pass_lo = (pass_only >= 0) ? pass_only : 0, pass_hi = (pass_only >= 0) ? pass_only + 1 : n_pass;
     HGT_LOAD_STAGE(0, pass_lo * n_kc)
     HGT_LOAD_STAGE(1, pass_lo * n_kc + 1)
-#if HGT_NSTAGE == 4
-    HGT_LOAD_STAGE(2, pass_lo * n_kc + 2)
-    HGT_LOAD_STAGE(3, pass_lo * n_kc + 3)
-#endif
+    if constexpr (NSTG == 4) {
+        HGT_LOAD_STAGE(2, pass_lo * n_kc + 2)
+        HGT_LOAD_STAGE(3, pass_lo * n_kc + 3)
+    }
 
     load_a_panel<PROLOGUE, F16>(0, tid, s_rid, x, ldx, k, vec_ok, sA, false, s_scale, s_inv, n_panel == 1);
 
@@ -390,7 +387,7 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
         const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(sA + ao + 32 * A_STRIDE);                              \
         const bf16x8 am1 = *reinterpret_cast<const bf16x8*>(sA + A_PLANE + ao + 32 * A_STRIDE);                    \
         const bf16x8 bh = s##S##h, bm = s##S##m;                                                                   \
-        HGT_LOAD_STAGE(S, (T) + HGT_NSTAGE)                                                                        \
+        HGT_LOAD_STAGE(S, (T) + NSTG)                                                                              \
         /* small terms first, hi*hi last; the two accumulators alternate */                                        \
         acc[0] = mfma32_t<F16>(am0, bh, acc[0]);                                \
         acc[1] = mfma32_t<F16>(am1, bh, acc[1]);                                \
@@ -406,17 +403,17 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
             const int nkc_p = min(KP / KC, n_kc - panel * (KP / KC));
             const int tbase = pass * n_kc + panel * (KP / KC);
             for (int kq = 0; kq < nkc_p; kq += 4) {
-#if HGT_NSTAGE == 4
-                HGT_STEP(0, tbase + kq, kq)
-                HGT_STEP(1, tbase + kq + 1, kq + 1)
-                HGT_STEP(2, tbase + kq + 2, kq + 2)
-                HGT_STEP(3, tbase + kq + 3, kq + 3)
-#else
-                HGT_STEP(0, tbase + kq, kq)
-                HGT_STEP(1, tbase + kq + 1, kq + 1)
-                HGT_STEP(0, tbase + kq + 2, kq + 2)
-                HGT_STEP(1, tbase + kq + 3, kq + 3)
-#endif
+                if constexpr (NSTG == 4) {
+                    HGT_STEP(0, tbase + kq, kq)
+                    HGT_STEP(1, tbase + kq + 1, kq + 1)
+                    HGT_STEP(2, tbase + kq + 2, kq + 2)
+                    HGT_STEP(3, tbase + kq + 3, kq + 3)
+                } else {
+                    HGT_STEP(0, tbase + kq, kq)
+                    HGT_STEP(1, tbase + kq + 1, kq + 1)
+                    HGT_STEP(0, tbase + kq + 2, kq + 2)
+                    HGT_STEP(1, tbase + kq + 3, kq + 3)
+                }
             }
         }
         if constexpr (UPD) {
@@ -965,14 +962,14 @@ static int typed_linear_split_impl(const float* x, int64_t ldx, const int32_t* r
         return HGT_OK;
     }
     const unsigned grid_s = (unsigned)(row_tiles * pass_split);
-    if (prologue == 0)
-        k_typed_linear_split<0, false, F16><<<grid_s, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out, (const unsigned short*)w_split,
-                                                                   bias, b_group_stride, out0, out1, out2, block_cols, out_by_position, vec_ok,
-                                                                   noupd, pass_split);
-    else
-        k_typed_linear_split<1, false, F16><<<grid_s, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out, (const unsigned short*)w_split,
-                                                                   bias, b_group_stride, out0, out1, out2, block_cols, out_by_position, vec_ok,
-                                                                   noupd, pass_split);
+    const bool deep = row_tiles * pass_split <= 2 * pc_grid();      // latency regime: four B-fragment stages (see the kernel)
+#define HGT_SPLIT_LAUNCH(P, NS)                                                                                                        \
+    k_typed_linear_split<P, false, F16, NS><<<grid_s, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,                   \
+                                                                        (const unsigned short*)w_split, bias, b_group_stride, out0, out1, \
+                                                                        out2, block_cols, out_by_position, vec_ok, noupd, pass_split)
+    if (prologue == 0) { if (deep) HGT_SPLIT_LAUNCH(0, 4); else HGT_SPLIT_LAUNCH(0, 2); }
+    else               { if (deep) HGT_SPLIT_LAUNCH(1, 4); else HGT_SPLIT_LAUNCH(1, 2); }
+#undef HGT_SPLIT_LAUNCH
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }
