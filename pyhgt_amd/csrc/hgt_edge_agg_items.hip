@@ -84,8 +84,10 @@ __global__ __launch_bounds__(256, 2) void k_edge_runs_mfma(
     float minv = 1.0f;
     if constexpr (F16) minv = reinterpret_cast<const float*>(msgF + (int64_t)R * NY * NCT * NKS * 2 * 512)[0];
 
-    constexpr int STEPS = NCT * NKS, GS = HGT_AGI_GS < STEPS ? HGT_AGI_GS : STEPS, NG = STEPS / GS;
+    constexpr int STEPS = NCT * NKS, GSW = (STEPS >= 32 ? 2 : 1) * HGT_AGI_GS, GS = GSW < STEPS ? GSW : STEPS, NG = STEPS / GS;
     static_assert(STEPS % GS == 0, "column-tile steps come in multiples of 4");
+    // (d_k >= 64, 32 steps: groups of 16 -- two fragment round trips per transform instead of four; the LDS tile caps the kernel at
+    //  two wavefronts per SIMD anyway, so the 64 extra registers are free)
 
     for (int base = beg; base < end; base += 64) {
         const int nb = min(64, end - base);
