@@ -112,6 +112,10 @@ int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride
                    int64_t n_nodes, int64_t n_q_rows, int64_t n_edges, int32_t n_types, int32_t n_relations,
                    void* plan, uint64_t plan_bytes, void* tmp, uint64_t tmp_bytes, void* stream);
 
+/* ABI 5: the first 16 bytes of a plan (int32 n_items, bad_index, n_hubs, n_unknown_q) copied to PINNED host memory without a
+ * synchronisation (one hipMemcpyAsync on `stream`): how the host learns "no hub target / no unknown rows / malformed ids". */
+int hgt_plan_header_to_host(const void* plan, void* host_dst_pinned, void* stream);
+
 /* Plan from a graph that is ALREADY in the order the reference's sampler produces (data.py:183-209,
  * 227-246): nodes type-contiguous with ascending types (type t = ids [type_off[t], type_off[t+1])), edges grouped by relation
  * (relation r = positions [rel_ptr[r], rel_ptr[r+1]) of src / dst / edge_time) with NON-DECREASING target ids inside a

@@ -96,6 +96,7 @@ SIGNATURES = {
     "hgt_relation_frag_pack_f16": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "hgt_edge_aggregate_items_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_u64)]),
     "hgt_edge_aggregate_items": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _u64, _vp]),
+    "hgt_plan_header_to_host": (C.c_int, [_vp, _vp, _vp]),
     "hgt_relation_frag_bytes": (C.c_int, [_i32, _i32, _i32, C.POINTER(_u64)]),
     "hgt_relation_frag_pack": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "hgt_hub_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_u64)]),

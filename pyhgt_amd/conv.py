@@ -58,11 +58,29 @@ class _Workspace:
             cls._bufs.clear()
 
 
+_PLAN_SIZES = {}
+
+
+def _plan_sizes(N, E, T, R):
+    """(plan_bytes, tmp_bytes, max_items) of hgt_plan_sizes_for, memoised: sampled batches repeat a handful of shapes."""
+    key = (N, E, T, R)
+    v = _PLAN_SIZES.get(key)
+    if v is None:
+        sz = _lib.HgtPlanSizes()
+        _lib.check(_lib.load().hgt_plan_sizes_for(N, E, T, R, C.byref(sz)), "hgt_plan_sizes_for")
+        v = (int(sz.plan_bytes), int(sz.tmp_bytes), int(sz.max_items))
+        if len(_PLAN_SIZES) > 4096:
+            _PLAN_SIZES.clear()
+        _PLAN_SIZES[key] = v
+    return v
+
+
 class _HeaderSlots:
     """A small ring of pinned host slots for the asynchronous read-back of plan headers (allocating pinned memory per plan
     costs ~20 us).  A plan whose slot is taken over before it looked at it simply never learns its hub count (safe)."""
     N = 64
     buf = None
+    base = 0
     owners = [None] * 64
     nxt = 0
 
@@ -70,6 +88,7 @@ class _HeaderSlots:
     def acquire(cls, plan):
         if cls.buf is None:
             cls.buf = torch.zeros(cls.N, 4, dtype=torch.int32).pin_memory()
+            cls.base = cls.buf.data_ptr()
         i = cls.nxt
         cls.nxt = (i + 1) % cls.N
         old = cls.owners[i]() if cls.owners[i] is not None else None
@@ -148,7 +167,9 @@ class GraphPlan:
         self._no_unknown = None
         self._bad = None
         self._hdr_slot = _HeaderSlots.acquire(self)
-        _HeaderSlots.buf[self._hdr_slot].copy_(self.buf[:16].view(torch.int32), non_blocking=True)
+        # (one hipMemcpyAsync through the C ABI: slicing + view + copy_ on the torch side cost ~8 us of host time per plan)
+        _lib.check(_lib.load().hgt_plan_header_to_host(self.buf.data_ptr(), _HeaderSlots.base + 16 * self._hdr_slot, _stream()),
+                   "hgt_plan_header_to_host")
         self._hdr_event = torch.cuda.Event()
         self._hdr_event.record()
 
@@ -170,12 +191,10 @@ class GraphPlan:
                 raise TypeError("from_sorted takes contiguous int32 device arrays")
         if rel_ptr.numel() != self.R + 1 or type_off.numel() != self.T + 1:
             raise ValueError("rel_ptr must have R+1 and type_off T+1 entries")
-        sz = _lib.HgtPlanSizes()
-        _lib.check(lib.hgt_plan_sizes_for(self.N, self.E, self.T, self.R, C.byref(sz)), "hgt_plan_sizes_for")
+        plan_bytes, tmp_bytes, self.max_items = _plan_sizes(self.N, self.E, self.T, self.R)
         dev = node_type.device
-        self.buf = torch.empty(int(sz.plan_bytes), dtype=torch.uint8, device=dev)
-        tmp = torch.empty(int(sz.tmp_bytes), dtype=torch.uint8, device=dev)
-        self.max_items = int(sz.max_items)
+        self.buf = torch.empty(plan_bytes, dtype=torch.uint8, device=dev)
+        tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
         self.node_type = node_type
         self._graph = (node_type, edge_index, edge_type, edge_time)
         self._transposed = None

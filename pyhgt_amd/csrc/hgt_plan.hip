@@ -562,6 +562,13 @@ extern "C" int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int
     return HGT_OK;
 }
 
+// the 16-byte plan header (n_items, bad_index, n_hubs, n_unknown_q) -> pinned host memory, asynchronously on `stream`
+extern "C" int hgt_plan_header_to_host(const void* plan, void* host_dst, void* stream) {
+    if (!plan || !host_dst) return HGT_ERR_INVALID_ARG;
+    if (hipMemcpyAsync(host_dst, plan, 16, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return HGT_ERR_LAUNCH;
+    return HGT_OK;
+}
+
 extern "C" int hgt_plan_from_sorted(const int32_t* src, const int32_t* dst, const int32_t* edge_time, const int32_t* rel_ptr,
                                     const int32_t* type_off, int64_t N, int64_t NQ, int64_t E, int32_t T, int32_t R, void* plan,
                                     uint64_t plan_bytes, void* tmp, uint64_t tmp_bytes, void* stream_) {
