@@ -75,7 +75,7 @@ def _gpu_run(layer, x, nt, ei, et, tm, use_RTE):
 
 
 @pytest.mark.gpu
-@settings(max_examples=20, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(CASE, st.sampled_from(["bf16x3", "f16x3", "fp32"]))
 def test_hip_path_properties_small_graphs(case, precision):
     N, E, (d, H), T, R, use_RTE, seed = case
