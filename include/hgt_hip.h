@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HGT_ABI_VERSION 5
+#define HGT_ABI_VERSION 6
 
 /* error codes */
 #define HGT_OK 0
@@ -101,6 +101,12 @@ typedef struct hgt_plan_rows {
 int hgt_plan_row_lists(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types,
                        int32_t n_relations, hgt_plan_rows* out_host);
 
+/* ABI 6: the per-tile item table of a plan: int32[*n_tiles + 1] at byte offset *offset of the plan buffer; the logits work items of
+ * destination tile t (tile_nodes targets each, hgt_plan_constants) are [table[t], table[t + 1]).  pyhgt_amd.dist reads it once per
+ * graph to launch the edge phase of ONE target block (hgt_conv_forward stage 5). */
+int hgt_plan_tile_items_offset(int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations, uint64_t* offset_host,
+                               int64_t* n_tiles_host);
+
 /* edge_index: int64, element (row, e) at edge_index[row * stride_row + e * stride_col]; row 0 =
  * source j, row 1 = target i (conv.py:60-63, data.py:245,254 -- the reference hands over the
  * (1,2)-strided transpose of an [E,2] tensor).  edge_time may be NULL (use_RTE = False).
@@ -140,7 +146,9 @@ int hgt_plan_from_sorted(const int32_t* src, const int32_t* dst, const int32_t* 
  *   bias      fp32 [n_groups][n_out] with stride b_group_stride, or NULL
  *   out0..2   the n_out columns are split into blocks of block_cols columns, block c is written
  *             to out{c}[row * block_cols + col]; row = rows[p] (out_by_position = 0) or p (= 1)
- *   prologue  0 = none, 1 = exact (erf) GELU applied to x on load (conv.py:119)
+ *   prologue  0 = none, 1 = exact (erf) GELU applied to x on load (conv.py:119); split variants only (ABI 6): 2 = x holds rows in the
+ *             24-bit transport format of the multi-GPU exchange (hgt_gather_rows_c24; ldx = 3 k / 4 dwords, k <= 256, k % 4 == 0),
+ *             decoded by the kernel's loader -- the halo rows a rank receives are projected straight off the wire buffer
  *   precision must be 0 (fp32 MFMA, exact fp32 FMA chain); the split-bf16 variant is below
  * ---------------------------------------------------------------------------------------------- */
 int hgt_typed_linear(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off,
@@ -230,6 +238,12 @@ int hgt_edge_logits(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t 
 int hgt_edge_logits_mfma(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                          int32_t n_heads, int32_t dk_pad, const float* Q, const float* K, const float* rte_k,
                          const float* att_t, const void* att_frag, int32_t frag_f16, float* logits, void* stream);
+/* ABI 6: the work items [item_begin, item_end) only = the items of a range of destination tiles (hgt_plan_tile_items_offset): the
+ * logits of ONE target block of the multi-GPU path.  att_frag may be NULL (vector-ALU kernel). */
+int hgt_edge_logits_range(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                          int32_t n_heads, int32_t dk_pad, const float* Q, const float* K, const float* rte_k,
+                          const float* att_t, const void* att_frag, int32_t frag_f16, float* logits, int32_t item_begin,
+                          int32_t item_end, void* stream);
 int hgt_edge_softmax(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                      int32_t n_heads, float* logits_att, void* stream);
 int hgt_edge_aggregate(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
@@ -341,6 +355,16 @@ int hgt_edge_aggregate_update_f16x3(const void* plan, int64_t n_nodes, int64_t n
                                     int32_t* pending, const int64_t* node_type, const void* w_a_split, const float* b_a,
                                     const float* x_skip, int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b,
                                     int32_t use_norm, int32_t n_out, float* out, void* stream);
+
+/* ABI 6: hgt_edge_aggregate_update for the targets [q_begin, q_end) only (q_begin a multiple of the plan tile, q_end <= n_q_rows):
+ * one TARGET BLOCK of the multi-GPU path, whose in-edges only reference source rows that have already arrived.  `pending` is indexed
+ * from the block's first workgroup.  Matrix-core kernel only (msg_frag required). */
+int hgt_edge_aggregate_update_range(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                                    int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
+                                    const float* msg_p, const void* msg_frag, float* agg, int64_t n_q_rows, void* hub_ws,
+                                    int32_t* pending, const int64_t* node_type, const void* w_a_split, const float* b_a,
+                                    const float* x_skip, int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b,
+                                    int32_t use_norm, int32_t n_out, float* out, void* stream, int64_t q_begin, int64_t q_end);
 
 /* ----------------------------------------------------------------------------------------------
  * Backward pass (the reference gets it from autograd: OAG/train_paper_field.py:249,
@@ -456,7 +480,12 @@ typedef struct hgt_conv_args {
      *      from slice to slice in the workspace; the LAST slice also takes the unclaimed edges and runs the update.  For
      *      source-bucketed graphs: the caller numbers relations bucket * R' + relation (n_relations = slice_count * R', the
      *      relation parameters repeated slice_count times), so slice b = the edges whose source rows arrived with bucket b
-     *      and the edge phase overlaps the exchange of the later buckets.  bf16x3 precision, HGTConv update only.       */
+     *      and the edge phase overlaps the exchange of the later buckets.  bf16x3 precision, HGTConv update only.
+     *   5  (ABI 6) edge phase + fused node update of the TARGET BLOCK [q_begin, q_end) (q_begin a multiple of the plan tile; its
+     *      logits work items are [item_begin, item_end), hgt_plan_tile_items_offset).  pyhgt_amd.dist orders a rank's halo rows by
+     *      the first target block that needs them, so block b can run as soon as halo chunks 0..b have been projected (stage 2):
+     *      no state is carried between blocks, every block is the single-GPU kernel pair on a tile range.  Split precisions, HGTConv
+     *      update, padded row <= 256 columns (HGT_ERR_UNSUPPORTED otherwise: the caller falls back to stages 1/2/3).          */
     int32_t stage;
     const int32_t* proj_rows;
     const int32_t* proj_off;
@@ -480,6 +509,14 @@ typedef struct hgt_conv_args {
     /* ABI 4: stage 4 only */
     int32_t slice_index;
     int32_t slice_count;
+    /* ABI 6: stage 5 only */
+    int64_t q_begin, q_end;
+    int32_t item_begin, item_end;
+    /* ABI 6: stage 2 only, optional: the rows of proj_rows are read from this buffer of 24-bit wire rows (hgt_gather_rows_c24 format,
+     * 3 * in_dim bytes per row) instead of from x -- wire row = node row - proj_c24_row0 (the chunk's first local row).  Needs
+     * in_dim <= 256, in_dim % 4 == 0 and a split precision (HGT_ERR_UNSUPPORTED otherwise -> hgt_unpack_rows_c24 + plain stage 2). */
+    const void* proj_c24;
+    int64_t proj_c24_row0;
 } hgt_conv_args;
 
 /* hgt_conv_args.flags: explicit kernel-selection switches (A/B measurements, tests); never read from the environment */

@@ -14,6 +14,11 @@ HGT_RTE_LEN = 240
 HGT_N_PHASE_EVENTS = 7
 HGT_FLAG_NO_FUSED_UPDATE = 1
 HGT_FLAG_VALU_AGGREGATE = 2
+HGT_FLAG_MFMA_LOGITS = 4
+HGT_FLAG_VALU_LOGITS = 8
+HGT_FLAG_ITEM_AGGREGATE = 16
+HGT_FLAG_NO_ITEM_AGGREGATE = 32
+HGT_FLAG_FUSED_ANY_SIZE = 64
 
 
 class HgtLayout(C.Structure):
@@ -52,10 +57,13 @@ class HgtConvArgs(C.Structure):
         ("flags", C.c_int32),
         ("slice_index", C.c_int32),
         ("slice_count", C.c_int32),
+        ("q_begin", C.c_int64), ("q_end", C.c_int64),
+        ("item_begin", C.c_int32), ("item_end", C.c_int32),
+        ("proj_c24", C.c_void_p), ("proj_c24_row0", C.c_int64),
     ]
 
 
-ABI_VERSION = 5          # HGT_ABI_VERSION of include/hgt_hip.h this binding was written against
+ABI_VERSION = 6          # HGT_ABI_VERSION of include/hgt_hip.h this binding was written against
 
 _i32, _i64, _u64, _vp = C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
 
@@ -68,6 +76,7 @@ SIGNATURES = {
     "hgt_plan_constants": (C.c_int, [C.POINTER(_i32), C.POINTER(_i32)]),
     "hgt_plan_item_edges": (C.c_int, [_i64, C.POINTER(_i32)]),
     "hgt_plan_row_lists": (C.c_int, [_vp, _i64, _i64, _i32, _i32, C.POINTER(HgtPlanRows)]),
+    "hgt_plan_tile_items_offset": (C.c_int, [_i64, _i64, _i32, _i32, C.POINTER(_u64), C.POINTER(_i64)]),
     "hgt_plan_build": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _u64, _vp, _u64, _vp]),
     "hgt_plan_from_sorted": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _u64, _vp, _u64, _vp]),
     "hgt_typed_linear": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
@@ -87,6 +96,9 @@ SIGNATURES = {
     "hgt_relation_pack": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "hgt_edge_logits": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hgt_edge_logits_mfma": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "hgt_edge_logits_range": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
+    "hgt_edge_aggregate_update_range": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
+                                                  _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _i64]),
     "hgt_edge_logits_slice": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "hgt_edge_aggregate_slice": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp,
                                            _i32, _i32, _vp, _i32, _i32, _vp]),

@@ -258,6 +258,18 @@ class GraphPlan:
         _lib.check(_lib.load().hgt_plan_row_lists(self.ptr, self.N, self.E, self.T, self.R, C.byref(pr)), "hgt_plan_row_lists")
         return pr
 
+    def tile_items(self):
+        """Host copy (synchronises; once per graph) of the plan's per-tile item table: the logits work items of destination tile
+        t are [table[t], table[t + 1]).  Returns (int64 tensor [n_tiles + 1] on the CPU, targets per tile).  pyhgt_amd.dist uses
+        it to launch the edge phase of one target block (hgt_conv_forward stage 5)."""
+        off, nt = C.c_uint64(), C.c_int64()
+        _lib.check(_lib.load().hgt_plan_tile_items_offset(self.N, self.E, self.T, self.R, C.byref(off), C.byref(nt)),
+                   "hgt_plan_tile_items_offset")
+        tile, item = C.c_int32(), C.c_int32()
+        _lib.check(_lib.load().hgt_plan_constants(C.byref(tile), C.byref(item)), "hgt_plan_constants")
+        tab = self.buf[int(off.value):int(off.value) + 4 * (int(nt.value) + 1)].view(torch.int32).cpu().to(torch.int64)
+        return tab, int(tile.value)
+
     def check_indices(self):
         """Debug aid (synchronises): raise if an edge endpoint was outside [0, N) (the reference
         would have raised an IndexError inside index_select)."""
@@ -544,7 +556,7 @@ class HGTConv(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def forward(self, node_inp, node_type, edge_index, edge_type, edge_time=None, plan=None, n_q_rows=None,
-                phase_events=None, stage=0, proj=None, workspace=None, slices=None):
+                phase_events=None, stage=0, proj=None, workspace=None, slices=None, block=None, out=None, proj_c24=None):
         """node_inp f32[N,in_dim], node_type i64[N], edge_index i64[2,E] (row 0 = source, row 1 =
         target; any strides), edge_type i64[E], edge_time i64[E] (needed iff use_RTE).
         Returns f32[N,out_dim] (or [n_q_rows,out_dim] when only the first n_q_rows nodes are targets).
@@ -555,6 +567,12 @@ class HGTConv(nn.Module):
         slices = (index, count) with stage 4 (count alone matters for stages 1/2 of the same forward): the plan numbers
         relations `source bucket * num_relations + relation` (count buckets; pyhgt_amd.dist builds it), stage 4 runs the edge
         phase of bucket `index` with the softmax state carried in the workspace, and the last bucket's call returns the output.
+        block = (q_begin, q_end, item_begin, item_end) with stage 5: edge phase + fused node update of the TARGET BLOCK
+        [q_begin, q_end) (q_begin a multiple of the plan tile; its logits work items from GraphPlan.tile_items()); `out` must be
+        the [n_q_rows, out_dim] tensor all blocks of the forward write into (returned).  pyhgt_amd.dist orders the halo rows by
+        the first block that needs them, so block b runs as soon as halo chunks 0..b are projected -- no state between blocks.
+        proj_c24 = (wire uint8 tensor, first local row) with stage 2: the rows of `proj` are projected straight off the 24-bit
+        wire buffer of the exchange (hgt_gather_rows_c24 format) instead of from node_inp.
         workspace: caller-owned uint8 device buffer (>= workspace_bytes(N, E)) instead of the per-(device, stream) scratch;
         staged callers MUST pass one (Q/K/V live in it between the stages)."""
         lib = _lib.load()
@@ -618,7 +636,13 @@ class HGTConv(nn.Module):
                 raise ValueError("staged execution keeps Q/K/V in the workspace between calls: pass workspace=")
             ws = _Workspace.get(x.device, nbytes.value)
         final = stage in (0, 3) or (stage == 4 and int(slices[0]) == n_slices - 1)
-        out = torch.empty(NQ, self.out_dim, dtype=torch.float32, device=x.device) if final else None
+        if stage == 5:
+            if block is None or out is None or out.shape != (NQ, self.out_dim) or out.dtype != torch.float32 or not out.is_contiguous():
+                raise ValueError("stage 5 takes block=(q_begin, q_end, item_begin, item_end) and out=f32[n_q_rows, out_dim]")
+            if self.keep_att:
+                raise ValueError("keep_att is not available in the target-blocked multi-GPU schedule")
+        else:
+            out = torch.empty(NQ, self.out_dim, dtype=torch.float32, device=x.device) if final else None
         att = torch.empty(E, self.n_heads, dtype=torch.float32, device=x.device) if (self.keep_att and final) else None
         ntype = node_type.contiguous()
 
@@ -643,11 +667,13 @@ class HGTConv(nn.Module):
         self._set_update_args(a, pk)
         a.rte_emb, a.rte_w, a.rte_b = _ptr(pk.get("rte_emb")), _ptr(pk.get("rte_w")), _ptr(pk.get("rte_b"))
         a.workspace, a.workspace_bytes = _ptr(ws), ws.numel()
-        a.out, a.att_out = _ptr(out) if final else _ptr(ws), _ptr(att)   # stages 1/2 write no output (non-NULL placeholder)
+        a.out, a.att_out = _ptr(out) if (final or stage == 5) else _ptr(ws), _ptr(att)   # stages 1/2 write no output (non-NULL placeholder)
         a.want_att = int(self.keep_att and final)
         a.stage = int(stage)
         if stage == 4:
             a.slice_index, a.slice_count = int(slices[0]), n_slices
+        if stage == 5:
+            a.q_begin, a.q_end, a.item_begin, a.item_end = (int(v) for v in block)
         a.plan_no_hubs = int(plan.no_hubs) | (2 if plan.no_unknown_rows else 0)
         a.flags = int(self.kernel_flags)
         prep = self._prepared_buffer(x.device, n_slices, prec)          # after _pack_parameters: a re-pack has invalidated it
@@ -657,6 +683,11 @@ class HGTConv(nn.Module):
             if rows.dtype != torch.int32 or off.dtype != torch.int32 or off.numel() != self.num_types + 1:
                 raise TypeError("proj must be (int32 rows, int32 offsets[T+1])")
             a.proj_rows, a.proj_off, a.proj_n = _ptr(rows), _ptr(off), int(rows.numel())
+            if proj_c24 is not None:
+                wire, row0 = proj_c24
+                if wire.dtype != torch.uint8 or not wire.is_contiguous() or wire.device != x.device:
+                    raise TypeError("proj_c24 must be (contiguous uint8 device tensor of 24-bit rows, first local row)")
+                a.proj_c24, a.proj_c24_row0 = _ptr(wire), int(row0)
         if phase_events is not None:      # ctypes array of HGT_N_PHASE_EVENTS hipEvent_t (bench.py instrumentation)
             a.phase_events = C.cast(phase_events, C.c_void_p)
         _lib.check(lib.hgt_conv_forward(C.byref(a), _stream()), "hgt_conv_forward")

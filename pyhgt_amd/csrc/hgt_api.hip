@@ -224,17 +224,29 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     // relation transforms of the aggregation: matrix cores (split-bf16 x3) with the split precision, exact fp32 mat-vecs otherwise
     uint64_t frag_bytes = 0;
     hgt_relation_frag_bytes(R, H, lay.dk_pad, &frag_bytes);
-    const bool mfma_agg = (a->precision >= 1) && frag_bytes > 0 && !(a->flags & HGT_FLAG_VALU_AGGREGATE);
+    const bool have_frags = (a->precision >= 1) && frag_bytes > 0;
+    void* const msg_f_buf = msg_f;      // where the fragment images live (the kernel arguments below may be nulled by the flags)
+    void* const att_f_buf = att_f;
+    const bool mfma_agg = have_frags && !(a->flags & HGT_FLAG_VALU_AGGREGATE);
     if (!mfma_agg) msg_f = nullptr;
     // logits: the target-side transforms on the matrix cores where the vector-ALU kernel is instruction-bound (d_k >= 64)
-    const bool mfma_logits = (a->precision >= 1) && frag_bytes > 0 && !(a->flags & HGT_FLAG_VALU_LOGITS) && a->stage != 4 &&
+    const bool mfma_logits = have_frags && !(a->flags & HGT_FLAG_VALU_LOGITS) && a->stage != 4 &&
                              (lay.dk_pad >= 64 || (a->flags & HGT_FLAG_MFMA_LOGITS));
 
     auto mark = [&](int i) {
         if (a->phase_events && a->phase_events[i]) (void)hipEventRecord((hipEvent_t)a->phase_events[i], stream);
     };
     const int stage = a->stage;
-    if (stage < 0 || stage > 4) return HGT_ERR_INVALID_ARG;
+    if (stage < 0 || stage > 5) return HGT_ERR_INVALID_ARG;
+    // stage 5: edge phase + fused update of ONE target block (multi-GPU path: the block's in-edges only reference source rows of the
+    // halo chunks that have arrived); every block is the single-GPU kernel pair on a range of destination tiles
+    const bool blocked = (stage == 5);
+    if (blocked) {
+        if (a->q_begin < 0 || a->q_end < a->q_begin || a->q_end > NQ || (a->q_begin % HGT_TD) != 0 || a->item_begin < 0 ||
+            a->item_end < a->item_begin)
+            return HGT_ERR_INVALID_ARG;
+        if (!mfma_agg || dense || a->want_att) return HGT_ERR_UNSUPPORTED;
+    }
     // stage 4: the edge phase over ONE slice of the relation buckets (multi-GPU path: relation id = source bucket * R' + relation)
     const bool sliced = (stage == 4);
     int sl_lo = 0, sl_hi = R + 1, sl_more = 0;
@@ -252,18 +264,18 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     rc = hgt_plan_row_lists(a->plan, N, E, T, R, &pr);
     if (rc != HGT_OK) return rc;
 
-    // (1) relation matrices: fold pri/sqrt(dk), transpose att, zero-pad heads (conv.py:98-99,104)
+    // (1) relation matrices: fold pri/sqrt(dk), transpose att, zero-pad heads (conv.py:98-99,104).  BOTH fragment images are made
+    // whenever the split precision has them, whatever kernels this call's flags select: a `prepared` buffer outlives the call and a
+    // later call with other flags trusts it (round-3 advisor finding: a flag change on a live layer read an image that was never written)
     if ((stage == 0 || stage == 1) && fresh) {
         rc = hgt_relation_pack(a->relation_att, a->relation_msg, a->relation_pri, R, Hreal, H, lay.d_k, lay.dk_pad, att_t, msg_p, stream);
         if (rc != HGT_OK) return rc;
-        if (mfma_agg) {
-            rc = f16 ? hgt_relation_frag_pack_f16(msg_p, R, H, lay.dk_pad, msg_f, stream)
-                     : hgt_relation_frag_pack(msg_p, R, H, lay.dk_pad, msg_f, stream);
+        if (have_frags) {
+            rc = f16 ? hgt_relation_frag_pack_f16(msg_p, R, H, lay.dk_pad, msg_f_buf, stream)
+                     : hgt_relation_frag_pack(msg_p, R, H, lay.dk_pad, msg_f_buf, stream);
             if (rc != HGT_OK) return rc;
-        }
-        if (mfma_logits) {
-            rc = f16 ? hgt_relation_frag_pack_f16(att_t, R, H, lay.dk_pad, att_f, stream)
-                     : hgt_relation_frag_pack(att_t, R, H, lay.dk_pad, att_f, stream);
+            rc = f16 ? hgt_relation_frag_pack_f16(att_t, R, H, lay.dk_pad, att_f_buf, stream)
+                     : hgt_relation_frag_pack(att_t, R, H, lay.dk_pad, att_f_buf, stream);
             if (rc != HGT_OK) return rc;
         }
     }
@@ -295,10 +307,17 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     const int64_t wstride = (int64_t)3 * dp * din;
     if (stage == 2) {   // K|V of one received chunk of halo rows (the K|V split tiles are re-made each time: tiny)
         if (a->proj_n == 0) return HGT_OK;
+        if (a->proj_c24) {   // straight off the wire buffer (24-bit rows): no expansion pass, 3/4 of the bytes read
+            if (!split) return HGT_ERR_UNSUPPORTED;
+            const int64_t ldw = 3 * (int64_t)(din / 4);      // dwords per wire row
+            const float* xw = reinterpret_cast<const float*>(a->proj_c24) - a->proj_c24_row0 * ldw;   // indexed by the LOCAL row id
+            return linear(xw, ldw, a->proj_rows, a->proj_off, T, a->proj_n, din, 2 * dp, a->w_qkv + (int64_t)dp * din, wstride,
+                          a->b_qkv + dp, 3 * dp, K, V, nullptr, dp, 0, ws_a, 2);
+        }
         return linear(a->x, din, a->proj_rows, a->proj_off, T, a->proj_n, din, 2 * dp, a->w_qkv + (int64_t)dp * din, wstride, a->b_qkv + dp,
                       3 * dp, K, V, nullptr, dp, 0, ws_a);
     }
-    if (stage == 3 || stage == 4) goto edge_phase;
+    if (stage == 3 || stage == 4 || stage == 5) goto edge_phase;
     if (stage == 1) {   // own rows only: one fused Q|K|V launch, exactly like the single-GPU layer
         rc = linear(a->x, din, pr.rows_q, pr.off_q, T, NQ, din, 3 * dp, a->w_qkv, wstride, a->b_qkv, 3 * dp, Q, K, V, dp, 0, ws_qkv, 0, !fresh);
         if (rc != HGT_OK) return rc;
@@ -337,13 +356,44 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
         if (rc != HGT_OK) return rc;
     }
 
-    if (stage == 1) return HGT_OK;
+    if (stage == 1) {
+        // staged forwards whose edge phase runs per target block (stage 5) find the image of W_a in the prepared buffer
+        if (pb && fresh && split && !dense && dp <= 256 && dout <= dp && (dout & 3) == 0) {
+            rc = split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
+            if (rc != HGT_OK) return rc;
+        }
+        return HGT_OK;
+    }
 edge_phase:
     if (a->use_rte) {   // (also for stage 3 and for calls that trust the prepared tables)
         rte_k = pb ? (float*)(pb + pl.off_rte_k) : (float*)(wb + w.off_rte_k);
         rte_v = pb ? (float*)(pb + pl.off_rte_v) : (float*)(wb + w.off_rte_v);
     }
     mark(1);
+    if (blocked) {
+        const bool can_fuse = split && dp <= 256 && dout <= dp && (dout & 3) == 0 && (din & 3) == 0;
+        if (!can_fuse) return HGT_ERR_UNSUPPORTED;
+        if (a->q_begin == a->q_end) return HGT_OK;
+        if (E > 0 && a->item_end > a->item_begin) {
+            rc = hgt_edge_logits_range(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, mfma_logits ? att_f : nullptr, 0, logits,
+                                       a->item_begin, a->item_end, stream);
+            if (rc != HGT_OK) return rc;
+        }
+        mark(2);
+        mark(3);
+        // (the image of W_a was written by stage 1 when the prepared buffer is fresh -- see below -- or is made here)
+        if (!pb) {
+            rc = split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
+            if (rc != HGT_OK) return rc;
+        }
+        rc = hgt_edge_aggregate_update_range(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ, hub_ws,
+                                             (int32_t*)(wb + w.off_pending), a->node_type, ws_upd, a->b_a, a->x, din, a->skip, a->ln_w,
+                                             a->ln_b, a->use_norm, dout, a->out, stream, a->q_begin, a->q_end);
+        mark(4);
+        mark(5);
+        mark(6);
+        return rc;
+    }
     // (4) edge phase: logits, then softmax fused into the aggregation (online, per target sub-tile)
     if (E > 0) {
         rc = sliced ? hgt_edge_logits_slice(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, sl_lo, sl_hi, stream)

@@ -777,7 +777,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_mfma(
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* my_sig = s_sig[F16 ? wib : 0];
-    const int64_t row0 = (int64_t)blockIdx.x * (4 * sub) + wib * sub;
+    const int64_t row0 = sl.q_lo + (int64_t)blockIdx.x * (4 * sub) + wib * sub;
     if (row0 >= NQ) return;
     unsigned hub_mask = 0;
     if (hub_slot) {
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
     float* s_sig = s_scale + (F16 ? 4 * 16 : 0);                           // fp16 split: row scales of the targets, [4][16]
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int64_t row0 = fu.q_lo + (int64_t)blockIdx.x * 64;
     const int64_t wrow0 = row0 + wib * 16;
 
     unsigned hub_mask = 0;
@@ -978,7 +978,7 @@ static int launch_agg_mfma(HGT_MFMA_AGG_ARGS) {
     // (2 targets per wavefront only up to a few thousand targets: at 16 000 the 8 000 wavefronts re-read 2 GB of fragments -- 937 us
     //  per layer against 320 us with 4; since round 3 these sizes take hgt_edge_aggregate_items unless it is switched off)
     const int sub = (NQ < 65536) ? ((NQ < 6144 && ny_ == 1 && R <= 16) ? HGT_SMALL_SUB : 4) : HGT_SUB;
-    const int64_t tiles = (NQ + 4 * sub - 1) / (4 * sub);
+    const int64_t tiles = (NQ - sl.q_lo + 4 * sub - 1) / (4 * sub);      // NQ = end of the launch's target range
     const unsigned ny = (unsigned)(HT / (64 / LPH));
     dim3 grid((unsigned)tiles, ny);
     const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
@@ -993,7 +993,7 @@ template <int VEC, int LPH, bool RTE, bool F16>
 static int launch_aggupd_mfma(HGT_MFMA_AGGUPD_ARGS) {
     if (HT != 64 / LPH) return HGT_ERR_UNSUPPORTED;   // a head-group split leaves a workgroup with part of the row
     if (R >= 64) return HGT_ERR_UNSUPPORTED;          // the streaming walk keeps the R + 1 ranges in lane registers
-    const int64_t tiles = (NQ + 63) / 64;
+    const int64_t tiles = (NQ - fu.q_lo + 63) / 64;      // NQ = end of the launch's target range
     dim3 grid((unsigned)tiles, 1);
     const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
     k_edge_aggregate_update_mfma<VEC, LPH, RTE, F16><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
@@ -1205,14 +1205,21 @@ static int edge_aggregate_update_impl(bool f16, const void* plan, int64_t N, int
                                       const void* msg_frag, float* agg, int64_t n_q_rows, void* hub_ws, int32_t* pending,
                                       const int64_t* node_type, const void* w_a_split, const float* b_a, const float* x_skip,
                                       int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm,
-                                      int32_t n_out, float* out, void* stream) {
+                                      int32_t n_out, float* out, void* stream, int64_t q_begin = 0, int64_t q_end = -1) {
     if (f16 && !msg_frag) return HGT_ERR_INVALID_ARG;
     if (!plan || !V || !msg_p || !agg || !pending || !node_type || !w_a_split || !b_a || !x_skip || !skip || !out || H <= 0 ||
         64 % H != 0 || dk_pad <= 0 || n_out <= 0)
         return HGT_ERR_INVALID_ARG;
     if (E > 0 && !logits) return HGT_ERR_INVALID_ARG;
     if (use_norm && (!ln_w || !ln_b)) return HGT_ERR_INVALID_ARG;
-    const int64_t NQ = (n_q_rows > 0 && n_q_rows <= N) ? n_q_rows : N;
+    int64_t NQ = (n_q_rows > 0 && n_q_rows <= N) ? n_q_rows : N;
+    const bool ranged = (q_end >= 0);      // a target block [q_begin, q_end) of the multi-GPU path (include/hgt_hip.h, ABI 6)
+    if (ranged) {
+        if (q_begin < 0 || q_begin > q_end || q_end > NQ || (q_begin % HGT_TD) != 0) return HGT_ERR_INVALID_ARG;
+        if (!msg_frag) return HGT_ERR_UNSUPPORTED;      // the vector-ALU kernels always walk the whole graph
+        NQ = q_end;
+        if (q_begin == q_end) return HGT_OK;
+    }
     if (NQ == 0) return HGT_OK;
     const int lph = 64 / H;
     if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
@@ -1220,7 +1227,9 @@ static int edge_aggregate_update_impl(bool f16, const void* plan, int64_t N, int
     if (dp > KP || n_out > dp || (n_out & 3) != 0 || (ld_skip & 3) != 0 || ((uintptr_t)x_skip & 15) != 0) return HGT_ERR_UNSUPPORTED;
     HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
     HgtHubBuffers hb = carve_hub(hub_ws, pv, H, E);
-    HgtFusedUpdate fu = {node_type, (const unsigned short*)w_a_split, b_a, x_skip, ld_skip, skip, ln_w, ln_b, use_norm, T, n_out, out};
+    HgtFusedUpdate fu = {node_type, (const unsigned short*)w_a_split, b_a, x_skip, ld_skip, skip, ln_w, ln_b, use_norm, T, n_out, out,
+                         ranged ? q_begin : 0};
+    if (ranged) { hb.q_lo = q_begin; hb.q_hi = q_end; }
     int rc = HGT_ERR_UNSUPPORTED;
     if (msg_frag && mfma_split_for(dk_pad / lph, lph) == 1)
         rc = mfma_aggupd_dispatch(dk_pad / lph, lph, f16, pv, logits, V, rte_v, msg_p, (const unsigned short*)msg_frag, agg,
@@ -1242,6 +1251,11 @@ static int edge_aggregate_update_impl(bool f16, const void* plan, int64_t N, int
 extern "C" int hgt_edge_aggregate_update(HGT_AGGUPD_PARAMS) { return edge_aggregate_update_impl(false, HGT_AGGUPD_PASS); }
 // msg_frag = hgt_relation_frag_pack_f16 image, w_a_split = hgt_split_weights_f16 image (both required)
 extern "C" int hgt_edge_aggregate_update_f16x3(HGT_AGGUPD_PARAMS) { return edge_aggregate_update_impl(true, HGT_AGGUPD_PASS); }
+// ABI 6: the targets [q_begin, q_end) only (q_begin a multiple of the plan tile): one target block of the multi-GPU path
+extern "C" int hgt_edge_aggregate_update_range(HGT_AGGUPD_PARAMS, int64_t q_begin, int64_t q_end) {
+    if (q_end < 0) return HGT_ERR_INVALID_ARG;
+    return edge_aggregate_update_impl(false, HGT_AGGUPD_PASS, q_begin, q_end);
+}
 
 // out[i][ld_out] = sum_rel ( sum_{e in (i,rel)} w_e rows[src_e] ) F[rel]  -- the aggregation kernel without the softmax: the edge
 // weights are given.  The backward pass is three of these (include/hgt_hip.h).

@@ -9,6 +9,7 @@ struct HgtHubBuffers {
     int* mx;      // [max_hubs][HT] ordered-int max logit
     float* l;     // [max_hubs][HT]
     float* acc;   // [max_hubs][HT * DKP]
+    int64_t q_lo, q_hi;   // only hubs in [q_lo, q_hi) are processed (a target block of the multi-GPU path); q_hi <= 0: all
 };
 
 // arguments of the fused node update (hgt_fused_update.h)
@@ -19,6 +20,7 @@ struct HgtRelSlice {
     float* state;     // f32[NQ][H][2] = (reference, exp-sum) per (target, head); NULL: the whole layer in one launch
     int has_prev;     // an earlier slice left state + un-normalised rows (in agg): merge with them
     int more;         // further slices follow: leave state + un-normalised rows instead of finishing
+    int64_t q_lo;     // first target row of the launch (a multiple of 64; target blocks of the multi-GPU path), 0 = the whole graph
 };
 
 struct HgtFusedUpdate {
@@ -32,6 +34,7 @@ struct HgtFusedUpdate {
     const float* lnb;
     int use_norm, n_types, n_out;
     float* out;                      // [NQ][n_out]
+    int64_t q_lo;                    // first target row of the launch (a multiple of 64): workgroup b owns rows q_lo + 64 b ..
 };
 
 // hub kernels (hgt_edge_hub.hip): max / exp-sum + weighted sum / finalize for the targets the plan marked as hubs.

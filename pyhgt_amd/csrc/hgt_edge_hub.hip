@@ -35,7 +35,8 @@ __global__ void k_hub_init(const HgtPlanHeader* __restrict__ hdr, HgtHubBuffers 
 
 // work id w -> (hub slot, relation bucket, piece); edges [pb, pe) of that piece
 __device__ __forceinline__ bool hub_piece(int w, int n_hubs, int R, const int32_t* __restrict__ hub_list,
-                                          const int32_t* __restrict__ segptr, int& slot, int& rel, int& pb, int& pe) {
+                                          const int32_t* __restrict__ segptr, int& slot, int& rel, int& pb, int& pe,
+                                          int64_t q_lo, int64_t q_hi) {
     const int per_hub = (R + 1) * HUB_CHUNKS;
     slot = w / per_hub;
     if (slot >= n_hubs) return false;
@@ -43,6 +44,7 @@ __device__ __forceinline__ bool hub_piece(int w, int n_hubs, int R, const int32_
     rel = r2 / HUB_CHUNKS;
     const int c = r2 - rel * HUB_CHUNKS;
     const int64_t dst = hub_list[slot];
+    if (q_hi > 0 && (dst < q_lo || dst >= q_hi)) return false;      // a hub of another target block (multi-GPU path)
     const int64_t b = ((dst / HGT_TD) * (R + 1) + rel) * HGT_TD + dst % HGT_TD;
     const int beg = segptr[b], end = segptr[b + 1];
     const int len = end - beg, piece = (len + HUB_CHUNKS - 1) / HUB_CHUNKS;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void k_hub_max(const HgtPlanHeader* __restrict
     const int total = n_hubs * (R + 1) * HUB_CHUNKS;
     for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < total; w += gridDim.x * 4) {
         int slot, rel, pb, pe;
-        if (!hub_piece(w, n_hubs, R, hub_list, segptr, slot, rel, pb, pe)) continue;
+        if (!hub_piece(w, n_hubs, R, hub_list, segptr, slot, rel, pb, pe, hb.q_lo, hb.q_hi)) continue;
         float m = -1.0e30f;
         if (rel < R) {
             for (int e = pb + eo; e < pe; e += epw) m = fmaxf(m, logits[(int64_t)e * HT + hh]);
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void k_hub_accumulate(
     const int total = n_hubs * (R + 1) * HUB_CHUNKS;
     for (int w = blockIdx.x * 4 + wib; w < total; w += gridDim.x * 4) {
         int slot, rel, pb, pe;
-        if (!hub_piece(w, n_hubs, R, hub_list, segptr, slot, rel, pb, pe)) continue;
+        if (!hub_piece(w, n_hubs, R, hub_list, segptr, slot, rel, pb, pe, hb.q_lo, hb.q_hi)) continue;
         slot = __builtin_amdgcn_readfirstlane(slot);
         rel = __builtin_amdgcn_readfirstlane(rel);
         pb = __builtin_amdgcn_readfirstlane(pb);
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void k_hub_finalize(const HgtPlanHeader* __res
     const int dfull = HT * dkp;
     for (int slot = blockIdx.x * 4 + (threadIdx.x >> 6); slot < n_hubs; slot += gridDim.x * 4) {
         const int64_t row = hub_list[slot];
-        if (row >= NQ) continue;
+        if (row >= NQ || (hb.q_hi > 0 && (row < hb.q_lo || row >= hb.q_hi))) continue;
         for (int c = lane; c < dfull; c += 64) {
             float v = hb.acc[(int64_t)slot * dfull + c];
             if (apply_gelu != 2) v /= (hb.l[slot * HT + c / dkp] + 1e-16f);

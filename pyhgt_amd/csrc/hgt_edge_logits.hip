@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_edge_logits(
     const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
     const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ Q,
     const float* __restrict__ K, const float* __restrict__ rteK, const float* __restrict__ attT, float* __restrict__ logits, int R,
-    int HT, int rel_lo, int rel_hi) {
+    int HT, int rel_lo, int rel_hi, int item_lo, int item_hi) {
     // A wave covers DP = 64*VEC consecutive floats of a row = H = 64/LPH heads.  When the row has more heads (HT > H),
     // blockIdx.y selects the head group: used when the full-width relation fragment (dk_pad*vec floats per lane) would
     // not fit in registers (d = 512: 512 floats) -- narrower slices keep it register-resident.
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_edge_logits(
     // (adjacent in the item list) all read the tile's Q rows.  The XCDs take runs of 16 consecutive item groups in turn, so a
     // tile's items meet in one L2 at about the same time instead of pulling the tile through eight of them (HGT_LOGITS_XCD=0:
     // the plain order; gridDim.x is a multiple of 128)
-    const int n_items = hdr->n_items;
+    const int n_items = item_hi >= 0 ? item_hi : hdr->n_items;      // (item_lo, item_hi): the items of a target block, or (0, -1)
 #if HGT_LOGITS_XCD
     // (chunks of HGT_XCD_CHUNK workgroups, dealt to the XCDs in turn: contiguous EIGHTHS of the list put all the heavy items of a
     //  skewed graph -- its hub tiles come first -- on one XCD: Zipf(0.8) logits 2.2 -> 3.2 ms)
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_edge_logits(
 #else
     const int vblock = blockIdx.x;
 #endif
-    const int item = vblock * 4 + wib;
+    const int item = item_lo + vblock * 4 + wib;
     if (item >= n_items) return;
     const HgtItem it = items[item];
     const int beg = __builtin_amdgcn_readfirstlane(it.beg), end = __builtin_amdgcn_readfirstlane(it.end);
@@ -204,13 +204,14 @@ __global__ void k_relation_pack(const float* __restrict__ ratt, const float* __r
 template <int VEC, int LPH>
 struct LaunchLogits {
     static int run(const HgtPlanView& pv, const float* Q, const float* K, const float* rteK, const float* attT, float* logits,
-                   int R, int HT, int rel_lo, int rel_hi, hipStream_t stream) {
-        const unsigned blocks = ((unsigned)((pv.L.max_items + 3) / 4) + 127u) & ~127u;      // (a multiple of 8 XCDs x 16: XCD-aware item order)
+                   int R, int HT, int rel_lo, int rel_hi, int item_lo, int item_hi, hipStream_t stream) {
+        const int64_t n_launch = item_hi >= 0 ? (int64_t)(item_hi - item_lo) : pv.L.max_items;
+        const unsigned blocks = ((unsigned)((n_launch + 3) / 4) + 127u) & ~127u;      // (a multiple of 8 XCDs x 16: XCD-aware item order)
         dim3 grid(blocks, (unsigned)(HT / (64 / LPH)));
         if (rteK)
-            k_edge_logits<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi);
+            k_edge_logits<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi, item_lo, item_hi);
         else
-            k_edge_logits<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi);
+            k_edge_logits<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi, item_lo, item_hi);
         return HGT_OK;
     }
 };
@@ -230,7 +231,7 @@ extern "C" int hgt_relation_pack(const float* relation_att, const float* relatio
 
 // hgt_edge_logits_mfma.hip
 int hgt_launch_logits_mfma(int vec, int lph, bool f16, const HgtPlanView& pv, const float* Q, const float* K, const float* rteK,
-                           const unsigned short* attF, float* logits, int R, int HT, int rel_lo, int rel_hi, hipStream_t stream);
+                           const unsigned short* attF, float* logits, int R, int HT, int rel_lo, int rel_hi, int item_lo, int item_hi, hipStream_t stream);
 
 // head-group split of the matrix-core kernels (hgt_edge_agg_mfma.hip): the wave's slice must be <= 256 columns
 static int mfma_logits_split_for(int vec_full, int lph_full) {
@@ -241,7 +242,7 @@ static int mfma_logits_split_for(int vec_full, int lph_full) {
 
 static int edge_logits_impl(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad, const float* Q,
                             const float* K, const float* rte_k, const float* att_t, float* logits, int rel_lo, int rel_hi, void* stream,
-                            const void* att_frag = nullptr, int frag_f16 = 0) {
+                            const void* att_frag = nullptr, int frag_f16 = 0, int item_lo = 0, int item_hi = -1) {
     if (!plan || !Q || !K || !att_t || !logits || H <= 0 || 64 % H != 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
     if (rel_lo < 0 || rel_hi > R + 1 || rel_lo > rel_hi) return HGT_ERR_INVALID_ARG;
     if (E == 0) return HGT_OK;
@@ -252,14 +253,14 @@ static int edge_logits_impl(const void* plan, int64_t N, int64_t E, int32_t T, i
         const int spm = mfma_logits_split_for(dk_pad / lph, lph);
         if (spm != 0) {
             int rc = hgt_launch_logits_mfma(dk_pad / lph / spm, lph * spm, frag_f16 != 0, pv, Q, K, rte_k, (const unsigned short*)att_frag,
-                                            logits, (int)R, (int)H, rel_lo, rel_hi, (hipStream_t)stream);
+                                            logits, (int)R, (int)H, rel_lo, rel_hi, item_lo, item_hi, (hipStream_t)stream);
             if (rc == HGT_OK) HGT_CHECK_LAUNCH();
             if (rc != HGT_ERR_UNSUPPORTED) return rc;
         }
     }
     const int sp = head_split_for(dk_pad / lph, lph, dk_pad);
     int rc = dispatch_layout<LaunchLogits>(dk_pad / lph / sp, lph * sp, pv, Q, K, rte_k, att_t, logits, (int)R, (int)H, rel_lo, rel_hi,
-                                           (hipStream_t)stream);
+                                           item_lo, item_hi, (hipStream_t)stream);
     if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();
     return HGT_OK;
@@ -281,6 +282,16 @@ extern "C" int hgt_edge_logits_slice(const void* plan, int64_t N, int64_t E, int
                                      const float* Q, const float* K, const float* rte_k, const float* att_t, float* logits,
                                      int32_t rel_lo, int32_t rel_hi, void* stream) {
     return edge_logits_impl(plan, N, E, T, R, H, dk_pad, Q, K, rte_k, att_t, logits, rel_lo, rel_hi, stream);
+}
+
+// ABI 6: the work items [item_begin, item_end) only (the items of a range of target tiles: hgt_plan_tile_items_offset) -- one
+// target block of the multi-GPU path.  att_frag may be NULL (vector-ALU kernel).
+extern "C" int hgt_edge_logits_range(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                     const float* Q, const float* K, const float* rte_k, const float* att_t, const void* att_frag,
+                                     int32_t frag_f16, float* logits, int32_t item_begin, int32_t item_end, void* stream) {
+    if (item_begin < 0 || item_end < item_begin) return HGT_ERR_INVALID_ARG;
+    if (item_begin == item_end) return HGT_OK;
+    return edge_logits_impl(plan, N, E, T, R, H, dk_pad, Q, K, rte_k, att_t, logits, 0, R + 1, stream, att_frag, frag_f16, item_begin, item_end);
 }
 
 extern "C" int hgt_edge_softmax(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, float* logits_att,

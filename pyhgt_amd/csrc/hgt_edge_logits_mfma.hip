@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_logits_mfma(
     const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
     const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ Q,
     const float* __restrict__ K, const float* __restrict__ rteK, const unsigned short* __restrict__ attF, float* __restrict__ logits,
-    int R, int HT, int rel_lo, int rel_hi) {
+    int R, int HT, int rel_lo, int rel_hi, int item_lo, int item_hi) {
     using G = LG<VEC, LPH>;
     constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS, QS = G::QS;
     constexpr int UN = RTE ? (unroll_for<VEC>() * 3) / 4 : unroll_for<VEC>(), HB = UN / 2;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_logits_mfma(
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n_items = hdr->n_items;
+    const int n_items = item_hi >= 0 ? item_hi : hdr->n_items;      // (item_lo, item_hi): the items of a target block, or (0, -1)
 #if HGT_LOGITS_XCD     // XCD-aware item order, see k_edge_logits
     // (chunks of HGT_XCD_CHUNK workgroups, dealt to the XCDs in turn: contiguous EIGHTHS of the list put all the heavy items of a
     //  skewed graph -- its hub tiles come first -- on one XCD: Zipf(0.8) logits 2.2 -> 3.2 ms)
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_logits_mfma(
 #else
     const int vblock = blockIdx.x;
 #endif
-    const int item = vblock * 4 + wib;
+    const int item = item_lo + vblock * 4 + wib;
     if (item >= n_items) return;
     const HgtItem it = items[item];
     const int beg = __builtin_amdgcn_readfirstlane(it.beg), end = __builtin_amdgcn_readfirstlane(it.end);
@@ -261,12 +261,13 @@ __global__ __launch_bounds__(256, 2) void k_edge_logits_mfma(
 
 template <int VEC, int LPH>
 static int launch_logits_mfma(bool f16, const HgtPlanView& pv, const float* Q, const float* K, const float* rteK, const unsigned short* attF,
-                              float* logits, int R, int HT, int rel_lo, int rel_hi, hipStream_t stream) {
-    const unsigned blocks = ((unsigned)((pv.L.max_items + 3) / 4) + 127u) & ~127u;      // (a multiple of 8 XCDs x 16: XCD-aware item order)
+                              float* logits, int R, int HT, int rel_lo, int rel_hi, int item_lo, int item_hi, hipStream_t stream) {
+    const int64_t n_launch = item_hi >= 0 ? (int64_t)(item_hi - item_lo) : pv.L.max_items;
+        const unsigned blocks = ((unsigned)((n_launch + 3) / 4) + 127u) & ~127u;      // (a multiple of 8 XCDs x 16: XCD-aware item order)
     dim3 grid(blocks, (unsigned)(HT / (64 / LPH)));
 #define LGM_LAUNCH(RTE_, F16_)                                                                                                   \
     k_edge_logits_mfma<VEC, LPH, RTE_, F16_><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attF, \
-                                                                       logits, R, HT, rel_lo, rel_hi)
+                                                                       logits, R, HT, rel_lo, rel_hi, item_lo, item_hi)
     if (rteK) { if (f16) LGM_LAUNCH(true, true); else LGM_LAUNCH(true, false); }
     else      { if (f16) LGM_LAUNCH(false, true); else LGM_LAUNCH(false, false); }
 #undef LGM_LAUNCH
@@ -278,10 +279,10 @@ static int launch_logits_mfma(bool f16, const HgtPlanView& pv, const float* Q, c
 // vec / lph: the wavefront's layout after the head-group split of the matrix-core kernels (<= 256 columns per wavefront)
 __attribute__((visibility("hidden"))) int hgt_launch_logits_mfma(int vec, int lph, bool f16, const HgtPlanView& pv, const float* Q,
                                                                  const float* K, const float* rteK, const unsigned short* attF,
-                                                                 float* logits, int R, int HT, int rel_lo, int rel_hi,
+                                                                 float* logits, int R, int HT, int rel_lo, int rel_hi, int item_lo, int item_hi,
                                                                  hipStream_t stream) {
 #define LGM_CASE(V, L) \
-    if (vec == V && lph == L) return launch_logits_mfma<V, L>(f16, pv, Q, K, rteK, attF, logits, R, HT, rel_lo, rel_hi, stream);
+    if (vec == V && lph == L) return launch_logits_mfma<V, L>(f16, pv, Q, K, rteK, attF, logits, R, HT, rel_lo, rel_hi, item_lo, item_hi, stream);
 #ifdef HGT_DEV_LAYOUTS
     LGM_CASE(4, 8) LGM_CASE(4, 16)
 #else

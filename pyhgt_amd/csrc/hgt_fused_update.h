@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void k_update_pending(const float* __restri
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_PLANE + 4096];
     if (pending[blockIdx.x] == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int64_t row0 = fu.q_lo + (int64_t)blockIdx.x * 64;
     float vals[16][VEC];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

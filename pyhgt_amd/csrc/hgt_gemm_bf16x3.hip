@@ -466,11 +466,28 @@ __device__ __forceinline__ bool tile_lookup(int t, const int32_t* __restrict__ g
 // producer: request the rows of one tile (wave pw fetches rows pw, pw+4, ..., one coalesced 1 KB row per instruction).
 // Fast path: 16 unconditional back-to-back 16 B loads (absent rows read row 0 and are zeroed in pc_commit); written
 // with per-row conditions hipcc lowers the whole thing to 4 B loads behind branches (measured: 47k cycles per tile).
+template <int PROLOGUE>
 __device__ __forceinline__ void pc_issue(float4 (&a)[PC_AREGS], int& v_rid, int pw, int lane, int row0, int nrows,
                                          const int32_t* __restrict__ rows, const float* __restrict__ x, int64_t ldx, int k, int vec_ok) {
     const int myrow = pw + PC_PROD * lane;   // lanes 0..15 carry the 16 row ids of this wave
     v_rid = (lane < PC_AREGS && myrow < nrows) ? rows[row0 + myrow] : -1;
     const int kk = lane * 4;
+    if constexpr (PROLOGUE == 2) {
+        // x holds rows in the 24-bit transport format of the multi-GPU exchange (hgt_gather_rows_c24: 4 values = 3 dwords, ldx =
+        // 3 k / 4 dwords per row; k % 4 == 0 checked by the launcher): one 12-byte load per lane, decoded in pc_commit
+        if (kk < k) {
+#pragma unroll
+            for (int j = 0; j < PC_AREGS; ++j) {
+                const int rid = max(__builtin_amdgcn_readlane(v_rid, j), 0);
+                const float* px = x + (int64_t)rid * ldx + lane * 3;
+                a[j] = make_float4(px[0], px[1], px[2], 0.0f);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PC_AREGS; ++j) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     if (vec_ok) {   // k % 4 == 0: a lane is entirely inside or entirely outside the row
         if (kk < k) {
 #pragma unroll
@@ -506,6 +523,13 @@ __device__ __forceinline__ void pc_commit(const float4 (&a)[PC_AREGS], int v_rid
 #pragma unroll
     for (int j = 0; j < PC_AREGS; ++j) {
         float4 v = a[j];
+        if constexpr (PROLOGUE == 2) {      // 3 dwords of the 24-bit format -> 4 floats (value = 24 bits << 8: hgt_update.hip)
+            const unsigned w0 = __builtin_bit_cast(unsigned, v.x), w1 = __builtin_bit_cast(unsigned, v.y), w2 = __builtin_bit_cast(unsigned, v.z);
+            v.x = __builtin_bit_cast(float, w0 << 8);
+            v.y = __builtin_bit_cast(float, ((w0 >> 24) | (w1 << 8)) << 8);
+            v.z = __builtin_bit_cast(float, ((w1 >> 16) | (w2 << 16)) << 8);
+            v.w = __builtin_bit_cast(float, w2 & 0xFFFFFF00u);
+        }
         if (__builtin_amdgcn_readlane(v_rid, j) < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);   // row beyond the tile
         if (PROLOGUE == 1) { v.x = gelu_erf_(v.x); v.y = gelu_erf_(v.y); v.z = gelu_erf_(v.z); v.w = gelu_erf_(v.w); }
         float scale = 1.0f;
@@ -701,11 +725,11 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
         float4 a[PC_AREGS];
         int v_rid, g, row0, nrows;
         tile_lookup(first / pass_split, group_off, n_groups, g, row0, nrows);
-        pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
+        pc_issue<PROLOGUE>(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
         pc_commit<PROLOGUE, F16>(a, v_rid, pw, lane, sA[0], s_rid[0], s_rinv[0]);
         if (n_mine > 1) {
             tile_lookup((first + stride) / pass_split, group_off, n_groups, g, row0, nrows);
-            pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
+            pc_issue<PROLOGUE>(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
         }
         pc_barrier();                                   // B_0
         for (int i = 0; i < n_mine; ++i) {
@@ -713,7 +737,7 @@ __global__ __launch_bounds__(PC_THREADS) void k_typed_linear_pc(
                 pc_commit<PROLOGUE, F16>(a, v_rid, pw, lane, sA[(i + 1) & 1], s_rid[(i + 1) % 3], s_rinv[F16 ? (i + 1) % 3 : 0]);
                 if (i + 2 < n_mine) {
                     tile_lookup((first + (i + 2) * stride) / pass_split, group_off, n_groups, g, row0, nrows);
-                    pc_issue(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
+                    pc_issue<PROLOGUE>(a, v_rid, pw, lane, row0, nrows, rows, x, ldx, k, vec_ok);
                 }
             }
             if constexpr (UPD) {
@@ -930,7 +954,8 @@ static int typed_linear_split_impl(const float* x, int64_t ldx, const int32_t* r
         return HGT_ERR_INVALID_ARG;
     const int n_blocks_out = (n_out + block_cols - 1) / block_cols;
     if (n_blocks_out > 3 || (n_blocks_out > 1 && !out1) || (n_blocks_out > 2 && !out2)) return HGT_ERR_INVALID_ARG;
-    if (prologue != 0 && prologue != 1) return HGT_ERR_INVALID_ARG;
+    if (prologue < 0 || prologue > 2) return HGT_ERR_INVALID_ARG;
+    if (prologue == 2 && (k > KP || (k & 3) != 0 || ldx != 3 * (int64_t)(k / 4))) return HGT_ERR_UNSUPPORTED;   // 24-bit wire rows: the persistent kernel only
     if (((n_out | block_cols) & 3) != 0) return HGT_ERR_UNSUPPORTED;   // 16-byte epilogue stores; use hgt_typed_linear (fp32) instead
     if (n_rows == 0) return HGT_OK;
     hipStream_t stream = (hipStream_t)stream_;
@@ -954,10 +979,14 @@ static int typed_linear_split_impl(const float* x, int64_t ldx, const int32_t* r
             k_typed_linear_pc<0, false, F16><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
                                                                          (const unsigned short*)w_split, bias, b_group_stride, out0, out1,
                                                                          out2, block_cols, out_by_position, vec_ok, noupd, pass_split);
-        else
+        else if (prologue == 1)
             k_typed_linear_pc<1, false, F16><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
                                                                          (const unsigned short*)w_split, bias, b_group_stride, out0, out1,
                                                                          out2, block_cols, out_by_position, vec_ok, noupd, pass_split);
+        else
+            k_typed_linear_pc<2, false, F16><<<grid, PC_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,
+                                                                         (const unsigned short*)w_split, bias, b_group_stride, out0, out1,
+                                                                         out2, block_cols, out_by_position, 1, noupd, pass_split);
         HGT_CHECK_LAUNCH();
         return HGT_OK;
     }

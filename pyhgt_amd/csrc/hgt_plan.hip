@@ -483,6 +483,18 @@ extern "C" int hgt_plan_row_lists(const void* plan, int64_t n_nodes, int64_t n_e
     return HGT_OK;
 }
 
+// ABI 6: where the per-tile item table lives inside a plan buffer: int32[n_tiles + 1] at byte offset *offset, the logits work
+// items of destination tile t (tile_nodes targets, hgt_plan_constants) are [table[t], table[t + 1]).  The multi-GPU path reads it
+// once per graph to launch the edge phase of one target block (hgt_conv_forward stage 5).
+extern "C" int hgt_plan_tile_items_offset(int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations, uint64_t* offset,
+                                          int64_t* n_tiles) {
+    if (!offset || !n_tiles || n_nodes < 0 || n_edges < 0) return HGT_ERR_INVALID_ARG;
+    const HgtPlanLayout L = hgt_plan_layout(n_nodes, n_edges, n_types, n_relations);
+    *offset = L.off_tile_items;
+    *n_tiles = L.n_tiles;
+    return HGT_OK;
+}
+
 extern "C" int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col,
                               const int64_t* edge_type, const int64_t* edge_time, const int64_t* node_type,
                               int64_t N, int64_t NQ, int64_t E, int32_t T, int32_t R,

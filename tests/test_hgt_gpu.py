@@ -1065,23 +1065,39 @@ def test_classifier_and_matcher_heads():
     assert torch.equal(cached, full) and torch.equal(cached2, full)
 
 
-def _halo_worker(rank, world, port, N, E, d, T, R, offsets, n_chunks, tmpdir):
-    """CPU / gloo: negotiate the HaloPlan of `rank` exactly like a real run, then hand it to the parent."""
+def _halo_worker(rank, world, port, N, E, d, T, R, offsets, n_chunks, tmpdir, blocked=False, hub=False):
+    """CPU / gloo: negotiate the HaloPlan of `rank` exactly like a real run, then hand it to the parent.  blocked: first-use
+    chunks of the target-blocked schedule (n_chunks = target blocks)."""
     import os
     import torch.distributed as dist
-    from pyhgt_amd.dist import HaloPlan
+    from pyhgt_amd.dist import HaloPlan, target_blocks
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=91, sorted_types=False)
+        x, nt, ei, et, tm = _halo_graph(N, E, d, T, R, offsets, hub)
         lo, hi = offsets[rank], offsets[rank + 1]
         mine = (ei[1] >= lo) & (ei[1] < hi)
-        hp = HaloPlan(nt[lo:hi], ei[0][mine], offsets, rank, world, n_chunks=n_chunks)
+        eblock = None
+        if blocked:
+            dst_l = ei[1][mine] - lo
+            bounds = target_blocks(dst_l, hi - lo, n_chunks)
+            eblock = torch.searchsorted(torch.tensor(bounds[1:]), dst_l, right=True).clamp(max=n_chunks - 1)
+        hp = HaloPlan(nt[lo:hi], ei[0][mine], offsets, rank, world, n_chunks=n_chunks, edge_block=eblock)
         hp.group = None
         torch.save(hp, os.path.join(tmpdir, "halo%d.pt" % rank))
     finally:
         dist.destroy_process_group()
+
+
+def _halo_graph(N, E, d, T, R, offsets, hub):
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=91, sorted_types=False)
+    if hub:      # a hub target (> 1024 in-edges) in the second rank's range, unclaimed edges, nodes of no known type
+        nt, ei, et = nt.clone(), ei.clone(), et.clone()
+        ei[1, :2500] = offsets[1] + 300
+        et[::13] = R + 1
+        nt[::29] = T
+    return x, nt, ei, et, tm
 
 
 def _c24_round_trip(rows):
@@ -1108,51 +1124,219 @@ def test_c24_transport_format_round_trip():
     assert torch.equal(back[0, :4], x[0, :4])
 
 
-@pytest.mark.parametrize("precision,compress,bucketed", [("fp32", False, None), ("bf16x3", False, None), ("bf16x3", True, None),
-                                                         ("bf16x3", False, False)])
-def test_pipelined_partitioned_forward_with_real_halos(precision, compress, bucketed, tmp_path):
-    """The multi-GPU step of pyhgt_amd/dist.py (chunked exchange + hgt_conv_forward stages 1/2/3) on ONE GPU: the halo
-    plans of a 3-rank partition are negotiated over gloo in CPU worker processes, every rank's pipelined forward then
+class _DoneWork:
+    def wait(self):
+        return True
+
+
+def _fake_exchange_for(hp, xg):
+    """The all-to-all of one chunk replaced by a copy out of the global feature table (one GPU plays every rank)."""
+    lib = _lib.load()
+
+    def fake_exchange(c, x_own, x_local, pack=None, async_op=False, compress=False, expand=True):
+        a, b = hp.recv_chunk_off[c], hp.recv_chunk_off[c + 1]
+        rows = xg[hp.need[hp.halo_order[a:b]]].contiguous()
+        wire = None
+        if compress:
+            n, d = rows.shape
+            wire = torch.empty(n, 3 * d, dtype=torch.uint8, device=rows.device)
+            if n:
+                idx = torch.arange(n, dtype=torch.int32, device=rows.device)
+                assert lib.hgt_gather_rows_c24(rows.data_ptr(), d, idx.data_ptr(), n, d, wire.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream) == 0
+        if not compress or expand:
+            x_local[hp.n_own + a:hp.n_own + b] = _c24_round_trip(rows) if (compress and b > a) else rows
+        else:
+            x_local[hp.n_own + a:hp.n_own + b] = float("nan")      # nothing may read the fp32 halo rows in the direct mode
+        bufs = (x_local[:0], wire) if compress else (x_local[:0],)
+        return (_DoneWork(), bufs) if async_op else None
+    return fake_exchange
+
+
+@pytest.mark.parametrize("precision,compress,mode", [("fp32", False, "blocked"), ("bf16x3", False, "pipelined"), ("bf16x3", True, "bucketed"),
+                                                     ("bf16x3", False, "bucketed")])
+def test_pipelined_partitioned_forward_with_real_halos(precision, compress, mode, tmp_path):
+    """The multi-GPU step of pyhgt_amd/dist.py (chunked exchange + hgt_conv_forward stages 1/2/3 or 1/2/4) on ONE GPU: the halo
+    plans of a 3-rank partition are negotiated over gloo in CPU worker processes, every rank's forward then
     runs on the device with the all-to-all replaced by a copy out of the global feature table, and the stitched outputs
-    must equal the oracle on the whole graph.  bucketed=None: the source-bucketed edge phase (stages 1/2/4) wherever it applies
-    (split-bf16 precision); False: the edge phase after the last chunk (stages 1/2/3)."""
+    must equal the oracle on the whole graph.  An exact-fp32 layer falls back to the pipelined schedule whatever the graph's mode."""
     import socket
     import torch.multiprocessing as mp
     from pyhgt_amd.dist import PartitionedGraph
     N, E, d, T, R, H, world, n_chunks = 900, 9000, 64, 3, 4, 4, 3, 3
     offsets = [0, 250, 610, 900]
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_halo_worker, args=(world, port, N, E, d, T, R, offsets, n_chunks, str(tmp_path)), nprocs=world, join=True)
-    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=91, sorted_types=False)
+    mp.spawn(_halo_worker, args=(world, port, N, E, d, T, R, offsets, n_chunks, str(tmp_path), mode == "blocked"), nprocs=world, join=True)
+    x, nt, ei, et, tm = _halo_graph(N, E, d, T, R, offsets, False)
     sd = O.make_state_dict(d, d, T, R, H, True, True, seed=92)
     ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, dtype=torch.float64)
     layer = _layer_from(sd, d, T, R, H, True, True, keep_att=False, precision=precision)
     xg = x.to(DEV)
-
-    class _Done:
-        def wait(self):
-            return True
-
     for rank in range(world):
         lo, hi = offsets[rank], offsets[rank + 1]
         mine = (ei[1] >= lo) & (ei[1] < hi)
         hp = torch.load(os.path.join(str(tmp_path), "halo%d.pt" % rank), weights_only=False).to(DEV)
         assert hp.n_halo > 0 and hp.n_chunks == n_chunks
-
-        def fake_exchange(c, x_own, x_local, pack=None, async_op=False, compress=False, hp=hp):
-            a, b = hp.recv_chunk_off[c], hp.recv_chunk_off[c + 1]
-            rows = xg[hp.need[hp.halo_order[a:b]]].contiguous()
-            x_local[hp.n_own + a:hp.n_own + b] = _c24_round_trip(rows) if (compress and b > a) else rows
-            return (_Done(), (x_local[:0],)) if async_op else None
-        hp.exchange_chunk = fake_exchange
+        hp.exchange_chunk = _fake_exchange_for(hp, xg)
         pg = PartitionedGraph(None, None, (ei[1][mine] - lo).to(DEV), et[mine].to(DEV), tm[mine].to(DEV), T, R, 0, rank, world,
-                              node_offsets=offsets, halo=hp, compress=compress, bucketed=bucketed)
-        assert pg.bucketed == (bucketed is None) and (pg.bucket_plan is not None) == pg.bucketed
+                              node_offsets=offsets, halo=hp, compress=compress, mode=mode, n_chunks=n_chunks)
+        assert pg.mode == mode and (pg.bucket_plan is not None) == (mode == "bucketed")
+        assert pg.layer_mode(layer) == ("pipelined" if precision == "fp32" else mode)
         GraphPlan.clear_cache()
         with torch.no_grad():
             out = pg.forward(layer, xg[lo:hi].contiguous())
         assert out.shape == (hi - lo, d)
         assert (out.cpu().double() - ref[lo:hi]).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("compress,use_rte", [(False, True), (True, False), (True, True)])
+def test_target_blocked_schedule_with_real_halos(compress, use_rte, tmp_path):
+    """The round-4 schedule (pyhgt_amd/dist.py "blocked": first-use halo chunks + hgt_conv_forward stage 5 per target block) on
+    ONE GPU, like the test above: 3 ranks x 4 target blocks of whole plan tiles, a hub target, unclaimed edges and unknown node
+    types; with compress the halo rows are projected straight off the 24-bit wire buffer (the fp32 halo rows are poisoned with
+    NaN).  Every rank's stitched output must equal the oracle on the whole graph, and the blocked forward must be BIT-IDENTICAL to
+    the pipelined forward of the same rank (the same kernels on tile ranges: no state, no different rounding points)."""
+    import socket
+    import torch.multiprocessing as mp
+    from pyhgt_amd.dist import PartitionedGraph
+    N, E, d, T, R, H, world, n_blocks = 9000, 110000, 64, 3, 4, 4, 3, 4
+    offsets = [0, 2900, 6100, 9000]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_halo_worker, args=(world, port, N, E, d, T, R, offsets, n_blocks, str(tmp_path), True, True), nprocs=world, join=True)
+    x, nt, ei, et, tm = _halo_graph(N, E, d, T, R, offsets, True)
+    sd = O.make_state_dict(d, d, T, R, H, True, use_rte, seed=92)
+    ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm if use_rte else None, dtype=torch.float64, use_RTE=use_rte)
+    layer = _layer_from(sd, d, T, R, H, True, use_rte, keep_att=False, precision="bf16x3")
+    xg = x.to(DEV)
+    for rank in range(world):
+        lo, hi = offsets[rank], offsets[rank + 1]
+        mine = (ei[1] >= lo) & (ei[1] < hi)
+        hp = torch.load(os.path.join(str(tmp_path), "halo%d.pt" % rank), weights_only=False).to(DEV)
+        hp.exchange_chunk = _fake_exchange_for(hp, xg)
+        tmr = tm[mine].to(DEV) if use_rte else None
+        pg = PartitionedGraph(None, None, (ei[1][mine] - lo).to(DEV), et[mine].to(DEV), tmr, T, R, 0, rank, world,
+                              node_offsets=offsets, halo=hp, compress=compress, mode="blocked", n_chunks=n_blocks)
+        assert pg.layer_mode(layer) == "blocked" and len(pg.blocks) == n_blocks
+        assert pg.blocks[0][0] == 0 and pg.blocks[-1][1] == hi - lo and all(b[0] % 256 == 0 for b in pg.blocks)
+        assert all(pg.blocks[i][1] == pg.blocks[i + 1][0] and pg.blocks[i][3] == pg.blocks[i + 1][2] for i in range(n_blocks - 1))
+        GraphPlan.clear_cache()
+        with torch.no_grad():
+            out = pg.forward(layer, xg[lo:hi].contiguous())
+            pg.mode = "pipelined"
+            layer.kernel_flags = _lib.HGT_FLAG_FUSED_ANY_SIZE      # the same fused aggregation + update kernel, over the whole range
+            out_p = pg.forward(layer, xg[lo:hi].contiguous())
+            layer.kernel_flags = 0
+        assert out.shape == (hi - lo, d) and torch.isfinite(out).all()
+        assert (out.cpu().double() - ref[lo:hi]).abs().max().item() < TOL
+        assert torch.equal(out, out_p)
+
+
+@pytest.mark.parametrize("use_rte,zipf", [(False, False), (True, True)])
+def test_target_blocks_are_bit_identical_to_the_one_call_layer(use_rte, zipf):
+    """hgt_conv_forward stage 5 (ABI 6): the edge phase + fused update of a range of destination tiles.  Running the blocks of a
+    graph one after the other (in any order) must reproduce the one-call layer BIT FOR BIT -- with source-only halo rows, hub
+    targets inside and outside a block (the hub kernels filter by range), unclaimed edges and unknown node types."""
+    T, R, H, d, N, NQ, E = 4, 8, 8, 256, 90_000, 70_000, 900_000
+    sd = O.make_state_dict(d, d, T, R, H, True, use_rte, seed=51)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=52, sorted_types=False)
+    nt, ei, et = nt.clone(), ei.clone(), et.clone()
+    ei[1] = ei[1] % NQ                     # targets are the first NQ rows, the rest are source-only halo rows
+    if zipf:
+        ei[1, :4000] = 70                  # hub in the first block
+        ei[1, 4000:6500] = 40_000          # hub in a later block
+    et[::11] = R + 2
+    nt[::17] = T
+    layer = _layer_from(sd, d, T, R, H, True, use_rte, keep_att=False, precision="bf16x3")
+    xd, ntd, eid, etd, tmd = _to_dev(x, nt, ei, et, tm)
+    GraphPlan.clear_cache()
+    plan = GraphPlan(ntd, eid, etd, tmd if use_rte else None, T, R, n_q_rows=NQ)
+    ws = torch.empty(layer.workspace_bytes(N, E), dtype=torch.uint8, device=DEV)
+    args = (xd, ntd, eid, etd, tmd if use_rte else None)
+    with torch.no_grad():
+        ref = layer(*args, plan=plan, n_q_rows=NQ, workspace=ws).clone()
+        tab, tile = plan.tile_items()
+        assert tile == 256 and tab.numel() == (N + tile - 1) // tile + 1 and (tab[1:] >= tab[:-1]).all()
+        bounds = [0, 256 * 40, 256 * 41, 256 * 41, 256 * 200, NQ]              # uneven blocks, an EMPTY one, a ragged last tile
+        out = torch.full((NQ, d), float("nan"), device=DEV)
+        kw = dict(plan=plan, n_q_rows=NQ, workspace=ws)
+        layer(*args, stage=1, **kw)
+        halo = torch.arange(NQ, N, device=DEV)
+        hp_types = ntd[NQ:]
+        order = torch.argsort(torch.where(hp_types < T, hp_types, torch.full_like(hp_types, T)), stable=True)
+        cnt = torch.bincount(hp_types.clamp(max=T), minlength=T + 1)[:T]
+        off = torch.zeros(T + 1, dtype=torch.int32, device=DEV)
+        off[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+        rows = halo[order][:int(cnt.sum())].to(torch.int32).contiguous()
+        layer(*args, stage=2, proj=(rows, off), **kw)
+        for b in (3, 0, 4, 2, 1):          # any order: the blocks are independent
+            q0, q1 = bounds[b], bounds[b + 1]
+            blk = (q0, q1, int(tab[q0 // tile]), int(tab[(q1 + tile - 1) // tile]))
+            assert layer(*args, stage=5, block=blk, out=out, **kw) is out
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    fwd = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm if use_rte else None, use_norm=True, use_RTE=use_rte)
+    assert (out.cpu().double() - fwd[:NQ]).abs().max().item() < TOL
+    # argument checks of the new stage
+    with torch.no_grad():
+        with pytest.raises(RuntimeError):
+            layer(*args, stage=5, block=(100, 512, 0, 1), out=out, **kw)          # q_begin is not a multiple of the plan tile
+        with pytest.raises(ValueError):
+            layer(*args, stage=5, block=(0, 256, 0, 1), out=out[:10], **kw)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+def test_typed_linear_reads_the_24_bit_wire_format(precision):
+    """prologue 2 of the split typed linears (ABI 6): x = rows in the 24-bit transport format of the halo exchange, decoded by the
+    kernel's loader.  Must be bit-identical to unpacking the rows first (the decoded value has 16 significant bits, so its bf16
+    hi / mid split is exact) -- ragged row tiles, several groups, rows addressed through a row list with an offset base."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    n, k, n_out, G = 1000, 256, 512, 3
+    x = (torch.randn(n, k, generator=g) * torch.logspace(-3, 3, k)).to(DEV)
+    W = (torch.randn(G, n_out, k, generator=g) / 16).to(DEV)
+    bias = torch.randn(G, n_out, generator=g).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    idx = torch.arange(n, dtype=torch.int32, device=DEV)
+    wire = torch.empty(n, 3 * k, dtype=torch.uint8, device=DEV)
+    assert lib.hgt_gather_rows_c24(x.data_ptr(), k, idx.data_ptr(), n, k, wire.data_ptr(), st) == 0
+    xu = torch.empty_like(x)
+    assert lib.hgt_unpack_rows_c24(wire.data_ptr(), n, k, xu.data_ptr(), k, st) == 0
+    base = 5000                                                    # local id of the wire buffer's first row
+    perm = torch.randperm(n, generator=g).to(DEV)
+    rows = (base + perm[:900]).to(torch.int32).contiguous()        # 900 of the 1000 rows, shuffled, in 3 groups
+    off = torch.tensor([0, 301, 301 + 64, 900], dtype=torch.int32, device=DEV)
+    nb = C.c_uint64()
+    assert lib.hgt_split_weights_bytes(G, k, n_out, C.byref(nb)) == 0
+    wsplit = torch.empty(int(nb.value), dtype=torch.uint8, device=DEV)
+    split = lib.hgt_split_weights_f16 if precision == "f16x3" else lib.hgt_split_weights
+    lin = lib.hgt_typed_linear_f16x3 if precision == "f16x3" else lib.hgt_typed_linear_bf16x3
+    assert split(W.data_ptr(), n_out * k, G, k, n_out, wsplit.data_ptr(), st) == 0
+    outs = []
+    for mode in (0, 2):
+        o0 = torch.zeros(base + n, 256, device=DEV)
+        o1 = torch.zeros(base + n, 256, device=DEV)
+        if mode == 0:      # plain fp32 rows, addressed by the same local ids
+            xin, ldx = xu.data_ptr() - base * k * 4, k
+        else:
+            xin, ldx = wire.data_ptr() - base * (3 * k // 4) * 4, 3 * k // 4
+        assert lin(xin, ldx, rows.data_ptr(), off.data_ptr(), G, 900, k, n_out, wsplit.data_ptr(), bias.data_ptr(), n_out,
+                   o0.data_ptr(), o1.data_ptr(), None, 256, 0, mode, st) == 0
+        outs.append((o0, o1))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    refK = torch.zeros(base + n, n_out, dtype=torch.float64)
+    offl = off.tolist()
+    for gi in range(G):
+        r = rows[offl[gi]:offl[gi + 1]].long().cpu()
+        refK[r] = xu.cpu().double()[r - base] @ W[gi].cpu().double().T + bias[gi].cpu().double()
+    got = torch.cat([outs[1][0], outs[1][1]], 1).cpu().double()
+    scale = (xu.cpu().double().abs() @ W.abs().amax(0).cpu().double().T).max().item()
+    assert (got - refK).abs().max().item() <= (1e-6 if precision == "f16x3" else 3e-5) * scale
+    # prologue values beyond 2 are rejected; a K the persistent kernel does not cover is "unsupported" (the caller unpacks first)
+    assert lin(wire.data_ptr(), 3 * k // 4, rows.data_ptr(), off.data_ptr(), G, 900, k, n_out, wsplit.data_ptr(), bias.data_ptr(), n_out,
+               outs[0][0].data_ptr(), outs[0][1].data_ptr(), None, 256, 0, 3, st) == -1
+    assert lin(wire.data_ptr(), 3 * 512 // 4, rows.data_ptr(), off.data_ptr(), G, 900, 512, n_out, wsplit.data_ptr(), bias.data_ptr(), n_out,
+               outs[0][0].data_ptr(), outs[0][1].data_ptr(), None, 256, 0, 2, st) == -2
 
 
 @pytest.mark.parametrize("use_rte,n_slices,N,E", [(False, 4, 70000, 700000), (True, 3, 70000, 500000), (True, 5, 3000, 40000)])
