@@ -372,6 +372,98 @@ def replicas_c5(args, world, rank, dev, backend_name):
         dist.destroy_process_group()
 
 
+def configs3_share(dev, world, rank, Nl, El, T, R, use_rte, locality, skew, keep_global_types=False):
+    """BASELINE.json configs[3] recipe: ONE global graph of world x (Nl nodes, El edges), generated identically on every rank (device
+    generator, same seed), cut by the in-edge-balanced partitioner of pyhgt_amd.dist; returns this rank's share.
+    locality p: a fraction p of the sources is drawn from the target's own natural partition (the 'schema/locality' variant of
+    SURVEY 8e), the rest uniformly from ALL nodes; 0 = the uniform worst case (1 / world of the edges stay local)."""
+    from pyhgt_amd.dist import partition
+    gg = torch.Generator(device=dev).manual_seed(1234)
+    Ng, Eg = Nl * world, El * world
+    node_type_g = torch.randint(0, T, (world, Nl), generator=gg, device=dev).sort(dim=1).values.reshape(-1)
+    dst_g = torch.randint(0, Ng, (Eg,), generator=gg, device=dev)
+    if skew > 0.0:
+        u = torch.rand(Eg, generator=gg, device=dev)
+        dst_g = (dst_g // Nl) * Nl + (Nl * u ** (1.0 / (1.0 - skew))).long().clamp(0, Nl - 1)
+    src_g = torch.randint(0, Ng, (Eg,), generator=gg, device=dev)
+    if locality > 0.0:
+        near = torch.rand(Eg, generator=gg, device=dev) < locality
+        src_g = torch.where(near, (dst_g // Nl) * Nl + src_g % Nl, src_g)
+        del near
+    et_g = torch.randint(0, R, (Eg,), generator=gg, device=dev)
+    tm_g = torch.randint(0, 240, (Eg,), generator=gg, device=dev) if use_rte else None
+    share = partition(node_type_g, torch.stack([src_g, dst_g]), et_g, tm_g, world, rank)
+    share["edge_ids"] = None
+    del src_g, dst_g, et_g, tm_g
+    torch.cuda.empty_cache()
+    return share, (node_type_g if keep_global_types else None)
+
+
+XGMI_LINK_GBS = 76.8      # per direction and peer link (7 peers per GPU: 538 GB/s egress), /opt/skills/guides/MI355X_MICROARCH.md / task statement
+
+
+def stage_times(timeline_sets):
+    """Mean milliseconds per stage label from the (label, event) marks PartitionedGraph.forward left on the compute stream."""
+    acc, n = {}, 0
+    for marks in timeline_sets:
+        if len(marks) < 2:
+            continue
+        n += 1
+        for (_, e0), (lab, e1) in zip(marks[:-1], marks[1:]):
+            acc[lab] = acc.get(lab, 0.0) + e0.elapsed_time(e1)
+    return {k: round(v / max(n, 1), 4) for k, v in acc.items()}
+
+
+def emulate_rank(dev, W, Nl, El, d, H, T, R, locality, blocks, compress, steps, precision):
+    """ONE GPU plays rank 0 of a W-rank partition of the configs[3] recipe (pyhgt_amd.dist.HaloPlan(emulate=...)): the real receive
+    side (ids, first-use chunks, types), a mirrored send side, and the all-to-all replaced by a device copy of the same size.  What is
+    measured is everything a rank's GPU does in a step -- packing, own Q|K|V, halo K|V off the wire buffer, the target blocks --
+    i.e. the compute side of the multi-GPU model in DESIGN.md section 6; the link time is bytes / (7 links x 76.8 GB/s x 0.7)."""
+    from pyhgt_amd import HGTConv
+    from pyhgt_amd.dist import HaloPlan, PartitionedGraph, target_blocks
+    share, nt_g = configs3_share(dev, W, 0, Nl, El, T, R, False, locality, 0.0, keep_global_types=True)
+    n_own = int(share["node_type_own"].numel())
+    bounds = target_blocks(share["dst_local"], n_own, blocks)
+    eblock = torch.searchsorted(torch.tensor(bounds[1:], device=dev), share["dst_local"], right=True).clamp(max=blocks - 1)
+    hp = HaloPlan(share["node_type_own"], share["src_global"], share["node_offsets"], 0, W, n_chunks=blocks, edge_block=eblock,
+                  emulate={"node_type_global": nt_g})
+    del nt_g, eblock
+    pg = PartitionedGraph(None, None, share["dst_local"], share["edge_type"], None, T, R, Nl, 0, W, node_offsets=share["node_offsets"],
+                          halo=hp, compress=compress, mode="blocked", n_chunks=blocks)
+    torch.manual_seed(0)
+    layer = HGTConv(d, d, T, R, H, 0.2, True, False, precision=precision).eval().to(dev)
+    pg.x_local = torch.empty(pg.n_local, d, dtype=torch.float32, device=dev)
+    pg.x_local[:n_own].normal_(generator=torch.Generator(device=dev).manual_seed(7))
+    x_own = pg.x_local[:n_own]
+    sets = []
+    with torch.no_grad():
+        for _ in range(2):
+            pg.forward(layer, x_own)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pg.timeline = []
+            out = pg.forward(layer, x_own)
+            sets.append(pg.timeline)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    assert torch.isfinite(out).all()
+    pg.timeline = None
+    E_own = int(share["dst_local"].numel())
+    halo_bytes = int(hp.n_halo) * d * (3 if compress else 4)
+    link_ms = halo_bytes / (7 * XGMI_LINK_GBS * 1e9 * 0.7) * 1e3
+    chunk_rows = [hp.recv_chunk_off[c + 1] - hp.recv_chunk_off[c] for c in range(blocks)]
+    res = {"world": W, "locality": locality, "blocks": blocks, "own_nodes": n_own, "own_edges": E_own, "halo_rows": int(hp.n_halo),
+           "halo_rows_per_chunk": chunk_rows, "halo_format": "c24" if compress else "fp32", "halo_bytes": halo_bytes,
+           "gpu_ms_per_step": round(ms, 4), "stage_ms": stage_times(sets),
+           "link_ms_at_70pct_of_7x76.8GBs": round(link_ms, 3),
+           "note": "GPU side of one rank's step measured on ONE GPU (exchange = device copies of the same size); a real step is "
+                   "max(this, link time + the last block's tail), see DESIGN.md section 6"}
+    del pg, hp, layer, out
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -388,11 +480,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the sampled-target oracle check after the timed region")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (other precision / other halo format)")
-    ap.add_argument("--no-buckets", action="store_true", help="multi-GPU: edge phase after the last halo chunk (stages 1/2/3) instead of "
-                    "the source-bucketed edge phase that overlaps the exchange (stages 1/2/4, pyhgt_amd/dist.py)")
-    ap.add_argument("--halo-c24", action="store_true", help="multi-GPU: ship halo rows in the 24-bit transport format in the JUDGED run "
-                    "(default: exact fp32 rows; the 24-bit variant is then reported as a secondary figure)")
-    ap.add_argument("--halo-fp32", action="store_true", help=argparse.SUPPRESS)   # the default now; kept for old command lines
+    ap.add_argument("--mode", default="blocked", choices=["blocked", "bucketed", "pipelined"],
+                    help="multi-GPU schedule (pyhgt_amd/dist.py): target-blocked (first-use halo chunks, stage 5; default), source-bucketed "
+                         "(stage 4) or the edge phase after the last chunk (stages 1/2/3)")
+    ap.add_argument("--no-buckets", action="store_true", help=argparse.SUPPRESS)   # round-2/3 spelling of --mode pipelined
+    ap.add_argument("--blocks", type=int, default=8, help="multi-GPU: target blocks = halo chunks of the blocked schedule")
+    ap.add_argument("--locality", type=float, default=0.0, help="multi-GPU: fraction p of the edges whose source is drawn from the target's "
+                    "own partition (SURVEY 8e 'schema/locality' variant); the rest is uniform over ALL nodes.  0 = the uniform worst case")
+    ap.add_argument("--halo-fp32", action="store_true", help="multi-GPU: ship exact fp32 halo rows in the JUDGED run (default: the 24-bit "
+                    "transport format, whose 16 significant bits are exactly what the split-bf16 projections consume; DESIGN.md section 6)")
+    ap.add_argument("--halo-c24", action="store_true", help=argparse.SUPPRESS)    # the default now; kept for old command lines
+    ap.add_argument("--emulate-world", type=int, default=0, help="N = 1 only: ONE GPU plays rank 0 of a W-rank partition of the configs[3] "
+                    "recipe (exchange replaced by device copies of the same size): the per-rank GPU work of a multi-GPU step, measured")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f16x3", "fp32"],
                     help="typed linears / relation transforms: 3-term split-bf16 MFMA with fp32 accumulation (default; parity-tested "
                          "at 1e-4) or exact fp32")
@@ -440,20 +539,31 @@ def main():
     d, H, T, R = args.dim, args.heads, args.types, args.relations
     Nl, El = args.nodes_per_gpu, args.edges_per_gpu
     use_rte = bool(args.rte)
+    if world == 1 and args.emulate_world > 1:      # tool mode: the GPU side of one rank's multi-GPU step, on one GPU
+        print(json.dumps(emulate_rank(dev, args.emulate_world, Nl, El, d, H, T, R, args.locality, args.blocks, not args.halo_fp32,
+                                      args.steps, args.precision if args.precision != "fp32" else "bf16x3")))
+        return
 
     # ---------------- synthetic inputs, generated on the device (SURVEY.md section 8d recipe) -------------
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    Ng = Nl * world                                            # global node count
-    node_type_own = torch.randint(0, T, (Nl,), generator=g, device=dev).sort().values
-    x_own = torch.randn(Nl, d, generator=g, device=dev)
-    src_global = torch.randint(0, Ng, (El,), generator=g, device=dev)
-    dst_local = torch.randint(0, Nl, (El,), generator=g, device=dev)
-    if args.dst_skew > 0.0:   # hub targets (SURVEY.md section 8d secondary variant)
-        # Zipf-like: P(rank k) ~ k^-a with a = dst_skew in (0,1); rank 0 gets ~E*(1-a)/N^(1-a) edges
-        u = torch.rand(El, generator=g, device=dev)
-        dst_local = (Nl * u ** (1.0 / (1.0 - args.dst_skew))).long().clamp(0, Nl - 1)
-    edge_type = torch.randint(0, R, (El,), generator=g, device=dev)
-    edge_time = torch.randint(0, 240, (El,), generator=g, device=dev) if use_rte else None
+    share = None
+    if world == 1:
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        node_type_own = torch.randint(0, T, (Nl,), generator=g, device=dev).sort().values
+        x_own = torch.randn(Nl, d, generator=g, device=dev)
+        src_global = torch.randint(0, Nl, (El,), generator=g, device=dev)
+        dst_local = torch.randint(0, Nl, (El,), generator=g, device=dev)
+        if args.dst_skew > 0.0:   # hub targets (SURVEY.md section 8d secondary variant)
+            # Zipf-like: P(rank k) ~ k^-a with a = dst_skew in (0,1); rank 0 gets ~E*(1-a)/N^(1-a) edges
+            u = torch.rand(El, generator=g, device=dev)
+            dst_local = (Nl * u ** (1.0 / (1.0 - args.dst_skew))).long().clamp(0, Nl - 1)
+        edge_type = torch.randint(0, R, (El,), generator=g, device=dev)
+        edge_time = torch.randint(0, 240, (El,), generator=g, device=dev) if use_rte else None
+    else:
+        share, _ = configs3_share(dev, world, rank, Nl, El, T, R, use_rte, args.locality, args.dst_skew)
+        node_type_own, src_global, dst_local = share["node_type_own"], share["src_global"], share["dst_local"]
+        edge_type, edge_time = share["edge_type"], share["edge_time"]
+        Nl_own, El_own = int(node_type_own.numel()), int(dst_local.numel())
+        x_own = torch.randn(Nl_own, d, generator=torch.Generator(device=dev).manual_seed(4321 + rank), device=dev)
 
     def make_layer(precision):
         torch.manual_seed(0)
@@ -486,9 +596,12 @@ def main():
     else:
         from pyhgt_amd.dist import PartitionedGraph
         import torch.distributed as dist
+        mode = "pipelined" if args.no_buckets else args.mode
         pg = PartitionedGraph(node_type_own, src_global, dst_local, edge_type, edge_time, T, R, Nl, rank, world,
-                              compress=bool(args.halo_c24), bucketed=False if args.no_buckets else None)
+                              node_offsets=share["node_offsets"], compress=not args.halo_fp32, mode=mode,
+                              n_chunks=args.blocks if mode == "blocked" else None)
         plan_ms = None
+        Nl, El = Nl_own, El_own
         # own features live at the front of the [own ; halo] buffer, so a step does not copy them (pyhgt_amd/dist.py)
         pg.x_local = torch.empty(pg.n_local, d, dtype=torch.float32, device=dev)
         pg.x_local[:Nl].copy_(x_own)
@@ -507,22 +620,33 @@ def main():
         with torch.no_grad():
             for _ in range(warmup):
                 out = step()
-            event_sets = [ev.make_set(_lib.HGT_N_PHASE_EVENTS) for _ in range(steps)]
+            # one GPU: hgt_conv_forward records HIP events at its phase boundaries (one call = one layer).  Several GPUs: a step is
+            # many staged calls, so the phase events of single calls say nothing about the step (round-3 review: fractions > 1);
+            # PartitionedGraph.forward marks its own stage boundaries on the compute stream instead (stage_times)
+            event_sets = [ev.make_set(_lib.HGT_N_PHASE_EVENTS) for _ in range(steps)] if world == 1 else None
+            timelines = []
             torch.cuda.synchronize()
             barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(steps):
-                out = step(event_sets[i])
+                if world == 1:
+                    out = step(event_sets[i])
+                else:
+                    pg.timeline = []
+                    out = step(None)
+                    timelines.append(pg.timeline)
             torch.cuda.synchronize()
             barrier()
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
         if world > 1:
             import torch.distributed as dist
+            pg.timeline = None
             tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
+            return out, elapsed, stage_times(timelines), elapsed / steps * 1e3
         phase_ms = {p: 0.0 for p in PHASES}
         per_step = []
         for es in event_sets:
@@ -539,6 +663,11 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     total_edges = El * world
+    if world > 1:      # the partitioner balances in-edges to one plan tile of targets: count what the ranks really hold
+        import torch.distributed as dist
+        te = torch.tensor([El], device=dev, dtype=torch.int64)
+        dist.all_reduce(te)
+        total_edges = int(te.item())
     value = total_edges / (elapsed / args.steps)
 
     # ---------------- parity of the benchmarked configuration itself (after the timed region) ----------------
@@ -550,40 +679,60 @@ def main():
         # a rank's local graph [own ; halo]: exact for its own targets only if the exchanged halo rows are right
         return parity_check(sd, o, pg.x_local, pg.node_type_local, pg.edge_index, pg.edge_type, pg.edge_time, T, R, H, use_rte,
                             n_q_rows=Nl)
+    if world > 1 and not args.no_parity:
+        # the checker wants the fp32 halo rows; the blocked schedule projects them straight off the wire buffer and never expands
+        # them, so one plain exchange (a collective: every rank) fills them in after the timed region
+        with torch.no_grad():
+            for c in range(pg.halo.n_chunks):
+                pg.halo.exchange_chunk(c, x_own, pg.x_local, compress=pg.compress)
+        torch.cuda.synchronize()
     parity = check(out, layer_sd) if rank == 0 else None
     del out
 
     n_local_nodes = Nl if world == 1 else pg.n_local
     alg = algorithmic_bytes(Nl, El, d, use_rte)
-    fused_update = (phase_ms["a_linear"] + phase_ms["node_update"]) < 0.05 * phase_ms["edge_aggregate"]
-    if fused_update:   # hgt_edge_aggregate_update: the node update runs as the epilogue of the aggregation kernel
-        alg["edge_aggregate"] += alg["node_update"]
-        alg["node_update"] = 0
-    dom = max(("edge_logits", "edge_aggregate", "project_qkv"), key=lambda p: phase_ms[p])
-    ach = alg[dom] / (phase_ms[dom] * 1e-3) / 1e9
-    # counter-derived figures come from the committed rocprofv3 passes of this same command (profiles/pmc_summary.json names
-    # the commit they were taken at); they are not re-measured inside the run
     pmc = {}
-    import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")))
-    if cands:      # the newest round's passes
-        try:
-            pmc = json.load(open(cands[-1]))
-        except Exception:
-            pmc = {}
-    traffic = (pmc.get("traffic_bytes") or {}).get(dom) if (world == 1 and not use_rte and args.dst_skew == 0.0) else None
-    roofline = {"bound": "hbm", "kernel": dom + ("+node_update (fused)" if fused_update and dom == "edge_aggregate" else ""),
-                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": round(phase_ms[dom], 4),
-                "layer_achieved_GBs": round(alg["layer"] / (ms_per_step * 1e-3) / 1e9, 1),
-                "layer_frac": round(alg["layer"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "phase_ms": {p: round(v, 4) for p, v in phase_ms.items()},
-                "per_kernel_frac": {p: round(alg[p] / (phase_ms[p] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                    for p in ("project_qkv", "edge_logits", "edge_aggregate") if phase_ms[p] > 0},
-                "mfma_busy_pct": pmc.get("mfma_busy_pct"), "pmc_commit": pmc.get("commit"),
-                # counter figures are quoted from the committed passes: flagged when the kernel sources changed since
-                "pmc_stale": bool(pmc) and pmc.get("kernel_sources_sha16") != kernel_sources_sha16()}
+    if world > 1:
+        # Several GPUs: ONE figure for the whole step of a rank -- the algorithmic bytes of the rank's own layer (SURVEY 8d on its
+        # own nodes / edges: halo projections, packing and the exchange are overhead, not credited) over the step time -- and the
+        # mean time of every stage on the compute stream.  No per-kernel fractions: no timed interval brackets a single kernel here.
+        stage_ms = phase_ms
+        ach = alg["layer"] / (ms_per_step * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "whole step of a rank (pack, own Q|K|V, halo K|V, target blocks; waits on the exchange included)",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": alg["layer"], "avg_launch_ms": round(ms_per_step, 4),
+                    "layer_achieved_GBs": round(ach, 1), "layer_frac": round(ach / HBM_PEAK_GBS, 4),
+                    "stage_ms": stage_ms, "stage_note": "mean ms between marks on rank 0's compute stream: pack = gather kernels + "
+                    "queueing the all-to-alls, wait = stalls on a chunk that has not arrived, halo_kv / edge_blocks summed over blocks"}
+    else:
+        fused_update = (phase_ms["a_linear"] + phase_ms["node_update"]) < 0.05 * phase_ms["edge_aggregate"]
+        if fused_update:   # hgt_edge_aggregate_update: the node update runs as the epilogue of the aggregation kernel
+            alg["edge_aggregate"] += alg["node_update"]
+            alg["node_update"] = 0
+        dom = max(("edge_logits", "edge_aggregate", "project_qkv"), key=lambda p: phase_ms[p])
+        ach = alg[dom] / (phase_ms[dom] * 1e-3) / 1e9
+        # counter-derived figures come from the committed rocprofv3 passes of this same command (profiles/pmc_summary.json names
+        # the commit they were taken at); they are not re-measured inside the run
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")))
+        if cands:      # the newest round's passes
+            try:
+                pmc = json.load(open(cands[-1]))
+            except Exception:
+                pmc = {}
+        traffic = (pmc.get("traffic_bytes") or {}).get(dom) if (not use_rte and args.dst_skew == 0.0) else None
+        roofline = {"bound": "hbm", "kernel": dom + ("+node_update (fused)" if fused_update and dom == "edge_aggregate" else ""),
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": round(phase_ms[dom], 4),
+                    "layer_achieved_GBs": round(alg["layer"] / (ms_per_step * 1e-3) / 1e9, 1),
+                    "layer_frac": round(alg["layer"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "phase_ms": {p: round(v, 4) for p, v in phase_ms.items()},
+                    "per_kernel_frac": {p: round(alg[p] / (phase_ms[p] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                        for p in ("project_qkv", "edge_logits", "edge_aggregate") if phase_ms[p] > 0},
+                    "mfma_busy_pct": pmc.get("mfma_busy_pct"), "pmc_commit": pmc.get("commit"),
+                    # counter figures are quoted from the committed passes: flagged when the kernel sources changed since
+                    "pmc_stale": bool(pmc) and pmc.get("kernel_sources_sha16") != kernel_sources_sha16()}
 
     # ---------------- secondary measurements (never `value`) ----------------
     secondary = {}
@@ -602,25 +751,34 @@ def main():
                     "parity_max_abs_err": None if par2 is None else par2["max_abs_err"]}
                 del out2, lay2
         else:
-            out2, el2, ph2, med2 = timed(make_step(layer, compress=not args.halo_c24), args.steps, 2)
+            def refill():      # (the parity checker reads the fp32 halo rows: see above)
+                if not args.no_parity:
+                    with torch.no_grad():
+                        for c in range(pg.halo.n_chunks):
+                            pg.halo.exchange_chunk(c, x_own, pg.x_local, compress=pg.compress)
+                    torch.cuda.synchronize()
+            judged_compress = pg.compress
+            out2, el2, st2, _ = timed(make_step(layer, compress=not judged_compress), args.steps, 2)
             ms2 = el2 / args.steps * 1e3
+            refill()
             par2 = check(out2, layer_sd) if rank == 0 else None
-            secondary["halo_" + ("fp32" if args.halo_c24 else "c24")] = {
-                "ms_per_step": ms2, "median_ms_per_step": med2, "edges_per_s": total_edges / (ms2 * 1e-3),
+            secondary["halo_" + ("fp32" if judged_compress else "c24")] = {
+                "ms_per_step": ms2, "edges_per_s": total_edges / (ms2 * 1e-3), "stage_ms": st2,
                 "parity_max_abs_err": None if par2 is None else par2["max_abs_err"],
-                "note": "24-bit transport format (sign, 8 exponent, 15 mantissa bits): narrower than the reference on the wire, "
-                        "reported for information only" if not args.halo_c24 else "exact fp32 halo rows"}
-            pg.compress = bool(args.halo_c24)
+                "note": "exact fp32 halo rows on the links (4/3 of the bytes)" if judged_compress else
+                        "24-bit transport format (sign, 8 exponent, 15 mantissa bits)"}
+            pg.compress = judged_compress
             del out2
-            if pg.bucket_plan is not None:      # the other edge-phase schedule (both plans exist; the switch is per forward)
-                pg.bucketed = not pg.bucketed
-                out3, el3, ph3, med3 = timed(make_step(layer), args.steps, 2)
+            if pg.mode != "pipelined":      # the schedule without overlap of exchange and edge phase, same graph / chunks
+                judged_mode, pg.mode = pg.mode, "pipelined"
+                out3, el3, st3, _ = timed(make_step(layer), args.steps, 2)
                 ms3 = el3 / args.steps * 1e3
+                refill()
                 par3 = check(out3, layer_sd) if rank == 0 else None
-                secondary["edge_phase_" + ("source_bucketed" if pg.bucketed else "after_last_chunk")] = {
-                    "ms_per_step": ms3, "median_ms_per_step": med3, "edges_per_s": total_edges / (ms3 * 1e-3),
+                secondary["edge_phase_after_last_chunk"] = {
+                    "ms_per_step": ms3, "edges_per_s": total_edges / (ms3 * 1e-3),
                     "parity_max_abs_err": None if par3 is None else par3["max_abs_err"]}
-                pg.bucketed = not pg.bucketed
+                pg.mode = judged_mode
                 del out3
 
     # ---------------- the other BASELINE.json configurations + shape variants of configs[1], each with its own parity ------------
@@ -665,6 +823,12 @@ def main():
             secondary["d512_h8"] = large_variant(Nl // 2, El // 2, 512, 8, False, 0.0, 4323)
             torch.cuda.empty_cache()
         secondary["latency_regime"] = small_regime(dev)
+        if d == 256 and H == 8 and Nl == 1_000_000 and El == 10_000_000:
+            # configs[3] on ONE GPU: rank 0 of an 8-rank partition, exchange emulated by device copies (what a rank's GPU does per step;
+            # the model of DESIGN.md section 6 combines it with the link time).  Uniform sources = worst case; 0.75 = a partition with locality
+            torch.cuda.empty_cache()
+            secondary["rank_of_8_uniform"] = emulate_rank(dev, 8, Nl, El, d, H, T, R, 0.0, args.blocks, True, 5, "bf16x3")
+            secondary["rank_of_8_locality0.75"] = emulate_rank(dev, 8, Nl, El, d, H, T, R, 0.75, args.blocks, True, 5, "bf16x3")
 
     if rank == 0:
         cpu = None
@@ -683,15 +847,21 @@ def main():
             "config": {"workload": "%s: synthetic %d-type/%d-relation graph, %d nodes / %d edges per GPU, "
                                    "d=%d, n_heads=%d, use_RTE=%s, use_norm=True, plan cached%s" % (
                                        "BASELINE.json configs[1]" if world == 1 else
-                                       "BASELINE.json configs[3] recipe (configs[1] per GPU, sources uniform over all ranks)",
+                                       "BASELINE.json configs[3] recipe (one global graph of configs[1] per GPU, cut by the in-edge-balanced "
+                                       "partitioner; sources %s)" % ("uniform over all ranks" if args.locality <= 0 else
+                                                                      "%.2f from the target's partition, the rest uniform" % args.locality),
                                        T, R, Nl, El, d, H, use_rte, (", Zipf(%.2f) targets" % args.dst_skew) if args.dst_skew > 0 else ""),
                        "nodes_per_gpu": Nl, "edges_per_gpu": El, "local_nodes_incl_halo": int(n_local_nodes),
                        "halo_exchange_bytes_per_gpu_per_step": 0 if world == 1 else int(pg.halo.n_halo) * d * (3 if pg.compress else 4),
                        "halo_format": None if world == 1 else ("24-bit (sign, 8 exp, 15 mantissa; fp32 arithmetic)" if pg.compress else "fp32"),
                        "halo_chunks": 0 if world == 1 else int(pg.halo.n_chunks),
-                       "edge_phase": None if world == 1 else ("source-bucketed, overlaps the exchange (hgt_conv_forward stages 1/2/4)"
-                                                              if pg.bucketed and args.precision != "fp32" else
-                                                              "after the last halo chunk (stages 1/2/3)"),
+                       "edge_phase": None if world == 1 else {
+                           "blocked": "target-blocked: %d blocks, halo chunks by first use, every block = the single-GPU kernel pair on a tile "
+                                      "range (hgt_conv_forward stages 1/2/5)" % pg.halo.n_chunks,
+                           "bucketed": "source-bucketed, softmax state carried between buckets (stages 1/2/4)",
+                           "pipelined": "after the last halo chunk (stages 1/2/3)"}[pg.layer_mode(layer)],
+                       "locality": None if world == 1 else args.locality,
+                       "node_offsets": None if world == 1 else share["node_offsets"],
                        "parallelism": "single" if world == 1 else "dst-partition x%d + RCCL all-to-all halo" % world,
                        "backend": backend_name + (" (RCCL)" if backend_name == "nccl" else ""),
                        "plan_build_ms": plan_ms, "precision": args.precision, "kernel_flags": args.kernel_flags},

@@ -536,6 +536,12 @@ typedef struct hgt_conv_args {
 int hgt_conv_workspace_bytes(int64_t n_nodes, int64_t n_edges, int32_t in_dim, int32_t out_dim,
                              int32_t n_types, int32_t n_relations, int32_t n_heads, int32_t use_rte,
                              uint64_t* out_host);
+/* ABI 6: item_scratch = 0 leaves out the scratch of hgt_edge_aggregate_items (E*d*4 + E*H*8 + E bytes, up to 1 GiB, on graphs below
+ * 65536 nodes) for calls that cannot take that kernel (exact fp32, HGT_FLAG_NO_ITEM_AGGREGATE, staged multi-GPU calls);
+ * hgt_conv_forward accepts either size. */
+int hgt_conv_workspace_bytes_ex(int64_t n_nodes, int64_t n_edges, int32_t in_dim, int32_t out_dim,
+                                int32_t n_types, int32_t n_relations, int32_t n_heads, int32_t use_rte, int32_t item_scratch,
+                                uint64_t* out_host);
 int hgt_conv_prepared_bytes(int32_t in_dim, int32_t out_dim, int32_t n_types, int32_t n_relations, int32_t n_heads,
                             int32_t use_rte, uint64_t* out_host);
 int hgt_conv_forward(const hgt_conv_args* args_host, void* stream);

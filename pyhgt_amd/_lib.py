@@ -140,6 +140,7 @@ SIGNATURES = {
     "hgt_unpack_rows_c24": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp]),
     "hgt_gather_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "hgt_conv_workspace_bytes": (C.c_int, [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_u64)]),
+    "hgt_conv_workspace_bytes_ex": (C.c_int, [_i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_u64)]),
     "hgt_conv_prepared_bytes": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_u64)]),
     "hgt_conv_forward": (C.c_int, [C.POINTER(HgtConvArgs), _vp]),
 }

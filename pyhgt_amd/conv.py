@@ -113,6 +113,10 @@ class GraphPlan:
     _cache = OrderedDict()
     _cache_lock = threading.Lock()
     CACHE_SIZE = 4          # plans (and the graph tensors they were built from) kept alive; set to 0 to disable caching
+    STRICT = False          # True: the first forward on a NEW plan waits for the plan build and raises IndexError for malformed ids
+                            # before any layer kernel runs -- the reference's behaviour (index_select / nn.Embedding raise at once);
+                            # costs one host synchronisation per new graph.  False: the flag arrives asynchronously and the error
+                            # surfaces on the first forward after it has landed (raise_if_bad).  HGTConv(strict=...) overrides it.
 
     def __init__(self, node_type, edge_index, edge_type, edge_time, num_types, num_relations, n_q_rows=None, reverse=False):
         """reverse=True builds the plan of the TRANSPOSED graph (every edge j -> i taken as i -> j; used by the backward pass,
@@ -327,7 +331,10 @@ class GraphPlan:
         with cls._cache_lock:
             hit = cls._cache.get(key)
             if hit is not None:
-                cls._cache.move_to_end(key)
+                # a registered plan sits under two keys (with / without edge_time): refresh both, or the sibling of a hot plan
+                # stays at the front of the eviction order
+                for k in [k for k, v in cls._cache.items() if v[0] is hit[0]]:
+                    cls._cache.move_to_end(k)
                 return hit[0]
         plan = cls(node_type, edge_index, edge_type, edge_time, num_types, num_relations, n_q_rows)
         with cls._cache_lock:
@@ -385,11 +392,14 @@ class HGTConv(nn.Module):
     (every matrix-core product of the layer: typed Linears, relation transforms of the aggregation, fused a_linear) -- as
     close to the fp64 result as the reference's own fp32 arithmetic (<= 1e-6), at the speed of "bf16x3"; "fp32" uses the exact
     fp32 MFMA chain (<= 2e-6, 1.6x slower at c2).  Training (autograd) and the staged multi-GPU calls evaluate an "f16x3"
-    layer with the "bf16x3" kernels.
+    layer with the "bf16x3" kernels.  strict=True (or GraphPlan.STRICT = True): node ids outside [0, N) / edge_time outside [0, 240)
+    raise IndexError on the FIRST forward of a new graph, before any layer kernel runs, like the reference's index_select /
+    nn.Embedding (one host synchronisation per new graph); by default the check is asynchronous and the same IndexError surfaces
+    on the first forward after the plan's flag has reached the host.
     """
 
     def __init__(self, in_dim, out_dim, num_types, num_relations, n_heads, dropout=0.2, use_norm=True, use_RTE=True,
-                 keep_att=False, precision="bf16x3", **kwargs):
+                 keep_att=False, precision="bf16x3", strict=None, **kwargs):
         super().__init__()
         self.in_dim, self.out_dim = in_dim, out_dim
         self.num_types, self.num_relations = num_types, num_relations
@@ -403,6 +413,7 @@ class HGTConv(nn.Module):
             raise ValueError("precision must be one of %s" % (PRECISIONS,))
         self.precision = precision
         self.kernel_flags = 0          # hgt_conv_args.flags (HGT_FLAG_*): explicit kernel selection for A/B runs and tests
+        self.strict = strict           # None = GraphPlan.STRICT; True: malformed ids raise IndexError on the very first forward
         self.att = None
 
         self.k_linears = nn.ModuleList(nn.Linear(in_dim, out_dim) for _ in range(num_types))
@@ -424,7 +435,7 @@ class HGTConv(nn.Module):
     _warned_eval_grad = False
 
     # -- state that is not part of the reference module: caches of packed parameters / device-side weight images ------
-    _RUNTIME_DEFAULTS = dict(keep_att=False, precision="bf16x3", kernel_flags=0, att=None, _packed=None, _packed_key=None,
+    _RUNTIME_DEFAULTS = dict(keep_att=False, precision="bf16x3", kernel_flags=0, strict=None, att=None, _packed=None, _packed_key=None,
                              _prepared=None, _prepared_tag=None, _prepared_valid=False, _plist=None)
 
     def _init_runtime_state(self):
@@ -457,7 +468,8 @@ class HGTConv(nn.Module):
         _apply, which calls this) -- but writes through `.data` (`p.data.copy_()`, `p.data[...] = x`; EMA / manual
         initialisation code) do NOT bump `_version`, and neither does replacing a Parameter object of a sub-module
         (`layer.k_linears[0].weight = nn.Parameter(...)`): call invalidate() after such an update (training mode re-packs
-        on every forward anyway)."""
+        on every forward anyway).  Detected without a call: optimizer steps / in-place torch ops (version counters),
+        `p.data = tensor` (storage address), re-assigning a Parameter or sub-module attribute of the layer itself."""
         self._packed = self._packed_key = None
         self._prepared_valid = False
         self.__dict__["_plist"] = None
@@ -465,6 +477,13 @@ class HGTConv(nn.Module):
     def _load_from_state_dict(self, *args, **kwargs):
         self.invalidate()
         return super()._load_from_state_dict(*args, **kwargs)
+
+    def __setattr__(self, name, value):
+        # `layer.skip = nn.Parameter(...)` (or any re-assigned sub-module) replaces objects the cached parameter list points at
+        if isinstance(value, (nn.Parameter, nn.Module)) and "_plist" in self.__dict__:
+            self.__dict__["_plist"] = None
+            self.__dict__["_packed_key"] = None
+        super().__setattr__(name, value)
 
     def _apply(self, fn, *args, **kwargs):
         self.invalidate()
@@ -485,16 +504,16 @@ class HGTConv(nn.Module):
         """Stack the per-type Linear / LayerNorm parameters into the contiguous, head-padded arrays
         hgt_conv_forward takes (pure data movement; cached until a parameter changes).  grad=True: built with autograd
         recording (never cached), so that gradients of the packed arrays flow back to the reference-named parameters."""
-        # cache key: the SUM of the parameters' version counters over a parameter list that is itself cached -- a few
-        # microseconds per forward (the round-2 key, a 47-tuple of (data_ptr, _version), cost ~50 us of host time per layer and
+        # cache key: the SUM of the parameters' version counters and storage addresses over a parameter list that is itself cached
+        # -- a few microseconds per forward (the round-2 key, a 47-tuple of (data_ptr, _version), cost ~50 us of host time per layer and
         # would have bounded the latency regime).  Optimizer steps, in-place torch ops and load_state_dict bump a version;
         # .to() / .float() / load_state_dict also pass through _apply / _load_from_state_dict (invalidate()).
         plist = self.__dict__.get("_plist")
         if plist is None:
             plist = self.__dict__["_plist"] = list(self.parameters())
         key = 0
-        for p in plist:
-            key += p._version
+        for p in plist:      # (+ the storage address: `p.data = new_tensor` -- common in weight-loading code -- keeps the version)
+            key += p._version + p.data_ptr()
         if not grad and self._packed is not None and self._packed_key == key and not self.training:
             return self._packed
         lay = _lib.layout_for(self.out_dim, self.n_heads)
@@ -606,7 +625,8 @@ class HGTConv(nn.Module):
         R_plan = self.num_relations * n_slices
         if plan.N != N or plan.T != self.num_types or plan.R != R_plan:
             raise ValueError("plan was built for a different graph / schema")
-        plan.raise_if_bad(ignore_time=not self.use_RTE)
+        strict = GraphPlan.STRICT if self.strict is None else self.strict
+        plan.raise_if_bad(wait=bool(strict) and plan._bad is None, ignore_time=not self.use_RTE)
         NQ, E = plan.NQ, plan.E
         if needs_grad and not self.training and not HGTConv._warned_eval_grad:
             HGTConv._warned_eval_grad = True
@@ -625,8 +645,11 @@ class HGTConv(nn.Module):
         if pk["w_qkv"].device != x.device:
             raise RuntimeError("module parameters and node_inp are on different devices")
         nbytes = C.c_uint64()
-        _lib.check(lib.hgt_conv_workspace_bytes(N, E, self.in_dim, self.out_dim, self.num_types, R_plan,
-                                                self.n_heads, int(self.use_RTE), C.byref(nbytes)), "hgt_conv_workspace_bytes")
+        # (the item-parallel aggregation's scratch only where this call can take that kernel: whole-layer calls of a split precision)
+        # (a caller-owned workspace may come without it: hgt_conv_forward then simply rules that kernel out)
+        item_scratch = int(workspace is None and stage == 0 and prec != "fp32" and not (self.kernel_flags & _lib.HGT_FLAG_NO_ITEM_AGGREGATE))
+        _lib.check(lib.hgt_conv_workspace_bytes_ex(N, E, self.in_dim, self.out_dim, self.num_types, R_plan,
+                                                   self.n_heads, int(self.use_RTE), item_scratch, C.byref(nbytes)), "hgt_conv_workspace_bytes_ex")
         if workspace is not None:
             if workspace.dtype != torch.uint8 or workspace.device != x.device or workspace.numel() < nbytes.value:
                 raise ValueError("workspace must be a uint8 tensor of >= %d bytes on %s" % (nbytes.value, x.device))
@@ -696,11 +719,13 @@ class HGTConv(nn.Module):
             self._prepared_valid = True                 # every image was written by this forward (or an earlier one)
         return out
 
-    def workspace_bytes(self, n_nodes, n_edges, n_slices=1):
+    def workspace_bytes(self, n_nodes, n_edges, n_slices=1, staged=True):
+        """Size of a caller-owned workspace (staged callers: pyhgt_amd.dist).  staged=False adds the scratch of the item-parallel
+        aggregation that only whole-layer calls on small graphs use."""
         n = C.c_uint64()
-        _lib.check(_lib.load().hgt_conv_workspace_bytes(int(n_nodes), int(n_edges), self.in_dim, self.out_dim, self.num_types,
-                                                        self.num_relations * int(n_slices), self.n_heads, int(self.use_RTE), C.byref(n)),
-                   "hgt_conv_workspace_bytes")
+        _lib.check(_lib.load().hgt_conv_workspace_bytes_ex(int(n_nodes), int(n_edges), self.in_dim, self.out_dim, self.num_types,
+                                                           self.num_relations * int(n_slices), self.n_heads, int(self.use_RTE),
+                                                           int(not staged), C.byref(n)), "hgt_conv_workspace_bytes_ex")
         return int(n.value)
 
     def __repr__(self):

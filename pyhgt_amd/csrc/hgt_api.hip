@@ -24,7 +24,7 @@ struct ConvWorkspace {
 };
 
 static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim, int out_dim, int T, int R, int /*n_heads*/, int use_rte,
-                                    const hgt_layout& lay) {
+                                    const hgt_layout& lay, bool item_scratch = true) {
     const int H = lay.heads;     // layout heads (n_heads rounded up to a power of two)
     ConvWorkspace w;
     uint64_t o = 0;
@@ -76,7 +76,7 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
     w.off_state = take((uint64_t)NQ * H * 2 * 4);   // softmax state carried between relation slices (stage 4)
     // scratch of the item-parallel aggregation (hgt_edge_aggregate_items): only for graphs in the latency regime
     w.zitems_bytes = 0;
-    if (N < HGT_ITEM_AGG_MAX_NODES) {
+    if (item_scratch && N < HGT_ITEM_AGG_MAX_NODES) {
         uint64_t zb = 0;
         hgt_edge_aggregate_items_bytes(E, H, lay.dk_pad, &zb);
         if (zb <= ((uint64_t)1 << 30)) w.zitems_bytes = zb;
@@ -156,6 +156,19 @@ extern "C" int hgt_conv_workspace_bytes(int64_t n_nodes, int64_t n_edges, int32_
     return HGT_OK;
 }
 
+// ABI 6: the same without the scratch of the item-parallel aggregation (up to 1 GiB on graphs below 65536 nodes) for callers that
+// know the call cannot take it: exact fp32 precision, HGT_FLAG_NO_ITEM_AGGREGATE, staged multi-GPU calls.  hgt_conv_forward
+// accepts either size (a workspace without the scratch simply rules the item-parallel kernel out).
+extern "C" int hgt_conv_workspace_bytes_ex(int64_t n_nodes, int64_t n_edges, int32_t in_dim, int32_t out_dim, int32_t n_types,
+                                           int32_t n_relations, int32_t n_heads, int32_t use_rte, int32_t item_scratch, uint64_t* out) {
+    if (!out || n_nodes < 0 || n_edges < 0 || in_dim <= 0) return HGT_ERR_INVALID_ARG;
+    hgt_layout lay;
+    int rc = hgt_layout_for(out_dim, n_heads, &lay);
+    if (rc != HGT_OK) return rc;
+    *out = conv_workspace(n_nodes, n_nodes, n_edges, in_dim, out_dim, n_types, n_relations, n_heads, use_rte, lay, item_scratch != 0).total;
+    return HGT_OK;
+}
+
 extern "C" int hgt_conv_prepared_bytes(int32_t in_dim, int32_t out_dim, int32_t n_types, int32_t n_relations, int32_t n_heads,
                                        int32_t use_rte, uint64_t* out) {
     if (!out || in_dim <= 0 || n_types <= 0 || n_relations <= 0) return HGT_ERR_INVALID_ARG;
@@ -193,7 +206,10 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     const int H = lay.heads;     // the kernels run with the layout's head count (extra heads are all-zero)
     const int dp = lay.d_pad;
     ConvWorkspace w = conv_workspace(N, N, E, din, dout, T, R, H, a->use_rte, lay);   // sized for NQ == N (upper bound)
-    if (a->workspace_bytes < w.total) return HGT_ERR_WORKSPACE;
+    if (a->workspace_bytes < w.total) {      // a workspace sized without the item-aggregation scratch (hgt_conv_workspace_bytes_ex)
+        w = conv_workspace(N, N, E, din, dout, T, R, H, a->use_rte, lay, false);
+        if (a->workspace_bytes < w.total) return HGT_ERR_WORKSPACE;
+    }
     if (N == 0) return HGT_OK;
     char* wb = (char*)a->workspace;
     float* Q = (float*)(wb + w.off_q);

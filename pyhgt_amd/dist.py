@@ -152,8 +152,14 @@ class HaloPlan:
       * edge_block = int64[E], the target block of every edge (n_chunks = number of blocks): chunk c holds the remote rows whose
         FIRST use is in block c, so that the in-edges of block b only reference own rows and chunks 0..b (blocked schedule)."""
 
-    def __init__(self, node_type_own, src_global, node_offsets, rank, world, group=None, n_chunks=1, edge_block=None):
+    def __init__(self, node_type_own, src_global, node_offsets, rank, world, group=None, n_chunks=1, edge_block=None, emulate=None):
+        """emulate = {"node_type_global": i64[N_global]}: ONE process plays `rank` of a `world`-rank partition without a process
+        group (bench.py --emulate-world: the per-rank GPU work of a multi-GPU step measured on one GPU).  The receive side is
+        exact (ids, chunks, types from the global node_type); the send side mirrors it -- every peer is assumed to ask for as many
+        of my rows, per chunk, as I ask of it, drawn uniformly from my rows -- and exchange_chunk replaces the all-to-all by a
+        device copy of the packed rows (same bytes written, read and moved through HBM as the link transfer would)."""
         dev = src_global.device
+        self.emulate = emulate
         self.rank, self.world, self.group = rank, world, group
         self.n_chunks = C = max(1, int(n_chunks))
         self.offsets = torch.as_tensor(node_offsets, dtype=torch.int64, device=dev)       # [world+1]
@@ -186,17 +192,24 @@ class HaloPlan:
         counts = torch.bincount(key_ask, minlength=world * C).reshape(world, C)
         # per-peer totals, then the per-(peer, chunk) counts: both sides need them to cut the chunked all-to-alls
         tot = counts.sum(1)
-        got = torch.empty_like(tot)
-        _all_to_all(got, tot, None, None, group)
-        self.send_splits = got.tolist()
-        send_counts = torch.empty_like(counts)
-        _all_to_all(send_counts.view(-1), counts.reshape(-1).contiguous(), [C] * world, [C] * world, group)   # [peer q][chunk] rows q wants
-        # tell every owner which of its rows I need (owner, chunk, id order); receive which of my rows the peers need
-        asked = _all_to_all_int64(need[ask_order].contiguous(), self.recv_splits, self.send_splits, group)
+        if emulate is not None:
+            self.send_splits = tot.tolist()
+            send_counts = counts.clone()
+            g = torch.Generator(device=dev).manual_seed(977 + rank)
+            asked = lo + torch.randint(0, max(self.n_own, 1), (int(tot.sum()),), generator=g, device=dev)
+            halo_types_ask = emulate["node_type_global"].to(dev)[need[ask_order]]
+        else:
+            got = torch.empty_like(tot)
+            _all_to_all(got, tot, None, None, group)
+            self.send_splits = got.tolist()
+            send_counts = torch.empty_like(counts)
+            _all_to_all(send_counts.view(-1), counts.reshape(-1).contiguous(), [C] * world, [C] * world, group)   # [peer q][chunk] rows q wants
+            # tell every owner which of its rows I need (owner, chunk, id order); receive which of my rows the peers need
+            asked = _all_to_all_int64(need[ask_order].contiguous(), self.recv_splits, self.send_splits, group)
+            # node types of my halo rows (owners answer in the order I asked)
+            types_for_peers = node_type_own[(asked - lo)]
+            halo_types_ask = _all_to_all_int64(types_for_peers.contiguous(), self.send_splits, self.recv_splits, group)
         send_rows = (asked - lo).to(torch.int32)                                           # local row ids, (peer, chunk, id) order
-        # node types of my halo rows (owners answer in the order I asked)
-        types_for_peers = node_type_own[(asked - lo)]
-        halo_types_ask = _all_to_all_int64(types_for_peers.contiguous(), self.send_splits, self.recv_splits, group)
 
         def chunk_major(cnt):
             """(peer, chunk, id) -> (chunk, peer, id): gather order + per-chunk split sizes, from a [world, C] count matrix."""
@@ -242,7 +255,7 @@ class HaloPlan:
         # chunks in which NO rank sends or receives anything are skipped by every rank (the collective is not even entered)
         vol = torch.tensor([sum(self.recv_chunk_splits[c]) + sum(self.send_chunk_splits[c]) for c in range(C)], dtype=torch.int64,
                            device=dev)
-        if world > 1:
+        if world > 1 and emulate is None:
             vol = vol.cpu() if _host_staged(vol, group) else vol
             dist.all_reduce(vol, group=group)
         self.chunk_live = [bool(v > 0) for v in vol.tolist()]
@@ -288,6 +301,17 @@ class HaloPlan:
         return torch.where(claimed, self.edge_buckets() * num_relations + edge_type,
                            torch.full_like(edge_type, (self.n_chunks + 1) * num_relations))
 
+    def _transfer(self, recv, send, c, async_op):
+        """The all-to-all of chunk c (or, emulating, a device copy of as many bytes)."""
+        if getattr(self, "emulate", None) is not None:
+            n = min(recv.size(0), send.size(0))
+            if n:
+                recv[:n].copy_(send[:n])
+            return _Done() if async_op else None
+        if not self.chunk_live[c]:
+            return None
+        return _all_to_all(recv, send, list(self.recv_chunk_splits[c]), list(self.send_chunk_splits[c]), self.group, async_op=async_op)
+
     def exchange_chunk(self, c, x_own, x_local, pack=None, async_op=False, compress=False, expand=True):
         """One chunk of the exchange: pack the rows of chunk c the peers need, all-to-all them into the halo rows of chunk c.
         Returns (work, buffers) when async_op: work.wait() makes the current stream wait for the rows (and, with compress and
@@ -299,7 +323,6 @@ class HaloPlan:
         d = x_own.size(1)
         rows = self.send_rows[self.send_chunk_off[c]:self.send_chunk_off[c + 1]]
         recv = x_local[self.n_own + self.recv_chunk_off[c]:self.n_own + self.recv_chunk_off[c + 1]]
-        live = self.chunk_live[c]
         lib = _lib.load() if x_own.is_cuda else None
         st = torch.cuda.current_stream().cuda_stream if x_own.is_cuda else None
         if compress and pack is None and x_own.is_cuda and d % 4 == 0:
@@ -308,8 +331,7 @@ class HaloPlan:
                 _lib.check(lib.hgt_gather_rows_c24(x_own.data_ptr(), x_own.stride(0), rows.data_ptr(), rows.numel(), d,
                                                    send.data_ptr(), st), "hgt_gather_rows_c24")
             wire = torch.empty(recv.size(0), 3 * d, dtype=torch.uint8, device=x_own.device)
-            work = _all_to_all(wire, send, list(self.recv_chunk_splits[c]), list(self.send_chunk_splits[c]), self.group,
-                               async_op=async_op) if live else None
+            work = self._transfer(wire, send, c, async_op)
             n_recv, ld = recv.size(0), x_local.stride(0)
 
             def expand_rows():
@@ -336,8 +358,7 @@ class HaloPlan:
                                                send.data_ptr(), st), "hgt_gather_rows")
         else:
             send = pack(x_own, rows)
-        work = _all_to_all(recv, send, list(self.recv_chunk_splits[c]), list(self.send_chunk_splits[c]), self.group,
-                           async_op=async_op) if live else None
+        work = self._transfer(recv, send, c, async_op)
         if async_op:
             return (work if work is not None else _Done()), (send,)
         return None
@@ -420,6 +441,13 @@ class PartitionedGraph:
                 self.blocks.append((q0, q1, int(tab[t0]), int(tab[t1])))
         self.x_local = None
         self.workspace = None      # owned here: Q/K/V stay in it between the stages of one step
+        self.timeline = None       # set to a list: forward() appends (label, torch.cuda.Event) marks on the compute stream (bench.py)
+
+    def _mark(self, label):
+        if self.timeline is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.timeline.append((label, ev))
 
     def layer_mode(self, layer):
         """The schedule this layer runs (a layer outside a schedule's coverage takes the pipelined one)."""
@@ -457,21 +485,27 @@ class PartitionedGraph:
             kw = dict(plan=self.plan, n_q_rows=self.n_own, workspace=self.workspace)
             # the halo rows are projected straight off the 24-bit wire buffer where the projection kernel can read it
             direct = self.compress and d % 4 == 0 and d <= 256
+            self._mark("start")
             # every chunk is packed and queued on the links up front: the transfers run back to back on RCCL's stream
             pending = [self.halo.exchange_chunk(c, x_own_v, self.x_local, async_op=True, compress=self.compress, expand=not direct)
                        for c in range(C)]
+            self._mark("pack")
             layer(*args, stage=1, phase_events=phase_events, **kw)                         # Q|K|V of the own rows
+            self._mark("own_qkv")
             out = torch.empty(self.n_own, layer.out_dim, dtype=torch.float32, device=x_own.device)
             for b in range(C):
                 work, bufs = pending[b]
                 work.wait()
                 for t in bufs:
                     t.record_stream(cur())
+                self._mark("wait")
                 rows, off = self.chunk_lists[b]
                 if rows.numel():
                     c24 = (bufs[1], self.n_own + self.halo.recv_chunk_off[b]) if direct else None
                     layer(*args, stage=2, proj=(rows, off), proj_c24=c24, **kw)            # K|V of the halo rows of chunk b
+                self._mark("halo_kv")
                 layer(*args, stage=5, block=self.blocks[b], out=out, phase_events=phase_events if b == C - 1 else None, **kw)
+                self._mark("edge_blocks")
             layer._prepared_valid = True      # (stage 5 is not a "final" call of HGTConv.forward: the images were all written)
             return out
         if bucketed:

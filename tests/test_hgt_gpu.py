@@ -1427,3 +1427,216 @@ def test_bench_line_of_a_multi_rank_run_reports_world_size_and_backend(tmp_path)
     assert j["n_gpus"] == 2 and j["steps"] == 6 and j["scaling"] == "weak" and j["unit"] == "edges/s"
     assert j["config"]["parallelism"] == "replicas x2" and j["config"]["backend"].startswith("gloo")
     assert j["value"] > 0 and j["parity_max_abs_err"] is not None and j["parity_max_abs_err"] <= 1e-4
+
+
+def test_bench_line_of_a_two_rank_partitioned_run(tmp_path):
+    """`bench.py --gpus 2` on the configs[3] recipe at a reduced size, both ranks on the one GPU of the test box (gloo, host-staged
+    exchange): global graph -> in-edge-balanced partitioner -> first-use halo chunks negotiated between the ranks -> target-blocked
+    steps with 24-bit halo rows projected off the wire buffer.  The line must carry the parity of the benchmarked tensors, a
+    whole-step roofline without per-kernel fractions (round-3 review: fractions > 1 from phase events that bracket no kernel),
+    the stage times, and the two secondary schedules with their own parity."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HGT_BENCH_DEVICE="0", HGT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--nodes-per-gpu", "40000", "--edges-per-gpu", "400000", "--blocks", "4", "--locality", "0.5", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    cfg = j["config"]
+    assert cfg["parallelism"].startswith("dst-partition x2") and cfg["edge_phase"].startswith("target-blocked: 4 blocks")
+    assert cfg["halo_format"].startswith("24-bit") and cfg["locality"] == 0.5 and len(cfg["node_offsets"]) == 3
+    assert abs(cfg["node_offsets"][1] - 40000) <= 512 and cfg["node_offsets"][1] % 256 == 0
+    assert j["parity_max_abs_err"] is not None and j["parity_max_abs_err"] <= 1e-4
+    rf = j["roofline"]
+    assert "per_kernel_frac" not in rf and 0.0 < rf["frac"] <= 1.0 and rf["frac"] == rf["layer_frac"]
+    assert {"pack", "own_qkv", "wait", "halo_kv", "edge_blocks"} <= set(rf["stage_ms"])
+    sec = j["secondary"]
+    assert sec["halo_fp32"]["parity_max_abs_err"] <= 1e-4 and sec["edge_phase_after_last_chunk"]["parity_max_abs_err"] <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: parity-evidence gaps named by the round-3 review
+# ---------------------------------------------------------------------------------------------------------------------
+class _ReferenceShapedGNN(torch.nn.Module):
+    """The reference's wrapper, statement for statement (pyHGT/model.py:51-80), as TEST scaffolding: a torch adapter
+    (`adapt_ws[t]` + tanh through boolean masks and `res[idx] = ...`), dropout, and the POSITIONAL 5-argument call
+    `gc(meta_xs, node_type, edge_index, edge_type, edge_time)` of model.py:79 into `GeneralConv` -- which is what runs when the
+    reference's own model.py is used with `pyhgt_amd.install_into(pyHGT.conv)` (the reference itself cannot travel to the GPU box)."""
+
+    def __init__(self, in_dim, n_hid, num_types, num_relations, n_heads, n_layers, dropout=0.2, conv_name='hgt', prev_norm=False,
+                 last_norm=False, use_RTE=True):
+        super().__init__()
+        self.gcs = torch.nn.ModuleList()
+        self.num_types, self.in_dim, self.n_hid = num_types, in_dim, n_hid
+        self.adapt_ws = torch.nn.ModuleList()
+        self.drop = torch.nn.Dropout(dropout)
+        for t in range(num_types):
+            self.adapt_ws.append(torch.nn.Linear(in_dim, n_hid))
+        for l in range(n_layers - 1):
+            self.gcs.append(GeneralConv(conv_name, n_hid, n_hid, num_types, num_relations, n_heads, dropout, use_norm=prev_norm, use_RTE=use_RTE))
+        self.gcs.append(GeneralConv(conv_name, n_hid, n_hid, num_types, num_relations, n_heads, dropout, use_norm=last_norm, use_RTE=use_RTE))
+
+    def forward(self, node_feature, node_type, edge_time, edge_index, edge_type):
+        res = torch.zeros(node_feature.size(0), self.n_hid).to(node_feature.device)
+        for t_id in range(self.num_types):
+            idx = (node_type == int(t_id))
+            if idx.sum() == 0:
+                continue
+            res[idx] = torch.tanh(self.adapt_ws[t_id](node_feature[idx]))
+        meta_xs = self.drop(res)
+        del res
+        for gc in self.gcs:
+            meta_xs = gc(meta_xs, node_type, edge_index, edge_type, edge_time)
+        return meta_xs
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("name", ["gnn_oag2", "gnn_mag4"])
+def test_reference_call_sequence_through_general_conv_matches_reference_goldens(name, precision):
+    """The drop-in as the reference's unmodified GNN.forward drives it (model.py:69-80): torch adapter, masks, positional call into
+    GeneralConv -> HGTConv on the HIP path, the same graph tensors handed to every layer (one cached plan), reference parameter
+    names loaded with load_state_dict -- against the outputs of the verbatim reference GNN (tests/golden/gnn_*.npz)."""
+    from oracle.gen_golden_gnn import GNN_CASES, build_batch
+    c = GNN_CASES[name]
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    _, (x, nt, tm, ei, et, _, _) = build_batch(c)
+    sd = O.make_gnn_state_dict(c["in_dim"], c["n_hid"], c["T"], c["R"], c["H"], c["n_layers"], c["prev_norm"], c["last_norm"],
+                               c["use_RTE"], seed=c["seed"])
+    gnn = _ReferenceShapedGNN(c["in_dim"], c["n_hid"], c["T"], c["R"], c["H"], c["n_layers"], 0.2, "hgt", c["prev_norm"], c["last_norm"],
+                              c["use_RTE"]).eval()
+    missing, unexpected = gnn.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    gnn = gnn.to(DEV)
+    for gc in gnn.gcs:
+        assert type(gc.base_conv) is HGTConv
+        gc.base_conv.precision = precision
+    GraphPlan.clear_cache()
+    built = []
+    orig = GraphPlan.__init__
+    GraphPlan.__init__ = lambda self, *a, **k: (built.append(1), orig(self, *a, **k))[1]
+    try:
+        with torch.no_grad():
+            out = gnn(*_to_dev(x, nt, tm, ei, et))
+    finally:
+        GraphPlan.__init__ = orig
+    torch.cuda.synchronize()
+    assert len(built) == 1                                   # every layer found the first layer's plan
+    rows = torch.from_numpy(z["rows"]).long().to(DEV)
+    err = (out[rows].cpu() - torch.from_numpy(z["layers"][-1])).abs().max().item()
+    print("%s %s reference call sequence: max|err| %.1e" % (name, precision, err))
+    assert err < 1e-4
+    GraphPlan.clear_cache()
+
+
+def test_strict_mode_raises_like_the_reference_on_the_first_forward():
+    """conv.py:57 (index_select inside propagate) raises IndexError at once for a node id outside [0, N).  strict=True (or
+    GraphPlan.STRICT) reproduces that on the very FIRST forward of a new graph; the default surfaces it on a later forward."""
+    T, R, H, d, N, E = 3, 4, 4, 64, 500, 3000
+    sd = O.make_state_dict(d, d, T, R, H, True, True, seed=5)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=6)
+    ei = ei.clone()
+    ei[0, 17] = N + 3
+    layer = _layer_from(sd, d, T, R, H, True, True, keep_att=False, precision="bf16x3")
+    args = _to_dev(x, nt, ei, et, tm)
+    GraphPlan.clear_cache()
+    layer.strict = True
+    with torch.no_grad(), pytest.raises(IndexError):
+        layer(*args)
+    GraphPlan.clear_cache()
+    layer.strict = None
+    GraphPlan.STRICT = True
+    try:
+        with torch.no_grad(), pytest.raises(IndexError):
+            layer(*args)
+        tm_bad = tm.clone()
+        tm_bad[5] = 240
+        good_ei = _to_dev(synthetic_typed_graph(N, E, d, T, R, seed=6)[2])[0]
+        with torch.no_grad(), pytest.raises(IndexError):
+            layer(args[0], args[1], good_ei, args[3], tm_bad.to(DEV))
+        with torch.no_grad():                                 # a well-formed graph is unaffected
+            out = layer(args[0], args[1], good_ei, args[3], args[4])
+        assert torch.isfinite(out).all()
+    finally:
+        GraphPlan.STRICT = False
+        GraphPlan.clear_cache()
+
+
+def test_plan_cache_and_weight_cache_follow_in_place_edits():
+    """GraphPlan.cached keys on (address, version counter, shape, strides) of the graph tensors; the packed-weight cache on the
+    parameters' version counters AND storage addresses.  What bumps a version (every torch in-place op) or moves a storage
+    (`p.data = tensor`, a re-assigned Parameter) is picked up; a write THROUGH `.data` is invisible to both -- documented, and
+    undone by GraphPlan.clear_cache() / layer.invalidate()."""
+    T, R, H, d, N, E = 3, 4, 4, 64, 800, 6000
+    sd = O.make_state_dict(d, d, T, R, H, True, False, seed=7)
+    x, nt, ei, et, _ = synthetic_typed_graph(N, E, d, T, R, seed=8)
+    layer = _layer_from(sd, d, T, R, H, True, False, keep_att=False, precision="bf16x3")
+    xd, ntd, eid, etd = _to_dev(x, nt, ei.contiguous(), et)
+    oracle = lambda ei_, sd_: O.forward_closed_form(sd_, T, R, H, x, nt, ei_, et, None, use_RTE=False)
+    GraphPlan.clear_cache()
+    with torch.no_grad():
+        assert (layer(xd, ntd, eid, etd).cpu().double() - oracle(ei, sd)).abs().max().item() < TOL
+        # 1. an in-place torch op on edge_index bumps its version: a new plan is built
+        ei2 = ei.clone()
+        ei2[0] = torch.roll(ei[0], 1)
+        eid.copy_(ei2.to(DEV))
+        assert (layer(xd, ntd, eid, etd).cpu().double() - oracle(ei2, sd)).abs().max().item() < TOL
+        # 2. a write through .data does not: the stale plan (of ei2) is served until the cache is cleared
+        eid.data.copy_(ei.to(DEV))
+        stale = layer(xd, ntd, eid, etd).cpu().double()
+        assert (stale - oracle(ei2, sd)).abs().max().item() < TOL
+        GraphPlan.clear_cache()
+        assert (layer(xd, ntd, eid, etd).cpu().double() - oracle(ei, sd)).abs().max().item() < TOL
+        # 3. weights: `p.data = tensor` and a re-assigned Parameter are detected without invalidate()
+        sd2 = {k: v.clone() for k, v in sd.items()}
+        sd2["k_linears.1.weight"] = sd["k_linears.1.weight"] * 0.5
+        layer.k_linears[1].weight.data = sd2["k_linears.1.weight"].to(DEV)
+        assert (layer(xd, ntd, eid, etd).cpu().double() - oracle(ei, sd2)).abs().max().item() < TOL
+        sd2["skip"] = sd["skip"] + 1.0
+        layer.skip = torch.nn.Parameter(sd2["skip"].to(DEV))
+        assert (layer(xd, ntd, eid, etd).cpu().double() - oracle(ei, sd2)).abs().max().item() < TOL
+    # 4. LRU order: a hit refreshes BOTH keys of a registered plan (with / without edge_time)
+    GraphPlan.clear_cache()
+    old = GraphPlan.CACHE_SIZE
+    GraphPlan.CACHE_SIZE = 2
+    try:
+        tms = [torch.zeros(E, dtype=torch.int64, device=DEV) for _ in range(3)]
+        eis = [eid.clone() for _ in range(3)]
+        plans = [GraphPlan(ntd, eis[i], etd, tms[i], T, R) for i in range(3)]
+        GraphPlan.register(plans[0], ntd, eis[0], etd, tms[0], T, R)
+        GraphPlan.register(plans[1], ntd, eis[1], etd, tms[1], T, R)
+        assert GraphPlan.cached(ntd, eis[0], etd, tms[0], T, R) is plans[0]        # plan 0 is now the most recently used
+        GraphPlan.register(plans[2], ntd, eis[2], etd, tms[2], T, R)              # evicts plan 1, not the sibling key of plan 0
+        assert GraphPlan.cached(ntd, eis[0], etd, None, T, R) is plans[0]
+        assert GraphPlan.cached(ntd, eis[2], etd, tms[2], T, R) is plans[2]
+    finally:
+        GraphPlan.CACHE_SIZE = old
+        GraphPlan.clear_cache()
+
+
+def test_prepared_images_survive_a_change_of_kernel_flags():
+    """Round-3 advisor finding: the fragment images of the prepared buffer were only written when the FIRST forward's flags selected
+    the kernels that read them; a later flag change on the live layer then read uninitialised memory.  Every order must work."""
+    T, R, H, d, N, E = 3, 4, 8, 256, 3000, 30000
+    sd = O.make_state_dict(d, d, T, R, H, True, True, seed=9)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=10)
+    ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm)
+    args = _to_dev(x, nt, ei, et, tm)
+    F = _lib
+    orders = [(F.HGT_FLAG_VALU_LOGITS | F.HGT_FLAG_VALU_AGGREGATE, 0, F.HGT_FLAG_MFMA_LOGITS), (F.HGT_FLAG_VALU_AGGREGATE, F.HGT_FLAG_MFMA_LOGITS),
+              (F.HGT_FLAG_MFMA_LOGITS, F.HGT_FLAG_VALU_LOGITS, 0), (0, F.HGT_FLAG_MFMA_LOGITS | F.HGT_FLAG_NO_ITEM_AGGREGATE)]
+    for precision in ("bf16x3", "f16x3"):
+        for order in orders:
+            layer = _layer_from(sd, d, T, R, H, True, True, keep_att=False, precision=precision)
+            GraphPlan.clear_cache()
+            for fl in order:
+                layer.kernel_flags = fl
+                with torch.no_grad():
+                    out = layer(*args)
+                assert (out.cpu().double() - ref).abs().max().item() < TOL, (precision, order, fl)
