@@ -26,14 +26,6 @@
         if (hipGetLastError() != hipSuccess) return HGT_ERR_LAUNCH; \
     } while (0)
 
-#ifdef HGT_LAB_WIDE
-// tools/lab/hgt_gemm_wide.hip (experiment builds only)
-int hgt_launch_typed_linear_wide(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
-                                 int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias,
-                                 int64_t b_group_stride, float* out0, float* out1, float* out2, int32_t block_cols,
-                                 int32_t out_by_position, int n_cu, hipStream_t stream);
-#endif
-
 static inline uint64_t hgt_align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 // Device-written header at the start of the plan buffer.

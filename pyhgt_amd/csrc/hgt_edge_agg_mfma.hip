@@ -411,9 +411,15 @@ __device__ __forceinline__ void agg_mfma_stream(
     f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
     using G = MG<VEC, LPH>;
     constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS;
-    float sigv = 0.0f, thrv = 0.0f, rescv = 1.0f;   // fp16 split: the targets' scales / thresholds / pending moves, lane i = target i
-    int resc_any = 0;
-    if constexpr (F16) { if ((threadIdx.x & 63) < 16) s_sig[threadIdx.x & 63] = 0.0f; }
+    // fp16 split, OPTIMISTIC row scales (round 4): sigma_t (lane i = target i) is chosen when the target's first non-zero row is
+    // parked -- row maximum -> [1, 2), i.e. 2^14 of headroom for the rows of its other relations and still ~2^-25 of absolute
+    // resolution through the subnormal lo terms -- and later rows are NOT checked against it (round 3's per-row check: two
+    // v_readlane, a compare and a branch per parked row cost +0.26 ms at the benchmark size).  A row that leaves the fp16 range
+    // turns into inf in the U tile and NaN in the accumulators; that is looked for ONCE, after the walk, and the sub-tile is
+    // then walked again with 2^14 more headroom (f16_shift).  Rows within 2^14 of their target's first row -- a logit spread of
+    // ~9.7 above the first logit seen -- never retry.
+    float sigv = 0.0f;
+    int f16_shift = 0;
 #ifndef HGT_AGG_UN
 #define HGT_AGG_UN 4
 #endif
@@ -431,11 +437,6 @@ __device__ __forceinline__ void agg_mfma_stream(
     const int fi = lane & 15, fg = lane >> 4;
     const int tile = (int)(row0 / HGT_TD);
     const int within = (int)(row0 % HGT_TD);
-
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { s_m[j * 64 + lane] = HGT_NEG; s_l[j * 64 + lane] = 0.0f; }
 
     const int wb = lane * VEC * 2;
     const int rrow = fi * ROWB;
@@ -455,7 +456,21 @@ __device__ __forceinline__ void agg_mfma_stream(
     }
     const int my_pre = incl - my_len;
     const int total = __builtin_amdgcn_readlane(incl, 63);
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s_m[j * 64 + lane] = HGT_NEG; s_l[j * 64 + lane] = 0.0f; }
+    if constexpr (F16) { if (lane < 16) s_sig[lane] = 0.0f; }
     if (total == 0) return;
+  for (int attempt = 0;; ++attempt) {      // (one pass; the fp16 split may walk the sub-tile again with more headroom, see above)
+    if (attempt > 0) {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s_m[j * 64 + lane] = HGT_NEG; s_l[j * 64 + lane] = 0.0f; }
+        sigv = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+    }
 
     // stream entries [vbase, vbase + 64) -> lane registers; entries beyond the end replicate the last edge
     // (the relation and the target's position inside the sub-tile travel in ONE register, key = relation << 8 | target - row0:
@@ -499,7 +514,22 @@ __device__ __forceinline__ void agg_mfma_stream(
                 unsigned char* w = utile + dl * ROWB + ((((wb >> 4) ^ (dl & (NS - 1)))) << 4) + (wb & 15);
                 float sig = 1.0f;
                 if constexpr (F16) {
-                    sig = f16_target_scale<VEC>(U, sigv, thrv, rescv, resc_any, dl);
+                    const int dls = __builtin_amdgcn_readfirstlane(dl);
+                    unsigned sb = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, sigv), dls);
+                    if (sb == 0u) {      // the target's first row: its maximum decides sigma_t (an all-zero row decides nothing)
+                        float m = fabsf(U[0]);
+#pragma unroll
+                        for (int i = 1; i < VEC; ++i) m = fmaxf(m, fabsf(U[i]));
+                        unsigned e = wave_max_bits(__builtin_bit_cast(unsigned, m)) >> 23;
+                        sb = 0x3f800000u;
+                        if (e >= 40u) {
+                            e = e > 220u ? 220u : e;
+                            const int be = 254 - (int)e - f16_shift;          // sigma = 2^(-(e - 127) - shift): row maximum -> [1, 2) / 2^shift
+                            sb = (unsigned)(be < 1 ? 1 : be) << 23;
+                            sigv = (lane == dls) ? __builtin_bit_cast(float, sb) : sigv;
+                        }
+                    }
+                    sig = __builtin_bit_cast(float, sb);
                 }
                 if constexpr (VEC == 1) {
                     unsigned short hi, mid;
@@ -531,7 +561,6 @@ __device__ __forceinline__ void agg_mfma_stream(
     static_assert(STEPS % GS == 0, "column-tile steps come in multiples of 4 (DP is a multiple of 64)");
     auto relation_end = [&](int rel) {
         if (rowmask == 0) return;
-        if constexpr (F16) f16_apply_rescale<NCT>(rescv, resc_any, acc);
         for (int r = 0; r < SUBR; ++r) {
             if ((rowmask >> r) & 1u) continue;
             unsigned char* w = utile + r * ROWB + ((((wb >> 4) ^ (r & (NS - 1)))) << 4) + (wb & 15);
@@ -702,7 +731,20 @@ __device__ __forceinline__ void agg_mfma_stream(
     }
     flush();
     relation_end(cur_rel);
-    if constexpr (F16) { if ((threadIdx.x & 63) < 16) s_sig[threadIdx.x & 63] = sigv; }      // for agg_mfma_finish
+    if constexpr (F16) {
+        // did a row leave the fp16 range?  (inf in the tile -> NaN / inf in an accumulator; x * 0 keeps both as NaN)
+        float chk = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) chk = fmaf(acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3], 0.0f, chk);
+        if (__builtin_amdgcn_ballot_w64(chk != chk) == 0 || attempt >= 4) {
+            if (lane < 16) s_sig[lane] = sigv;      // for agg_mfma_finish
+            break;
+        }
+        f16_shift += 14;
+    } else {
+        break;
+    }
+  }
 #undef AGG_ISSUE
 #undef AGG_LOAD
 #undef AGG_WAIT

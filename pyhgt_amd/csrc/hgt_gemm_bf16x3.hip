@@ -25,7 +25,6 @@
 #include "hgt_common.h"
 #include "hgt_split_common.h"
 #include <algorithm>
-#include <cstdlib>
 
 
 namespace {
@@ -959,13 +958,6 @@ static int typed_linear_split_impl(const float* x, int64_t ldx, const int32_t* r
     if (((n_out | block_cols) & 3) != 0) return HGT_ERR_UNSUPPORTED;   // 16-byte epilogue stores; use hgt_typed_linear (fp32) instead
     if (n_rows == 0) return HGT_OK;
     hipStream_t stream = (hipStream_t)stream_;
-#ifdef HGT_LAB_WIDE   // tools/lab only: the wide persistent form measured in round 3 (slower)
-    if (prologue == 0 && getenv("HGT_WD_VARIANT") != nullptr) {
-        const int rw = hgt_launch_typed_linear_wide(x, ldx, rows, group_off, n_groups, n_rows, k, n_out, w_split, bias, b_group_stride, out0,
-                                                    out1, out2, block_cols, out_by_position, pc_grid(), stream);
-        if (rw != HGT_ERR_UNSUPPORTED) return rw;
-    }
-#endif
     const int64_t row_tiles = (n_rows + BM - 1) / BM + n_groups;   // device-side group sizes: launch the upper bound
     if (row_tiles > 0x7fffffffLL) return HGT_ERR_TOO_LARGE;
     const int vec_ok = (ldx % 4 == 0) && (k % 4 == 0) && (((uintptr_t)x & 15) == 0);

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--which", default="both")
     ap.add_argument("--bypos", type=int, default=0)
+    ap.add_argument("--c24", action="store_true", help="also time the split kernel reading 24-bit wire rows (prologue 2: the halo projections "
+                    "of the multi-GPU path) next to the unpack + project pair it replaces")
     args = ap.parse_args()
     lib = _lib.load()
     dev = "cuda:0"
@@ -48,8 +50,28 @@ def main():
         assert lib.hgt_typed_linear_bf16x3(x.data_ptr(), k, rows.data_ptr(), off.data_ptr(), T, N, k, n_out, ws.data_ptr(),
                                            b.data_ptr(), n_out, optr[0], optr[1], optr[2], bc, args.bypos, 0, st) == 0
 
-    for name, fn in (("fp32", run_fp32), ("bf16x3", run_split)):
-        if args.which not in ("both", name):
+    variants = [("fp32", run_fp32), ("bf16x3", run_split)]
+    if args.c24:
+        idx = torch.arange(N, dtype=torch.int32, device=dev)
+        wire = torch.empty(N, 3 * k, dtype=torch.uint8, device=dev)
+        xu = torch.empty_like(x)
+        assert lib.hgt_gather_rows_c24(x.data_ptr(), k, idx.data_ptr(), N, k, wire.data_ptr(), st) == 0
+        assert lib.hgt_split_weights(W.data_ptr(), n_out * k, T, k, n_out, ws.data_ptr(), st) == 0
+
+        def run_c24():
+            assert lib.hgt_typed_linear_bf16x3(wire.data_ptr(), 3 * k // 4, rows.data_ptr(), off.data_ptr(), T, N, k, n_out, ws.data_ptr(),
+                                               b.data_ptr(), n_out, optr[0], optr[1], optr[2], bc, args.bypos, 2, st) == 0
+
+        def run_unpack_then_split():
+            assert lib.hgt_unpack_rows_c24(wire.data_ptr(), N, k, xu.data_ptr(), k, st) == 0
+            assert lib.hgt_typed_linear_bf16x3(xu.data_ptr(), k, rows.data_ptr(), off.data_ptr(), T, N, k, n_out, ws.data_ptr(),
+                                               b.data_ptr(), n_out, optr[0], optr[1], optr[2], bc, args.bypos, 0, st) == 0
+
+        def run_pack():
+            assert lib.hgt_gather_rows_c24(x.data_ptr(), k, idx.data_ptr(), N, k, wire.data_ptr(), st) == 0
+        variants += [("c24", run_c24), ("unpack+x", run_unpack_then_split), ("pack_c24", run_pack)]
+    for name, fn in variants:
+        if args.which not in ("both", name) and not (args.c24 and name in ("c24", "unpack+x", "pack_c24")):
             continue
         for _ in range(3):
             fn()

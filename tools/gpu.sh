@@ -1,0 +1,74 @@
+#!/bin/bash
+# The one GPU-side driver script (run through gpurun from the repo root):   tools/gpu.sh <mode> [tag]
+#   quick     the round's new / changed tests, micro-benchmarks of the typed linears (incl. the 24-bit wire source) and the emulated
+#             rank-of-8 step of the multi-GPU path: minutes
+#   validate  pytest -m gpu, the judged bench line + a 2-rank walk of the multi-GPU path on one device, fuzzers, small / training benches
+#   profile   rocprofv3 passes of the judged command (tools/profile_pmc.sh <tag>) + kernel statistics of the latency regime
+#   final     smoke(), the example training loop, profile, then the judged line against this build's counters
+# Everything lands in gpurun_out/; summaries to be judged are copied to profiles/ by hand (or by `final`).
+MODE=${1:-quick}; TAG=${2:-r04}
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p gpurun_out
+export HGT_COMMIT=$(cat .commit 2>/dev/null || echo unknown)
+summ() { python - "$@" <<'PY'
+import json, sys
+for f in sys.argv[1:]:
+    try:
+        j = json.loads(open(f).read().strip().splitlines()[-1])
+    except Exception as e:
+        print(f, "unreadable", e); continue
+    if "ms_per_step" not in j:
+        print(f, json.dumps(j)[:900]); continue
+    r = j.get("roofline", {})
+    print(f, "ms", round(j["ms_per_step"], 3), "parity", j.get("parity_max_abs_err"), "frac", r.get("frac"), "layer_frac", r.get("layer_frac"),
+          r.get("phase_ms") or r.get("stage_ms"))
+    for k, v in (j.get("secondary") or {}).items():
+        if isinstance(v, dict):
+            print("   ", k, {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk in
+                             ("ms_per_step", "parity_max_abs_err", "layer_frac", "gpu_ms_per_step", "stage_ms", "halo_rows", "link_ms_at_70pct_of_7x76.8GBs", "phase_ms")})
+PY
+}
+case $MODE in
+quick)
+    timeout 1500 python -m pytest tests -m gpu -x -q -k "target_block or 24_bit or partitioned or real_halos or bucketed or staged or prepared or strict or in_place or reference_call or two_rank or f16_split_rows or golden" 2>&1 | tail -15 > gpurun_out/pytest_quick.log
+    tail -6 gpurun_out/pytest_quick.log
+    for n in 768 512; do python tools/bench_linear.py --which bf16x3 --n-out $n --c24 2>&1 | grep -v "^ *trace"; done > gpurun_out/linear_$TAG.log 2>&1
+    cat gpurun_out/linear_$TAG.log
+    for loc in 0 0.5 0.75 0.9; do
+        timeout 300 python bench.py --emulate-world 8 --locality $loc --steps 5 > gpurun_out/emu8_loc$loc.json 2> gpurun_out/emu8_loc$loc.err || tail -3 gpurun_out/emu8_loc$loc.err
+    done
+    timeout 300 python bench.py --emulate-world 8 --blocks 16 --steps 5 > gpurun_out/emu8_b16.json 2> gpurun_out/emu8_b16.err
+    timeout 300 python bench.py --emulate-world 8 --halo-fp32 --steps 5 > gpurun_out/emu8_fp32.json 2> gpurun_out/emu8_fp32.err
+    summ gpurun_out/emu8_*.json
+    for p in bf16x3 f16x3; do timeout 300 python bench.py --precision $p --no-secondary --no-cpu-baseline > gpurun_out/bench_quick_$p.json 2> gpurun_out/bench_quick_$p.err; done
+    summ gpurun_out/bench_quick_*.json
+    ;;
+validate)
+    python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/pytest_$TAG.log
+    tail -8 gpurun_out/pytest_$TAG.log
+    ( time timeout 900 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err ) 2>&1 | grep real
+    HGT_BENCH_DEVICE=0 HGT_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --nodes-per-gpu 200000 --edges-per-gpu 2000000 --no-cpu-baseline > gpurun_out/bench_${TAG}_dist2.json 2> gpurun_out/bench_${TAG}_dist2.err
+    summ gpurun_out/bench_$TAG.json gpurun_out/bench_${TAG}_dist2.json
+    tail -c 400 gpurun_out/bench_${TAG}_dist2.err
+    python tools/fuzz_parity.py 60 > gpurun_out/fuzz_$TAG.log 2>&1; tail -1 gpurun_out/fuzz_$TAG.log; grep -c FAIL gpurun_out/fuzz_$TAG.log
+    python tools/bench_small.py > gpurun_out/bench_small_$TAG.log 2>&1; tail -2 gpurun_out/bench_small_$TAG.log
+    python tools/bench_train.py > gpurun_out/bench_train_$TAG.log 2>&1; tail -2 gpurun_out/bench_train_$TAG.log
+    ;;
+profile)
+    tools/profile_pmc.sh $TAG > gpurun_out/prof_$TAG.log 2>&1
+    python - <<PY
+import json
+j = json.load(open("gpurun_out/prof_$TAG/${TAG}_pmc_summary.json"))
+for k in ("avg_kernel_ms", "traffic_bytes", "mfma_busy_pct", "valu_busy_pct", "waves_per_simd_avg", "wait_pct", "lds_bank_conflict_pct"): print(k, j.get(k))
+PY
+    tools/profile_small.sh $TAG > gpurun_out/prof_small_$TAG.log 2>&1; tail -3 gpurun_out/prof_small_$TAG.log
+    ;;
+final)
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+    timeout 300 python examples/train_synthetic.py --steps 6 2>&1 | tail -3
+    tools/profile_pmc.sh $TAG > gpurun_out/prof_$TAG.log 2>&1
+    cp gpurun_out/prof_$TAG/${TAG}_pmc_summary.json profiles/${TAG}_pmc_summary.json      # the line below is judged against THIS build's counters
+    ( time timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err ) 2>&1 | grep real
+    summ gpurun_out/${TAG}_bench.json
+    ;;
+esac
