@@ -128,7 +128,7 @@ extern "C" const char* hgt_strerror(int code) {
     switch (code) {
         case HGT_OK: return "ok";
         case HGT_ERR_INVALID_ARG: return "invalid argument";
-        case HGT_ERR_UNSUPPORTED: return "unsupported shape (need d % n_heads == 0, n_heads <= 16, padded row width <= 512)";
+        case HGT_ERR_UNSUPPORTED: return "unsupported shape (need d % n_heads == 0, n_heads <= 16, padded row width <= 1024)";
         case HGT_ERR_WORKSPACE: return "workspace too small";
         case HGT_ERR_TOO_LARGE: return "problem exceeds 32-bit plan indices";
         case HGT_ERR_LAUNCH: return "HIP launch/runtime error";
@@ -142,7 +142,9 @@ extern "C" int hgt_layout_for(int32_t d_out, int32_t n_heads, hgt_layout* out) {
     if (!out) return HGT_ERR_INVALID_ARG;
     int rc = hgt_layout_compute(d_out, n_heads, out);
     if (rc != HGT_OK) return rc;
-    if (out->vec > 8 || 64 / out->heads < 4) return HGT_ERR_UNSUPPORTED;   // kernels instantiated for vec <= 8, >= 4 lanes per head
+    // rows of up to 1024 padded columns (vec 16: n_hid 768 / 1024; the edge kernels split them into head groups of <= 256 or 512
+    // columns per wavefront), at least 4 lanes per head (n_heads <= 16)
+    if (out->vec > 16 || 64 / out->heads < 4) return HGT_ERR_UNSUPPORTED;
     return HGT_OK;
 }
 

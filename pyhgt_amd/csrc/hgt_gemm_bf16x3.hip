@@ -474,10 +474,14 @@ __device__ __forceinline__ void pc_issue(float4 (&a)[PC_AREGS], int& v_rid, int 
     if constexpr (PROLOGUE == 2) {
         // x holds rows in the 24-bit transport format of the multi-GPU exchange (hgt_gather_rows_c24: 4 values = 3 dwords, ldx =
         // 3 k / 4 dwords per row; k % 4 == 0 checked by the launcher): one 12-byte load per lane, decoded in pc_commit
+        // (rows beyond the tile re-read the tile's FIRST row -- always present -- not row 0: x is the wire buffer shifted back by the
+        //  chunk's first local row id (hgt_conv_forward stage 2), so "row 0" lies far outside any allocation)
+        const int rid_safe = rows[row0];
         if (kk < k) {
 #pragma unroll
             for (int j = 0; j < PC_AREGS; ++j) {
-                const int rid = max(__builtin_amdgcn_readlane(v_rid, j), 0);
+                const int rj = __builtin_amdgcn_readlane(v_rid, j);
+                const int rid = rj < 0 ? rid_safe : rj;
                 const float* px = x + (int64_t)rid * ldx + lane * 3;
                 a[j] = make_float4(px[0], px[1], px[2], 0.0f);
             }

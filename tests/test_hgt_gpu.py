@@ -82,6 +82,9 @@ CASES = [
     (5000, 60000, 64, 4, 3, 4, True, True, dict(dst_skew=1.1)),        # hubs: items split at 256 edges
     (700, 3000, 32, 2, 3, 2, True, False, dict(sorted_types=False, strided_edge_index=False)),
     (129, 1, 64, 4, 2, 2, True, True, {}),                             # a single edge
+    (700, 6000, 768, 8, 3, 5, True, True, {}),                         # n_hid 768: d_k = 96 padded to 128, rows of 1024 padded columns
+    (600, 5000, 1024, 16, 2, 4, True, False, {}),                      # n_hid 1024, 16 heads (conv.py:21 accepts any d % H == 0)
+    (500, 4000, 1024, 8, 2, 3, False, True, {}),                       # n_hid 1024, 8 heads: d_k = 128
 ]
 
 
@@ -435,7 +438,7 @@ def test_staged_forward_equals_whole_layer(precision, use_RTE):
         whole = layer(xd, ntd, eid, etd, tmd, n_q_rows=NQ).clone()
         # three chunks of the halo rows [NQ, N), each as a typed row list
         bounds = [NQ, NQ + 500, NQ + 1300, N]
-        ws = torch.empty(layer.workspace_bytes(N, E), dtype=torch.uint8, device=DEV)   # staged runs own their workspace
+        ws = torch.empty(layer.workspace_bytes(N, E, staged=False), dtype=torch.uint8, device=DEV)   # staged runs own their workspace (with the item-aggregation scratch: the same kernels as the whole-layer call)
         layer(xd, ntd, eid, etd, tmd, n_q_rows=NQ, stage=1, workspace=ws)
         for a, b in zip(bounds[:-1], bounds[1:]):
             tt = ntd[a:b]

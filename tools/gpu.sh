@@ -9,6 +9,7 @@
 MODE=${1:-quick}; TAG=${2:-r04}
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
+ulimit -c 0      # a faulting kernel must not fill the scratch disk with core files (every later command of the call then fails)
 export HGT_COMMIT=$(cat .commit 2>/dev/null || echo unknown)
 summ() { python - "$@" <<'PY'
 import json, sys
@@ -30,8 +31,8 @@ PY
 }
 case $MODE in
 quick)
-    timeout 1500 python -m pytest tests -m gpu -x -q -k "target_block or 24_bit or partitioned or real_halos or bucketed or staged or prepared or strict or in_place or reference_call or two_rank or f16_split_rows or golden" 2>&1 | tail -15 > gpurun_out/pytest_quick.log
-    tail -6 gpurun_out/pytest_quick.log
+    timeout 1500 python -m pytest tests -m gpu -q -k "target_block or 24_bit or partitioned or real_halos or bucketed or staged or prepared or strict or in_place or reference_call or two_rank or f16_split_rows or golden" 2>&1 | tail -60 > gpurun_out/pytest_quick.log
+    grep -E "^FAILED|^ERROR|passed|failed" gpurun_out/pytest_quick.log | tail -30
     for n in 768 512; do python tools/bench_linear.py --which bf16x3 --n-out $n --c24 2>&1 | grep -v "^ *trace"; done > gpurun_out/linear_$TAG.log 2>&1
     cat gpurun_out/linear_$TAG.log
     for loc in 0 0.5 0.75 0.9; do
