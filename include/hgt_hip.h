@@ -296,6 +296,15 @@ int hgt_edge_aggregate_f16x3(const void* plan, int64_t n_nodes, int64_t n_edges,
  * ranges are split over many wavefronts (max / sum-exp / weighted sum accumulated with atomics) instead of being
  * walked by the one wavefront that owns their 16-target sub-tile.  NULL = no hub path (correct, slow on hubs). */
 int hgt_hub_workspace_bytes(int64_t n_edges, int32_t n_heads, int32_t dk_pad, uint64_t* out_host);
+/* ABI 6: deterministic != 0 adds one partial slot per piece, (n_relations + 1) x 32 pieces per possible hub (n_edges / 1024 + 1 of them):
+ * about 0.28 * n_edges * (H * dk_pad + H) * 4 bytes.  hgt_edge_aggregate_ex / hgt_edge_aggregate_update_range take such a buffer with
+ * hub_deterministic = 1. */
+int hgt_hub_workspace_bytes_ex(int64_t n_edges, int32_t n_heads, int32_t dk_pad, int32_t n_relations, int32_t deterministic,
+                               uint64_t* out_host);
+int hgt_edge_aggregate_ex(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                          int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
+                          const float* msg_p, const void* msg_frag, int32_t frag_f16, float* agg, int64_t n_q_rows, int32_t apply_gelu,
+                          void* hub_ws, int32_t hub_deterministic, void* stream);
 int hgt_att_export(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                    int32_t n_heads, const float* att_sorted, float* att_out, int32_t n_heads_out, void* stream);
 /* att_sorted [E][n_heads] (layout heads) -> att_out [E][n_heads_out] (the first n_heads_out heads; the model's real heads) */
@@ -358,13 +367,15 @@ int hgt_edge_aggregate_update_f16x3(const void* plan, int64_t n_nodes, int64_t n
 
 /* ABI 6: hgt_edge_aggregate_update for the targets [q_begin, q_end) only (q_begin a multiple of the plan tile, q_end <= n_q_rows):
  * one TARGET BLOCK of the multi-GPU path, whose in-edges only reference source rows that have already arrived.  `pending` is indexed
- * from the block's first workgroup.  Matrix-core kernel only (msg_frag required). */
+ * from the block's first workgroup.  Matrix-core kernel only (msg_frag required).  frag_f16: msg_frag / w_a_split are the fp16 images;
+ * hub_deterministic: see HGT_FLAG_DETERMINISTIC_HUBS. */
 int hgt_edge_aggregate_update_range(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                                     int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
                                     const float* msg_p, const void* msg_frag, float* agg, int64_t n_q_rows, void* hub_ws,
                                     int32_t* pending, const int64_t* node_type, const void* w_a_split, const float* b_a,
                                     const float* x_skip, int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b,
-                                    int32_t use_norm, int32_t n_out, float* out, void* stream, int64_t q_begin, int64_t q_end);
+                                    int32_t use_norm, int32_t n_out, float* out, void* stream, int64_t q_begin, int64_t q_end,
+                                    int32_t frag_f16, int32_t hub_deterministic);
 
 /* ----------------------------------------------------------------------------------------------
  * Backward pass (the reference gets it from autograd: OAG/train_paper_field.py:249,
@@ -527,6 +538,11 @@ typedef struct hgt_conv_args {
 #define HGT_FLAG_ITEM_AGGREGATE 16   /* hgt_edge_aggregate_items wherever it applies (the default below 65536 nodes when its scratch is at most 1 GB) */
 #define HGT_FLAG_NO_ITEM_AGGREGATE 32 /* never hgt_edge_aggregate_items */
 #define HGT_FLAG_FUSED_ANY_SIZE 64   /* hgt_edge_aggregate_update below its default size too (>= 16384 targets) */
+#define HGT_FLAG_DETERMINISTIC_HUBS 128 /* ABI 6: targets with more than 1024 in-edges ("hubs") are aggregated WITHOUT atomics: every piece of a
+                                      * (hub, relation) range writes its partial row / exp-sum to its own slot and the finalize kernel sums
+                                      * the slots in (relation, piece) order, so two forwards are bit-identical on every row (the default
+                                      * hub path adds fp32 partials atomically: hub rows then differ in the last bits from run to run).
+                                      * Costs workspace: hgt_conv_workspace_bytes_ex(options bit 1) */
 
 /* phase boundaries at which hgt_conv_forward records phase_events[i]:
  *   0 start | 1 relation pack + Q/K/V (+ temporal tables) done | 2 logits done | 3 softmax done |
@@ -536,11 +552,11 @@ typedef struct hgt_conv_args {
 int hgt_conv_workspace_bytes(int64_t n_nodes, int64_t n_edges, int32_t in_dim, int32_t out_dim,
                              int32_t n_types, int32_t n_relations, int32_t n_heads, int32_t use_rte,
                              uint64_t* out_host);
-/* ABI 6: item_scratch = 0 leaves out the scratch of hgt_edge_aggregate_items (E*d*4 + E*H*8 + E bytes, up to 1 GiB, on graphs below
- * 65536 nodes) for calls that cannot take that kernel (exact fp32, HGT_FLAG_NO_ITEM_AGGREGATE, staged multi-GPU calls);
- * hgt_conv_forward accepts either size. */
+/* ABI 6: options bit 0 = include the scratch of hgt_edge_aggregate_items (E*d*4 + E*H*8 + E bytes, up to 1 GiB, on graphs below 65536
+ * nodes; calls that cannot take that kernel -- exact fp32, HGT_FLAG_NO_ITEM_AGGREGATE, staged multi-GPU calls -- leave it out, and
+ * hgt_conv_forward accepts either size); bit 1 = the partial slots of HGT_FLAG_DETERMINISTIC_HUBS (required when that flag is set). */
 int hgt_conv_workspace_bytes_ex(int64_t n_nodes, int64_t n_edges, int32_t in_dim, int32_t out_dim,
-                                int32_t n_types, int32_t n_relations, int32_t n_heads, int32_t use_rte, int32_t item_scratch,
+                                int32_t n_types, int32_t n_relations, int32_t n_heads, int32_t use_rte, int32_t options,
                                 uint64_t* out_host);
 int hgt_conv_prepared_bytes(int32_t in_dim, int32_t out_dim, int32_t n_types, int32_t n_relations, int32_t n_heads,
                             int32_t use_rte, uint64_t* out_host);

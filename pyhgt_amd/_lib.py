@@ -19,6 +19,7 @@ HGT_FLAG_VALU_LOGITS = 8
 HGT_FLAG_ITEM_AGGREGATE = 16
 HGT_FLAG_NO_ITEM_AGGREGATE = 32
 HGT_FLAG_FUSED_ANY_SIZE = 64
+HGT_FLAG_DETERMINISTIC_HUBS = 128
 
 
 class HgtLayout(C.Structure):
@@ -98,7 +99,9 @@ SIGNATURES = {
     "hgt_edge_logits_mfma": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "hgt_edge_logits_range": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     "hgt_edge_aggregate_update_range": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
-                                                  _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _i64]),
+                                                  _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _i64, _i32, _i32]),
+    "hgt_hub_workspace_bytes_ex": (C.c_int, [_i64, _i32, _i32, _i32, _i32, C.POINTER(_u64)]),
+    "hgt_edge_aggregate_ex": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _i32, _vp]),
     "hgt_edge_logits_slice": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "hgt_edge_aggregate_slice": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp,
                                            _i32, _i32, _vp, _i32, _i32, _vp]),

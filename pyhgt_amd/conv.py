@@ -648,8 +648,9 @@ class HGTConv(nn.Module):
         # (the item-parallel aggregation's scratch only where this call can take that kernel: whole-layer calls of a split precision)
         # (a caller-owned workspace may come without it: hgt_conv_forward then simply rules that kernel out)
         item_scratch = int(workspace is None and stage == 0 and prec != "fp32" and not (self.kernel_flags & _lib.HGT_FLAG_NO_ITEM_AGGREGATE))
+        options = item_scratch | (2 if (self.kernel_flags & _lib.HGT_FLAG_DETERMINISTIC_HUBS) else 0)
         _lib.check(lib.hgt_conv_workspace_bytes_ex(N, E, self.in_dim, self.out_dim, self.num_types, R_plan,
-                                                   self.n_heads, int(self.use_RTE), item_scratch, C.byref(nbytes)), "hgt_conv_workspace_bytes_ex")
+                                                   self.n_heads, int(self.use_RTE), options, C.byref(nbytes)), "hgt_conv_workspace_bytes_ex")
         if workspace is not None:
             if workspace.dtype != torch.uint8 or workspace.device != x.device or workspace.numel() < nbytes.value:
                 raise ValueError("workspace must be a uint8 tensor of >= %d bytes on %s" % (nbytes.value, x.device))
@@ -725,7 +726,8 @@ class HGTConv(nn.Module):
         n = C.c_uint64()
         _lib.check(_lib.load().hgt_conv_workspace_bytes_ex(int(n_nodes), int(n_edges), self.in_dim, self.out_dim, self.num_types,
                                                            self.num_relations * int(n_slices), self.n_heads, int(self.use_RTE),
-                                                           int(not staged), C.byref(n)), "hgt_conv_workspace_bytes_ex")
+                                                           int(not staged) | (2 if (self.kernel_flags & _lib.HGT_FLAG_DETERMINISTIC_HUBS) else 0),
+                                                           C.byref(n)), "hgt_conv_workspace_bytes_ex")
         return int(n.value)
 
     def __repr__(self):

@@ -24,7 +24,7 @@ struct ConvWorkspace {
 };
 
 static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim, int out_dim, int T, int R, int /*n_heads*/, int use_rte,
-                                    const hgt_layout& lay, bool item_scratch = true) {
+                                    const hgt_layout& lay, bool item_scratch = true, bool det_hubs = false) {
     const int H = lay.heads;     // layout heads (n_heads rounded up to a power of two)
     ConvWorkspace w;
     uint64_t o = 0;
@@ -43,7 +43,7 @@ static ConvWorkspace conv_workspace(int64_t N, int64_t NQ, int64_t E, int in_dim
     w.off_msg_f = take(fb);
     w.off_att_f = take(fb);
     uint64_t hb = 0;
-    hgt_hub_workspace_bytes(E, H, lay.dk_pad, &hb);
+    hgt_hub_workspace_bytes_ex(E, H, lay.dk_pad, R, det_hubs ? 1 : 0, &hb);
     w.off_hub = take(hb);
     if (use_rte) {
         w.off_rte_lin = take((uint64_t)HGT_RTE_LEN * in_dim * 4);
@@ -162,12 +162,12 @@ extern "C" int hgt_conv_workspace_bytes(int64_t n_nodes, int64_t n_edges, int32_
 // know the call cannot take it: exact fp32 precision, HGT_FLAG_NO_ITEM_AGGREGATE, staged multi-GPU calls.  hgt_conv_forward
 // accepts either size (a workspace without the scratch simply rules the item-parallel kernel out).
 extern "C" int hgt_conv_workspace_bytes_ex(int64_t n_nodes, int64_t n_edges, int32_t in_dim, int32_t out_dim, int32_t n_types,
-                                           int32_t n_relations, int32_t n_heads, int32_t use_rte, int32_t item_scratch, uint64_t* out) {
+                                           int32_t n_relations, int32_t n_heads, int32_t use_rte, int32_t options, uint64_t* out) {
     if (!out || n_nodes < 0 || n_edges < 0 || in_dim <= 0) return HGT_ERR_INVALID_ARG;
     hgt_layout lay;
     int rc = hgt_layout_for(out_dim, n_heads, &lay);
     if (rc != HGT_OK) return rc;
-    *out = conv_workspace(n_nodes, n_nodes, n_edges, in_dim, out_dim, n_types, n_relations, n_heads, use_rte, lay, item_scratch != 0).total;
+    *out = conv_workspace(n_nodes, n_nodes, n_edges, in_dim, out_dim, n_types, n_relations, n_heads, use_rte, lay, (options & 1) != 0, (options & 2) != 0).total;
     return HGT_OK;
 }
 
@@ -207,9 +207,10 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     if (rc != HGT_OK) return rc;
     const int H = lay.heads;     // the kernels run with the layout's head count (extra heads are all-zero)
     const int dp = lay.d_pad;
-    ConvWorkspace w = conv_workspace(N, N, E, din, dout, T, R, H, a->use_rte, lay);   // sized for NQ == N (upper bound)
+    const bool det_hubs = (a->flags & HGT_FLAG_DETERMINISTIC_HUBS) != 0;       // needs the larger hub region: options bit 1
+    ConvWorkspace w = conv_workspace(N, N, E, din, dout, T, R, H, a->use_rte, lay, true, det_hubs);   // sized for NQ == N (upper bound)
     if (a->workspace_bytes < w.total) {      // a workspace sized without the item-aggregation scratch (hgt_conv_workspace_bytes_ex)
-        w = conv_workspace(N, N, E, din, dout, T, R, H, a->use_rte, lay, false);
+        w = conv_workspace(N, N, E, din, dout, T, R, H, a->use_rte, lay, false, det_hubs);
         if (a->workspace_bytes < w.total) return HGT_ERR_WORKSPACE;
     }
     if (N == 0) return HGT_OK;
@@ -406,7 +407,7 @@ edge_phase:
         }
         rc = hgt_edge_aggregate_update_range(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ, hub_ws,
                                              (int32_t*)(wb + w.off_pending), a->node_type, ws_upd, a->b_a, a->x, din, a->skip, a->ln_w,
-                                             a->ln_b, a->use_norm, dout, a->out, stream, a->q_begin, a->q_end);
+                                             a->ln_b, a->use_norm, dout, a->out, stream, a->q_begin, a->q_end, 0, det_hubs ? 1 : 0);
         mark(4);
         mark(5);
         mark(6);
@@ -432,6 +433,13 @@ edge_phase:
             rc = split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
             if (rc != HGT_OK) return rc;
         }
+        if (det_hubs && hub_ws && msg_f)
+            rc = hgt_edge_aggregate_update_range(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ, hub_ws,
+                                                 (int32_t*)(wb + w.off_pending), a->node_type, ws_upd, a->b_a, a->x, din, a->skip, a->ln_w,
+                                                 a->ln_b, a->use_norm, dout, a->out, stream, 0, NQ, f16 ? 1 : 0, 1);
+        else if (det_hubs && hub_ws)
+            rc = HGT_ERR_UNSUPPORTED;      // (vector-ALU aggregation: the unfused kernels below carry the deterministic hub mode)
+        else
         rc = (f16 ? hgt_edge_aggregate_update_f16x3 : hgt_edge_aggregate_update)(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ,
                                        hub_ws, (int32_t*)(wb + w.off_pending), a->node_type,
                                        ws_upd, a->b_a, a->x, din, a->skip, a->ln_w, a->ln_b, a->use_norm, dout, a->out, stream);
@@ -466,8 +474,8 @@ edge_phase:
                                       (float*)(wb + w.off_state), sl_lo > 0, sl_more, stream);
         if (rc != HGT_OK || sl_more) return rc;      // state + un-normalised rows stay in the workspace for the next slice
     } else {
-        rc = (f16 && msg_f ? hgt_edge_aggregate_f16x3 : hgt_edge_aggregate)(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f,
-                                                                            agg, NQ, dense ? 0 : 1, hub_ws, stream);
+        rc = hgt_edge_aggregate_ex(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, (f16 && msg_f) ? 1 : 0, agg, NQ,
+                                   dense ? 0 : 1, hub_ws, det_hubs ? 1 : 0, stream);
     }
     if (rc != HGT_OK) return rc;
     if (a->want_att && E > 0) {   // self.att (conv.py:108): normalise the logits in place and un-sort them

@@ -416,10 +416,11 @@ __device__ __forceinline__ void agg_mfma_stream(
     // resolution through the subnormal lo terms -- and later rows are NOT checked against it (round 3's per-row check: two
     // v_readlane, a compare and a branch per parked row cost +0.26 ms at the benchmark size).  A row that leaves the fp16 range
     // turns into inf in the U tile and NaN in the accumulators; that is looked for ONCE, after the walk, and the sub-tile is
-    // then walked again with 2^14 more headroom (f16_shift).  Rows within 2^14 of their target's first row -- a logit spread of
-    // ~9.7 above the first logit seen -- never retry.
+    // then walked again with 2^14 more headroom FOR THE TARGETS THAT OVERFLOWED (shiftv; a column of the transposed product only
+    // depends on its own target's rows, so the other targets of the sub-tile keep their scales and reproduce their values).
+    // Rows within 2^14 of their target's first row -- a logit spread of ~9.7 above the first logit seen -- never retry.
     float sigv = 0.0f;
-    int f16_shift = 0;
+    int shiftv = 0;      // extra headroom (powers of two) per target, lane i = target i: grows by 14 for a target whose rows overflowed
 #ifndef HGT_AGG_UN
 #define HGT_AGG_UN 4
 #endif
@@ -524,7 +525,7 @@ __device__ __forceinline__ void agg_mfma_stream(
                         sb = 0x3f800000u;
                         if (e >= 40u) {
                             e = e > 220u ? 220u : e;
-                            const int be = 254 - (int)e - f16_shift;          // sigma = 2^(-(e - 127) - shift): row maximum -> [1, 2) / 2^shift
+                            const int be = 254 - (int)e - __builtin_amdgcn_readlane(shiftv, dls);   // sigma = 2^(-(e - 127) - shift): row maximum -> [1, 2) / 2^shift
                             sb = (unsigned)(be < 1 ? 1 : be) << 23;
                             sigv = (lane == dls) ? __builtin_bit_cast(float, sb) : sigv;
                         }
@@ -736,11 +737,13 @@ __device__ __forceinline__ void agg_mfma_stream(
         float chk = 0.0f;
 #pragma unroll
         for (int c = 0; c < NCT; ++c) chk = fmaf(acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3], 0.0f, chk);
-        if (__builtin_amdgcn_ballot_w64(chk != chk) == 0 || attempt >= 4) {
+        const unsigned long long bad = __builtin_amdgcn_ballot_w64(chk != chk);      // lane -> its target is (lane & 15)
+        if (bad == 0 || attempt >= 4) {
             if (lane < 16) s_sig[lane] = sigv;      // for agg_mfma_finish
             break;
         }
-        f16_shift += 14;
+        const unsigned bad_t = (unsigned)((bad | (bad >> 16) | (bad >> 32) | (bad >> 48)) & 0xFFFFull);
+        shiftv += ((bad_t >> (lane & 15)) & 1u) ? 14 : 0;
     } else {
         break;
     }
@@ -1056,13 +1059,20 @@ static int mfma_split_for(int vec_full, int lph_full) {
     return (vec_full / s <= 4) ? s : 0;   // 0: not covered (one head wider than 256 columns)
 }
 
-static HgtHubBuffers carve_hub(void* hub_ws, const HgtPlanView& pv, int H, int64_t E) {
+// det: the deterministic hub mode (one partial slot per piece behind the atomic accumulators; hgt_hub_workspace_bytes_ex)
+static HgtHubBuffers carve_hub(void* hub_ws, const HgtPlanView& pv, int H, int64_t E, int dk_pad = 0, int R = 0, bool det = false) {
     HgtHubBuffers hb = {nullptr, nullptr, nullptr};
     if (hub_ws && E > 0) {
         const uint64_t per = hgt_align_up((uint64_t)pv.L.max_hubs * H * 4, 256);
         hb.mx = (int*)hub_ws;
         hb.l = (float*)((char*)hub_ws + per);
         hb.acc = (float*)((char*)hub_ws + 2 * per);
+        if (det) {
+            const uint64_t acc_bytes = hgt_align_up((uint64_t)pv.L.max_hubs * H * dk_pad * 4, 256);
+            const uint64_t np = (uint64_t)(R + 1) * HGT_HUB_PIECES;
+            hb.part = (float*)((char*)hub_ws + 2 * per + acc_bytes);
+            hb.lpart = (float*)((char*)hb.part + hgt_align_up((uint64_t)pv.L.max_hubs * np * H * dk_pad * 4, 256));
+        }
     }
     return hb;
 }
@@ -1180,10 +1190,20 @@ extern "C" int hgt_hub_workspace_bytes(int64_t n_edges, int32_t n_heads, int32_t
     *out = hgt_align_up(max_hubs * n_heads * 4, 256) * 2 + hgt_align_up(max_hubs * n_heads * dk_pad * 4, 256);
     return HGT_OK;
 }
+// ABI 6: + the per-piece partial slots of the deterministic hub mode (n_relations + 1 buckets x 32 pieces per hub)
+extern "C" int hgt_hub_workspace_bytes_ex(int64_t n_edges, int32_t n_heads, int32_t dk_pad, int32_t n_relations, int32_t deterministic,
+                                          uint64_t* out) {
+    int rc = hgt_hub_workspace_bytes(n_edges, n_heads, dk_pad, out);
+    if (rc != HGT_OK || !deterministic) return rc;
+    if (n_relations <= 0) return HGT_ERR_INVALID_ARG;
+    const uint64_t max_hubs = (uint64_t)(n_edges / HGT_HUB_DEG + 1), np = (uint64_t)(n_relations + 1) * HGT_HUB_PIECES;
+    *out += hgt_align_up(max_hubs * np * n_heads * dk_pad * 4, 256) + hgt_align_up(max_hubs * np * n_heads * 4, 256);
+    return HGT_OK;
+}
 
 static int edge_aggregate_impl(bool f16, const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
                                const float* logits, const float* V, const float* rte_v, const float* msg_p, const void* msg_frag,
-                               float* agg, int64_t n_q_rows, int32_t apply_gelu, void* hub_ws, void* stream) {
+                               float* agg, int64_t n_q_rows, int32_t apply_gelu, void* hub_ws, void* stream, bool det_hubs = false) {
     if (f16 && !msg_frag) return HGT_ERR_INVALID_ARG;
     if (!plan || !V || !msg_p || !agg || (E > 0 && !logits) || H <= 0 || 64 % H != 0 || dk_pad <= 0) return HGT_ERR_INVALID_ARG;
     const int64_t NQ = (n_q_rows > 0 && n_q_rows <= N) ? n_q_rows : N;
@@ -1191,7 +1211,7 @@ static int edge_aggregate_impl(bool f16, const void* plan, int64_t N, int64_t E,
     const int lph = 64 / H;
     if (dk_pad % lph != 0) return HGT_ERR_INVALID_ARG;
     HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
-    HgtHubBuffers hb = carve_hub(hub_ws, pv, H, E);
+    HgtHubBuffers hb = carve_hub(hub_ws, pv, H, E, dk_pad, R, det_hubs);
     const HgtRelSlice whole = {0, (int)R + 1, nullptr, 0, 0};
     int rc = HGT_ERR_UNSUPPORTED;
     const int sp = msg_frag ? mfma_split_for(dk_pad / lph, lph) : 0;
@@ -1216,6 +1236,15 @@ extern "C" int hgt_edge_aggregate_f16x3(const void* plan, int64_t N, int64_t E, 
                                         const void* msg_frag, float* agg, int64_t n_q_rows, int32_t apply_gelu, void* hub_ws,
                                         void* stream) {
     return edge_aggregate_impl(true, plan, N, E, T, R, H, dk_pad, logits, V, rte_v, msg_p, msg_frag, agg, n_q_rows, apply_gelu, hub_ws, stream);
+}
+
+// ABI 6: hub_deterministic != 0: hub targets are accumulated without atomics (hub_ws of hgt_hub_workspace_bytes_ex(.., 1) bytes)
+extern "C" int hgt_edge_aggregate_ex(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                     const float* logits, const float* V, const float* rte_v, const float* msg_p, const void* msg_frag,
+                                     int32_t frag_f16, float* agg, int64_t n_q_rows, int32_t apply_gelu, void* hub_ws,
+                                     int32_t hub_deterministic, void* stream) {
+    return edge_aggregate_impl(frag_f16 != 0, plan, N, E, T, R, H, dk_pad, logits, V, rte_v, msg_p, msg_frag, agg, n_q_rows, apply_gelu, hub_ws,
+                               stream, hub_deterministic != 0);
 }
 
 // One slice [rel_lo, rel_hi) of the relation buckets (include/hgt_hip.h): matrix-core kernel only (msg_frag required).
@@ -1247,7 +1276,8 @@ static int edge_aggregate_update_impl(bool f16, const void* plan, int64_t N, int
                                       const void* msg_frag, float* agg, int64_t n_q_rows, void* hub_ws, int32_t* pending,
                                       const int64_t* node_type, const void* w_a_split, const float* b_a, const float* x_skip,
                                       int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm,
-                                      int32_t n_out, float* out, void* stream, int64_t q_begin = 0, int64_t q_end = -1) {
+                                      int32_t n_out, float* out, void* stream, int64_t q_begin = 0, int64_t q_end = -1,
+                                      bool det_hubs = false) {
     if (f16 && !msg_frag) return HGT_ERR_INVALID_ARG;
     if (!plan || !V || !msg_p || !agg || !pending || !node_type || !w_a_split || !b_a || !x_skip || !skip || !out || H <= 0 ||
         64 % H != 0 || dk_pad <= 0 || n_out <= 0)
@@ -1268,7 +1298,7 @@ static int edge_aggregate_update_impl(bool f16, const void* plan, int64_t N, int
     const int dp = H * dk_pad;
     if (dp > KP || n_out > dp || (n_out & 3) != 0 || (ld_skip & 3) != 0 || ((uintptr_t)x_skip & 15) != 0) return HGT_ERR_UNSUPPORTED;
     HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
-    HgtHubBuffers hb = carve_hub(hub_ws, pv, H, E);
+    HgtHubBuffers hb = carve_hub(hub_ws, pv, H, E, dk_pad, R, det_hubs);
     HgtFusedUpdate fu = {node_type, (const unsigned short*)w_a_split, b_a, x_skip, ld_skip, skip, ln_w, ln_b, use_norm, T, n_out, out,
                          ranged ? q_begin : 0};
     if (ranged) { hb.q_lo = q_begin; hb.q_hi = q_end; }
@@ -1294,9 +1324,11 @@ extern "C" int hgt_edge_aggregate_update(HGT_AGGUPD_PARAMS) { return edge_aggreg
 // msg_frag = hgt_relation_frag_pack_f16 image, w_a_split = hgt_split_weights_f16 image (both required)
 extern "C" int hgt_edge_aggregate_update_f16x3(HGT_AGGUPD_PARAMS) { return edge_aggregate_update_impl(true, HGT_AGGUPD_PASS); }
 // ABI 6: the targets [q_begin, q_end) only (q_begin a multiple of the plan tile): one target block of the multi-GPU path
-extern "C" int hgt_edge_aggregate_update_range(HGT_AGGUPD_PARAMS, int64_t q_begin, int64_t q_end) {
+// frag_f16: msg_frag / w_a_split are the fp16 images; hub_deterministic: hubs without atomics (hgt_hub_workspace_bytes_ex(.., 1))
+extern "C" int hgt_edge_aggregate_update_range(HGT_AGGUPD_PARAMS, int64_t q_begin, int64_t q_end, int32_t frag_f16,
+                                               int32_t hub_deterministic) {
     if (q_end < 0) return HGT_ERR_INVALID_ARG;
-    return edge_aggregate_update_impl(false, HGT_AGGUPD_PASS, q_begin, q_end);
+    return edge_aggregate_update_impl(frag_f16 != 0, HGT_AGGUPD_PASS, q_begin, q_end, hub_deterministic != 0);
 }
 
 // out[i][ld_out] = sum_rel ( sum_{e in (i,rel)} w_e rows[src_e] ) F[rel]  -- the aggregation kernel without the softmax: the edge

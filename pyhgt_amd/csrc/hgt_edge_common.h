@@ -10,7 +10,10 @@ struct HgtHubBuffers {
     float* l;     // [max_hubs][HT]
     float* acc;   // [max_hubs][HT * DKP]
     int64_t q_lo, q_hi;   // only hubs in [q_lo, q_hi) are processed (a target block of the multi-GPU path); q_hi <= 0: all
+    float* part;  // deterministic mode (HGT_FLAG_DETERMINISTIC_HUBS): [max_hubs][(R+1) * pieces][HT * DKP] partial rows, one slot per
+    float* lpart; // piece, and [max_hubs][(R+1) * pieces][HT] partial exp-sums -- summed by k_hub_finalize in piece order; NULL: atomics
 };
+constexpr int HGT_HUB_PIECES = 32;   // pieces per (hub, relation) range (hgt_edge_hub.hip)
 
 // arguments of the fused node update (hgt_fused_update.h)
 // A slice [lo, hi) of the plan's R + 1 relation buckets, and the softmax state carried from slice to slice (multi-GPU path:

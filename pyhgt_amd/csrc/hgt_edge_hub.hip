@@ -14,7 +14,7 @@ namespace {
 // All three exit immediately when the plan found no hub (hdr->n_hubs == 0).
 // ---------------------------------------------------------------------------------------------
 #ifndef HGT_HUB_CHUNKS
-#define HGT_HUB_CHUNKS 32      // pieces per (hub, relation) range: 64 -> 8.8 ms, 32 -> 8.4 ms, 16 -> 8.7 ms at c2 with Zipf(0.8) targets (the longest pieces of
+#define HGT_HUB_CHUNKS HGT_HUB_PIECES      // pieces per (hub, relation) range: 64 -> 8.8 ms, 32 -> 8.4 ms, 16 -> 8.7 ms at c2 with Zipf(0.8) targets (the longest pieces of
                                // the largest hub against the per-piece fixed cost)
 #endif
 constexpr int HUB_CHUNKS = HGT_HUB_CHUNKS;
@@ -22,6 +22,18 @@ constexpr int HUB_GRID_WAVES = 8192;
 
 __device__ __forceinline__ int f2ord(float f) { const int b = __builtin_bit_cast(int, f); return b ^ ((b >> 31) & 0x7fffffff); }
 __device__ __forceinline__ float ord2f(int o) { return __builtin_bit_cast(float, o ^ ((o >> 31) & 0x7fffffff)); }
+// deterministic mode: the partial slots of pieces without an edge are never written, so they start at zero
+__global__ void k_hub_init_parts(const HgtPlanHeader* __restrict__ hdr, HgtHubBuffers hb, int HT, int dfull, int R) {
+    const int64_t per_hub = (int64_t)(R + 1) * HUB_CHUNKS * (dfull + HT);
+    const int64_t total = (int64_t)hdr->n_hubs * per_hub;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t slot = i / per_hub, r = i % per_hub;
+        const int64_t n_acc = (int64_t)(R + 1) * HUB_CHUNKS * dfull;
+        if (r < n_acc) hb.part[slot * n_acc + r] = 0.0f;
+        else hb.lpart[slot * (int64_t)(R + 1) * HUB_CHUNKS * HT + (r - n_acc)] = 0.0f;
+    }
+}
+
 __global__ void k_hub_init(const HgtPlanHeader* __restrict__ hdr, HgtHubBuffers hb, int HT, int dfull) {
     const int n = hdr->n_hubs;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,9 +116,14 @@ __global__ __launch_bounds__(256) void k_hub_accumulate(
         // true max over ALL in-edges of the hub (k_hub_max folds a 0 in for a non-empty unclaimed bucket), like PyG's softmax
         const float mref = raw ? 0.0f : ord2f(hb.mx[slot * HT + hg * H + h]);   // raw: the array holds the weights (hgt_edge_spmm)
         float l_part = 0.0f;
+        // deterministic mode: this piece's own slot (summed by k_hub_finalize in piece order) instead of fp32 atomics
+        const int64_t pslot = w;      // (hub slot, relation bucket, piece) -> one slot per piece
         if (rel >= R) {                            // unclaimed: logit 0, no message
             l_part = (float)(pe - pb) * __expf(0.0f - mref);
-            if (p == 0) atomicAdd(&hb.l[slot * HT + hg * H + h], l_part);
+            if (p == 0) {
+                if (hb.part) hb.lpart[pslot * HT + hg * H + h] = l_part;
+                else atomicAdd(&hb.l[slot * HT + hg * H + h], l_part);
+            }
             continue;
         }
         const float* __restrict__ fglob = msgP + ((int64_t)(rel * HT + hg * H + h) * DKP) * DKP + p * VEC;
@@ -153,16 +170,23 @@ __global__ __launch_bounds__(256) void k_hub_accumulate(
         }
         float z[VEC];
         head_matvec<VEC, DKP, HOIST>(U, bounce, lane, h, frag, fglob, z);
-        float* o = hb.acc + (int64_t)slot * ld + co + lane * VEC;
+        if (hb.part) {
+            float* o = hb.part + pslot * ld + co + lane * VEC;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(o + i, z[i]);
-        if (p == 0) unsafeAtomicAdd(&hb.l[slot * HT + hg * H + h], l_part);
+            for (int i = 0; i < VEC; ++i) o[i] = z[i];
+            if (p == 0) hb.lpart[pslot * HT + hg * H + h] = l_part;
+        } else {
+            float* o = hb.acc + (int64_t)slot * ld + co + lane * VEC;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(o + i, z[i]);
+            if (p == 0) unsafeAtomicAdd(&hb.l[slot * HT + hg * H + h], l_part);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void k_hub_finalize(const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ hub_list,
                                                       HgtHubBuffers hb, float* __restrict__ agg, int HT, int dkp, int64_t NQ,
-                                                      int apply_gelu, int64_t ld_out) {
+                                                      int apply_gelu, int64_t ld_out, int R) {
     const int n_hubs = hdr->n_hubs;
     const int lane = threadIdx.x & 63;
     const int dfull = HT * dkp;
@@ -170,8 +194,19 @@ __global__ __launch_bounds__(256) void k_hub_finalize(const HgtPlanHeader* __res
         const int64_t row = hub_list[slot];
         if (row >= NQ || (hb.q_hi > 0 && (row < hb.q_lo || row >= hb.q_hi))) continue;
         for (int c = lane; c < dfull; c += 64) {
-            float v = hb.acc[(int64_t)slot * dfull + c];
-            if (apply_gelu != 2) v /= (hb.l[slot * HT + c / dkp] + 1e-16f);
+            float v, l;
+            if (hb.part) {      // deterministic mode: the pieces' partial rows and exp-sums in (relation, piece) order
+                const int np = (R + 1) * HUB_CHUNKS;
+                v = 0.0f; l = 0.0f;
+                for (int q = 0; q < np; ++q) {
+                    v += hb.part[((int64_t)slot * np + q) * dfull + c];
+                    l += hb.lpart[((int64_t)slot * np + q) * HT + c / dkp];
+                }
+            } else {
+                v = hb.acc[(int64_t)slot * dfull + c];
+                l = hb.l[slot * HT + c / dkp];
+            }
+            if (apply_gelu != 2) v /= (l + 1e-16f);
             if (apply_gelu == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
             agg[row * ld_out + c] = v;
         }
@@ -186,6 +221,7 @@ struct LaunchHub {
         const int dkp = VEC * LPH;
         const int64_t cells = (int64_t)pv.L.max_hubs * (2 * HT + HT * dkp);
         k_hub_init<<<(unsigned)((cells + 255) / 256), 256, 0, stream>>>(pv.hdr, hb, HT, HT * dkp);
+        if (hb.part) k_hub_init_parts<<<2048, 256, 0, stream>>>(pv.hdr, hb, HT, HT * dkp, R);
         k_hub_max<<<HUB_GRID_WAVES / 4, 256, 0, stream>>>(pv.hdr, pv.hub_list, pv.segptr, logits, R, HT, hb);
         dim3 hgrid(HUB_GRID_WAVES / 4, ny);
         if (rteV)
@@ -194,7 +230,7 @@ struct LaunchHub {
         else
             k_hub_accumulate<VEC, LPH, false><<<hgrid, 256, 0, stream>>>(pv.hdr, pv.hub_list, pv.segptr, pv.esrc, pv.ertei, logits, V, rteV,
                                                                          msgP, R, HT, hb, raw);
-        k_hub_finalize<<<256, 256, 0, stream>>>(pv.hdr, pv.hub_list, hb, agg, HT, dkp, NQ, apply_gelu, ld_out);
+        k_hub_finalize<<<256, 256, 0, stream>>>(pv.hdr, pv.hub_list, hb, agg, HT, dkp, NQ, apply_gelu, ld_out, R);
         return HGT_OK;
     }
 };

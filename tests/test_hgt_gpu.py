@@ -1210,6 +1210,8 @@ def test_target_blocked_schedule_with_real_halos(compress, use_rte, tmp_path):
     sd = O.make_state_dict(d, d, T, R, H, True, use_rte, seed=92)
     ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm if use_rte else None, dtype=torch.float64, use_RTE=use_rte)
     layer = _layer_from(sd, d, T, R, H, True, use_rte, keep_att=False, precision="bf16x3")
+    det = _lib.HGT_FLAG_DETERMINISTIC_HUBS      # (the default hub path adds fp32 partials atomically: not bit-reproducible)
+    layer.kernel_flags = det
     xg = x.to(DEV)
     for rank in range(world):
         lo, hi = offsets[rank], offsets[rank + 1]
@@ -1226,9 +1228,11 @@ def test_target_blocked_schedule_with_real_halos(compress, use_rte, tmp_path):
         with torch.no_grad():
             out = pg.forward(layer, xg[lo:hi].contiguous())
             pg.mode = "pipelined"
-            layer.kernel_flags = _lib.HGT_FLAG_FUSED_ANY_SIZE      # the same fused aggregation + update kernel, over the whole range
+            layer.kernel_flags = det | _lib.HGT_FLAG_FUSED_ANY_SIZE      # the same fused aggregation + update kernel, over the whole range
+            pg.workspace = None                                          # (sized per forward: flags changed)
             out_p = pg.forward(layer, xg[lo:hi].contiguous())
-            layer.kernel_flags = 0
+            layer.kernel_flags = det
+            pg.workspace = None
         assert out.shape == (hi - lo, d) and torch.isfinite(out).all()
         assert (out.cpu().double() - ref[lo:hi]).abs().max().item() < TOL
         assert torch.equal(out, out_p)
@@ -1250,6 +1254,7 @@ def test_target_blocks_are_bit_identical_to_the_one_call_layer(use_rte, zipf):
     et[::11] = R + 2
     nt[::17] = T
     layer = _layer_from(sd, d, T, R, H, True, use_rte, keep_att=False, precision="bf16x3")
+    layer.kernel_flags = _lib.HGT_FLAG_DETERMINISTIC_HUBS      # hub rows without atomics: bit-reproducible (the default path is not)
     xd, ntd, eid, etd, tmd = _to_dev(x, nt, ei, et, tm)
     GraphPlan.clear_cache()
     plan = GraphPlan(ntd, eid, etd, tmd if use_rte else None, T, R, n_q_rows=NQ)
@@ -1315,30 +1320,33 @@ def test_typed_linear_reads_the_24_bit_wire_format(precision):
     lin = lib.hgt_typed_linear_f16x3 if precision == "f16x3" else lib.hgt_typed_linear_bf16x3
     assert split(W.data_ptr(), n_out * k, G, k, n_out, wsplit.data_ptr(), st) == 0
     outs = []
+    rows0 = (rows - base).contiguous()                              # the same rows addressed from the start of the fp32 buffer
     for mode in (0, 2):
-        o0 = torch.zeros(base + n, 256, device=DEV)
-        o1 = torch.zeros(base + n, 256, device=DEV)
-        if mode == 0:      # plain fp32 rows, addressed by the same local ids
-            xin, ldx = xu.data_ptr() - base * k * 4, k
-        else:
-            xin, ldx = wire.data_ptr() - base * (3 * k // 4) * 4, 3 * k // 4
-        assert lin(xin, ldx, rows.data_ptr(), off.data_ptr(), G, 900, k, n_out, wsplit.data_ptr(), bias.data_ptr(), n_out,
-                   o0.data_ptr(), o1.data_ptr(), None, 256, 0, mode, st) == 0
-        outs.append((o0, o1))
+        if mode == 0:      # plain fp32 rows (unpacked first): ids relative to the buffer
+            o0, o1 = torch.zeros(n, 256, device=DEV), torch.zeros(n, 256, device=DEV)
+            assert lin(xu.data_ptr(), k, rows0.data_ptr(), off.data_ptr(), G, 900, k, n_out, wsplit.data_ptr(), bias.data_ptr(), n_out,
+                       o0.data_ptr(), o1.data_ptr(), None, 256, 0, 0, st) == 0
+            outs.append((o0, o1))
+        else:              # 24-bit wire rows, addressed by LOCAL row id through a base pointer shifted back by `base` rows (stage 2)
+            o0, o1 = torch.zeros(base + n, 256, device=DEV), torch.zeros(base + n, 256, device=DEV)
+            assert lin(wire.data_ptr() - base * (3 * k // 4) * 4, 3 * k // 4, rows.data_ptr(), off.data_ptr(), G, 900, k, n_out,
+                       wsplit.data_ptr(), bias.data_ptr(), n_out, o0.data_ptr(), o1.data_ptr(), None, 256, 0, 2, st) == 0
+            assert float(o0[:base].abs().max()) == 0.0 and float(o1[:base].abs().max()) == 0.0
+            outs.append((o0[base:], o1[base:]))
     torch.cuda.synchronize()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    refK = torch.zeros(base + n, n_out, dtype=torch.float64)
+    refK = torch.zeros(n, n_out, dtype=torch.float64)
     offl = off.tolist()
     for gi in range(G):
-        r = rows[offl[gi]:offl[gi + 1]].long().cpu()
-        refK[r] = xu.cpu().double()[r - base] @ W[gi].cpu().double().T + bias[gi].cpu().double()
+        r = rows0[offl[gi]:offl[gi + 1]].long().cpu()
+        refK[r] = xu.cpu().double()[r] @ W[gi].cpu().double().T + bias[gi].cpu().double()
     got = torch.cat([outs[1][0], outs[1][1]], 1).cpu().double()
     scale = (xu.cpu().double().abs() @ W.abs().amax(0).cpu().double().T).max().item()
     assert (got - refK).abs().max().item() <= (1e-6 if precision == "f16x3" else 3e-5) * scale
     # prologue values beyond 2 are rejected; a K the persistent kernel does not cover is "unsupported" (the caller unpacks first)
-    assert lin(wire.data_ptr(), 3 * k // 4, rows.data_ptr(), off.data_ptr(), G, 900, k, n_out, wsplit.data_ptr(), bias.data_ptr(), n_out,
+    assert lin(wire.data_ptr(), 3 * k // 4, rows0.data_ptr(), off.data_ptr(), G, 900, k, n_out, wsplit.data_ptr(), bias.data_ptr(), n_out,
                outs[0][0].data_ptr(), outs[0][1].data_ptr(), None, 256, 0, 3, st) == -1
-    assert lin(wire.data_ptr(), 3 * 512 // 4, rows.data_ptr(), off.data_ptr(), G, 900, 512, n_out, wsplit.data_ptr(), bias.data_ptr(), n_out,
+    assert lin(wire.data_ptr(), 3 * 512 // 4, rows0.data_ptr(), off.data_ptr(), G, 900, 512, n_out, wsplit.data_ptr(), bias.data_ptr(), n_out,
                outs[0][0].data_ptr(), outs[0][1].data_ptr(), None, 256, 0, 2, st) == -2
 
 
@@ -1643,3 +1651,37 @@ def test_prepared_images_survive_a_change_of_kernel_flags():
                 with torch.no_grad():
                     out = layer(*args)
                 assert (out.cpu().double() - ref).abs().max().item() < TOL, (precision, order, fl)
+
+
+@pytest.mark.parametrize("precision,flags", [("bf16x3", 0), ("f16x3", 0), ("bf16x3", _lib.HGT_FLAG_NO_FUSED_UPDATE), ("fp32", 0)])
+def test_deterministic_hub_mode_is_bit_reproducible(precision, flags):
+    """HGT_FLAG_DETERMINISTIC_HUBS (ABI 6): hub targets (> 1024 in-edges) are aggregated without atomics -- one partial slot per piece,
+    summed in a fixed order -- so repeated forwards are bit-identical on EVERY row, hubs included (the reference's scatter-add,
+    conv.py:13, gives no such guarantee on a GPU; the default hub path here does not either).  Fused and unfused aggregation, the
+    matrix-core and the exact vector-ALU kernels; result against the oracle like every other path."""
+    T, R, H, d, N, E = 3, 4, 8, 256, 70_000, 700_000
+    sd = O.make_state_dict(d, d, T, R, H, True, True, seed=61)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=62, sorted_types=False)
+    ei, et = ei.clone(), et.clone()
+    ei[1, :6000] = 11                      # hubs of very different size, in different workgroups
+    ei[1, 6000:7500] = 40_000
+    ei[1, 7500:9000] = 40_001
+    et[::9] = R + 1                        # unclaimed edges (also inside the hubs)
+    layer = _layer_from(sd, d, T, R, H, True, True, keep_att=False, precision=precision)
+    layer.kernel_flags = flags | _lib.HGT_FLAG_DETERMINISTIC_HUBS | _lib.HGT_FLAG_NO_ITEM_AGGREGATE
+    args = _to_dev(x, nt, ei, et, tm)
+    GraphPlan.clear_cache()
+    with torch.no_grad():
+        outs = [layer(*args).clone() for _ in range(4)]
+        layer.kernel_flags = flags | _lib.HGT_FLAG_NO_ITEM_AGGREGATE
+        atomics = layer(*args).clone()
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm)
+    assert (outs[0].cpu().double() - ref).abs().max().item() < TOL
+    assert (atomics - outs[0]).abs().max().item() < 1e-5       # same sums, another order
+    hubs = torch.tensor([11, 40_000, 40_001], device=DEV)
+    others = torch.ones(N, dtype=torch.bool, device=DEV)
+    others[hubs] = False
+    assert torch.equal(atomics[others], outs[0][others])       # every non-hub row is deterministic in both modes

@@ -31,8 +31,11 @@ PY
 }
 case $MODE in
 quick)
-    timeout 1500 python -m pytest tests -m gpu -q -k "target_block or 24_bit or partitioned or real_halos or bucketed or staged or prepared or strict or in_place or reference_call or two_rank or f16_split_rows or golden" 2>&1 | tail -60 > gpurun_out/pytest_quick.log
-    grep -E "^FAILED|^ERROR|passed|failed" gpurun_out/pytest_quick.log | tail -30
+    # (separate processes: a faulting kernel poisons every later test of its process)
+    grp() { timeout 900 python -m pytest tests -m gpu -q -k "$2" > gpurun_out/pytest_$1.log 2>&1; grep -E "^FAILED|^ERROR| passed| failed" gpurun_out/pytest_$1.log | tail -12; grep -E "^E  " gpurun_out/pytest_$1.log | head -12; }
+    grp A "target_block or real_halos or 24_bit or two_rank"
+    grp B "bucketed or staged or prepared or strict or in_place or reference_call or deterministic or f16_split_rows or partitioned_graph_on_gpu"
+    grp C "matches_oracle or fused_aggregate or golden"
     for n in 768 512; do python tools/bench_linear.py --which bf16x3 --n-out $n --c24 2>&1 | grep -v "^ *trace"; done > gpurun_out/linear_$TAG.log 2>&1
     cat gpurun_out/linear_$TAG.log
     for loc in 0 0.5 0.75 0.9; do
