@@ -69,7 +69,7 @@ def main():
             tmd = tm.cuda() if use_rte else None
             cuts = sorted(set([nq, N] + [rng.randint(nq, N) for _ in range(rng.randint(0, 2))]))
             with torch.no_grad():
-                ws = torch.empty(layer.workspace_bytes(N, ei.size(1)), dtype=torch.uint8, device="cuda:0")
+                ws = torch.empty(layer.workspace_bytes(N, ei.size(1), staged=False), dtype=torch.uint8, device="cuda:0")   # incl. the item-aggregation scratch: the same kernels as the one-call layer
                 layer(xd, ntd, eid, etd, tmd, n_q_rows=nq, stage=1, workspace=ws)
                 for a, b in zip(cuts[:-1], cuts[1:]):
                     tt = ntd[a:b]
