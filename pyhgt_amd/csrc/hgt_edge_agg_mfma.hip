@@ -939,7 +939,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
         hub_mask = (unsigned)(__builtin_amdgcn_ballot_w64(is_hub) & 0xFFFFull);
     }
     const bool any_hub = hub_slot ? (__syncthreads_or(hub_mask != 0) != 0) : false;
-    if (threadIdx.x == 0) pending[blockIdx.x] = any_hub ? 1 : 0;
+    if (threadIdx.x == 0) pending[fu.q_lo / 64 + blockIdx.x] = any_hub ? 1 : 0;      // (absolute workgroup index: target blocks may run concurrently)
 
     unsigned char* utile = smem + wib * 2 * G::PLANE;
     float* s_m = s_ml + wib * 512;

@@ -23,23 +23,32 @@ constexpr int HUB_GRID_WAVES = 8192;
 __device__ __forceinline__ int f2ord(float f) { const int b = __builtin_bit_cast(int, f); return b ^ ((b >> 31) & 0x7fffffff); }
 __device__ __forceinline__ float ord2f(int o) { return __builtin_bit_cast(float, o ^ ((o >> 31) & 0x7fffffff)); }
 // deterministic mode: the partial slots of pieces without an edge are never written, so they start at zero
-__global__ void k_hub_init_parts(const HgtPlanHeader* __restrict__ hdr, HgtHubBuffers hb, int HT, int dfull, int R) {
+__global__ void k_hub_init_parts(const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ hub_list, HgtHubBuffers hb, int HT,
+                                 int dfull, int R) {
     const int64_t per_hub = (int64_t)(R + 1) * HUB_CHUNKS * (dfull + HT);
     const int64_t total = (int64_t)hdr->n_hubs * per_hub;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t slot = i / per_hub, r = i % per_hub;
+        if (hb.q_hi > 0) {
+            const int64_t dst = hub_list[slot];
+            if (dst < hb.q_lo || dst >= hb.q_hi) continue;
+        }
         const int64_t n_acc = (int64_t)(R + 1) * HUB_CHUNKS * dfull;
         if (r < n_acc) hb.part[slot * n_acc + r] = 0.0f;
         else hb.lpart[slot * (int64_t)(R + 1) * HUB_CHUNKS * HT + (r - n_acc)] = 0.0f;
     }
 }
 
-__global__ void k_hub_init(const HgtPlanHeader* __restrict__ hdr, HgtHubBuffers hb, int HT, int dfull) {
+__global__ void k_hub_init(const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ hub_list, HgtHubBuffers hb, int HT, int dfull) {
     const int n = hdr->n_hubs;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t per = 2 * HT + dfull;
     if (i >= (int64_t)n * per) return;
     const int slot = (int)(i / per), r = (int)(i % per);
+    if (hb.q_hi > 0) {      // a target block: only ITS hubs (another block may be accumulating into the other slots right now)
+        const int64_t dst = hub_list[slot];
+        if (dst < hb.q_lo || dst >= hb.q_hi) return;
+    }
     if (r < HT) hb.mx[slot * HT + r] = f2ord(-1.0e30f);
     else if (r < 2 * HT) hb.l[slot * HT + r - HT] = 0.0f;
     else hb.acc[(int64_t)slot * dfull + r - 2 * HT] = 0.0f;
@@ -220,8 +229,8 @@ struct LaunchHub {
         const int raw = (apply_gelu == 2);
         const int dkp = VEC * LPH;
         const int64_t cells = (int64_t)pv.L.max_hubs * (2 * HT + HT * dkp);
-        k_hub_init<<<(unsigned)((cells + 255) / 256), 256, 0, stream>>>(pv.hdr, hb, HT, HT * dkp);
-        if (hb.part) k_hub_init_parts<<<2048, 256, 0, stream>>>(pv.hdr, hb, HT, HT * dkp, R);
+        k_hub_init<<<(unsigned)((cells + 255) / 256), 256, 0, stream>>>(pv.hdr, pv.hub_list, hb, HT, HT * dkp);
+        if (hb.part) k_hub_init_parts<<<2048, 256, 0, stream>>>(pv.hdr, pv.hub_list, hb, HT, HT * dkp, R);
         k_hub_max<<<HUB_GRID_WAVES / 4, 256, 0, stream>>>(pv.hdr, pv.hub_list, pv.segptr, logits, R, HT, hb);
         dim3 hgrid(HUB_GRID_WAVES / 4, ny);
         if (rteV)

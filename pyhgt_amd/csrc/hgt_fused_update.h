@@ -349,7 +349,7 @@ template <int VEC, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void k_update_pending(const float* __restrict__ agg, int64_t ld_agg, int64_t NQ,
                                                            const int32_t* __restrict__ pending, HgtFusedUpdate fu) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_PLANE + 4096];
-    if (pending[blockIdx.x] == 0) return;
+    if (pending[fu.q_lo / 64 + blockIdx.x] == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row0 = fu.q_lo + (int64_t)blockIdx.x * 64;
     float vals[16][VEC];

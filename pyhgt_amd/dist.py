@@ -396,7 +396,7 @@ class PartitionedGraph:
 
     def __init__(self, node_type_own, src_global, dst_local, edge_type, edge_time, num_types, num_relations,
                  nodes_per_rank, rank, world, group=None, node_offsets=None, n_chunks=None, halo=None, compress=False, bucketed=None,
-                 mode=None):
+                 mode=None, overlap_blocks=False):
         """mode: "blocked" (default) / "bucketed" / "pipelined"; bucketed=True/False is the round-2 spelling of the last two.
         n_chunks: halo chunks = target blocks of the blocked schedule (default 8), equal slices otherwise (default 4).
         halo: a prebuilt HaloPlan for this rank (tests build it on CPU over gloo and move it to the device with HaloPlan.to);
@@ -413,6 +413,14 @@ class PartitionedGraph:
         if n_chunks is None:
             n_chunks = 8 if mode == "blocked" else 4
         self.mode = mode
+        # overlap_blocks (experiment, OFF): the edge phases of consecutive target blocks on two side streams (block b on stream b % 2)
+        # while the main stream keeps projecting the next halo chunks.  Blocks are independent (disjoint targets, logits positions,
+        # pending entries, hub slots), and the 1/B-size launches have long grid tails (8 blocks: 6.5 ms of edge kernels against
+        # 5.6 ms for the one-call layer) -- but measured (round 4, emulated rank of 8): 23.5 ms per step instead of 15.9: the
+        # PERSISTENT projection kernel (one workgroup per CU, static tile partition) next to the edge kernels leaves half of its
+        # workgroups waiting for a CU while the rest finish early.  Kept for a projection kernel that can share a CU.
+        self.overlap_blocks = bool(overlap_blocks)
+        self._side = None
         self.block_bounds = None
         edge_block = None
         if mode == "blocked":
@@ -510,6 +518,10 @@ class PartitionedGraph:
             layer(*args, stage=1, phase_events=phase_events, **kw)                         # Q|K|V of the own rows
             self._mark("own_qkv")
             out = torch.empty(self.n_own, layer.out_dim, dtype=torch.float32, device=x_own.device)
+            overlap = self.overlap_blocks and C > 1 and x_own.is_cuda
+            main = cur()
+            if overlap and self._side is None:
+                self._side = [torch.cuda.Stream(device=x_own.device), torch.cuda.Stream(device=x_own.device)]
             for b in range(C):
                 work, bufs = pending[b]
                 work.wait()
@@ -521,8 +533,18 @@ class PartitionedGraph:
                     c24 = (bufs[1], self.n_own + self.halo.recv_chunk_off[b]) if direct else None
                     layer(*args, stage=2, proj=(rows, off), proj_c24=c24, **kw)            # K|V of the halo rows of chunk b
                 self._mark("halo_kv")
-                layer(*args, stage=5, block=self.blocks[b], out=out, phase_events=phase_events if b == C - 1 else None, **kw)
-                self._mark("edge_blocks")
+                if overlap:      # block b on a side stream, behind everything the main stream has enqueued so far (K|V of chunks <= b)
+                    side = self._side[b % 2]
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        layer(*args, stage=5, block=self.blocks[b], out=out, **kw)
+                else:
+                    layer(*args, stage=5, block=self.blocks[b], out=out, phase_events=phase_events if b == C - 1 else None, **kw)
+                    self._mark("edge_blocks")
+            if overlap:
+                main.wait_stream(self._side[0])
+                main.wait_stream(self._side[1])
+                self._mark("edge_blocks")     # (with overlap: what the edge phases add BEHIND the last projection)
             layer._prepared_valid = True      # (stage 5 is not a "final" call of HGTConv.forward: the images were all written)
             return out
         if bucketed:
