@@ -517,7 +517,7 @@ __device__ __forceinline__ void agg_mfma_stream(
                 if constexpr (F16) {
                     const int dls = __builtin_amdgcn_readfirstlane(dl);
                     unsigned sb = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, sigv), dls);
-                    if (sb == 0u) {      // the target's first row: its maximum decides sigma_t (an all-zero row decides nothing)
+                    if (__builtin_expect(sb == 0u, 0)) {      // the target's first row: its maximum decides sigma_t (an all-zero row decides nothing)
                         float m = fabsf(U[0]);
 #pragma unroll
                         for (int i = 1; i < VEC; ++i) m = fmaxf(m, fabsf(U[i]));
