@@ -260,6 +260,16 @@ int hgt_edge_aggregate_items(const void* plan, int64_t n_nodes, int64_t n_edges,
                              int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
                              const void* msg_frag, int32_t frag_f16, float* agg, int64_t n_q_rows, int32_t apply_gelu,
                              void* scratch, uint64_t scratch_bytes, void* stream);
+/* ABI 6: logits AND the item-parallel aggregation in one walk over the edges (sampled sub-graphs): per group of <= 16 runs the
+ * target-side transform q~ = q A'[r] on the matrix cores (att_frag = hgt_relation_frag_pack[_f16](att_t)), then per edge K and V
+ * gathered together, the logit, the run's online softmax and the weighted sum, then the message transform (msg_frag) -- no [E][H]
+ * logits array, one launch less per layer.  Same scratch, same fixed-order merge and (up to the fp32 summation order of the
+ * logits) the same result as hgt_edge_logits_mfma + hgt_edge_aggregate_items.  rte_k / rte_v: both tables or both NULL.
+ * HGT_ERR_UNSUPPORTED for layouts it is not instantiated for (the caller takes the two-kernel form). */
+int hgt_edge_single_pass_items(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                               int32_t n_heads, int32_t dk_pad, const float* Q, const float* K, const float* V, const float* rte_k,
+                               const float* rte_v, const void* att_frag, const void* msg_frag, int32_t frag_f16, float* agg,
+                               int64_t n_q_rows, int32_t apply_gelu, void* scratch, uint64_t scratch_bytes, void* stream);
 /* ABI 4: one slice [rel_lo, rel_hi) of the plan's n_relations + 1 relation buckets (bucket n_relations = unclaimed edges).
  * hgt_edge_logits_slice writes the logits of the slice's edges only.  hgt_edge_aggregate_slice (matrix-core kernel: msg_frag
  * required) aggregates the slice and combines it with what earlier slices left: state = f32[n_q_rows][n_heads][2] (softmax
@@ -538,6 +548,9 @@ typedef struct hgt_conv_args {
 #define HGT_FLAG_ITEM_AGGREGATE 16   /* hgt_edge_aggregate_items wherever it applies (the default below 65536 nodes when its scratch is at most 1 GB) */
 #define HGT_FLAG_NO_ITEM_AGGREGATE 32 /* never hgt_edge_aggregate_items */
 #define HGT_FLAG_FUSED_ANY_SIZE 64   /* hgt_edge_aggregate_update below its default size too (>= 16384 targets) */
+#define HGT_FLAG_SINGLE_PASS 256     /* ABI 6: hgt_edge_single_pass_items instead of logits + item-parallel aggregation where it applies (sampled
+                                      * sub-graphs, attention weights not exported).  Off by default: measured equal at c3 and 5 % slower at c5
+                                      * (its two LDS tiles cap it at 4 wavefronts per CU) */
 #define HGT_FLAG_DETERMINISTIC_HUBS 128 /* ABI 6: targets with more than 1024 in-edges ("hubs") are aggregated WITHOUT atomics: every piece of a
                                       * (hub, relation) range writes its partial row / exp-sum to its own slot and the finalize kernel sums
                                       * the slots in (relation, piece) order, so two forwards are bit-identical on every row (the default

@@ -20,6 +20,7 @@ HGT_FLAG_ITEM_AGGREGATE = 16
 HGT_FLAG_NO_ITEM_AGGREGATE = 32
 HGT_FLAG_FUSED_ANY_SIZE = 64
 HGT_FLAG_DETERMINISTIC_HUBS = 128
+HGT_FLAG_SINGLE_PASS = 256
 
 
 class HgtLayout(C.Structure):
@@ -111,6 +112,8 @@ SIGNATURES = {
     "hgt_relation_frag_pack_f16": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "hgt_edge_aggregate_items_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_u64)]),
     "hgt_edge_aggregate_items": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _u64, _vp]),
+    "hgt_edge_single_pass_items": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32,
+                                             _vp, _u64, _vp]),
     "hgt_plan_header_to_host": (C.c_int, [_vp, _vp, _vp]),
     "hgt_relation_frag_bytes": (C.c_int, [_i32, _i32, _i32, C.POINTER(_u64)]),
     "hgt_relation_frag_pack": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),

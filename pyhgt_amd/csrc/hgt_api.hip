@@ -413,8 +413,28 @@ edge_phase:
         mark(6);
         return rc;
     }
+    // (5') which aggregation form runs is decided BEFORE the logits: the single-pass form of the latency regime computes them itself
+    // (graphs below HGT_FUSED_MIN_NODES targets take the unfused kernels: the latency regime, see items_agg)
+    const bool fuse_all = split && !dense && dp <= 256 && dout <= dp && (dout & 3) == 0 && (din & 3) == 0 &&
+                          (NQ >= HGT_FUSED_MIN_NODES || (a->flags & HGT_FLAG_FUSED_ANY_SIZE)) &&
+                          !(a->flags & HGT_FLAG_NO_FUSED_UPDATE) && !sliced &&
+                          !(f16 && !mfma_agg);   // the vector-ALU kernel's fused epilogue only reads the bf16 image of W_a
+    // latency regime: the item-parallel form (hgt_edge_agg_items.hip), where a sub-tile wavefront's chain of edge batches and
+    // relation ends is the kernel time (c3: 80 -> 66 us per layer, c5: 195 -> 147 us); flags force / forbid it
+    const bool items_agg = mfma_agg && !sliced && w.zitems_bytes > 0 && NQ < HGT_ITEM_AGG_MAX_NODES && R < 64 &&
+                           !(a->flags & HGT_FLAG_NO_ITEM_AGGREGATE) &&
+                           (NQ < HGT_ITEM_AGG_DEFAULT_NODES || (a->flags & HGT_FLAG_ITEM_AGGREGATE));
+    // ... and, on request (HGT_FLAG_SINGLE_PASS) and when nobody asks for the attention weights, logits + runs in ONE walk
+    // (hgt_edge_single_pass.hip): one kernel and the [E][H] logits array less; not the default -- measured equal at c3, 5 % slower at c5
+    bool agg_done = false;
+    if (items_agg && !fuse_all && !a->want_att && have_frags && E > 0 && (a->flags & HGT_FLAG_SINGLE_PASS)) {
+        rc = hgt_edge_single_pass_items(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, V, rte_k, rte_v, att_f_buf, msg_f, f16 ? 1 : 0, agg, NQ,
+                                        dense ? 0 : 1, wb + w.off_zitems, w.zitems_bytes, stream);
+        if (rc == HGT_OK) agg_done = true;
+        else if (rc != HGT_ERR_UNSUPPORTED) return rc;      // (a layout it is not instantiated for: the two-kernel form below)
+    }
     // (4) edge phase: logits, then softmax fused into the aggregation (online, per target sub-tile)
-    if (E > 0) {
+    if (E > 0 && !agg_done) {
         rc = sliced ? hgt_edge_logits_slice(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, sl_lo, sl_hi, stream)
              : mfma_logits ? hgt_edge_logits_mfma(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, att_f, f16 ? 1 : 0, logits, stream)
                            : hgt_edge_logits(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, stream);
@@ -423,11 +443,6 @@ edge_phase:
     mark(2);
     mark(3);
     // (5) aggregation + update.  Preferred form: one kernel that never writes agg (hgt_edge_aggregate_update).
-    // (graphs below HGT_FUSED_MIN_NODES targets take the unfused kernels: the latency regime, see items_agg below)
-    const bool fuse_all = split && !dense && dp <= 256 && dout <= dp && (dout & 3) == 0 && (din & 3) == 0 &&
-                          (NQ >= HGT_FUSED_MIN_NODES || (a->flags & HGT_FLAG_FUSED_ANY_SIZE)) &&
-                          !(a->flags & HGT_FLAG_NO_FUSED_UPDATE) && !sliced &&
-                          !(f16 && !mfma_agg);   // the vector-ALU kernel's fused epilogue only reads the bf16 image of W_a
     if (fuse_all) {
         if (fresh || !pb) {
             rc = split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
@@ -460,11 +475,8 @@ edge_phase:
     // runs for E == 0 too: it writes the zero rows of isolated targets; HGTConv stores gelu(agg) (conv.py:119), DenseHGTConv agg
     // latency regime: the item-parallel form (hgt_edge_agg_items.hip), where a sub-tile wavefront's chain of edge batches and
     // relation ends is the kernel time (c3: 80 -> 66 us per layer, c5: 195 -> 147 us); flags force / forbid it
-    const bool items_agg = mfma_agg && !sliced && w.zitems_bytes > 0 && NQ < HGT_ITEM_AGG_MAX_NODES && R < 64 &&
-                           !(a->flags & HGT_FLAG_NO_ITEM_AGGREGATE) &&
-                           (NQ < HGT_ITEM_AGG_DEFAULT_NODES || (a->flags & HGT_FLAG_ITEM_AGGREGATE));
-    rc = HGT_ERR_UNSUPPORTED;
-    if (items_agg)
+    rc = agg_done ? HGT_OK : HGT_ERR_UNSUPPORTED;
+    if (items_agg && !agg_done)
         rc = hgt_edge_aggregate_items(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_f, f16 ? 1 : 0, agg, NQ, dense ? 0 : 1,
                                       wb + w.off_zitems, w.zitems_bytes, stream);
     if (rc != HGT_ERR_UNSUPPORTED) {

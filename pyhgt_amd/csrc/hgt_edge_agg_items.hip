@@ -363,12 +363,26 @@ extern "C" int hgt_edge_aggregate_items_bytes(int64_t n_edges, int32_t n_heads, 
     return HGT_OK;
 }
 
-extern "C" int hgt_edge_aggregate_items(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
-                                        const float* logits, const float* V, const float* rte_v, const void* msg_frag, int32_t frag_f16,
-                                        float* agg, int64_t n_q_rows, int32_t apply_gelu, void* scratch, uint64_t scratch_bytes,
-                                        void* stream_) {
-    if (!plan || !V || !msg_frag || !agg || (E > 0 && (!logits || !scratch)) || H <= 0 || 64 % H != 0 || dk_pad <= 0)
+// hgt_edge_single_pass.hip
+int hgt_launch_single_pass_runs(int vec, int lph, bool f16, const HgtPlanView& pv, const float* Q, const float* K, const float* V,
+                                const float* rteK, const float* rteV, const unsigned short* attF, const unsigned short* msgF, float* zrows,
+                                float* zstat, unsigned char* zflag, int R, int HT, hipStream_t stream);
+
+// sp != nullptr: the single-pass form (logits computed inside the runs kernel from Q, K and the attention fragments)
+struct SinglePassArgs {
+    const float* Q;
+    const float* K;
+    const float* rte_k;
+    const void* att_frag;
+};
+
+static int aggregate_items_impl(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                const float* logits, const float* V, const float* rte_v, const void* msg_frag, int32_t frag_f16,
+                                float* agg, int64_t n_q_rows, int32_t apply_gelu, void* scratch, uint64_t scratch_bytes,
+                                void* stream_, const SinglePassArgs* spa) {
+    if (!plan || !V || !msg_frag || !agg || (E > 0 && ((!spa && !logits) || !scratch)) || H <= 0 || 64 % H != 0 || dk_pad <= 0)
         return HGT_ERR_INVALID_ARG;
+    if (spa && (!spa->Q || !spa->K || !spa->att_frag || ((spa->rte_k == nullptr) != (rte_v == nullptr)))) return HGT_ERR_INVALID_ARG;
     if (apply_gelu != 0 && apply_gelu != 1) return HGT_ERR_INVALID_ARG;
     const int64_t NQ = (n_q_rows > 0 && n_q_rows <= N) ? n_q_rows : N;
     if (NQ == 0) return HGT_OK;
@@ -389,7 +403,11 @@ extern "C" int hgt_edge_aggregate_items(const void* plan, int64_t N, int64_t E, 
     while (vec_full / sp > 4 && lph * sp * 2 <= 64) sp *= 2;
     if (vec_full / sp > 4) return HGT_ERR_UNSUPPORTED;
     const int vec = vec_full / sp, lphs = lph * sp;
-    if (E > 0) {
+    if (E > 0 && spa) {
+        int rc = hgt_launch_single_pass_runs(vec, lphs, frag_f16 != 0, pv, spa->Q, spa->K, V, spa->rte_k, rte_v, (const unsigned short*)spa->att_frag,
+                                             (const unsigned short*)msg_frag, zrows, zstat, zflag, (int)R, (int)H, stream);
+        if (rc != HGT_OK) return rc;
+    } else if (E > 0) {
         int rc = HGT_ERR_UNSUPPORTED;
 #define AGI_CASE(V_, L_) \
         if (vec == V_ && lphs == L_) rc = launch_runs<V_, L_>(frag_f16 != 0, pv, logits, V, rte_v, (const unsigned short*)msg_frag, zrows, zstat, zflag, (int)R, (int)H, stream);
@@ -410,4 +428,25 @@ extern "C" int hgt_edge_aggregate_items(const void* plan, int64_t N, int64_t E, 
 #undef AGI_MERGE
     HGT_CHECK_LAUNCH();
     return HGT_OK;
+}
+
+extern "C" int hgt_edge_aggregate_items(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                        const float* logits, const float* V, const float* rte_v, const void* msg_frag, int32_t frag_f16,
+                                        float* agg, int64_t n_q_rows, int32_t apply_gelu, void* scratch, uint64_t scratch_bytes,
+                                        void* stream_) {
+    return aggregate_items_impl(plan, N, E, T, R, H, dk_pad, logits, V, rte_v, msg_frag, frag_f16, agg, n_q_rows, apply_gelu, scratch,
+                                scratch_bytes, stream_, nullptr);
+}
+
+// ABI 6: logits + item-parallel aggregation in ONE walk (hgt_edge_single_pass.hip) for sampled sub-graphs: no [E][H] logits array.
+// att_frag / msg_frag = hgt_relation_frag_pack[_f16] of att_t / msg_p; rte_k and rte_v both or neither; same scratch and the same
+// result (up to fp32 rounding of the logits' summation order) as hgt_edge_logits_mfma + hgt_edge_aggregate_items.
+// HGT_ERR_UNSUPPORTED for layouts the kernel is not instantiated for.
+extern "C" int hgt_edge_single_pass_items(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                          const float* Q, const float* K, const float* V, const float* rte_k, const float* rte_v,
+                                          const void* att_frag, const void* msg_frag, int32_t frag_f16, float* agg, int64_t n_q_rows,
+                                          int32_t apply_gelu, void* scratch, uint64_t scratch_bytes, void* stream_) {
+    const SinglePassArgs spa = {Q, K, rte_k, att_frag};
+    return aggregate_items_impl(plan, N, E, T, R, H, dk_pad, nullptr, V, rte_v, msg_frag, frag_f16, agg, n_q_rows, apply_gelu, scratch,
+                                scratch_bytes, stream_, &spa);
 }

@@ -182,6 +182,14 @@ def test_item_parallel_aggregation(case, precision):
     layer.kernel_flags = 32         # HGT_FLAG_NO_ITEM_AGGREGATE
     out2, _ = _run(layer, x, nt, ei, et, tm if use_RTE else None)
     assert (out2 - out).abs().max().item() < (1e-4 if precision == "bf16x3" else 1e-5)
+    # HGT_FLAG_SINGLE_PASS: logits inside the runs kernel (hgt_edge_single_pass.hip, where it is instantiated; the other layouts
+    # fall through to the two kernels): must agree with the two-kernel form to the split precision
+    layer.kernel_flags = 16 | _lib.HGT_FLAG_SINGLE_PASS
+    out3, _ = _run(layer, x, nt, ei, et, tm if use_RTE else None)
+    out3b, _ = _run(layer, x, nt, ei, et, tm if use_RTE else None)
+    assert torch.equal(out3, out3b)
+    assert (out3 - out).abs().max().item() < (2e-5 if precision == "bf16x3" else 2e-6)
+    assert (out3.double() - ref).abs().max().item() < PREC_TOL[precision]
 
 
 DENSE_CASES = [
