@@ -97,8 +97,39 @@ def partition(node_type, edge_index, edge_type, edge_time, world, rank, align=PL
                 edge_ids=mine)
 
 
-def target_blocks(dst_local, n_own, n_blocks, align=PLAN_TILE):
-    """Bounds (n_blocks + 1 offsets, multiples of `align` except the last) of contiguous target blocks with equal in-edge counts."""
+def partition_offsets_weighted(dst, n_nodes, weights, align=PLAN_TILE):
+    """partition_offsets with given relative in-edge shares per part (weights need not be normalised)."""
+    n_nodes, align = int(n_nodes), max(1, int(align))
+    parts = len(weights)
+    E = int(dst.numel())
+    if parts <= 1 or n_nodes == 0:
+        return [0] + [n_nodes] * max(parts, 1)
+    n_cand = (n_nodes + align - 1) // align + 1
+    deg_tile = torch.bincount(torch.div(dst, align, rounding_mode="floor"), minlength=n_cand - 1).to(torch.int64)
+    prefix = torch.zeros(n_cand, dtype=torch.int64, device=dst.device)
+    prefix[1:] = torch.cumsum(deg_tile, 0)
+    tot = float(sum(weights))
+    acc, tg = 0.0, []
+    for w in weights[:-1]:
+        acc += float(w)
+        tg.append(int(round(E * acc / tot)))
+    targets = torch.tensor(tg, dtype=torch.int64, device=dst.device)
+    hi = torch.searchsorted(prefix, targets).clamp(1, n_cand - 1)
+    lo = hi - 1
+    pick = torch.where((targets - prefix[lo]) <= (prefix[hi] - targets), lo, hi)
+    cuts = [0] + [min(int(c) * align, n_nodes) for c in pick.tolist()] + [n_nodes]
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts
+
+
+def target_blocks(dst_local, n_own, n_blocks, align=PLAN_TILE, shape="equal"):
+    """Bounds (n_blocks + 1 offsets, multiples of `align` except the last) of contiguous target blocks.  shape "equal": equal
+    in-edge counts (the smallest tail behind the exchange: 1 / n_blocks of the edge phase -- the choice when the links bound the
+    step); "geometric": shares 1, 1, 2, 4, ... (tiny first blocks start as soon as the first rows arrive, the large last ones run
+    at the one-call layer's efficiency -- the choice when the GPU side bounds the step; the tail is half the edge phase)."""
+    if shape == "geometric" and n_blocks > 1:
+        return partition_offsets_weighted(dst_local, n_own, [1.0] + [2.0 ** i for i in range(n_blocks - 1)], align)
     return partition_offsets(dst_local, n_own, n_blocks, align)
 
 
@@ -396,7 +427,7 @@ class PartitionedGraph:
 
     def __init__(self, node_type_own, src_global, dst_local, edge_type, edge_time, num_types, num_relations,
                  nodes_per_rank, rank, world, group=None, node_offsets=None, n_chunks=None, halo=None, compress=False, bucketed=None,
-                 mode=None, overlap_blocks=False):
+                 mode=None, overlap_blocks=False, block_shape="equal"):
         """mode: "blocked" (default) / "bucketed" / "pipelined"; bucketed=True/False is the round-2 spelling of the last two.
         n_chunks: halo chunks = target blocks of the blocked schedule (default 8), equal slices otherwise (default 4).
         halo: a prebuilt HaloPlan for this rank (tests build it on CPU over gloo and move it to the device with HaloPlan.to);
@@ -424,7 +455,7 @@ class PartitionedGraph:
         self.block_bounds = None
         edge_block = None
         if mode == "blocked":
-            self.block_bounds = target_blocks(dst_local, n_own, n_chunks)
+            self.block_bounds = target_blocks(dst_local, n_own, n_chunks, shape=block_shape)
             edge_block = torch.searchsorted(torch.tensor(self.block_bounds[1:], dtype=torch.int64, device=dst_local.device),
                                             dst_local, right=True).clamp(max=n_chunks - 1)
         if halo is not None:

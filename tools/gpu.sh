@@ -70,8 +70,17 @@ PY
 final)
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
     timeout 300 python examples/train_synthetic.py --steps 6 2>&1 | tail -3
+    python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/pytest_$TAG.log
+    grep -E "^FAILED|^ERROR| passed| failed" gpurun_out/pytest_$TAG.log | tail -10
     tools/profile_pmc.sh $TAG > gpurun_out/prof_$TAG.log 2>&1
     cp gpurun_out/prof_$TAG/${TAG}_pmc_summary.json profiles/${TAG}_pmc_summary.json      # the line below is judged against THIS build's counters
+    tools/profile_small.sh $TAG > gpurun_out/prof_small_$TAG.log 2>&1
+    tools/profile_train.sh $TAG > gpurun_out/prof_train_$TAG.log 2>&1
+    python tools/bench_train.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_training_step.json
+    for loc in 0 0.5 0.75 0.9; do
+        timeout 300 python bench.py --emulate-world 8 --locality $loc --steps 7 > gpurun_out/${TAG}_emu8_loc$loc.json 2> gpurun_out/${TAG}_emu8_loc$loc.err
+    done
+    summ gpurun_out/${TAG}_emu8_loc*.json
     ( time timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err ) 2>&1 | grep real
     summ gpurun_out/${TAG}_bench.json
     ;;
