@@ -640,6 +640,16 @@ def main():
         edge_time = torch.randint(0, 240, (El,), generator=g, device=dev) if use_rte else None
     else:
         share, _ = configs3_share(dev, world, rank, Nl, El, T, R, use_rte, args.locality, args.dst_skew)
+        # every rank generated the global graph itself (same seed, same device generator): make sure they all cut it the same way
+        # before anything is exchanged -- a mismatch would otherwise show up as a hang or a fault deep inside the first step
+        import torch.distributed as dist
+        sig = torch.tensor([float(sum(share["node_offsets"])), float(share["dst_local"].numel() if rank == 0 else 0)], device=dev,
+                           dtype=torch.float64)
+        lo_, hi_ = sig[:1].clone(), sig[:1].clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        if float(lo_.item()) != float(hi_.item()):
+            raise SystemExit("bench.py: the ranks derived different partitions of the global graph (device RNG not reproducible across GPUs?)")
         node_type_own, src_global, dst_local = share["node_type_own"], share["src_global"], share["dst_local"]
         edge_type, edge_time = share["edge_type"], share["edge_time"]
         Nl_own, El_own = int(node_type_own.numel()), int(dst_local.numel())

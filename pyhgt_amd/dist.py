@@ -238,6 +238,9 @@ class HaloPlan:
             _all_to_all(send_counts.view(-1), counts.reshape(-1).contiguous(), [C] * world, [C] * world, group)   # [peer q][chunk] rows q wants
             # tell every owner which of its rows I need (owner, chunk, id order); receive which of my rows the peers need
             asked = _all_to_all_int64(need[ask_order].contiguous(), self.recv_splits, self.send_splits, group)
+            if asked.numel() and (int(asked.min()) < lo or int(asked.max()) >= hi):      # (setup time: one synchronisation)
+                raise RuntimeError("pyhgt_amd.dist: rank %d was asked for rows outside its range [%d, %d): the ranks do not agree on "
+                                   "node_offsets (every rank must pass the same partition)" % (rank, lo, hi))
             # node types of my halo rows (owners answer in the order I asked)
             types_for_peers = node_type_own[(asked - lo)]
             halo_types_ask = _all_to_all_int64(types_for_peers.contiguous(), self.send_splits, self.recv_splits, group)
