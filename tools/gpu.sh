@@ -4,7 +4,10 @@
 #             rank-of-8 step of the multi-GPU path: minutes
 #   validate  pytest -m gpu, the judged bench line + a 2-rank walk of the multi-GPU path on one device, fuzzers, small / training benches
 #   profile   rocprofv3 passes of the judged command (tools/profile_pmc.sh <tag>) + kernel statistics of the latency regime
-#   final     smoke(), the example training loop, profile, then the judged line against this build's counters
+#   final     smoke(), the example training loop, pytest -m gpu, profile, the emulated rank-of-8 steps, then the judged line against this
+#             build's counters
+#   emuprof   rocprofv3 kernel statistics of the emulated rank-of-8 step (bench.py --emulate-world 8): the per-kernel split quoted in
+#             DESIGN.md section 6
 # Everything lands in gpurun_out/; summaries to be judged are copied to profiles/ by hand (or by `final`).
 MODE=${1:-quick}; TAG=${2:-r04}
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
@@ -83,5 +86,20 @@ final)
     summ gpurun_out/${TAG}_emu8_loc*.json
     ( time timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err ) 2>&1 | grep real
     summ gpurun_out/${TAG}_bench.json
+    ;;
+emuprof)
+    export TMPDIR=/tmp; ROOT=$(pwd); cd /tmp
+    for args in "--locality 0" "--locality 0.75"; do
+        rm -rf /tmp/pe
+        timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pe -o s -- python $ROOT/bench.py --emulate-world 8 $args --steps 5 > /tmp/pe.log 2>&1
+        python - "$args" <<'PY'
+import csv, glob, sys
+f = glob.glob("/tmp/pe/**/*kernel_stats.csv", recursive=True)
+rows = sorted(csv.DictReader(open(f[0])), key=lambda r: -float(r["TotalDurationNs"]))
+print("bench.py --emulate-world 8", sys.argv[1])
+for r in rows[:10]:
+    print("%-90s %6s %10.1f us %10.2f ms" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
+PY
+    done
     ;;
 esac
