@@ -26,6 +26,11 @@
         if (hipGetLastError() != hipSuccess) return HGT_ERR_LAUNCH; \
     } while (0)
 
+// hgt_gemm_xs.hip: the x-stationary form of the split typed linear (1 = launched, 0 = not its domain, < 0 = error)
+int hgt_typed_linear_xs_try(bool f16, const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
+                            int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias, int64_t bgs, float* out0,
+                            float* out1, float* out2, int32_t block_cols, int32_t by_pos, int32_t prologue, void* stream);
+
 static inline uint64_t hgt_align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 // Device-written header at the start of the plan buffer.

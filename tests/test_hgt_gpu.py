@@ -1693,3 +1693,32 @@ def test_deterministic_hub_mode_is_bit_reproducible(precision, flags):
     others = torch.ones(N, dtype=torch.bool, device=DEV)
     others[hubs] = False
     assert torch.equal(atomics[others], outs[0][others])       # every non-hub row is deterministic in both modes
+
+
+@pytest.mark.parametrize("N,k,n_out,T,f16,c24,bypos", [
+    (1000, 256, 768, 3, 0, 0, 0),          # a handful of units: one round per workgroup
+    (300007, 256, 768, 4, 0, 0, 1),        # several rounds per workgroup: the in-loop prefetch of the next item's rows
+    (300007, 256, 768, 4, 1, 0, 0),        # fp16 split: row scales found from the fragment-shaped rows
+    (200003, 256, 512, 3, 0, 1, 0),        # 24-bit wire rows (the halo K|V projection)
+    (150001, 64, 192, 5, 1, 0, 0),         # K = 64
+    (90001, 256, 200, 3, 0, 0, 0),         # a last step with one masked and one partly masked column tile
+])
+def test_xs_gemm_is_bit_identical_to_the_slab_kernel(N, k, n_out, T, f16, c24, bypos):
+    """csrc/hgt_gemm_xs.hip (x rows stationary in registers, W through an LDS ring by LDS-DMA) accumulates every output element in
+    the order of k_typed_linear_pc: on ragged, permuted inputs with an empty and a tiny group the two kernels must agree to the
+    bit, in both wavefront orders (staggered / lock-step), and untouched output rows must stay untouched."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_xs
+    lib = _lib.load()
+    saved = {v: os.environ.get(v) for v in ("HGT_GEMM_XS", "HGT_GEMM_XS_STAGGER")}
+    try:
+        for stagger in ("1", "0"):
+            os.environ["HGT_GEMM_XS_STAGGER"] = stagger
+            assert bench_xs.check(lib, N, k, n_out, T, f16, c24, bypos, ragged=1, seed=N % 97)
+    finally:
+        for v, old in saved.items():
+            if old is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = old
