@@ -17,7 +17,8 @@ DEV = "cuda:0"
 
 def setup(lib, N, k, n_out, T, f16, seed, ragged):
     g = torch.Generator().manual_seed(seed)
-    x = torch.randn(N, k, generator=g).to(DEV)
+    gd = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn(N, k, generator=gd, device=DEV)
     W = (torch.randn(T, n_out, k, generator=g) / k ** 0.5).to(DEV)
     b = torch.randn(T, n_out, generator=g).to(DEV)
     if ragged:      # uneven groups (one of them tiny, one empty when T >= 4), rows addressed through a permutation
