@@ -280,7 +280,11 @@ __global__ __launch_bounds__(XS_THREADS) void k_typed_linear_xs(
 
     // this wavefront's item of a round: rows [irow0, irow0 + inrows) of the row list; inrows = 0: idle (barriers and DMA only)
     const int uh = wave >> 2, wi = wave & 3;
-    const bool defer = stagger && uh;      // k-loop -> barrier -> epilogue (see the header)
+    // stagger bits 0-1: which wavefronts run  k-loop -> barrier -> epilogue  (0 none; n: bit n - 1 of the wavefront id);
+    // bits 4-6 (timing experiments only, results invalid): no stores / no epilogue / no item switch
+    const int pairing = stagger & 3;
+    const bool defer = pairing && ((wave >> (pairing - 1)) & 1);
+    const bool dbg_nostore = stagger & 16, dbg_noepi = stagger & 32, dbg_noswitch = stagger & 64;
     auto item_of = [&](const XsRound& r, int& irow0, int& inrows) {
         const int r0 = uh ? r.row0B : r.row0A, c = uh ? r.cntB : r.cntA;
         irow0 = r0 + XS_ROWS * wi;
@@ -342,12 +346,13 @@ __global__ __launch_bounds__(XS_THREADS) void k_typed_linear_xs(
         auto tail = [&](int s, const f32x16& acc0, const f32x16& acc1) {
             xs_wait_vm();
             if (defer) front(s);
-            if (inrows > 0) {
+            if (dbg_noepi) asm volatile("" : : "v"(acc0), "v"(acc1));      // (a use: the k-loop stays)
+            if (inrows > 0 && !dbg_noepi) {
                 int lane_e = lane;
                 asm volatile("" : "+v"(lane_e));     // (laundered: the epilogue's lane-derived masks / addresses are recomputed here)
                 const int colA = s * 64 + ((lane_e & 31) >> 2) * 4;
-                xs_store_tile<F16>(acc0, colA, lane_e, n_out, s_bias, out0, out1, out2, block_cols, s_orow_w, s_inv_w, winv);
-                xs_store_tile<F16>(acc1, colA + 32, lane_e, n_out, s_bias, out0, out1, out2, block_cols, s_orow_w, s_inv_w, winv);
+                xs_store_tile<F16>(acc0, colA, lane_e, dbg_nostore ? 0 : n_out, s_bias, out0, out1, out2, block_cols, s_orow_w, s_inv_w, winv);
+                xs_store_tile<F16>(acc1, colA + 32, lane_e, dbg_nostore ? 0 : n_out, s_bias, out0, out1, out2, block_cols, s_orow_w, s_inv_w, winv);
             }
             if (!defer) front(s);
             ++t;
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_typed_linear_xs(
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-            xs_kloop<PROLOGUE, F16, NKC, true>(smem + (t & 1) * SLOT + lane * 16, ah, am, acc0, acc1, xr, pn);
+            xs_kloop<PROLOGUE, F16, NKC, true>(smem + (t & 1) * SLOT + lane * 16, ah, am, acc0, acc1, xr, dbg_noswitch ? x : pn);
             tail(n_steps - 1, acc0, acc1);
         }
         if (!nxt.valid) break;
@@ -410,8 +415,8 @@ int hgt_typed_linear_xs_try(bool f16, const float* x, int64_t ldx, const int32_t
     if (prologue != 0 && prologue != 2) return 0;
     const int n_kc = k / KC;
     if (n_out > XS_MAXCOL || n_out <= 64 || (k != 64 && k != 128 && k != 256)) return 0;      // K = NKC * 16 exactly (see xs_issue_chunk)
-    const char* env_st = getenv("HGT_GEMM_XS_STAGGER");      // 0: the wavefront pairs of a SIMD in lock-step (experiments)
-    const int stagger = env_st ? atoi(env_st) : 1;
+    const char* env_st = getenv("HGT_GEMM_XS_STAGGER");      // experiments: see the kernel (default: lock-step, measured fastest)
+    const int stagger = env_st ? atoi(env_st) : 0;
     if (prologue == 0 && ((ldx & 3) != 0 || ((uintptr_t)x & 15) != 0)) return 0;
     if (prologue == 2 && (((uintptr_t)x & 7) != 0)) return 0;
     // one round of a full grid is 256 rows per CU: below a few rounds the persistent 64-row kernel (with its pass split) is the better fit

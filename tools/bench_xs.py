@@ -90,7 +90,7 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def bench(lib, N, k, n_out, T, f16, c24, iters=10):
+def bench(lib, N, k, n_out, T, f16, c24, iters=10, extra=False):
     x, W, b, rows, off, ws = setup(lib, N, k, n_out, T, f16, 3, False)
     nblk = 3 if n_out % 3 == 0 else 2
     bc = n_out // nblk
@@ -104,8 +104,12 @@ def bench(lib, N, k, n_out, T, f16, c24, iters=10):
     else:
         xptr, ldx, prologue = x.data_ptr(), k, 0
     line = "time  N=%d k=%d n_out=%d f16=%d c24=%d :" % (N, k, n_out, f16, c24)
-    for name, env in (("slab", {"HGT_GEMM_XS": "0"}), ("xs", {"HGT_GEMM_XS": "1", "HGT_GEMM_XS_STAGGER": "1"}),
-                      ("xs-lockstep", {"HGT_GEMM_XS": "1", "HGT_GEMM_XS_STAGGER": "0"})):
+    variants = [("slab", {"HGT_GEMM_XS": "0"}), ("xs", {"HGT_GEMM_XS": "1", "HGT_GEMM_XS_STAGGER": "0"})]
+    if extra:      # wavefront pairings of the staggered order, then timing-only eliminations (results invalid)
+        variants += [("stag%d" % p, {"HGT_GEMM_XS": "1", "HGT_GEMM_XS_STAGGER": str(p)}) for p in (1, 2, 3)]
+        variants += [(n, {"HGT_GEMM_XS": "1", "HGT_GEMM_XS_STAGGER": str(v)}) for n, v in
+                     (("nostore", 16), ("noepi", 32), ("norows", 64), ("noepi+norows", 96), ("stag1+nostore", 17))]
+    for name, env in variants:
         os.environ.update(env)
         ms = timeit(lambda: run(lib, f16, xptr, ldx, rows, off, T, N, k, n_out, ws, b, outs, bc, 0, prologue), iters)
         gb = (N * k * (3 if c24 else 4) + N * n_out * 4) / 1e9
@@ -129,7 +133,7 @@ def main():
             (150001, 128, 384, 2, 0, 0, 0, 1), (150001, 64, 192, 5, 1, 0, 0, 1), (90001, 256, 200, 3, 0, 0, 0, 1),
             (1000000, 256, 768, 4, 0, 0, 0, 0), (1000000, 256, 768, 4, 1, 0, 0, 0),
         ]:
-            for st in ("1", "0"):
+            for st in ("0", "1", "2"):
                 os.environ["HGT_GEMM_XS_STAGGER"] = st
                 ok &= check(lib, N, k, n_out, T, f16, c24, bypos, ragged)
                 if args.quick:
@@ -138,7 +142,7 @@ def main():
         print("ALL BIT-IDENTICAL" if ok else "MISMATCH", flush=True)
     for (N, k, n_out, f16, c24) in [(1000000, 256, 768, 0, 0), (1000000, 256, 768, 1, 0), (1000000, 256, 512, 0, 1), (1000000, 256, 512, 0, 0),
                                     (625000, 256, 512, 0, 1), (1000000, 128, 384, 0, 0)]:
-        bench(lib, N, k, n_out, 4, f16, c24)
+        bench(lib, N, k, n_out, 4, f16, c24, extra=(n_out == 768 and not f16))
     os.environ.pop("HGT_GEMM_XS", None)
     sys.exit(0 if ok else 1)
 
