@@ -193,13 +193,15 @@ __device__ __forceinline__ void xs_kloop(const unsigned char* slot_lane, const b
 #undef XS_LOAD_B
 }
 
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
 // one finished 32 x 32 tile: bias, 4x4 quad transpose (a lane then holds 4 consecutive columns of one row: 16-byte stores,
 // one wave instruction = 8 rows x 128 B), row scales of the fp16 split.  Output rows, inverse row scales and the bias come out of
 // LDS tables (in registers they would be live across the k-loop: 12 more VGPRs in a kernel that sits at the 256 cap).
 template <bool F16>
 __device__ __forceinline__ void xs_store_tile(const f32x16& acc, int col, int lane, int n_out, const float* s_bias, float* __restrict__ out0,
                                               float* __restrict__ out1, float* __restrict__ out2, int block_cols, const int* s_orow_w,
-                                              const float* s_inv_w, float winv) {
+                                              const float* s_inv_w, float winv, bool nt) {
     const bool col_ok = col < n_out;
     // at most three output blocks (Q | K | V): two compares instead of a division
     const bool b1 = col >= block_cols, b2 = col >= 2 * block_cols;
@@ -215,9 +217,12 @@ __device__ __forceinline__ void xs_store_tile(const f32x16& acc, int col, int la
         const int orow = s_orow_w[rt];
         float sc = 1.0f;
         if constexpr (F16) sc = s_inv_w[rt] * winv;
-        if (col_ok && orow >= 0)
-            *reinterpret_cast<float4*>(ob + (int64_t)orow * block_cols + cc) =
-                make_float4(v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w);
+        if (col_ok && orow >= 0) {
+            const f32x4s r = {v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w};
+            f32x4s* p = reinterpret_cast<f32x4s*>(ob + (int64_t)orow * block_cols + cc);
+            if (nt) __builtin_nontemporal_store(r, p);
+            else *p = r;
+        }
     }
 }
 
@@ -263,28 +268,38 @@ __global__ __launch_bounds__(XS_THREADS) void k_typed_linear_xs(
     };
     const float* winv_tab = reinterpret_cast<const float*>(wsplit + (int64_t)n_groups * gimg);   // fp16 image only: inverse group scales
 
+    // stagger bits 0-1: which wavefronts run  k-loop -> barrier -> epilogue  (0 none; n: bit n - 1 of the wavefront id);
+    // bit 2: those wavefronts own the whole LDS-DMA and wait for it with a COUNTED vmcnt that leaves their own output stores (issued
+    //        after the DMA) in flight; the other four never wait on the vector-memory counter at all;  bit 3: non-temporal stores;
+    // bits 4-6 (timing experiments only, results invalid): no stores / no epilogue / no row loads
+    const int pairing = stagger & 3;
+    const bool defer = pairing && ((wave >> (pairing - 1)) & 1);
+    const bool bdma = pairing && (stagger & 4);
+    const int drank = pairing ? (((wave >> pairing) << (pairing - 1)) | (wave & ((1 << (pairing - 1)) - 1))) : 0;   // rank among the staggered
+    const bool nt_store = stagger & 8;
+    const bool dbg_nostore = stagger & 16, dbg_noepi = stagger & 32, dbg_noswitch = stagger & 64;
     // the B fragments of step s of group g -> ring slot: NKC * 4 pieces of 1 KB, NKC / 2 per wavefront
+    // (bdma: only the four staggered wavefronts issue -- NKC pieces each -- so that the others never wait on a vector-memory counter)
     auto dma_step = [&](int g, int s, int slot) {
+        if (bdma && !defer) return;
         const int pass = s >> 2, ct0 = (s & 3) * 2;
         int lane_l = lane;
         asm volatile("" : "+v"(lane_l));     // (laundered, as in stage_bias)
         const unsigned short* wg = wsplit + (int64_t)g * gimg + (int64_t)pass * NKC * 2 * W_PLANE_ELEMS + lane_l * 8;
+        const int first = bdma ? drank * NKC : wave * (NKC / 2);
 #pragma unroll
-        for (int i = 0; i < NKC / 2; ++i) {
-            const int piece = wave * (NKC / 2) + i;
-            const int kc = piece >> 2, p = piece & 3;
-            const unsigned short* src = wg + (kc * 2 + (p >> 1)) * W_PLANE_ELEMS + (ct0 + (p & 1)) * 512;
-            xs_glds16(src, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * SLOT + piece * XS_PIECE)));
+        for (int i = 0; i < NKC; ++i) {
+            if (i < NKC / 2 || bdma) {
+                const int piece = first + i;
+                const int kc = piece >> 2, p = piece & 3;
+                const unsigned short* src = wg + (kc * 2 + (p >> 1)) * W_PLANE_ELEMS + (ct0 + (p & 1)) * 512;
+                xs_glds16(src, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * SLOT + piece * XS_PIECE)));
+            }
         }
     };
 
     // this wavefront's item of a round: rows [irow0, irow0 + inrows) of the row list; inrows = 0: idle (barriers and DMA only)
     const int uh = wave >> 2, wi = wave & 3;
-    // stagger bits 0-1: which wavefronts run  k-loop -> barrier -> epilogue  (0 none; n: bit n - 1 of the wavefront id);
-    // bits 4-6 (timing experiments only, results invalid): no stores / no epilogue / no item switch
-    const int pairing = stagger & 3;
-    const bool defer = pairing && ((wave >> (pairing - 1)) & 1);
-    const bool dbg_nostore = stagger & 16, dbg_noepi = stagger & 32, dbg_noswitch = stagger & 64;
     auto item_of = [&](const XsRound& r, int& irow0, int& inrows) {
         const int r0 = uh ? r.row0B : r.row0A, c = uh ? r.cntB : r.cntA;
         irow0 = r0 + XS_ROWS * wi;
@@ -323,6 +338,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_typed_linear_xs(
     // complete; DMA of step t + 2 into slot t & 1 }  and  { epilogue of step t }  in the wavefront's order (defer).
     int t = 0;
     int rpar = 0;      // parity of the round: its bias table
+    bool full8 = false;
     while (true) {
         bf16x8 ah[NKC], am[NKC];
         out_rows(irow0, inrows);
@@ -343,18 +359,45 @@ __global__ __launch_bounds__(XS_THREADS) void k_typed_linear_xs(
             if (s + 2 < n_steps) dma_step(cur.g, s + 2, t & 1);
             else if (nxt.valid) dma_step(nxt.g, s + 2 - n_steps, t & 1);
         };
-        auto tail = [&](int s, const f32x16& acc0, const f32x16& acc1) {
-            xs_wait_vm();
-            if (defer) front(s);
+        auto epilogue = [&](int s, const f32x16& acc0, const f32x16& acc1) {
             if (dbg_noepi) asm volatile("" : : "v"(acc0), "v"(acc1));      // (a use: the k-loop stays)
             if (inrows > 0 && !dbg_noepi) {
                 int lane_e = lane;
                 asm volatile("" : "+v"(lane_e));     // (laundered: the epilogue's lane-derived masks / addresses are recomputed here)
                 const int colA = s * 64 + ((lane_e & 31) >> 2) * 4;
-                xs_store_tile<F16>(acc0, colA, lane_e, dbg_nostore ? 0 : n_out, s_bias, out0, out1, out2, block_cols, s_orow_w, s_inv_w, winv);
-                xs_store_tile<F16>(acc1, colA + 32, lane_e, dbg_nostore ? 0 : n_out, s_bias, out0, out1, out2, block_cols, s_orow_w, s_inv_w, winv);
+                const int n_eff = dbg_nostore ? 0 : n_out;
+                xs_store_tile<F16>(acc0, colA, lane_e, n_eff, s_bias, out0, out1, out2, block_cols, s_orow_w, s_inv_w, winv, nt_store);
+                xs_store_tile<F16>(acc1, colA + 32, lane_e, n_eff, s_bias, out0, out1, out2, block_cols, s_orow_w, s_inv_w, winv, nt_store);
             }
-            if (!defer) front(s);
+            // exactly eight store instructions were issued? (all four row groups of both column tiles have an active lane)
+            full8 = inrows > 24 && s * 64 + 32 < n_out && !dbg_noepi && !dbg_nostore;
+        };
+        auto tail = [&](int s, const f32x16& acc0, const f32x16& acc1, auto pf_tag) {
+            constexpr bool PF = decltype(pf_tag)::value;
+            constexpr int NX = NKC * (PROLOGUE == 2 ? 3 : 2);      // row loads of the prefetching k-loop
+            if (bdma) {
+                if (defer) {
+                    // outstanding, oldest first: this wavefront's DMA pieces of step t + 1 (wanted), the stores of its last epilogue,
+                    // the row loads of a prefetching k-loop.  vmcnt retires in order: leaving exactly the younger ones in flight
+                    // proves the pieces have landed.
+                    if (full8) {
+                        if (PF) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 + NX) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(8)" : : : "memory");
+                    } else {
+                        xs_wait_vm();
+                    }
+                    front(s);
+                    epilogue(s, acc0, acc1);
+                } else {
+                    epilogue(s, acc0, acc1);
+                    front(s);
+                }
+            } else {
+                xs_wait_vm();
+                if (defer) front(s);
+                epilogue(s, acc0, acc1);
+                if (!defer) front(s);
+            }
             ++t;
         };
         for (int s = 0; s + 1 < n_steps; ++s) {
@@ -362,14 +405,14 @@ __global__ __launch_bounds__(XS_THREADS) void k_typed_linear_xs(
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
             if (inrows > 0) xs_kloop<PROLOGUE, F16, NKC, false>(smem + (t & 1) * SLOT + lane * 16, ah, am, acc0, acc1, xr, nullptr);
-            tail(s, acc0, acc1);
+            tail(s, acc0, acc1, std::false_type{});
         }
         {   // the last step of the round: every wavefront runs it (an idle one for its loads only: one definition of xr)
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
             xs_kloop<PROLOGUE, F16, NKC, true>(smem + (t & 1) * SLOT + lane * 16, ah, am, acc0, acc1, xr, dbg_noswitch ? x : pn);
-            tail(n_steps - 1, acc0, acc1);
+            tail(n_steps - 1, acc0, acc1, std::true_type{});
         }
         if (!nxt.valid) break;
         cur = nxt;

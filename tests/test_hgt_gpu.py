@@ -1706,14 +1706,15 @@ def test_deterministic_hub_mode_is_bit_reproducible(precision, flags):
 def test_xs_gemm_is_bit_identical_to_the_slab_kernel(N, k, n_out, T, f16, c24, bypos):
     """csrc/hgt_gemm_xs.hip (x rows stationary in registers, W through an LDS ring by LDS-DMA) accumulates every output element in
     the order of k_typed_linear_pc: on ragged, permuted inputs with an empty and a tiny group the two kernels must agree to the
-    bit, in every wavefront order (lock-step / two staggered pairings), and untouched output rows must stay untouched."""
+    bit, in every wavefront order (lock-step, staggered pairings, DMA owned by the staggered wavefronts with counted waits, non-temporal
+    stores), and untouched output rows must stay untouched."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import bench_xs
     lib = _lib.load()
     saved = {v: os.environ.get(v) for v in ("HGT_GEMM_XS", "HGT_GEMM_XS_STAGGER")}
     try:
-        for stagger in ("0", "1", "3"):
+        for stagger in ("0", "1", "3", "7", "14"):
             os.environ["HGT_GEMM_XS_STAGGER"] = stagger
             assert bench_xs.check(lib, N, k, n_out, T, f16, c24, bypos, ragged=1, seed=N % 97)
     finally:
