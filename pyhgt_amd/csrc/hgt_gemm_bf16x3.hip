@@ -969,11 +969,12 @@ static int typed_linear_split_impl(const float* x, int64_t ldx, const int32_t* r
     // latency regime (sampled sub-graphs: fewer row tiles than CUs): one workgroup per (row tile, 256-column pass)
     const int n_pass = (n_out + BNP - 1) / BNP;
     const int pass_split = (n_pass > 1 && row_tiles * 2 <= pc_grid()) ? n_pass : 1;
-    if (k <= KP) {
-        // millions of rows: the x-stationary kernel (hgt_gemm_xs.hip: W through LDS once per 256 rows)
+    {   // millions of rows: the x-stationary kernel (hgt_gemm_xs.hip: W through LDS once per 256 rows; K = 64 / 128 / 256 / 512)
         const int xs = hgt_typed_linear_xs_try(F16, x, ldx, rows, group_off, n_groups, n_rows, k, n_out, w_split, bias, b_group_stride, out0, out1,
                                                out2, block_cols, out_by_position, prologue, stream_);
         if (xs != 0) return xs < 0 ? xs : HGT_OK;
+    }
+    if (k <= KP) {
         // persistent producer/consumer kernel, one workgroup per CU
         const unsigned grid = (unsigned)std::min<int64_t>(row_tiles * pass_split, pc_grid());
         if (prologue == 0)

@@ -31,7 +31,6 @@
 
 namespace {
 
-constexpr int XS_WAVES = 8, XS_THREADS = 64 * XS_WAVES;
 constexpr int XS_ROWS = 32;                  // rows of a wavefront's item (one 32x32 MFMA row tile)
 constexpr int XS_UNIT = 4 * XS_ROWS;         // rows of a unit: the items of wavefronts 0-3 or 4-7 (one wavefront per SIMD each)
 constexpr int XS_PIECE = 1024;               // bytes of one B fragment (64 lanes x 8 bf16)
@@ -72,7 +71,7 @@ struct XsRound {      // up to two units of ONE group (the ring holds one group'
     int valid, g, used;
     int row0A, cntA, row0B, cntB;      // (scalar fields: an indexed array inside this struct is demoted to LDS / scratch)
 };
-__device__ __forceinline__ XsRound xs_round(int u, int u_end, const int32_t* __restrict__ group_off, int n_groups) {
+__device__ __forceinline__ XsRound xs_round(int u, int u_end, const int32_t* __restrict__ group_off, int n_groups, bool pair) {
     XsRound r;
     r.valid = 0; r.g = 0; r.used = 0;
     r.row0A = r.row0B = 0;
@@ -83,7 +82,7 @@ __device__ __forceinline__ XsRound xs_round(int u, int u_end, const int32_t* __r
     if (g < 0) return r;
     r.valid = 1; r.g = g; r.used = 1;
     r.row0A = row0; r.cntA = cnt;
-    if (u + 1 < u_end) {
+    if (pair && u + 1 < u_end) {
         int g2, row2, cnt2;
         xs_unit_lookup(u + 1, group_off, n_groups, g2, row2, cnt2);
         if (g2 == g) { r.used = 2; r.row0B = row2; r.cntB = cnt2; }
@@ -157,36 +156,33 @@ __device__ __forceinline__ void xs_split(float4 (&xr)[NKC][2], bf16x8 (&ah)[NKC]
     }
 }
 
-// one step's k-loop: 64 output columns (two 32-column tiles) x K out of the ring slot.  Piece order of a k-chunk in the slot:
-// (tile 0, hi), (tile 1, hi), (tile 0, lo), (tile 1, lo).  PREFETCH: the rows of the next item, chunk by chunk behind the MFMAs
-// that consumed the chunk's fragments.
-template <int PROLOGUE, bool F16, int NKC, bool PREFETCH>
-__device__ __forceinline__ void xs_kloop(const unsigned char* slot_lane, const bf16x8 (&ah)[NKC], const bf16x8 (&am)[NKC], f32x16& acc0,
-                                         f32x16& acc1, float4 (&xr)[NKC][2], const float* __restrict__ px_next) {
-    bf16x8 bh0[2], bh1[2], bm0[2], bm1[2];
-#define XS_LOAD_B(BUF, KCX)                                                                         \
-    {                                                                                               \
-        const unsigned char* b_ = slot_lane + (KCX) * (4 * XS_PIECE);                               \
-        bh0[BUF] = *reinterpret_cast<const bf16x8*>(b_);                                            \
-        bh1[BUF] = *reinterpret_cast<const bf16x8*>(b_ + XS_PIECE);                                 \
-        bm0[BUF] = *reinterpret_cast<const bf16x8*>(b_ + 2 * XS_PIECE);                             \
-        bm1[BUF] = *reinterpret_cast<const bf16x8*>(b_ + 3 * XS_PIECE);                             \
+// one step's k-loop: NT 32-column tiles x K out of the ring slot.  Piece order of a k-chunk in the slot: the NT tiles' hi planes,
+// then their lo planes.  PREFETCH: the rows of the next item, chunk by chunk behind the MFMAs that consumed the chunk's fragments.
+template <int PROLOGUE, bool F16, int NKC, int NT, bool PREFETCH>
+__device__ __forceinline__ void xs_kloop(const unsigned char* slot_lane, const bf16x8 (&ah)[NKC], const bf16x8 (&am)[NKC], f32x16 (&acc)[NT],
+                                         float4 (&xr)[NKC][2], const float* __restrict__ px_next) {
+    bf16x8 bh[2][NT], bm[2][NT];
+#define XS_LOAD_B(BUF, KCX)                                                                                          \
+    {                                                                                                                \
+        const unsigned char* b_ = slot_lane + (KCX) * (2 * NT * XS_PIECE);                                           \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) bh[BUF][j] = *reinterpret_cast<const bf16x8*>(b_ + j * XS_PIECE);          \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) bm[BUF][j] = *reinterpret_cast<const bf16x8*>(b_ + (NT + j) * XS_PIECE);   \
     }
     XS_LOAD_B(0, 0)
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
         const int cur = kc & 1;
         if (kc + 1 < NKC) XS_LOAD_B(cur ^ 1, kc + 1)
-        // small terms first, hi*hi last; the two accumulators alternate (the order of k_typed_linear_pc: bit-identical results)
-        acc0 = mfma32_t<F16>(am[kc], bh0[cur], acc0);
-        acc1 = mfma32_t<F16>(am[kc], bh1[cur], acc1);
-        acc0 = mfma32_t<F16>(ah[kc], bm0[cur], acc0);
-        acc1 = mfma32_t<F16>(ah[kc], bm1[cur], acc1);
-        acc0 = mfma32_t<F16>(ah[kc], bh0[cur], acc0);
-        acc1 = mfma32_t<F16>(ah[kc], bh1[cur], acc1);
+        // small terms first, hi*hi last; the accumulators alternate (the order of k_typed_linear_pc: bit-identical results)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = mfma32_t<F16>(am[kc], bh[cur][j], acc[j]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = mfma32_t<F16>(ah[kc], bm[cur][j], acc[j]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = mfma32_t<F16>(ah[kc], bh[cur][j], acc[j]);
         if constexpr (PREFETCH) xs_issue_chunk<PROLOGUE>(xr[kc], px_next, kc);
-        if (kc + 1 < NKC) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // the next chunk's 4 DS reads
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                        // 6 MFMAs
+        if (kc + 1 < NKC) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);      // the next chunk's DS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 0);                        // the chunk's MFMAs
         if constexpr (PREFETCH) __builtin_amdgcn_sched_group_barrier(0x020, PROLOGUE == 2 ? 3 : 2, 0);   // the freed registers' loads
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -226,15 +222,19 @@ __device__ __forceinline__ void xs_store_tile(const f32x16& acc, int col, int la
     }
 }
 
-template <int PROLOGUE, bool F16, int NKC>
-__global__ __launch_bounds__(XS_THREADS) void k_typed_linear_xs(
+// NW wavefronts of 32 rows each, NT column tiles per step:  <8, 2> for K <= 256 (two wavefronts per SIMD, 256 registers each, 64
+// columns per step);  <4, 1> for K = 512 (the 256 fragment registers of a row tile need the 512-register budget of ONE wavefront per
+// SIMD; 32 columns per step keep a ring slot at 64 KB).
+template <int PROLOGUE, bool F16, int NKC, int NW, int NT>
+__global__ __launch_bounds__(64 * NW) void k_typed_linear_xs(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off, int n_groups,
     int n_out, const unsigned short* __restrict__ wsplit, const float* __restrict__ bias, int64_t bgs, float* __restrict__ out0,
     float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos, int stagger) {
     // ONE shared object (a second one makes hipcc drain vmcnt before LDS reads):
-    // [2 ring slots][NKC][4 pieces][1 KB] | inverse row scales [8][32] | output rows [8][32] | bias [2 round parities][XS_MAXCOL]
-    constexpr int SLOT = NKC * 4 * XS_PIECE;
-    constexpr int OFF_INV = 2 * SLOT, OFF_OROW = OFF_INV + XS_WAVES * XS_ROWS * 4, OFF_BIAS = OFF_OROW + XS_WAVES * XS_ROWS * 4;
+    // [2 ring slots][NKC][2 NT pieces][1 KB] | inverse row scales [NW][32] | output rows [NW][32] | bias [2 round parities][XS_MAXCOL]
+    constexpr int XS_THREADS = 64 * NW, CW = 32 * NT;      // columns of a step
+    constexpr int PIECES = NKC * 2 * NT, SLOT = PIECES * XS_PIECE;
+    constexpr int OFF_INV = 2 * SLOT, OFF_OROW = OFF_INV + NW * XS_ROWS * 4, OFF_BIAS = OFF_OROW + NW * XS_ROWS * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_BIAS + 2 * XS_MAXCOL * 4];
 
     const int tid = threadIdx.x;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_typed_linear_xs(
     const int u_end = (int)((int64_t)(blockIdx.x + 1) * total_units / gridDim.x);
     if (u >= u_end) return;
 
-    const int n_steps = (n_out + 63) / 64;                               // >= 2 (launcher)
+    const int n_steps = (n_out + CW - 1) / CW;                           // >= 2 (launcher)
     const int n_pass = (n_out + BNP - 1) / BNP;
     const int64_t gimg = (int64_t)n_pass * NKC * 2 * W_PLANE_ELEMS;      // bf16 elements of one group's image
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -259,9 +259,9 @@ __global__ __launch_bounds__(XS_THREADS) void k_typed_linear_xs(
     // the bias of a round's group, zero-padded to whole steps.  Rounds alternate between two tables; the table of round r + 1 is
     // written behind the barrier that ends step 0 of round r: the last reader of that table -- a staggered wavefront's epilogue of
     // the last step of round r - 1 -- ran before that barrier, its first reader comes several barriers later.
-    auto stage_bias = [&](int g, int parity) {
+    auto stage_bias = [&](int g, int parity) __attribute__((always_inline)) {
         float* tb = reinterpret_cast<float*>(smem + OFF_BIAS) + parity * XS_MAXCOL;
-        const int padded = n_steps * 64;
+        const int padded = n_steps * CW;
         int tid_l = tid;
         asm volatile("" : "+v"(tid_l));      // (laundered: nothing derived from it is hoisted out of the step loop into live registers)
         for (int c = tid_l; c < padded; c += XS_THREADS) tb[c] = (bias && c < n_out) ? bias[(int64_t)g * bgs + c] : 0.0f;
@@ -275,32 +275,36 @@ __global__ __launch_bounds__(XS_THREADS) void k_typed_linear_xs(
     const int pairing = stagger & 3;
     const bool defer = pairing && ((wave >> (pairing - 1)) & 1);
     const bool bdma = pairing && (stagger & 4);
+    // 4 alone: EVERY wavefront runs  k-loop -> counted wait -> barrier -> DMA -> epilogue:  a step's LDS-DMA enters the CU's memory
+    // pipe ahead of all of the step's output stores (64 KB that drain at ~10 B/clk) and no wait ever covers a store
+    const bool defer_all = (stagger & 7) == 4;
     const int drank = pairing ? (((wave >> pairing) << (pairing - 1)) | (wave & ((1 << (pairing - 1)) - 1))) : 0;   // rank among the staggered
     const bool nt_store = stagger & 8;
     const bool dbg_nostore = stagger & 16, dbg_noepi = stagger & 32, dbg_noswitch = stagger & 64;
     // the B fragments of step s of group g -> ring slot: NKC * 4 pieces of 1 KB, NKC / 2 per wavefront
     // (bdma: only the four staggered wavefronts issue -- NKC pieces each -- so that the others never wait on a vector-memory counter)
-    auto dma_step = [&](int g, int s, int slot) {
+    auto dma_step = [&](int g, int s, int slot) __attribute__((always_inline)) {
         if (bdma && !defer) return;
-        const int pass = s >> 2, ct0 = (s & 3) * 2;
+        const int col0 = s * CW, pass = col0 >> 8, ct0 = (col0 & 255) >> 5;
         int lane_l = lane;
         asm volatile("" : "+v"(lane_l));     // (laundered, as in stage_bias)
         const unsigned short* wg = wsplit + (int64_t)g * gimg + (int64_t)pass * NKC * 2 * W_PLANE_ELEMS + lane_l * 8;
-        const int first = bdma ? drank * NKC : wave * (NKC / 2);
+        constexpr int PER = PIECES / NW;
+        const int first = bdma ? drank * (2 * PER) : wave * PER;
 #pragma unroll
-        for (int i = 0; i < NKC; ++i) {
-            if (i < NKC / 2 || bdma) {
-                const int piece = first + i;
-                const int kc = piece >> 2, p = piece & 3;
-                const unsigned short* src = wg + (kc * 2 + (p >> 1)) * W_PLANE_ELEMS + (ct0 + (p & 1)) * 512;
+        for (int i = 0; i < 2 * PER; ++i) {
+            if (i < PER || bdma) {
+                const unsigned piece = (unsigned)(first + i);
+                const unsigned kc = piece >> (NT == 2 ? 2 : 1), p = piece & (2 * NT - 1);      // (piece = kc * 2 NT + plane * NT + tile)
+                const unsigned short* src = wg + (kc * 2 + (p >> (NT - 1))) * W_PLANE_ELEMS + (ct0 + (p & (NT - 1))) * 512;
                 xs_glds16(src, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * SLOT + piece * XS_PIECE)));
             }
         }
     };
 
     // this wavefront's item of a round: rows [irow0, irow0 + inrows) of the row list; inrows = 0: idle (barriers and DMA only)
-    const int uh = wave >> 2, wi = wave & 3;
-    auto item_of = [&](const XsRound& r, int& irow0, int& inrows) {
+    const int uh = NW == 8 ? wave >> 2 : 0, wi = wave & 3;
+    auto item_of = [&](const XsRound& r, int& irow0, int& inrows) __attribute__((always_inline)) {
         const int r0 = uh ? r.row0B : r.row0A, c = uh ? r.cntB : r.cntA;
         irow0 = r0 + XS_ROWS * wi;
         inrows = r.valid ? max(0, min(XS_ROWS, c - XS_ROWS * wi)) : 0;
@@ -308,16 +312,16 @@ __global__ __launch_bounds__(XS_THREADS) void k_typed_linear_xs(
     // the lane's source row (advanced to its half); rows beyond the item repeat its last row (never stored).  An idle item reads
     // the first row of the round and is split like any other: no branches, no zero-initialised fragment registers meeting the
     // real ones in 128 phi nodes.
-    auto row_ptr = [&](const XsRound& r, int irow0, int inrows) -> const float* {
+    auto row_ptr = [&](const XsRound& r, int irow0, int inrows) __attribute__((always_inline)) -> const float* {
         const int pos = inrows > 0 ? irow0 + min(lane & 31, inrows - 1) : r.row0A;
         return x + (int64_t)rows[pos] * ldx + half * (PROLOGUE == 2 ? 6 : 8);
     };
     // the output row of every row of the item (-1 = none) into the wavefront's LDS table (read by its own epilogues only)
-    auto out_rows = [&](int irow0, int inrows) {
+    auto out_rows = [&](int irow0, int inrows) __attribute__((always_inline)) {
         if (lane < XS_ROWS) s_orow_w[lane] = (lane < inrows) ? (by_pos ? irow0 + lane : rows[irow0 + lane]) : -1;
     };
 
-    XsRound cur = xs_round(u, u_end, group_off, n_groups);
+    XsRound cur = xs_round(u, u_end, group_off, n_groups, NW == 8);
     u += cur.used;
     int irow0, inrows;
     item_of(cur, irow0, inrows);
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_typed_linear_xs(
         out_rows(irow0, inrows);
         xs_split<PROLOGUE, F16, NKC>(xr, ah, am, lane, s_inv_w);
 
-        const XsRound nxt = xs_round(u, u_end, group_off, n_groups);
+        const XsRound nxt = xs_round(u, u_end, group_off, n_groups, NW == 8);
         u += nxt.used;
         int nrow0, nnrows;
         item_of(nxt, nrow0, nnrows);
@@ -352,67 +356,75 @@ __global__ __launch_bounds__(XS_THREADS) void k_typed_linear_xs(
         const float* pn = (nxt.valid && nnrows > 0) ? row_ptr(nxt, nrow0, nnrows) : row_ptr(cur, irow0, inrows);
         const float winv = F16 ? winv_tab[cur.g] : 1.0f;
         const float* s_bias = reinterpret_cast<const float*>(smem + OFF_BIAS) + rpar * XS_MAXCOL;
-        auto front = [&](int s) {
+        auto front = [&](int s) __attribute__((always_inline)) {
             if (s == n_steps - 1 && !nxt.valid) return;      // the very last step: nothing follows
             xs_barrier();
             if (s == 0 && nxt.valid) stage_bias(nxt.g, rpar ^ 1);
             if (s + 2 < n_steps) dma_step(cur.g, s + 2, t & 1);
             else if (nxt.valid) dma_step(nxt.g, s + 2 - n_steps, t & 1);
         };
-        auto epilogue = [&](int s, const f32x16& acc0, const f32x16& acc1) {
-            if (dbg_noepi) asm volatile("" : : "v"(acc0), "v"(acc1));      // (a use: the k-loop stays)
+        auto epilogue = [&](int s, const f32x16 (&acc)[NT]) __attribute__((always_inline)) {
+            if (dbg_noepi) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) asm volatile("" : : "v"(acc[j]));      // (a use: the k-loop stays)
+            }
             if (inrows > 0 && !dbg_noepi) {
                 int lane_e = lane;
                 asm volatile("" : "+v"(lane_e));     // (laundered: the epilogue's lane-derived masks / addresses are recomputed here)
-                const int colA = s * 64 + ((lane_e & 31) >> 2) * 4;
+                const int colA = s * CW + ((lane_e & 31) >> 2) * 4;
                 const int n_eff = dbg_nostore ? 0 : n_out;
-                xs_store_tile<F16>(acc0, colA, lane_e, n_eff, s_bias, out0, out1, out2, block_cols, s_orow_w, s_inv_w, winv, nt_store);
-                xs_store_tile<F16>(acc1, colA + 32, lane_e, n_eff, s_bias, out0, out1, out2, block_cols, s_orow_w, s_inv_w, winv, nt_store);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    xs_store_tile<F16>(acc[j], colA + 32 * j, lane_e, n_eff, s_bias, out0, out1, out2, block_cols, s_orow_w, s_inv_w, winv, nt_store);
             }
-            // exactly eight store instructions were issued? (all four row groups of both column tiles have an active lane)
-            full8 = inrows > 24 && s * 64 + 32 < n_out && !dbg_noepi && !dbg_nostore;
+            // exactly 4 NT store instructions were issued? (all four row groups of every column tile have an active lane)
+            full8 = inrows > 24 && s * CW + 32 * (NT - 1) < n_out && !dbg_noepi && !dbg_nostore;
         };
-        auto tail = [&](int s, const f32x16& acc0, const f32x16& acc1, auto pf_tag) {
+        auto tail = [&](int s, const f32x16 (&acc)[NT], auto pf_tag) __attribute__((always_inline)) {
             constexpr bool PF = decltype(pf_tag)::value;
             constexpr int NX = NKC * (PROLOGUE == 2 ? 3 : 2);      // row loads of the prefetching k-loop
-            if (bdma) {
-                if (defer) {
+            if (defer_all || bdma) {
+                if (defer_all || defer) {
                     // outstanding, oldest first: this wavefront's DMA pieces of step t + 1 (wanted), the stores of its last epilogue,
                     // the row loads of a prefetching k-loop.  vmcnt retires in order: leaving exactly the younger ones in flight
                     // proves the pieces have landed.
-                    if (full8) {
-                        if (PF) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 + NX) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(8)" : : : "memory");
+                    if (full8 && 4 * NT + NX <= 63) {
+                        if (PF) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * NT + NX <= 63 ? 4 * NT + NX : 0) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * NT) : "memory");
                     } else {
                         xs_wait_vm();
                     }
                     front(s);
-                    epilogue(s, acc0, acc1);
+                    epilogue(s, acc);
                 } else {
-                    epilogue(s, acc0, acc1);
+                    epilogue(s, acc);
                     front(s);
                 }
             } else {
                 xs_wait_vm();
                 if (defer) front(s);
-                epilogue(s, acc0, acc1);
+                epilogue(s, acc);
                 if (!defer) front(s);
             }
             ++t;
         };
         for (int s = 0; s + 1 < n_steps; ++s) {
-            f32x16 acc0, acc1;
+            f32x16 acc[NT];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-            if (inrows > 0) xs_kloop<PROLOGUE, F16, NKC, false>(smem + (t & 1) * SLOT + lane * 16, ah, am, acc0, acc1, xr, nullptr);
-            tail(s, acc0, acc1, std::false_type{});
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+            if (inrows > 0) xs_kloop<PROLOGUE, F16, NKC, NT, false>(smem + (t & 1) * SLOT + lane * 16, ah, am, acc, xr, nullptr);
+            tail(s, acc, std::false_type{});
         }
         {   // the last step of the round: every wavefront runs it (an idle one for its loads only: one definition of xr)
-            f32x16 acc0, acc1;
+            f32x16 acc[NT];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-            xs_kloop<PROLOGUE, F16, NKC, true>(smem + (t & 1) * SLOT + lane * 16, ah, am, acc0, acc1, xr, dbg_noswitch ? x : pn);
-            tail(n_steps - 1, acc0, acc1, std::true_type{});
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+            xs_kloop<PROLOGUE, F16, NKC, NT, true>(smem + (t & 1) * SLOT + lane * 16, ah, am, acc, xr, dbg_noswitch ? x : pn);
+            tail(n_steps - 1, acc, std::true_type{});
         }
         if (!nxt.valid) break;
         cur = nxt;
@@ -436,12 +448,12 @@ template <int PROLOGUE, bool F16>
 static void xs_launch_nkc(int nkc, unsigned grid, hipStream_t stream, const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off,
                           int n_groups, int n_out, const unsigned short* w, const float* bias, int64_t bgs, float* out0, float* out1,
                           float* out2, int block_cols, int by_pos, int stagger) {
-    if (nkc == 16)
-        k_typed_linear_xs<PROLOGUE, F16, 16><<<grid, XS_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, n_out, w, bias, bgs, out0, out1, out2, block_cols, by_pos, stagger);
-    else if (nkc == 8)
-        k_typed_linear_xs<PROLOGUE, F16, 8><<<grid, XS_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, n_out, w, bias, bgs, out0, out1, out2, block_cols, by_pos, stagger);
-    else
-        k_typed_linear_xs<PROLOGUE, F16, 4><<<grid, XS_THREADS, 0, stream>>>(x, ldx, rows, group_off, n_groups, n_out, w, bias, bgs, out0, out1, out2, block_cols, by_pos, stagger);
+#define XS_ARGS x, ldx, rows, group_off, n_groups, n_out, w, bias, bgs, out0, out1, out2, block_cols, by_pos
+    if (nkc == 32) k_typed_linear_xs<PROLOGUE, F16, 32, 4, 1><<<grid, 256, 0, stream>>>(XS_ARGS, stagger & ~7);      // (one wavefront per SIMD: no pairs)
+    else if (nkc == 16) k_typed_linear_xs<PROLOGUE, F16, 16, 8, 2><<<grid, 512, 0, stream>>>(XS_ARGS, stagger);
+    else if (nkc == 8) k_typed_linear_xs<PROLOGUE, F16, 8, 8, 2><<<grid, 512, 0, stream>>>(XS_ARGS, stagger);
+    else k_typed_linear_xs<PROLOGUE, F16, 4, 8, 2><<<grid, 512, 0, stream>>>(XS_ARGS, stagger);
+#undef XS_ARGS
 }
 
 }  // namespace
@@ -456,16 +468,19 @@ int hgt_typed_linear_xs_try(bool f16, const float* x, int64_t ldx, const int32_t
     const int mode = env ? atoi(env) : -1;
     if (mode == 0) return 0;
     if (prologue != 0 && prologue != 2) return 0;
+    if (prologue == 2 && k > KP) return 0;
     const int n_kc = k / KC;
-    if (n_out > XS_MAXCOL || n_out <= 64 || (k != 64 && k != 128 && k != 256)) return 0;      // K = NKC * 16 exactly (see xs_issue_chunk)
-    const char* env_st = getenv("HGT_GEMM_XS_STAGGER");      // experiments: see the kernel (default: lock-step, measured fastest)
-    const int stagger = env_st ? atoi(env_st) : 0;
+    if (n_out > XS_MAXCOL || n_out <= 64 || (k != 64 && k != 128 && k != 256 && k != 512)) return 0;   // K = NKC * 16 exactly (see xs_issue_chunk)
+    // wavefront order: see the kernel.  Default 3 (wavefronts 4-7 staggered): Q|K|V at c2 1.28 ms against 1.31 in lock-step and 1.45
+    // for the slab kernel; the counted-wait forms (5-7) measure the same and are kept as experiments only
+    const char* env_st = getenv("HGT_GEMM_XS_STAGGER");
+    const int stagger = env_st ? atoi(env_st) : 3;
     if (prologue == 0 && ((ldx & 3) != 0 || ((uintptr_t)x & 15) != 0)) return 0;
     if (prologue == 2 && (((uintptr_t)x & 7) != 0)) return 0;
     // one round of a full grid is 256 rows per CU: below a few rounds the persistent 64-row kernel (with its pass split) is the better fit
     if (mode != 1 && n_rows < (int64_t)XS_UNIT * 2 * xs_grid() * 2) return 0;
     const int64_t units = (n_rows + XS_UNIT - 1) / XS_UNIT + n_groups;
-    const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>(units / 2, 1), xs_grid());
+    const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>(k == 512 ? units : units / 2, 1), xs_grid());
     hipStream_t stream = (hipStream_t)stream_;
     const unsigned short* w = (const unsigned short*)w_split;
 #define XS_GO(P, F) xs_launch_nkc<P, F>(n_kc, grid, stream, x, ldx, rows, group_off, n_groups, n_out, w, bias, bgs, out0, out1, out2, block_cols, by_pos, stagger)

@@ -1702,6 +1702,8 @@ def test_deterministic_hub_mode_is_bit_reproducible(precision, flags):
     (200003, 256, 512, 3, 0, 1, 0),        # 24-bit wire rows (the halo K|V projection)
     (150001, 64, 192, 5, 1, 0, 0),         # K = 64
     (90001, 256, 200, 3, 0, 0, 0),         # a last step with one masked and one partly masked column tile
+    (200003, 512, 1536, 3, 0, 0, 0),       # K = 512: four wavefronts of 512 registers, 32 columns per step
+    (120001, 512, 512, 4, 1, 0, 1),
 ])
 def test_xs_gemm_is_bit_identical_to_the_slab_kernel(N, k, n_out, T, f16, c24, bypos):
     """csrc/hgt_gemm_xs.hip (x rows stationary in registers, W through an LDS ring by LDS-DMA) accumulates every output element in
