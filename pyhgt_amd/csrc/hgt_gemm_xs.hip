@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64 * NW) void k_typed_linear_xs(
     // the bias of a round's group, zero-padded to whole steps.  Rounds alternate between two tables; the table of round r + 1 is
     // written behind the barrier that ends step 0 of round r: the last reader of that table -- a staggered wavefront's epilogue of
     // the last step of round r - 1 -- ran before that barrier, its first reader comes several barriers later.
-    auto stage_bias = [&](int g, int parity) __attribute__((always_inline)) {
+    auto stage_bias = [&](int g, int parity) {
         float* tb = reinterpret_cast<float*>(smem + OFF_BIAS) + parity * XS_MAXCOL;
         const int padded = n_steps * CW;
         int tid_l = tid;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * NW) void k_typed_linear_xs(
     const bool dbg_nostore = stagger & 16, dbg_noepi = stagger & 32, dbg_noswitch = stagger & 64;
     // the B fragments of step s of group g -> ring slot: NKC * 4 pieces of 1 KB, NKC / 2 per wavefront
     // (bdma: only the four staggered wavefronts issue -- NKC pieces each -- so that the others never wait on a vector-memory counter)
-    auto dma_step = [&](int g, int s, int slot) __attribute__((always_inline)) {
+    auto dma_step = [&](int g, int s, int slot) {
         if (bdma && !defer) return;
         const int col0 = s * CW, pass = col0 >> 8, ct0 = (col0 & 255) >> 5;
         int lane_l = lane;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64 * NW) void k_typed_linear_xs(
 
     // this wavefront's item of a round: rows [irow0, irow0 + inrows) of the row list; inrows = 0: idle (barriers and DMA only)
     const int uh = NW == 8 ? wave >> 2 : 0, wi = wave & 3;
-    auto item_of = [&](const XsRound& r, int& irow0, int& inrows) __attribute__((always_inline)) {
+    auto item_of = [&](const XsRound& r, int& irow0, int& inrows) {
         const int r0 = uh ? r.row0B : r.row0A, c = uh ? r.cntB : r.cntA;
         irow0 = r0 + XS_ROWS * wi;
         inrows = r.valid ? max(0, min(XS_ROWS, c - XS_ROWS * wi)) : 0;
@@ -312,12 +312,12 @@ __global__ __launch_bounds__(64 * NW) void k_typed_linear_xs(
     // the lane's source row (advanced to its half); rows beyond the item repeat its last row (never stored).  An idle item reads
     // the first row of the round and is split like any other: no branches, no zero-initialised fragment registers meeting the
     // real ones in 128 phi nodes.
-    auto row_ptr = [&](const XsRound& r, int irow0, int inrows) __attribute__((always_inline)) -> const float* {
+    auto row_ptr = [&](const XsRound& r, int irow0, int inrows) -> const float* {
         const int pos = inrows > 0 ? irow0 + min(lane & 31, inrows - 1) : r.row0A;
         return x + (int64_t)rows[pos] * ldx + half * (PROLOGUE == 2 ? 6 : 8);
     };
     // the output row of every row of the item (-1 = none) into the wavefront's LDS table (read by its own epilogues only)
-    auto out_rows = [&](int irow0, int inrows) __attribute__((always_inline)) {
+    auto out_rows = [&](int irow0, int inrows) {
         if (lane < XS_ROWS) s_orow_w[lane] = (lane < inrows) ? (by_pos ? irow0 + lane : rows[irow0 + lane]) : -1;
     };
 
@@ -356,18 +356,20 @@ __global__ __launch_bounds__(64 * NW) void k_typed_linear_xs(
         const float* pn = (nxt.valid && nnrows > 0) ? row_ptr(nxt, nrow0, nnrows) : row_ptr(cur, irow0, inrows);
         const float winv = F16 ? winv_tab[cur.g] : 1.0f;
         const float* s_bias = reinterpret_cast<const float*>(smem + OFF_BIAS) + rpar * XS_MAXCOL;
-        auto front = [&](int s) __attribute__((always_inline)) {
+        auto front = [&](int s) {
             if (s == n_steps - 1 && !nxt.valid) return;      // the very last step: nothing follows
             xs_barrier();
             if (s == 0 && nxt.valid) stage_bias(nxt.g, rpar ^ 1);
             if (s + 2 < n_steps) dma_step(cur.g, s + 2, t & 1);
             else if (nxt.valid) dma_step(nxt.g, s + 2 - n_steps, t & 1);
         };
-        auto epilogue = [&](int s, const f32x16 (&acc)[NT]) __attribute__((always_inline)) {
+        auto epilogue = [&](int s, const f32x16 (&acc)[NT]) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass rejects the constraint -- silently, together with the kernel's launch stub)
             if (dbg_noepi) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) asm volatile("" : : "v"(acc[j]));      // (a use: the k-loop stays)
             }
+#endif
             if (inrows > 0 && !dbg_noepi) {
                 int lane_e = lane;
                 asm volatile("" : "+v"(lane_e));     // (laundered: the epilogue's lane-derived masks / addresses are recomputed here)
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(64 * NW) void k_typed_linear_xs(
             // exactly 4 NT store instructions were issued? (all four row groups of every column tile have an active lane)
             full8 = inrows > 24 && s * CW + 32 * (NT - 1) < n_out && !dbg_noepi && !dbg_nostore;
         };
-        auto tail = [&](int s, const f32x16 (&acc)[NT], auto pf_tag) __attribute__((always_inline)) {
+        auto tail = [&](int s, const f32x16 (&acc)[NT], auto pf_tag) {
             constexpr bool PF = decltype(pf_tag)::value;
             constexpr int NX = NKC * (PROLOGUE == 2 ? 3 : 2);      // row loads of the prefetching k-loop
             if (defer_all || bdma) {
