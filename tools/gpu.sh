@@ -8,6 +8,8 @@
 #             build's counters
 #   emuprof   rocprofv3 kernel statistics of the emulated rank-of-8 step (bench.py --emulate-world 8): the per-kernel split quoted in
 #             DESIGN.md section 6
+#   xs        the x-stationary typed linear (csrc/hgt_gemm_xs.hip): bit-identity against the slab kernel in every wavefront order,
+#             timings with the elimination switches (tools/bench_xs.py), the c2 / d = 512 layers with and without it
 # Everything lands in gpurun_out/; summaries to be judged are copied to profiles/ by hand (or by `final`).
 MODE=${1:-quick}; TAG=${2:-r04}
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
@@ -75,6 +77,9 @@ final)
     timeout 300 python examples/train_synthetic.py --steps 6 2>&1 | tail -3
     python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/pytest_$TAG.log
     grep -E "^FAILED|^ERROR| passed| failed" gpurun_out/pytest_$TAG.log | tail -10
+    # the x-stationary GEMM forced onto the small graphs of the backward / staged tests (its size threshold keeps it off them otherwise)
+    HGT_GEMM_XS=1 timeout 600 python -m pytest tests -m gpu -q -k "backward or staged or two_rank or matches_oracle" 2>&1 | tail -3
+    timeout 300 python tools/bench_xs.py > gpurun_out/${TAG}_xs_check.log 2>&1; grep -v "BIT-IDENTICAL (" gpurun_out/${TAG}_xs_check.log | tail -12
     tools/profile_pmc.sh $TAG > gpurun_out/prof_$TAG.log 2>&1
     cp gpurun_out/prof_$TAG/${TAG}_pmc_summary.json profiles/${TAG}_pmc_summary.json      # the line below is judged against THIS build's counters
     tools/profile_small.sh $TAG > gpurun_out/prof_small_$TAG.log 2>&1
@@ -86,6 +91,15 @@ final)
     summ gpurun_out/${TAG}_emu8_loc*.json
     ( time timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err ) 2>&1 | grep real
     summ gpurun_out/${TAG}_bench.json
+    ;;
+xs)
+    timeout 420 python tools/bench_xs.py > gpurun_out/xs_check_$TAG.log 2>&1; echo "bench_xs rc=$?"
+    grep -v "BIT-IDENTICAL (" gpurun_out/xs_check_$TAG.log | tail -30
+    for m in 0 1; do
+        HGT_GEMM_XS=$m timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 40 > gpurun_out/xs_c2_$m.json 2> gpurun_out/xs_c2_$m.err
+        HGT_GEMM_XS=$m timeout 300 python bench.py --dim 512 --nodes-per-gpu 500000 --edges-per-gpu 5000000 --no-secondary --no-cpu-baseline > gpurun_out/xs_d512_$m.json 2> gpurun_out/xs_d512_$m.err
+    done
+    summ gpurun_out/xs_c2_0.json gpurun_out/xs_c2_1.json gpurun_out/xs_d512_0.json gpurun_out/xs_d512_1.json
     ;;
 emuprof)
     export TMPDIR=/tmp; ROOT=$(pwd); cd /tmp

@@ -15,7 +15,7 @@ import re
 import shutil
 import sys
 
-HOT = [("project_qkv", r"k_typed_linear_pc<0,\s*false(,\s*(false|true))?>|k_typed_linear_pcILi0ELb0E"),
+HOT = [("project_qkv", r"k_typed_linear_xs<0|k_typed_linear_xsILi0E|k_typed_linear_pc<0,\s*false(,\s*(false|true))?>|k_typed_linear_pcILi0ELb0E"),
        ("edge_logits", r"k_edge_logits"),
        ("edge_aggregate", r"k_edge_aggregate"),
        ("plan_sort", r"radix|onesweep")]
