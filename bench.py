@@ -566,9 +566,12 @@ def main():
     ap.add_argument("--halo-c24", action="store_true", help=argparse.SUPPRESS)    # the default now; kept for old command lines
     ap.add_argument("--emulate-world", type=int, default=0, help="N = 1 only: ONE GPU plays rank 0 of a W-rank partition of the configs[3] "
                     "recipe (exchange replaced by device copies of the same size): the per-rank GPU work of a multi-GPU step, measured")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f16x3", "fp32"],
-                    help="typed linears / relation transforms: 3-term split-bf16 MFMA with fp32 accumulation (default; parity-tested "
-                         "at 1e-4) or exact fp32")
+    ap.add_argument("--precision", default=None, choices=["bf16x3", "f16x3", "fp32"],
+                    help="typed linears / relation transforms.  Default at N = 1: f16x3 = 3-term fp16 hi/lo MFMA with power-of-two row "
+                         "scales, fp32 accumulation -- the reference's own fp32 accuracy (<= 2e-6 from the fp64 oracle), the mode the "
+                         "round-3 review asked to be judged; bf16x3 (3-term split-bf16, <= 3.5e-5, ~4 %% faster, the layer's default) and "
+                         "exact fp32 are reported next to it under `secondary`.  Default at N > 1: bf16x3 (the staged calls of the "
+                         "multi-GPU path run an f16x3 layer on the split-bf16 kernels anyway)")
     ap.add_argument("--kernel-flags", type=int, default=0, help="hgt_conv_args.flags (HGT_FLAG_*), A/B runs")
     ap.add_argument("--workload", default="c2", choices=["c2", "c5"],
                     help="c2 (default): BASELINE.json configs[1] at N=1, the configs[3] recipe (dst partition + RCCL halo all-to-all) at N>1.  "
@@ -588,6 +591,8 @@ def main():
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.precision is None:      # (see --precision)
+        args.precision = "f16x3" if world == 1 and not args.emulate_world and args.workload == "c2" else "bf16x3"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
@@ -889,22 +894,28 @@ def main():
             etv = torch.randint(0, R, (Ev,), generator=gv, device=dev)
             tmv = torch.randint(0, 240, (Ev,), generator=gv, device=dev) if rte else None
             eiv = torch.stack([srcv, dstv], dim=1).t()
-            torch.manual_seed(0)
-            lay = HGTConv(dv, dv, T, R, Hv, 0.2, True, rte, precision=args.precision).eval()
-            with torch.no_grad():
-                lay.relation_pri.uniform_(0.5, 1.5)
-                lay.skip.normal_()
-            lay = lay.to(dev)
-            sdv = {k: v.detach().cpu() for k, v in lay.state_dict().items()}
             planv = GraphPlan(ntv, eiv, etv, tmv, T, R)
-            outv, elv, phv, medv = timed(lambda events=None: lay(xv, ntv, eiv, etv, tmv, plan=planv, phase_events=events), 10, 2)
-            msv = elv / 10 * 1e3
-            par = None if args.no_parity else parity_check(sdv, outv, xv, ntv, eiv, etv, tmv, T, R, Hv, rte)
             algv = algorithmic_bytes(Nv, Ev, dv, rte)["layer"]
-            return {"workload": "T=%d R=%d N=%d E=%d d=%d H=%d use_RTE=%s%s" % (T, R, Nv, Ev, dv, Hv, rte, ", Zipf(%.1f) targets" % skew if skew else ""),
-                    "ms_per_step": msv, "median_ms_per_step": medv, "edges_per_s": Ev / (msv * 1e-3),
-                    "layer_frac": round(algv / (msv * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "phase_ms": {p: round(v, 4) for p, v in phv.items()},
-                    "parity_max_abs_err": None if par is None else par["max_abs_err"]}
+
+            def one(prec):
+                torch.manual_seed(0)
+                lay = HGTConv(dv, dv, T, R, Hv, 0.2, True, rte, precision=prec).eval()
+                with torch.no_grad():
+                    lay.relation_pri.uniform_(0.5, 1.5)
+                    lay.skip.normal_()
+                lay = lay.to(dev)
+                sdv = {k: v.detach().cpu() for k, v in lay.state_dict().items()}
+                outv, elv, phv, medv = timed(lambda events=None: lay(xv, ntv, eiv, etv, tmv, plan=planv, phase_events=events), 10, 2)
+                msv = elv / 10 * 1e3
+                par = None if args.no_parity else parity_check(sdv, outv, xv, ntv, eiv, etv, tmv, T, R, Hv, rte)
+                return {"precision": prec, "ms_per_step": msv, "median_ms_per_step": medv, "edges_per_s": Ev / (msv * 1e-3),
+                        "layer_frac": round(algv / (msv * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "phase_ms": {p: round(v, 4) for p, v in phv.items()},
+                        "parity_max_abs_err": None if par is None else par["max_abs_err"]}
+            res = {"workload": "T=%d R=%d N=%d E=%d d=%d H=%d use_RTE=%s%s" % (T, R, Nv, Ev, dv, Hv, rte, ", Zipf(%.1f) targets" % skew if skew else "")}
+            res.update(one(args.precision))
+            if args.precision == "f16x3":      # the faster split inside the 1e-4 bound next to the judged mode
+                res["bf16x3"] = one("bf16x3")
+            return res
         secondary["c2_rte"] = large_variant(Nl, El, d, H, True, 0.0, 4321)
         torch.cuda.empty_cache()
         secondary["c2_zipf0.8"] = large_variant(Nl, El, d, H, False, 0.8, 4322)

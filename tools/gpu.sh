@@ -8,6 +8,7 @@
 #             build's counters
 #   emuprof   rocprofv3 kernel statistics of the emulated rank-of-8 step (bench.py --emulate-world 8): the per-kernel split quoted in
 #             DESIGN.md section 6
+#   judged    rocprofv3 passes of the judged command + the judged line (what `final` ends with)
 #   xs        the x-stationary typed linear (csrc/hgt_gemm_xs.hip): bit-identity against the slab kernel in every wavefront order,
 #             timings with the elimination switches (tools/bench_xs.py), the c2 / d = 512 layers with and without it
 # Everything lands in gpurun_out/; summaries to be judged are copied to profiles/ by hand (or by `final`).
@@ -100,6 +101,13 @@ xs)
         HGT_GEMM_XS=$m timeout 300 python bench.py --dim 512 --nodes-per-gpu 500000 --edges-per-gpu 5000000 --no-secondary --no-cpu-baseline > gpurun_out/xs_d512_$m.json 2> gpurun_out/xs_d512_$m.err
     done
     summ gpurun_out/xs_c2_0.json gpurun_out/xs_c2_1.json gpurun_out/xs_d512_0.json gpurun_out/xs_d512_1.json
+    ;;
+judged)
+    # the judged command under rocprofv3 (kernel statistics + counter passes), then the judged line against this build's counters
+    tools/profile_pmc.sh $TAG > gpurun_out/prof_$TAG.log 2>&1
+    cp gpurun_out/prof_$TAG/${TAG}_pmc_summary.json profiles/${TAG}_pmc_summary.json
+    ( time timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err ) 2>&1 | grep real
+    summ gpurun_out/${TAG}_bench.json
     ;;
 emuprof)
     export TMPDIR=/tmp; ROOT=$(pwd); cd /tmp
