@@ -28,7 +28,7 @@ for f in sys.argv[1:]:
         print(f, json.dumps(j)[:900]); continue
     r = j.get("roofline", {})
     print(f, "ms", round(j["ms_per_step"], 3), "parity", j.get("parity_max_abs_err"), "frac", r.get("frac"), "layer_frac", r.get("layer_frac"),
-          r.get("phase_ms") or r.get("stage_ms"))
+          r.get("phase_ms") or r.get("stage_ms"), "fp32_accurate", j.get("fp32_accurate"))
     for k, v in (j.get("secondary") or {}).items():
         if isinstance(v, dict):
             print("   ", k, {kk: (float("%.4g" % vv) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk in
