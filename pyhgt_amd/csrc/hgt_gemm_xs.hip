@@ -479,8 +479,10 @@ int hgt_typed_linear_xs_try(bool f16, const float* x, int64_t ldx, const int32_t
     const int stagger = env_st ? atoi(env_st) : 3;
     if (prologue == 0 && ((ldx & 3) != 0 || ((uintptr_t)x & 15) != 0)) return 0;
     if (prologue == 2 && (((uintptr_t)x & 7) != 0)) return 0;
-    // one round of a full grid is 256 rows per CU: below a few rounds the persistent 64-row kernel (with its pass split) is the better fit
-    if (mode != 1 && n_rows < (int64_t)XS_UNIT * 2 * xs_grid() * 2) return 0;
+    // measured crossover against the slab kernels (tools/bench_xs.py --threshold, profiles/r04_xs_threshold.txt): K <= 256 even at
+    // 160-260 k rows, ahead from ~300 k (a full grid needs 65 536 rows per round; below a few rounds the tail costs what the smaller W
+    // traffic gains); K = 512 ahead from 66 k rows on (the slab kernel re-splits x per 256-column pass there)
+    if (mode != 1 && n_rows < (k == 512 ? 65536 : 262144)) return 0;
     const int64_t units = (n_rows + XS_UNIT - 1) / XS_UNIT + n_groups;
     const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>(k == 512 ? units : units / 2, 1), xs_grid());
     hipStream_t stream = (hipStream_t)stream_;

@@ -119,9 +119,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--threshold", action="store_true", help="only: slab vs xs at row counts around the dispatch threshold")
     args = ap.parse_args()
     lib = _lib.load()
     ok = True
+    if args.threshold:
+        for N in (40000, 66000, 100000, 131072, 160000, 200000, 262144, 330000, 400000, 524288):
+            bench(lib, N, 256, 768, 4, 0, 0, [3], iters=8, reps=3)
+        for N in (66000, 131072, 200000, 330000):
+            bench(lib, N, 256, 512, 4, 0, 1, [3], iters=8, reps=3)
+            bench(lib, N, 512, 1536, 4, 0, 0, [0], iters=8, reps=3)
+        return
     if not args.no_check:
         # one round per workgroup, several rounds, ragged groups with an empty and a tiny group, both output addressings, both formats
         for (N, k, n_out, T, f16, c24, bypos, ragged) in [
