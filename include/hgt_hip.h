@@ -181,6 +181,16 @@ int hgt_typed_linear_f16x3(const float* x, int64_t ldx, const int32_t* rows, con
                            const float* bias, int64_t b_group_stride, float* out0, float* out1, float* out2,
                            int32_t block_cols, int32_t out_by_position, int32_t prologue, void* stream);
 
+/* Introspection (host only, no GPU): the work decomposition of the x-stationary kernel behind hgt_typed_linear_bf16x3 / _f16x3 on
+ * large inputs (csrc/hgt_gemm_xs.hip), enumerated with the kernel's own scheduling helpers.  group_off_host = the [n_groups + 1]
+ * offsets as a HOST array, n_cu = number of workgroups the launch may use (the device's CU count), k selects the form (512: four
+ * wavefronts per workgroup, otherwise eight).  items[i] = {workgroup, round, wavefront, group, first position in the row list,
+ * rows (1..32)}; *n_items = number of entries the schedule has; HGT_ERR_TOO_LARGE (with *n_items set) if max_items is smaller.
+ * Replaces nothing in the reference (its Linear layers have no decomposition to inspect); it exists so that the partition of the row
+ * list -- every position exactly once, no round mixing two groups -- is tested on the CPU (tests/test_xs_schedule.py). */
+int hgt_typed_linear_xs_schedule(const int32_t* group_off_host, int32_t n_groups, int64_t n_rows, int32_t k, int32_t n_cu,
+                                 int32_t* items_host, int64_t max_items, int64_t* n_items_host);
+
 /* a_linear (conv.py:125) with the node update (conv.py:129-133, see hgt_node_update) fused into its epilogue:
  *   out[n] = LN_t( (agg[n] @ W_a[t]^T + b_a[t]) * sigmoid(skip[t]) + x_skip[n] * (1 - sigmoid(skip[t])) )
  * for the rows of every group; split-bf16 x3 MFMA; needs n_out <= 256 and n_out % 4 == 0 (HGT_ERR_UNSUPPORTED

@@ -90,6 +90,7 @@ SIGNATURES = {
     "hgt_linear_update_bf16x3": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                                            _i32, _vp, _vp]),
     "hgt_split_weights_f16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "hgt_typed_linear_xs_schedule": (C.c_int, [_vp, _i32, _i64, _i32, _i32, _vp, _i64, C.POINTER(_i64)]),
     "hgt_typed_linear_f16x3": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp,
                                          _i32, _i32, _i32, _vp]),
     "hgt_linear_update_f16x3": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp,

@@ -50,7 +50,7 @@ __device__ __forceinline__ void xs_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 __device__ __forceinline__ void xs_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // unit u of the concatenated per-group unit lists -> (group, first row position, rows); g = -1 past the end
-__device__ __forceinline__ void xs_unit_lookup(int u, const int32_t* __restrict__ group_off, int n_groups, int& g, int& row0, int& cnt) {
+__host__ __device__ __forceinline__ void xs_unit_lookup(int u, const int32_t* __restrict__ group_off, int n_groups, int& g, int& row0, int& cnt) {
     int before = 0;
     g = -1;
     row0 = 0;
@@ -61,7 +61,7 @@ __device__ __forceinline__ void xs_unit_lookup(int u, const int32_t* __restrict_
         if (g < 0 && u < before + nu) {
             g = gg;
             row0 = gb + (u - before) * XS_UNIT;
-            cnt = min(XS_UNIT, ge - row0);
+            cnt = (ge - row0 < XS_UNIT) ? ge - row0 : XS_UNIT;
         }
         before += nu;
     }
@@ -71,7 +71,7 @@ struct XsRound {      // up to two units of ONE group (the ring holds one group'
     int valid, g, used;
     int row0A, cntA, row0B, cntB;      // (scalar fields: an indexed array inside this struct is demoted to LDS / scratch)
 };
-__device__ __forceinline__ XsRound xs_round(int u, int u_end, const int32_t* __restrict__ group_off, int n_groups, bool pair) {
+__host__ __device__ __forceinline__ XsRound xs_round(int u, int u_end, const int32_t* __restrict__ group_off, int n_groups, bool pair) {
     XsRound r;
     r.valid = 0; r.g = 0; r.used = 0;
     r.row0A = r.row0B = 0;
@@ -88,6 +88,17 @@ __device__ __forceinline__ XsRound xs_round(int u, int u_end, const int32_t* __r
         if (g2 == g) { r.used = 2; r.row0B = row2; r.cntB = cnt2; }
     }
     return r;
+}
+
+// wavefront `wave` of a round: rows [irow0, irow0 + inrows) of the row list (inrows = 0: idle).  nw = 8: wavefronts 0-3 take unit A,
+// 4-7 unit B; nw = 4: unit A only.  Shared by the kernel and the host-side enumerator (hgt_typed_linear_xs_schedule).
+__host__ __device__ __forceinline__ void xs_item_of(const XsRound& r, int wave, int nw, int& irow0, int& inrows) {
+    const int uh = nw == 8 ? wave >> 2 : 0, wi = wave & 3;
+    const int r0 = uh ? r.row0B : r.row0A, c = uh ? r.cntB : r.cntA;
+    irow0 = r0 + XS_ROWS * wi;
+    int n = c - XS_ROWS * wi;
+    n = n > XS_ROWS ? XS_ROWS : n;
+    inrows = (r.valid && n > 0) ? n : 0;
 }
 
 // the 24-bit transport format of the multi-GPU exchange (hgt_gather_rows_c24): 4 values = 3 dwords, value = 24 bits << 8
@@ -304,11 +315,7 @@ __global__ __launch_bounds__(64 * NW) void k_typed_linear_xs(
 
     // this wavefront's item of a round: rows [irow0, irow0 + inrows) of the row list; inrows = 0: idle (barriers and DMA only)
     const int uh = NW == 8 ? wave >> 2 : 0, wi = wave & 3;
-    auto item_of = [&](const XsRound& r, int& irow0, int& inrows) {
-        const int r0 = uh ? r.row0B : r.row0A, c = uh ? r.cntB : r.cntA;
-        irow0 = r0 + XS_ROWS * wi;
-        inrows = r.valid ? max(0, min(XS_ROWS, c - XS_ROWS * wi)) : 0;
-    };
+    auto item_of = [&](const XsRound& r, int& irow0, int& inrows) { xs_item_of(r, wave, NW, irow0, inrows); };
     // the lane's source row (advanced to its half); rows beyond the item repeat its last row (never stored).  An idle item reads
     // the first row of the round and is split like any other: no branches, no zero-initialised fragment registers meeting the
     // real ones in 128 phi nodes.
@@ -460,6 +467,46 @@ static void xs_launch_nkc(int nkc, unsigned grid, hipStream_t stream, const floa
 
 }  // namespace
 
+static unsigned xs_grid_for(int64_t n_rows, int32_t n_groups, int32_t k, int n_cu) {
+    const int64_t units = (n_rows + XS_UNIT - 1) / XS_UNIT + n_groups;
+    return (unsigned)std::min<int64_t>(std::max<int64_t>(k == 512 ? units : units / 2, 1), n_cu);
+}
+
+// The kernel's work decomposition, enumerated on the HOST with the kernel's own helpers (tests/test_xs_schedule.py: every position of
+// the row list is covered exactly once, a round never mixes groups, workgroups get contiguous balanced unit ranges).  group_off is a
+// HOST array here.  items[i] = {workgroup, round, wavefront, group, first position, rows}; returns HGT_ERR_TOO_LARGE if max_items is
+// too small (n_items then holds the count needed).
+extern "C" int hgt_typed_linear_xs_schedule(const int32_t* group_off, int32_t n_groups, int64_t n_rows, int32_t k, int32_t n_cu,
+                                            int32_t* items, int64_t max_items, int64_t* n_items) {
+    if (!group_off || !n_items || n_groups <= 0 || n_cu <= 0 || (max_items > 0 && !items)) return HGT_ERR_INVALID_ARG;
+    const int nw = k == 512 ? 4 : 8;
+    const unsigned grid = xs_grid_for(n_rows, n_groups, k, n_cu);
+    int total_units = 0;
+    for (int g = 0; g < n_groups; ++g) total_units += (group_off[g + 1] - group_off[g] + XS_UNIT - 1) / XS_UNIT;
+    int64_t n = 0;
+    for (unsigned b = 0; b < grid; ++b) {
+        int u = (int)((int64_t)b * total_units / grid);
+        const int u_end = (int)((int64_t)(b + 1) * total_units / grid);
+        for (int round = 0; u < u_end; ++round) {
+            const XsRound r = xs_round(u, u_end, group_off, n_groups, nw == 8);
+            if (!r.valid) break;
+            u += r.used;
+            for (int w = 0; w < nw; ++w) {
+                int irow0, inrows;
+                xs_item_of(r, w, nw, irow0, inrows);
+                if (inrows <= 0) continue;
+                if (n < max_items) {
+                    int32_t* it = items + n * 6;
+                    it[0] = (int32_t)b; it[1] = round; it[2] = w; it[3] = r.g; it[4] = irow0; it[5] = inrows;
+                }
+                ++n;
+            }
+        }
+    }
+    *n_items = n;
+    return n > max_items ? HGT_ERR_TOO_LARGE : HGT_OK;
+}
+
 // 1 = launched, 0 = shape / size outside this kernel's domain (the caller falls back to k_typed_linear_pc), < 0 = error.
 // HGT_GEMM_XS=0 switches it off, =1 takes it for every eligible shape whatever the row count (tests, tools/bench_linear.py).
 // In a wire-format call (prologue 2) ldx / x follow hgt_typed_linear_bf16x3: dwords per row, 8-byte aligned.
@@ -483,8 +530,7 @@ int hgt_typed_linear_xs_try(bool f16, const float* x, int64_t ldx, const int32_t
     // 160-260 k rows, ahead from ~300 k (a full grid needs 65 536 rows per round; below a few rounds the tail costs what the smaller W
     // traffic gains); K = 512 ahead from 66 k rows on (the slab kernel re-splits x per 256-column pass there)
     if (mode != 1 && n_rows < (k == 512 ? 65536 : 262144)) return 0;
-    const int64_t units = (n_rows + XS_UNIT - 1) / XS_UNIT + n_groups;
-    const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>(k == 512 ? units : units / 2, 1), xs_grid());
+    const unsigned grid = xs_grid_for(n_rows, n_groups, k, xs_grid());
     hipStream_t stream = (hipStream_t)stream_;
     const unsigned short* w = (const unsigned short*)w_split;
 #define XS_GO(P, F) xs_launch_nkc<P, F>(n_kc, grid, stream, x, ldx, rows, group_off, n_groups, n_out, w, bias, bgs, out0, out1, out2, block_cols, by_pos, stagger)
