@@ -1,6 +1,7 @@
 // Typed (grouped) linear layer, split x3 variant with the x rows STATIONARY in registers ("xs", round 4).
 //
-//   y[n, :] = x[n, :] @ W[type(n)]^T + b[type(n)]          K <= 256, millions of rows (the Q|K|V projection of conv.py:96-97,103)
+//   y[n, :] = x[n, :] @ W[type(n)]^T + b[type(n)]          K = 64 / 128 / 256 / 512, hundreds of thousands of rows and more
+//                                                          (the Q|K|V projection of conv.py:96-97,103; the halo K|V projections)
 //
 // Why another form.  k_typed_linear_pc (hgt_gemm_bf16x3.hip) keeps the 64-row x slab in LDS and streams the WHOLE split image of W
 // (786 KB at d = 256) from L2 into registers once per 64 rows: 12.3 GB per launch at c2 through the CUs' vector-memory pipes, next
@@ -15,13 +16,17 @@
 //     every wavefront's k-loop contains only ds_read_b128 + MFMA (4 reads per 6 MFMAs: a third of the LDS read rate);
 //   * one workgroup barrier per step (3072 MFMA cycles per wavefront); the only vector-memory wait sits at the END of a
 //     k-loop, when the DMA issued a whole step earlier has long landed, in front of the step's 8 output stores;
-//   * the two wavefronts of a SIMD are staggered: wavefronts 0-3 run  k-loop -> epilogue -> barrier,  wavefronts 4-7
-//     k-loop -> barrier -> epilogue,  so one's stores and bookkeeping fall into the other's MFMA stream (in lock-step both would
-//     leave the matrix cores idle during every epilogue);
+//   * the wavefronts are staggered: wavefronts 0-3 run  k-loop -> epilogue -> barrier,  wavefronts 4-7  k-loop -> barrier ->
+//     epilogue,  so that one half's stores and bookkeeping fall into the other half's MFMA stream (measured: 2-3 % over lock-step;
+//     the other orders behind the `stagger` argument -- other pairings, the LDS-DMA owned by half the wavefronts with counted
+//     vmcnt waits, every store behind the step's DMA, non-temporal stores -- are all within +-3 % of it: DESIGN.md section 4);
 //   * the rows of the NEXT item are requested inside the last step's k-loop, k-chunk by k-chunk into the registers the chunk
 //     just released, and split when the loop is done.
 // The accumulation order per output element (k-chunks ascending; lo*hi, hi*lo, hi*hi) is the one of k_typed_linear_pc, so the
-// two kernels are BIT-IDENTICAL (tools/bench_linear.py --xs-check, tests/test_hgt_gpu.py::test_xs_gemm_*).
+// two kernels are BIT-IDENTICAL (tools/bench_xs.py, tests/test_hgt_gpu.py::test_xs_gemm_is_bit_identical_to_the_slab_kernel).
+// K = 512 runs as <NKC 32, 4 wavefronts, 1 column tile per step>: the 256 fragment registers of 32 rows need the 512-register budget of
+// one wavefront per SIMD.  The row-list partition (units of 128 rows, rounds of one or two units of ONE group, contiguous balanced unit
+// ranges per workgroup) is shared with the host-side enumerator hgt_typed_linear_xs_schedule and tested on the CPU.
 // Reads the unchanged image of hgt_split_weights[_f16]: a B fragment is one contiguous 1 KB piece of it.
 #include "hgt_common.h"
 #include "hgt_split_common.h"
