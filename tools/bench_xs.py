@@ -139,7 +139,7 @@ def main():
             (1000000, 256, 768, 4, 0, 0, 0, 0), (1000000, 256, 768, 4, 1, 0, 0, 0),
             (200003, 512, 1536, 3, 0, 0, 0, 1), (200003, 512, 1536, 4, 1, 0, 1, 1), (120001, 512, 512, 3, 0, 0, 0, 1), (3000, 512, 1536, 3, 0, 0, 0, 0),
         ]:
-            for st in ("0", "3", "4", "7", "15"):
+            for st in ("0", "3", "7", "15", "128"):
                 os.environ["HGT_GEMM_XS_STAGGER"] = st
                 ok &= check(lib, N, k, n_out, T, f16, c24, bypos, ragged)
                 if args.quick:
@@ -151,7 +151,7 @@ def main():
         full = n_out == 768 and not f16
         # wavefront orders (see the kernel: 1-3 staggered pairings, +4 DMA owned by the staggered four with counted waits, +8
         # non-temporal stores), then timing-only eliminations on the default (16 no stores, 32 no epilogue, 64 no row loads)
-        bench(lib, N, k, n_out, 4, f16, c24, [0, 3, 6, 16, 32, 64, 96] if full else ([0, 16, 32, 64, 96] if k == 512 and n_out == 1536 and not f16 else [0, 3]))
+        bench(lib, N, k, n_out, 4, f16, c24, [0, 3, 128, 6, 16, 32, 64, 96, 128 + 16, 128 + 64] if full else ([0, 16, 32, 64, 96] if k == 512 and n_out == 1536 and not f16 else [0, 3, 128]))
     os.environ.pop("HGT_GEMM_XS", None)
     sys.exit(0 if ok else 1)
 
