@@ -1695,6 +1695,55 @@ def test_deterministic_hub_mode_is_bit_reproducible(precision, flags):
     assert torch.equal(atomics[others], outs[0][others])       # every non-hub row is deterministic in both modes
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("N,k,n_out,T,prologue", [
+    (300_007, 256, 768, 4, 0),       # the Q|K|V shape: several rounds per workgroup, ragged groups incl. an empty and a 37-row one
+    (1_000_000, 256, 768, 4, 0),     # BASELINE configs[1] row count
+    (300_007, 256, 512, 4, 2),       # halo K|V straight off 24-bit wire rows
+    (300_007, 512, 1536, 4, 0),      # K = 512 (n_hid 512): four wavefronts of 512 registers
+    (1_000_000, 512, 512, 3, 0),
+])
+def test_xs_gemm_against_fp64_at_its_dispatch_sizes(N, k, n_out, T, prologue, precision):
+    """csrc/hgt_gemm_xs.hip is only taken for >= 262 144 rows (K = 512: >= 65 536), so test_typed_linear_against_torch_fp32 (N = 1000)
+    never reaches it and the bit-identity test compares it with another HIP kernel.  Here its output is compared DIRECTLY with a
+    float64 matmul (torch, on the GPU) at the sizes where it is dispatched: ragged, permuted row lists with an empty group, fp32 rows
+    and 24-bit wire rows (conv.py:96-97,103 typed projections).  Tolerances: those of test_typed_linear_against_torch_fp32."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_xs
+    lib = _lib.load()
+    f16 = 1 if precision == "f16x3" else 0
+    x, W, b, rows, off, ws = bench_xs.setup(lib, N, k, n_out, T, f16, seed=N % 89 + k, ragged=1)
+    st = torch.cuda.current_stream().cuda_stream
+    if prologue == 2:
+        idx = torch.arange(N, dtype=torch.int32, device=DEV)
+        wire = torch.empty(N, 3 * k, dtype=torch.uint8, device=DEV)
+        assert lib.hgt_gather_rows_c24(x.data_ptr(), k, idx.data_ptr(), N, k, wire.data_ptr(), st) == 0
+        xin = torch.empty_like(x)
+        assert lib.hgt_unpack_rows_c24(wire.data_ptr(), N, k, xin.data_ptr(), k, st) == 0      # what the kernel's loader decodes
+        xptr, ldx = wire.data_ptr(), 3 * k // 4
+    else:
+        xin, xptr, ldx = x, x.data_ptr(), k
+    nblk = 3 if n_out % 3 == 0 else 2
+    bc = n_out // nblk
+    outs = [torch.full((N, bc), float("nan"), device=DEV) for _ in range(nblk)]
+    bench_xs.run(lib, f16, xptr, ldx, rows, off, T, N, k, n_out, ws, b, outs, bc, 0, prologue)
+    torch.cuda.synchronize()
+    got = torch.cat(outs, 1)
+    assert not torch.isnan(got).any()          # every row of the list was written
+    offl = off.tolist()
+    tol = (4e-6 if f16 else 1e-4) * (k // 256)      # (K = 512: twice the terms per sum)
+    worst = 0.0
+    for t in range(T):
+        r = rows[offl[t]:offl[t + 1]].long()
+        for lo in range(0, r.numel(), 131072):                 # (fp64 reference in slices: 1M x 1536 doubles would be 12 GB)
+            rr = r[lo:lo + 131072]
+            ref = xin[rr].double() @ W[t].double().T + b[t].double()
+            worst = max(worst, float((got[rr].double() - ref).abs().max()))
+    print("xs typed_linear N=%d k=%d n=%d prologue=%d %s err %.2e" % (N, k, n_out, prologue, precision, worst))
+    assert worst < tol
+
+
 @pytest.mark.parametrize("N,k,n_out,T,f16,c24,bypos", [
     (1000, 256, 768, 3, 0, 0, 0),          # a handful of units: one round per workgroup
     (300007, 256, 768, 4, 0, 0, 1),        # several rounds per workgroup: the in-loop prefetch of the next item's rows
