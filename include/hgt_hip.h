@@ -561,6 +561,8 @@ typedef struct hgt_conv_args {
 #define HGT_FLAG_SINGLE_PASS 256     /* ABI 6: hgt_edge_single_pass_items instead of logits + item-parallel aggregation where it applies (sampled
                                       * sub-graphs, attention weights not exported).  Off by default: measured equal at c3 and 5 % slower at c5
                                       * (its two LDS tiles cap it at 4 wavefronts per CU) */
+#define HGT_FLAG_ROUND4_AGGREGATE 512 /* the round-4 fused aggregation kernel (rows gathered through registers) where the default is the LDS-ring
+                                       * form of round 5 (d = 256 / 8 heads, no temporal rows, bf16 split): A/B runs and the bit-identity test */
 #define HGT_FLAG_DETERMINISTIC_HUBS 128 /* ABI 6: targets with more than 1024 in-edges ("hubs") are aggregated WITHOUT atomics: every piece of a
                                       * (hub, relation) range writes its partial row / exp-sum to its own slot and the finalize kernel sums
                                       * the slots in (relation, piece) order, so two forwards are bit-identical on every row (the default

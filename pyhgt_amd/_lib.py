@@ -21,6 +21,7 @@ HGT_FLAG_NO_ITEM_AGGREGATE = 32
 HGT_FLAG_FUSED_ANY_SIZE = 64
 HGT_FLAG_DETERMINISTIC_HUBS = 128
 HGT_FLAG_SINGLE_PASS = 256
+HGT_FLAG_ROUND4_AGGREGATE = 512
 
 
 class HgtLayout(C.Structure):

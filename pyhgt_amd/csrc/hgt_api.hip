@@ -405,9 +405,11 @@ edge_phase:
             rc = split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
             if (rc != HGT_OK) return rc;
         }
-        rc = hgt_edge_aggregate_update_range(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ, hub_ws,
-                                             (int32_t*)(wb + w.off_pending), a->node_type, ws_upd, a->b_a, a->x, din, a->skip, a->ln_w,
-                                             a->ln_b, a->use_norm, dout, a->out, stream, a->q_begin, a->q_end, 0, det_hubs ? 1 : 0);
+        if (a->q_end < 0) return HGT_ERR_INVALID_ARG;
+        rc = hgt_edge_aggregate_update_sel(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ, hub_ws,
+                                           (int32_t*)(wb + w.off_pending), a->node_type, ws_upd, a->b_a, a->x, din, a->skip, a->ln_w,
+                                           a->ln_b, a->use_norm, dout, a->out, stream, a->q_begin, a->q_end, 0, det_hubs ? 1 : 0,
+                                           (a->flags & HGT_FLAG_ROUND4_AGGREGATE) ? 1 : 0);
         mark(4);
         mark(5);
         mark(6);
@@ -448,16 +450,13 @@ edge_phase:
             rc = split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
             if (rc != HGT_OK) return rc;
         }
-        if (det_hubs && hub_ws && msg_f)
-            rc = hgt_edge_aggregate_update_range(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ, hub_ws,
-                                                 (int32_t*)(wb + w.off_pending), a->node_type, ws_upd, a->b_a, a->x, din, a->skip, a->ln_w,
-                                                 a->ln_b, a->use_norm, dout, a->out, stream, 0, NQ, f16 ? 1 : 0, 1);
-        else if (det_hubs && hub_ws)
+        if (det_hubs && hub_ws && !msg_f)
             rc = HGT_ERR_UNSUPPORTED;      // (vector-ALU aggregation: the unfused kernels below carry the deterministic hub mode)
         else
-        rc = (f16 ? hgt_edge_aggregate_update_f16x3 : hgt_edge_aggregate_update)(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ,
-                                       hub_ws, (int32_t*)(wb + w.off_pending), a->node_type,
-                                       ws_upd, a->b_a, a->x, din, a->skip, a->ln_w, a->ln_b, a->use_norm, dout, a->out, stream);
+            rc = hgt_edge_aggregate_update_sel(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ, hub_ws,
+                                               (int32_t*)(wb + w.off_pending), a->node_type, ws_upd, a->b_a, a->x, din, a->skip, a->ln_w,
+                                               a->ln_b, a->use_norm, dout, a->out, stream, 0, (det_hubs && hub_ws) ? NQ : -1, f16 ? 1 : 0,
+                                               (det_hubs && hub_ws) ? 1 : 0, (a->flags & HGT_FLAG_ROUND4_AGGREGATE) ? 1 : 0);
         if (rc == HGT_OK) {
             if (a->want_att && E > 0) {
                 rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);

@@ -959,12 +959,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
     unsigned char* utile = smem + wib * 2 * G::PLANE;
     float* s_m = s_ml + wib * 512;
     float* s_l = s_m + 256;
-    if (any_hub) {      // (the launcher only takes this kernel for R < 64; hub workgroups walk run by run, all four sub-tiles)
-        if (wrow0 < NQ)
-            agg_mfma_hub_workgroup<VEC, LPH, RTE, F16>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, agg, R, NQ, HT, hub_mask, wrow0,
-                                                       utile, s_m, s_l, s_scale + wib * 16, s_sig + wib * 16);
-        return;
-    }
+    if (any_hub) return;      // k_edge_aggregate_hub_workgroups walks the 64 targets of such a workgroup (same launcher)
     f32x4 acc[G::NCT];
     if (wrow0 < NQ) {
         agg_mfma_stream<VEC, LPH, RTE, F16>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, 0, R + 1, HT, 16, wrow0, utile, s_m, s_l,
@@ -1011,6 +1006,41 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
     fused_update_tail<VEC, HGT_FU_NSTG, true, F16>(smem, smem + FRONT, row0, NQ, fu, type_pre);
 }
 
+// The workgroups of the fused kernels that contain a hub target (pending[workgroup] != 0): their non-hub targets are walked run by
+// run here, agg is written, and k_update_pending finishes the rows after the hub kernels.  Its own kernel since round 5: as an
+// out-of-line call inside the fused kernels it gave every launch of them a 504-byte scratch frame (rocprofv3 Scratch_Size).
+template <int VEC, int LPH, bool RTE, bool F16>
+__global__ __launch_bounds__(256, 2) void k_edge_aggregate_hub_workgroups(
+    const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
+    const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
+    const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, float* __restrict__ agg, int R, int64_t NQ, int HT,
+    const int32_t* __restrict__ hub_slot, const int32_t* __restrict__ pending, int64_t q_lo) {
+    using G = MG<VEC, LPH>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 2 * G::PLANE + 4 * 2 * 256 * 4 + 4 * 16 * 4 + (F16 ? 4 * 16 * 4 : 0)];
+    if (pending[q_lo / 64 + blockIdx.x] == 0) return;
+    float* s_ml = reinterpret_cast<float*>(smem + 4 * 2 * G::PLANE);
+    float* s_scale = s_ml + 4 * 2 * 256;
+    float* s_sig = s_scale + (F16 ? 4 * 16 : 0);
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wrow0 = q_lo + (int64_t)blockIdx.x * 64 + wib * 16;
+    if (wrow0 >= NQ) return;
+    const int64_t rr = wrow0 + (lane & 15);
+    const bool is_hub = (lane < 16) && (rr < NQ) && (hub_slot[rr] >= 0);
+    const unsigned hub_mask = (unsigned)(__builtin_amdgcn_ballot_w64(is_hub) & 0xFFFFull);
+    float* s_m = s_ml + wib * 512;
+    agg_mfma_hub_workgroup<VEC, LPH, RTE, F16>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, agg, R, NQ, HT, hub_mask, wrow0,
+                                               smem + wib * 2 * G::PLANE, s_m, s_m + 256, s_scale + wib * 16, s_sig + wib * 16);
+}
+
+#ifndef HGT_AGG_RING
+#define HGT_AGG_RING 1      // 0: d = 256 / 8 heads keeps k_edge_aggregate_update_mfma (A/B builds)
+#endif
+#if defined(HGT_MFMA_PART_VEC) && HGT_MFMA_PART_VEC == 4 && HGT_MFMA_PART_RTE == 0 && HGT_MFMA_PART_F16 == 0 && HGT_AGG_RING
+#define HGT_HAVE_RING 1
+#include "hgt_edge_agg_ring.h"
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // Launchers.  This file is compiled THIRTEEN times (csrc/Makefile): once as the main translation unit (C entry points, dispatch) and
 // once per (VEC, RTE, F16) PART, which instantiates the kernels of its five lane layouts -- the 60 x 2 kernel instantiations are then
@@ -1056,9 +1086,22 @@ static int launch_aggupd_mfma(HGT_MFMA_AGGUPD_ARGS) {
     const int64_t tiles = (NQ - fu.q_lo + 63) / 64;      // NQ = end of the launch's target range
     dim3 grid((unsigned)tiles, 1);
     const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
-    k_edge_aggregate_update_mfma<VEC, LPH, RTE, F16><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
-                                                                              agg, R, NQ, HT, hub_slot, pending, fu);
-    if (hb.mx) {   // hub path + the update of the workgroups that had to wait for it
+    bool ring = false;
+#ifdef HGT_HAVE_RING
+    // d = 256 / 8 heads, no temporal rows, bf16 split: the ring form (hgt_edge_agg_ring.h; bit-identical, rows by LDS-DMA)
+    if constexpr (VEC == 4 && LPH == 8 && !RTE && !F16) {
+      if (!fu.no_ring) {
+        ring = true;
+        k_edge_aggregate_update_ring<false><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, logits, V, msgF, R, NQ, hub_slot, pending, fu);
+      }
+    }
+#endif
+    if (!ring)
+        k_edge_aggregate_update_mfma<VEC, LPH, RTE, F16><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
+                                                                                  agg, R, NQ, HT, hub_slot, pending, fu);
+    if (hb.mx) {   // workgroups with a hub target: their other targets, then the hub path + the update of those workgroups
+        k_edge_aggregate_hub_workgroups<VEC, LPH, RTE, F16><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
+                                                                                     agg, R, NQ, HT, hub_slot, pending, fu.q_lo);
         int rc = hgt_launch_hub(VEC, LPH, pv, logits, V, rteV, msgP, agg, R, NQ, 1, HT, hb, 1u, (int64_t)HT * (VEC * LPH), stream);
         if (rc != HGT_OK) return rc;
         k_update_pending<VEC, F16><<<grid, 256, 0, stream>>>(agg, (int64_t)HT * (VEC * LPH), NQ, pending, fu);
@@ -1292,7 +1335,7 @@ static int edge_aggregate_update_impl(bool f16, const void* plan, int64_t N, int
                                       const int64_t* node_type, const void* w_a_split, const float* b_a, const float* x_skip,
                                       int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm,
                                       int32_t n_out, float* out, void* stream, int64_t q_begin = 0, int64_t q_end = -1,
-                                      bool det_hubs = false) {
+                                      bool det_hubs = false, bool no_ring = false) {
     if (f16 && !msg_frag) return HGT_ERR_INVALID_ARG;
     if (!plan || !V || !msg_p || !agg || !pending || !node_type || !w_a_split || !b_a || !x_skip || !skip || !out || H <= 0 ||
         64 % H != 0 || dk_pad <= 0 || n_out <= 0)
@@ -1315,7 +1358,7 @@ static int edge_aggregate_update_impl(bool f16, const void* plan, int64_t N, int
     HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
     HgtHubBuffers hb = carve_hub(hub_ws, pv, H, E, dk_pad, R, det_hubs);
     HgtFusedUpdate fu = {node_type, (const unsigned short*)w_a_split, b_a, x_skip, ld_skip, skip, ln_w, ln_b, use_norm, T, n_out, out,
-                         ranged ? q_begin : 0};
+                         ranged ? q_begin : 0, no_ring ? 1 : 0};
     if (ranged) { hb.q_lo = q_begin; hb.q_hi = q_end; }
     int rc = HGT_ERR_UNSUPPORTED;
     if (msg_frag && mfma_split_for(dk_pad / lph, lph) == 1)
@@ -1344,6 +1387,10 @@ extern "C" int hgt_edge_aggregate_update_range(HGT_AGGUPD_PARAMS, int64_t q_begi
                                                int32_t hub_deterministic) {
     if (q_end < 0) return HGT_ERR_INVALID_ARG;
     return edge_aggregate_update_impl(frag_f16 != 0, HGT_AGGUPD_PASS, q_begin, q_end, hub_deterministic != 0);
+}
+
+int hgt_edge_aggregate_update_sel(HGT_AGGUPD_PARAMS, int64_t q_begin, int64_t q_end, int32_t frag_f16, int32_t hub_deterministic, int32_t no_ring) {
+    return edge_aggregate_update_impl(frag_f16 != 0, HGT_AGGUPD_PASS, q_begin, q_end, hub_deterministic != 0, no_ring != 0);
 }
 
 // out[i][ld_out] = sum_rel ( sum_{e in (i,rel)} w_e rows[src_e] ) F[rel]  -- the aggregation kernel without the softmax: the edge

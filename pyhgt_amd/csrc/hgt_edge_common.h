@@ -38,7 +38,9 @@ struct HgtFusedUpdate {
     int use_norm, n_types, n_out;
     float* out;                      // [NQ][n_out]
     int64_t q_lo;                    // first target row of the launch (a multiple of 64): workgroup b owns rows q_lo + 64 b ..
+    int no_ring;                     // HGT_FLAG_ROUND4_AGGREGATE: keep k_edge_aggregate_update_mfma where the ring form would run
 };
+
 
 // hub kernels (hgt_edge_hub.hip): max / exp-sum + weighted sum / finalize for the targets the plan marked as hubs.
 // vec / lph = the (possibly head-group split) layout the calling aggregation kernel runs with, ny = number of head groups.

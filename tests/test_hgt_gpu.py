@@ -1021,6 +1021,55 @@ def test_fused_aggregate_update_matches_oracle(case, precision):
     assert out[nt == T + 3].abs().max().item() == 0.0
 
 
+RING_CASES = [
+    # N, E, T, R, graph kwargs, edits
+    (70_000, 700_000, 4, 8, {}, ""),                                   # the benchmark's shape: ~10 in-edges per target, every relation in every sub-tile
+    (66_001, 150_000, 3, 8, dict(sorted_types=False), "unknown"),       # ragged last tile, empty relations / targets, unknown types, unclaimed edges
+    (70_000, 2_000_000, 4, 33, {}, ""),                                # long streams (several 64-entry chunks per sub-tile), 33 relations
+    (80_000, 400_000, 2, 5, dict(dst_skew=1.05), "hubs"),              # hub workgroups leave the kernel (k_edge_aggregate_hub_workgroups)
+    (65_536, 70_000, 4, 8, {}, "one_relation"),                        # one relation only: a single fragment set, long runs of one target
+]
+
+
+@pytest.mark.parametrize("case", RING_CASES, ids=[str(i) for i in range(len(RING_CASES))])
+def test_ring_aggregation_is_bit_identical_to_the_round4_kernel(case):
+    """csrc/hgt_edge_agg_ring.h (round 5: gathered rows through an LDS ring by LDS-DMA, U tile in registers, fragments requested a
+    relation ahead, hand-counted vmcnt waits) performs the arithmetic of k_edge_aggregate_update_mfma in the same order: at
+    d = 256 / 8 heads the two must agree to the BIT (HGT_FLAG_ROUND4_AGGREGATE selects the old kernel), and with the fp64 oracle to
+    the split-bf16 bound."""
+    N, E, T, R, gk, edit = case
+    d, H = 256, 8
+    sd = O.make_state_dict(d, d, T, R, H, True, False, seed=N % 1000 + R)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=E % 1000 + 9, with_time=False, **gk)
+    nt, et, ei = nt.clone(), et.clone(), ei.clone()
+    if edit == "unknown":
+        nt[::211] = T + 3
+        et[::97] = R
+    if edit == "hubs":
+        ei[1, :3000] = 12_345
+        ei[1, 3000:5000] = 70_001
+    if edit == "one_relation":
+        et[:] = 3
+        ei[1, :40_000] = ei[1, :40_000] % 97          # runs of ~400 edges into one target (below the hub threshold)
+    layer = _layer_from(sd, d, T, R, H, True, False, keep_att=False, precision="bf16x3")
+    outs = []
+    det = _lib.HGT_FLAG_DETERMINISTIC_HUBS if edit == "hubs" else 0      # (hub rows: atomics by default, not run-to-run reproducible)
+    for flags in (0, _lib.HGT_FLAG_ROUND4_AGGREGATE, 0):
+        layer.kernel_flags = flags | det
+        out, _ = _run(layer, x, nt, ei, et, None)
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[2])                       # run-to-run
+    same = torch.equal(outs[0], outs[1])
+    if not same:
+        bad = (outs[0] != outs[1]).any(dim=1).nonzero().flatten()
+        print("ring vs round-4 kernel: %d differing rows, first %s, max |d| %.3e" % (
+            bad.numel(), bad[:8].tolist(), (outs[0] - outs[1]).abs().max().item()))
+    assert same
+    if N * E <= 70_000 * 700_000:
+        ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, None, use_norm=True, use_RTE=False, dtype=torch.float64)
+        assert (outs[0].double() - ref).abs().max().item() < PREC_TOL["bf16x3"]
+
+
 @pytest.mark.parametrize("order", ["small_first", "large_first"])
 @pytest.mark.parametrize("N", [3000, 70_000])        # unfused (4 targets per wavefront) and fused (streaming walk) aggregation
 def test_f16_split_rows_of_very_different_size_per_relation(N, order):
