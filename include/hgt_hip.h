@@ -148,9 +148,14 @@ int hgt_plan_from_sorted(const int32_t* src, const int32_t* dst, const int32_t* 
  *             to out{c}[row * block_cols + col]; row = rows[p] (out_by_position = 0) or p (= 1)
  *   prologue  0 = none, 1 = exact (erf) GELU applied to x on load (conv.py:119); split variants only (ABI 6): 2 = x holds rows in the
  *             24-bit transport format of the multi-GPU exchange (hgt_gather_rows_c24; ldx = 3 k / 4 dwords, k <= 256, k % 4 == 0),
- *             decoded by the kernel's loader -- the halo rows a rank receives are projected straight off the wire buffer
+ *             decoded by the kernel's loader -- the halo rows a rank receives are projected straight off the wire buffer.
+ *             Split variants: | HGT_LINEAR_FORCE_XS takes the x-stationary kernel (hgt_gemm_xs.hip) for every shape it covers
+ *             whatever the row count (default: from 262 144 rows, K = 512 from 65 536), | HGT_LINEAR_NO_XS never takes it -- the
+ *             two kernels are bit-identical; the bits exist for tests and A/B timings (no environment variable is read)
  *   precision must be 0 (fp32 MFMA, exact fp32 FMA chain); the split-bf16 variant is below
  * ---------------------------------------------------------------------------------------------- */
+#define HGT_LINEAR_FORCE_XS 0x100
+#define HGT_LINEAR_NO_XS 0x200
 int hgt_typed_linear(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off,
                      int32_t n_groups, int64_t n_rows, int32_t k, int32_t n_out,
                      const float* W, int64_t w_group_stride, const float* bias, int64_t b_group_stride,
@@ -386,8 +391,9 @@ int hgt_edge_aggregate_update_f16x3(const void* plan, int64_t n_nodes, int64_t n
                                     int32_t use_norm, int32_t n_out, float* out, void* stream);
 
 /* ABI 6: hgt_edge_aggregate_update for the targets [q_begin, q_end) only (q_begin a multiple of the plan tile, q_end <= n_q_rows):
- * one TARGET BLOCK of the multi-GPU path, whose in-edges only reference source rows that have already arrived.  `pending` is indexed
- * from the block's first workgroup.  Matrix-core kernel only (msg_frag required).  frag_f16: msg_frag / w_a_split are the fp16 images;
+ * one TARGET BLOCK of the multi-GPU path, whose in-edges only reference source rows that have already arrived.  `pending` must hold
+ * (n_q_rows + 63) / 64 entries like in the whole-graph call: the kernels index it by ABSOLUTE 64-row tile (q_begin / 64 + workgroup),
+ * so that target blocks of one layer may run concurrently.  Matrix-core kernel only (msg_frag required).  frag_f16: msg_frag / w_a_split are the fp16 images;
  * hub_deterministic: see HGT_FLAG_DETERMINISTIC_HUBS. */
 int hgt_edge_aggregate_update_range(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                                     int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
@@ -561,8 +567,12 @@ typedef struct hgt_conv_args {
 #define HGT_FLAG_SINGLE_PASS 256     /* ABI 6: hgt_edge_single_pass_items instead of logits + item-parallel aggregation where it applies (sampled
                                       * sub-graphs, attention weights not exported).  Off by default: measured equal at c3 and 5 % slower at c5
                                       * (its two LDS tiles cap it at 4 wavefronts per CU) */
-#define HGT_FLAG_ROUND4_AGGREGATE 512 /* the round-4 fused aggregation kernel (rows gathered through registers) where the default is the LDS-ring
-                                       * form of round 5 (d = 256 / 8 heads, no temporal rows, bf16 split): A/B runs and the bit-identity test */
+#define HGT_FLAG_XS_GEMM_ALWAYS 1024 /* ABI 6: the x-stationary split GEMM (hgt_gemm_xs.hip) for every typed linear of the layer it covers, whatever
+                                      * the row count (HGT_LINEAR_FORCE_XS); */
+#define HGT_FLAG_XS_GEMM_NEVER 2048  /* ... never (HGT_LINEAR_NO_XS): the slab kernels.  Bit-identical results either way: tests / A/B timings */
+#define HGT_FLAG_RING_AGGREGATE 512 /* ABI 6: the LDS-ring form of the fused aggregation kernel (round 5, csrc/hgt_edge_agg_ring.h: rows by LDS-DMA,
+                                     * U tile in registers) where it exists (d = 256 / 8 heads, no temporal rows, bf16 split) instead of the
+                                     * default kernel: bit-identical, measured 4 % slower at c2 -- kept for A/B runs */
 #define HGT_FLAG_DETERMINISTIC_HUBS 128 /* ABI 6: targets with more than 1024 in-edges ("hubs") are aggregated WITHOUT atomics: every piece of a
                                       * (hub, relation) range writes its partial row / exp-sum to its own slot and the finalize kernel sums
                                       * the slots in (relation, piece) order, so two forwards are bit-identical on every row (the default

@@ -21,7 +21,11 @@ HGT_FLAG_NO_ITEM_AGGREGATE = 32
 HGT_FLAG_FUSED_ANY_SIZE = 64
 HGT_FLAG_DETERMINISTIC_HUBS = 128
 HGT_FLAG_SINGLE_PASS = 256
-HGT_FLAG_ROUND4_AGGREGATE = 512
+HGT_FLAG_RING_AGGREGATE = 512
+HGT_FLAG_XS_GEMM_ALWAYS = 1024
+HGT_FLAG_XS_GEMM_NEVER = 2048
+HGT_LINEAR_FORCE_XS = 0x100
+HGT_LINEAR_NO_XS = 0x200
 
 
 class HgtLayout(C.Structure):

@@ -435,6 +435,7 @@ class HGTConv(nn.Module):
     _warned_eval_grad = False
 
     # -- state that is not part of the reference module: caches of packed parameters / device-side weight images ------
+    EXTRA_KERNEL_FLAGS = 0      # OR-ed into every layer's kernel_flags (tests: tests/conftest.py sets it from HGT_TEST_KERNEL_FLAGS)
     _RUNTIME_DEFAULTS = dict(keep_att=False, precision="bf16x3", kernel_flags=0, strict=None, att=None, _packed=None, _packed_key=None,
                              _prepared=None, _prepared_tag=None, _prepared_valid=False, _plist=None)
 
@@ -699,7 +700,7 @@ class HGTConv(nn.Module):
         if stage == 5:
             a.q_begin, a.q_end, a.item_begin, a.item_end = (int(v) for v in block)
         a.plan_no_hubs = int(plan.no_hubs) | (2 if plan.no_unknown_rows else 0)
-        a.flags = int(self.kernel_flags)
+        a.flags = int(self.kernel_flags) | int(HGTConv.EXTRA_KERNEL_FLAGS)
         prep = self._prepared_buffer(x.device, n_slices, prec)          # after _pack_parameters: a re-pack has invalidated it
         a.prepared, a.prepared_bytes, a.prepared_valid = _ptr(prep), prep.numel(), int(self._prepared_valid)
         if stage == 2:

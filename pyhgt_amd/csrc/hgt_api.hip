@@ -313,8 +313,10 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
             int r2 = split_weights(Wp, wgs, ng, kk, nout, wsplit, stream);
             if (r2 != HGT_OK) return r2;
         }
-        return f16 ? hgt_typed_linear_f16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos, prologue, stream)
-                   : hgt_typed_linear_bf16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos, prologue,
+        // (kernel-selection bits of the split linears: HGT_FLAG_XS_GEMM_ALWAYS / _NEVER -- tests and A/B runs)
+        const int sel = (a->flags & HGT_FLAG_XS_GEMM_NEVER) ? HGT_LINEAR_NO_XS : ((a->flags & HGT_FLAG_XS_GEMM_ALWAYS) ? HGT_LINEAR_FORCE_XS : 0);
+        return f16 ? hgt_typed_linear_f16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos, prologue | sel, stream)
+                   : hgt_typed_linear_bf16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos, prologue | sel,
                                              stream);
     };
     void* ws_qkv_scratch = wb + w.off_ws_qkv;                       // K|V-only tiles of the halo branch
@@ -409,7 +411,7 @@ edge_phase:
         rc = hgt_edge_aggregate_update_sel(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ, hub_ws,
                                            (int32_t*)(wb + w.off_pending), a->node_type, ws_upd, a->b_a, a->x, din, a->skip, a->ln_w,
                                            a->ln_b, a->use_norm, dout, a->out, stream, a->q_begin, a->q_end, 0, det_hubs ? 1 : 0,
-                                           (a->flags & HGT_FLAG_ROUND4_AGGREGATE) ? 1 : 0);
+                                           (a->flags & HGT_FLAG_RING_AGGREGATE) ? 1 : 0);
         mark(4);
         mark(5);
         mark(6);
@@ -456,7 +458,7 @@ edge_phase:
             rc = hgt_edge_aggregate_update_sel(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_p, msg_f, agg, NQ, hub_ws,
                                                (int32_t*)(wb + w.off_pending), a->node_type, ws_upd, a->b_a, a->x, din, a->skip, a->ln_w,
                                                a->ln_b, a->use_norm, dout, a->out, stream, 0, (det_hubs && hub_ws) ? NQ : -1, f16 ? 1 : 0,
-                                               (det_hubs && hub_ws) ? 1 : 0, (a->flags & HGT_FLAG_ROUND4_AGGREGATE) ? 1 : 0);
+                                               (det_hubs && hub_ws) ? 1 : 0, (a->flags & HGT_FLAG_RING_AGGREGATE) ? 1 : 0);
         if (rc == HGT_OK) {
             if (a->want_att && E > 0) {
                 rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);

@@ -37,7 +37,7 @@ int hgt_edge_aggregate_update_sel(const void* plan, int64_t N, int64_t E, int32_
                                   void* hub_ws, int32_t* pending, const int64_t* node_type, const void* w_a_split, const float* b_a,
                                   const float* x_skip, int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm,
                                   int32_t n_out, float* out, void* stream, int64_t q_begin, int64_t q_end, int32_t frag_f16,
-                                  int32_t hub_deterministic, int32_t no_ring);
+                                  int32_t hub_deterministic, int32_t use_ring);
 
 static inline uint64_t hgt_align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 

@@ -422,6 +422,8 @@ __device__ __forceinline__ void agg_mfma_stream(
     // then walked again with 2^14 more headroom FOR THE TARGETS THAT OVERFLOWED (shiftv; a column of the transposed product only
     // depends on its own target's rows, so the other targets of the sub-tile keep their scales and reproduce their values).
     // Rows within 2^14 of their target's first row -- a logit spread of ~9.7 above the first logit seen -- never retry.
+    // The retries are not capped below the fp32 range (round-4 advisor finding: a cap of 4 published NaN for a target whose first row
+    // was 2^70 smaller than a later one).
     float sigv = 0.0f;
     int shiftv = 0;      // extra headroom (powers of two) per target, lane i = target i: grows by 14 for a target whose rows overflowed
 #ifndef HGT_AGG_UN
@@ -694,12 +696,12 @@ __device__ __forceinline__ void agg_mfma_stream(
                     dlt = SL[u] - m_ref;                                                           \
                 }                                                                                  \
                 const float pe = raw ? SL[u] : __expf(dlt);   /* raw: the array holds the edge weights themselves */ \
-                if (claimed_) {                                                                    \
-                    _Pragma("unroll") for (int i = 0; i < VEC; ++i) {                              \
-                        float vv = row_elem(VR[u], i);                                             \
-                        if constexpr (RTE) vv += row_elem(TR[u], i);                               \
-                        U[i] = fmaf(pe, vv, U[i]);                                                 \
-                    }                                                                              \
+                /* (no `if (claimed_)`: the rows of the unclaimed bucket are gathered too -- valid addresses -- and their sums are */ \
+                /*  never parked (seg_claimed); as a condition it compiled to four v_cndmask per row, round-5 ISA audit) */          \
+                _Pragma("unroll") for (int i = 0; i < VEC; ++i) {                                  \
+                    float vv = row_elem(VR[u], i);                                                 \
+                    if constexpr (RTE) vv += row_elem(TR[u], i);                                   \
+                    U[i] = fmaf(pe, vv, U[i]);                                                     \
                 }                                                                                  \
                 l_seg += pe;                                                                       \
             }                                                                                      \
@@ -752,7 +754,7 @@ __device__ __forceinline__ void agg_mfma_stream(
 #pragma unroll
         for (int c = 0; c < NCT; ++c) chk = fmaf(acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3], 0.0f, chk);
         const unsigned long long bad = __builtin_amdgcn_ballot_w64(chk != chk);      // lane -> its target is (lane & 15)
-        if (bad == 0 || attempt >= 4) {
+        if (bad == 0 || attempt >= 20) {      // (every retry adds 2^14 of headroom: 18 cover the whole fp32 range -- finite rows always end with bad == 0)
             if (lane < 16) s_sig[lane] = sigv;      // for agg_mfma_finish
             break;
         }
@@ -1034,7 +1036,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_hub_workgroups(
 }
 
 #ifndef HGT_AGG_RING
-#define HGT_AGG_RING 1      // 0: d = 256 / 8 heads keeps k_edge_aggregate_update_mfma (A/B builds)
+#define HGT_AGG_RING 1      // 0: the ring form is not built
 #endif
 #if defined(HGT_MFMA_PART_VEC) && HGT_MFMA_PART_VEC == 4 && HGT_MFMA_PART_RTE == 0 && HGT_MFMA_PART_F16 == 0 && HGT_AGG_RING
 #define HGT_HAVE_RING 1
@@ -1088,9 +1090,9 @@ static int launch_aggupd_mfma(HGT_MFMA_AGGUPD_ARGS) {
     const int32_t* hub_slot = hb.mx ? pv.hub_slot : nullptr;
     bool ring = false;
 #ifdef HGT_HAVE_RING
-    // d = 256 / 8 heads, no temporal rows, bf16 split: the ring form (hgt_edge_agg_ring.h; bit-identical, rows by LDS-DMA)
+    // d = 256 / 8 heads, no temporal rows, bf16 split, on request (HGT_FLAG_RING_AGGREGATE): the ring form (hgt_edge_agg_ring.h)
     if constexpr (VEC == 4 && LPH == 8 && !RTE && !F16) {
-      if (!fu.no_ring) {
+      if (fu.ring) {
         ring = true;
         k_edge_aggregate_update_ring<false><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, logits, V, msgF, R, NQ, hub_slot, pending, fu);
       }
@@ -1335,7 +1337,7 @@ static int edge_aggregate_update_impl(bool f16, const void* plan, int64_t N, int
                                       const int64_t* node_type, const void* w_a_split, const float* b_a, const float* x_skip,
                                       int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b, int32_t use_norm,
                                       int32_t n_out, float* out, void* stream, int64_t q_begin = 0, int64_t q_end = -1,
-                                      bool det_hubs = false, bool no_ring = false) {
+                                      bool det_hubs = false, bool use_ring = false) {
     if (f16 && !msg_frag) return HGT_ERR_INVALID_ARG;
     if (!plan || !V || !msg_p || !agg || !pending || !node_type || !w_a_split || !b_a || !x_skip || !skip || !out || H <= 0 ||
         64 % H != 0 || dk_pad <= 0 || n_out <= 0)
@@ -1358,7 +1360,7 @@ static int edge_aggregate_update_impl(bool f16, const void* plan, int64_t N, int
     HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
     HgtHubBuffers hb = carve_hub(hub_ws, pv, H, E, dk_pad, R, det_hubs);
     HgtFusedUpdate fu = {node_type, (const unsigned short*)w_a_split, b_a, x_skip, ld_skip, skip, ln_w, ln_b, use_norm, T, n_out, out,
-                         ranged ? q_begin : 0, no_ring ? 1 : 0};
+                         ranged ? q_begin : 0, use_ring ? 1 : 0};
     if (ranged) { hb.q_lo = q_begin; hb.q_hi = q_end; }
     int rc = HGT_ERR_UNSUPPORTED;
     if (msg_frag && mfma_split_for(dk_pad / lph, lph) == 1)
@@ -1389,8 +1391,8 @@ extern "C" int hgt_edge_aggregate_update_range(HGT_AGGUPD_PARAMS, int64_t q_begi
     return edge_aggregate_update_impl(frag_f16 != 0, HGT_AGGUPD_PASS, q_begin, q_end, hub_deterministic != 0);
 }
 
-int hgt_edge_aggregate_update_sel(HGT_AGGUPD_PARAMS, int64_t q_begin, int64_t q_end, int32_t frag_f16, int32_t hub_deterministic, int32_t no_ring) {
-    return edge_aggregate_update_impl(frag_f16 != 0, HGT_AGGUPD_PASS, q_begin, q_end, hub_deterministic != 0, no_ring != 0);
+int hgt_edge_aggregate_update_sel(HGT_AGGUPD_PARAMS, int64_t q_begin, int64_t q_end, int32_t frag_f16, int32_t hub_deterministic, int32_t use_ring) {
+    return edge_aggregate_update_impl(frag_f16 != 0, HGT_AGGUPD_PASS, q_begin, q_end, hub_deterministic != 0, use_ring != 0);
 }
 
 // out[i][ld_out] = sum_rel ( sum_{e in (i,rel)} w_e rows[src_e] ) F[rel]  -- the aggregation kernel without the softmax: the edge

@@ -24,6 +24,9 @@
 #ifndef RG_LAB
 #define RG_LAB 0      // timing-only experiment switches (wrong results): see the uses
 #endif
+#ifndef RG_OFF
+#define RG_OFF 0      // timing-only: bit mask of parts left out -- 1 node update, 2 register fills of parked rows, 4 parking (split + LDS
+#endif                // writes + fills), 8 relation transforms, 16 waits for rows, 32 the row DMA instruction, 64 exp + fma
 #ifndef RG_DEPTH
 #define RG_DEPTH 8
 #endif
@@ -31,7 +34,8 @@ constexpr int RG_D = RG_DEPTH;                            // ring slots: RG_D - 
 constexpr int RG_RING = RG_D * 1024;
 constexpr int RG_LOG = 2 * 2048;                          // logits of two 64-entry chunks ([2 halves of the heads][64 entries][4 floats])
 constexpr int RG_META = 2 * 512;                          // source ids | target ids of two chunks
-constexpr int RG_BNC = 1024;                              // bounce row: hi plane | mid plane
+constexpr int RG_PARK = 4;                                // parked rows per fill of the U registers
+constexpr int RG_BNC = RG_PARK * 1024;                    // park buffer: RG_PARK x (hi plane | mid plane)
 constexpr int RG_PEND = 512;                              // pending scales of the accumulator columns, [16 targets][8 heads]
 constexpr int RG_WAVE = RG_RING + RG_LOG + RG_META + RG_BNC + RG_PEND;
 constexpr int RG_FRONT = 4 * RG_WAVE > 2 * A_PLANE ? 4 * RG_WAVE : 2 * A_PLANE;      // the epilogue's A slab overlays the wavefronts' regions
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_ring(
             int i_idx = 0, i_par = 0;              // issue pointer: entry inside its chunk, the chunk's buffers
             int i_slot = 0;
             int skip = 0;                          // rows known to have landed (no wait)
-            bool started = false, pend_any = false;
+            bool started = false, pend_any = false, chunk_due = false;
             int cur_dl = -1;
             unsigned rowmask = 0;
             float U0 = 0.f, U1 = 0.f, U2 = 0.f, U3 = 0.f, m_ref = 0.0f, l_seg = 0.0f, l_old = 0.0f;
@@ -176,57 +180,81 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_ring(
 
             // one row issued: entry at the issue pointer -> slot i_slot; the pointer advances
             auto issue_row = [&]() {
-                const int src = __builtin_amdgcn_readlane(v_src, i_idx);
-                if constexpr (WIDE) rg_dma16_s(V + (int64_t)src * 256, voff, lds_w + (unsigned)i_slot);
+                const int src = (RG_LAB == 5) ? 0 : __builtin_amdgcn_readlane(v_src, i_idx);      // (5: every gather reads row 0: cache hits)
+                if (RG_OFF & 32) asm volatile("" ::"v"(((unsigned)src << 10) + voff), "s"(lds_w + (unsigned)i_slot));
+                else if constexpr (WIDE) rg_dma16_s(V + (int64_t)src * 256, voff, lds_w + (unsigned)i_slot);
                 else rg_dma16_s(V, ((unsigned)src << 10) + voff, lds_w + (unsigned)i_slot);
-                i_slot = (i_slot + 1024 == RG_RING) ? 0 : i_slot + 1024;
                 if (++i_idx == 64) {      // the issue pointer enters the next chunk: its ids landed long ago (>= 64 - RG_D rows consumed since)
                     i_idx = 0;
                     i_par ^= 1;
                     v_src = *reinterpret_cast<const int*>(metab + i_par * 512 + lane * 4);
+                    // (waited for HERE, once per 64 rows: left pending, the loop head's merged scoreboard puts an lgkmcnt(0) -- a full
+                    //  drain of the LDS queue, parked-row reads included -- in front of every v_readlane of it)
+                    asm volatile("" : "+v"(v_src));
                 }
             };
-            // row at the fetch pointer -> registers (its logit, its target, its target's softmax state); the pointer advances
-            auto fetch_row = [&](float4& row, float& sl, int& dl, float& mt, float& lo) {
-                if (skip > 0) --skip;
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RG_D - 1) : "memory");      // (the row RG_D - 1 issues ago)
-                row = *reinterpret_cast<const float4*>(p_ring + f_slot);
-                sl = *reinterpret_cast<const float*>(p_log + f_par * 2048 + f_idx * 16);
-                dl = __builtin_amdgcn_readlane(v_dst, f_idx);
-                mt = p_state[dl * 8];
-                lo = p_state[dl * 8 + 128];
-                f_slot = (f_slot + 1024 == RG_RING) ? 0 : f_slot + 1024;
-                if (++f_idx == 64) {      // the fetch pointer enters the next chunk: the previous chunk's buffers are free
-                    f_idx = 0;
-                    f_par ^= 1;
-                    ++f_chunk;
-                    v_dst = *reinterpret_cast<const int*>(metab + f_par * 512 + 256 + lane * 4) - (int)wrow0;
-                    if ((f_chunk + 1) * 64 < total_iss) chunk_issue((f_chunk + 1) * 64, f_par ^ 1);
-                }
-            };
+            // row at the fetch pointer -> registers (and its logit, its target); the pointer advances.  WAIT = the vmcnt immediate: RG_D - 1
+            // when this iteration's row has been issued already, RG_D - 2 before it
+#define RG_FETCH(row, sl, dl, WAIT)                                                                                                \
+    {                                                                                                                              \
+        if (skip > 0) --skip;                                                                                                      \
+        else if (RG_LAB != 6 && !(RG_OFF & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");                                          \
+        row = *reinterpret_cast<const float4*>(p_ring + f_slot);                                                                   \
+        sl = *reinterpret_cast<const float*>(p_log + f_par * 2048 + f_idx * 16);                                                   \
+        dl = __builtin_amdgcn_readlane(v_dst, f_idx);                                                                              \
+        n_slot = f_slot;                                                                                                           \
+        f_slot = (f_slot + 1024 == RG_RING) ? 0 : f_slot + 1024;                                                                   \
+        if (++f_idx == 64) {      /* the fetch pointer enters the next chunk: the previous chunk's buffers are free (chunk_due) */ \
+            f_idx = 0;                                                                                                             \
+            f_par ^= 1;                                                                                                            \
+            ++f_chunk;                                                                                                             \
+            v_dst = *reinterpret_cast<const int*>(metab + f_par * 512 + 256 + lane * 4) - (int)wrow0;                              \
+            asm volatile("" : "+v"(v_dst));                                                                                        \
+            chunk_due = true;                                                                                                      \
+        }                                                                                                                          \
+    }
+            int n_slot = 0;
 
+            // Parked rows wait in the park buffer (RG_PARK slots of hi | mid) and reach the U registers RG_PARK at a time: the exec-masked
+            // fill is 16 ds_read_b128 whatever the number of lanes -- per row it cost 0.3 ms of the launch (profiles/r05_*), now a quarter.
+            //   pk = rows waiting, pmask = the lanes that hold their targets' columns, slotv = byte offset of each such lane's slot
+            int pk = 0;
+            unsigned long long pmask = 0;
+            int slotv = 0;
+            auto fill = [&]() {
+                if (pk > 0) {
+                    if ((pmask >> lane) & 1ull) {
+                        const unsigned char* b = bnc + fg * 16 + slotv;
+#pragma unroll
+                        for (int hh = 0; hh < 8; ++hh) {
+                            ubh[hh] = *reinterpret_cast<const bf16x8*>(b + 64 * hh);
+                            ubm[hh] = *reinterpret_cast<const bf16x8*>(b + 512 + 64 * hh);
+                        }
+                    }
+                    pk = 0;
+                    pmask = 0;
+                }
+            };
+            // park the running segment: its exp-sum joins the target's state, its row goes into the U tile.  Afterwards (m_ref, l_old) are
+            // the state of target cur_dl as it stands in LDS.
             auto flush = [&]() {
                 if (cur_dl >= 0) {
                     const int dl = cur_dl;
-                    // (every lane of a head writes the same pair: no exec mask)
-                    const float l_new = l_old + l_seg;
-                    s_m[dl * 8 + h] = m_ref;
-                    s_l[dl * 8 + h] = l_new;
-                    l_old = l_new;      // (the next segment may belong to the same target: its state is what was just written)
-                    if (con_rel < R && RG_LAB != 4) {
+                    l_old = l_old + l_seg;
+                    l_seg = 0.0f;
+                    s_m[dl * 8 + h] = m_ref;      // (every lane of a head writes the same pair: no exec mask)
+                    s_l[dl * 8 + h] = l_old;
+                    if (con_rel < R && RG_LAB != 4 && !(RG_OFF & 4)) {
                         uint2 hi, mid;
                         split4(make_float4(U0, U1, U2, U3), hi, mid);
-                        *reinterpret_cast<uint2*>(bnc + lane * 8) = hi;
-                        *reinterpret_cast<uint2*>(bnc + 512 + lane * 8) = mid;
-                        if (fi == dl && RG_LAB != 2) {      // the four lanes of this target's column: 8 heads x (hi, mid) x 16 B
-                            const unsigned char* b = bnc + fg * 16;
-#pragma unroll
-                            for (int hh = 0; hh < 8; ++hh) {
-                                ubh[hh] = *reinterpret_cast<const bf16x8*>(b + 64 * hh);
-                                ubm[hh] = *reinterpret_cast<const bf16x8*>(b + 512 + 64 * hh);
-                            }
-                        }
+                        unsigned char* w = bnc + pk * 1024 + lane * 8;
+                        *reinterpret_cast<uint2*>(w) = hi;
+                        *reinterpret_cast<uint2*>(w + 512) = mid;
+                        const bool mine = (fi == dl);
+                        slotv = mine ? pk * 1024 : slotv;
+                        pmask |= __builtin_amdgcn_ballot_w64(mine);
                         rowmask |= 1u << dl;
+                        if (++pk == RG_PARK && RG_LAB != 2 && !(RG_OFF & 2)) fill();
                     }
                 }
             };
@@ -250,11 +278,12 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_ring(
 #define RG_BOUNDARY()                                                                                                              \
     {                                                                                                                              \
         flush();                                                                                                                   \
+        if (RG_LAB != 2 && !(RG_OFF & 2)) fill();                                                                                  \
         cur_dl = -1;                                                                                                               \
         bool drained = false;                                                                                                      \
-        if (rowmask != 0 && RG_LAB != 3) {   /* Z^T += M_r^T . U_r^T for the rows parked during relation con_rel */                  \
+        if (rowmask != 0 && RG_LAB != 3 && !(RG_OFF & 8)) {   /* Z^T += M_r^T . U_r^T for the rows parked during relation con_rel */                  \
             const unsigned short* fb_cur = msgF + (int64_t)con_rel * (NCT * 2 * 512);                                              \
-            if (!started_frag_ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
+            if (rel_len < RG_D) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* (a relation shorter than the ring) */        \
             float pf[8];      /* pending scales of this lane's target, head by head (1.0 unless a softmax reference moved) */      \
             {                                                                                                                      \
                 const float4 p0 = *reinterpret_cast<const float4*>(s_pend + fi * 8), p1 = *reinterpret_cast<const float4*>(s_pend + fi * 8 + 4); \
@@ -281,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_ring(
         if (rows_left == 0) break;                                                                                                 \
         do { ++con_rel; } while (con_rel < 63 && __builtin_amdgcn_readlane(my_len, con_rel) == 0);                                 \
         con_left = __builtin_amdgcn_readlane(my_len, con_rel);                                                                     \
+        rel_len = con_left;                                                                                                        \
         if (con_rel < R) {      /* the first half of this relation's fragments: consumed at its end */                            \
             if (started && !drained) {      /* (rare: a relation that parked nothing) rows in flight are older than these loads */ \
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
@@ -288,37 +318,44 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_ring(
             }                                                                                                                      \
             const unsigned short* fb_cur = msgF + (int64_t)con_rel * (NCT * 2 * 512);                                              \
             RG_FRAG_HALF(0)                                                                                                        \
-            since_frag = 0;                                                                                                        \
         }                                                                                                                          \
         if (drained) skip = RG_D - 1;                                                                                              \
         if (!started) {      /* the first rows of the stream (issued behind the first relation's fragments) */                    \
             started = true;                                                                                                        \
-            _Pragma("nounroll") for (int k = 0; k < RG_D - 1; ++k) issue_row();                                                    \
+            _Pragma("nounroll") for (int k = 0; k < RG_D; ++k) { i_slot = k * 1024; issue_row(); }                                 \
+            RG_FETCH(rowC, slC, dlC, RG_D - 1)                                                                                     \
+            i_slot = n_slot;                                                                                                       \
+            mtC = HGT_NEG;      /* (nothing has been parked yet: every target's state is the initial one) */                      \
+            loC = 0.0f;                                                                                                            \
         }                                                                                                                          \
     }
             // The fragments of half 0 are older than every row issued after them, and a row issued after them has been waited for before
-            // the relation ends unless the relation is shorter than the ring: then the boundary's own wait covers them (vmcnt(0) below).
-            // (kept simple: the first-half products always run behind a full wait when fewer than RG_D rows were fetched since)
-            // -> started_frag_ok: at least RG_D rows were fetched since the fragments were requested
-            int since_frag = 0;
-#define started_frag_ok (since_frag >= RG_D)
-
+            // the relation ends unless the relation is shorter than the ring: then the boundary waits for everything (rel_len).
+            int rel_len = 0;
+            // One iteration per row: row r sits in the C registers (fetched one iteration ahead); the row behind it is fetched at the TOP of
+            // the iteration, so that its LDS round trip runs behind the parking of the finished segment, the next row's issue and row r's
+            // arithmetic.  Every helper has ONE expansion site in the loop (two copies of the row step, with the register sets swapped
+            // instead of copied, cost 236 B of scratch per lane: the accumulators).
             int prev_dl = -1;
-            bool have_cur = false;
             float4 rowC = make_float4(0.f, 0.f, 0.f, 0.f);
             float slC = 0.0f, mtC = 0.0f, loC = 0.0f;
             int dlC = 0;
-            // One iteration per row: row r sits in the C registers (fetched one iteration ahead); the row behind it is fetched while r is
-            // processed.  The first iteration only fetches.  Every helper has ONE expansion site.
             for (;;) {
                 if (con_left == 0) RG_BOUNDARY()
-                // a new segment begins with row r: park the finished one BEFORE the next row's state is fetched (the row after r may
-                // belong to the target whose segment is parked here -- in the next relation)
-                if (have_cur && dlC != cur_dl) {
+                if (chunk_due) {      // ids + logits of the chunk after the fetch pointer's, into the buffers it just left
+                    chunk_due = false;
+                    if ((f_chunk + 1) * 64 < total_iss) chunk_issue((f_chunk + 1) * 64, f_par ^ 1);
+                }
+                float4 rowN;
+                float slN;
+                int dlN;
+                RG_FETCH(rowN, slN, dlN, RG_D - 2)
+                // a new segment begins with row r: park the finished one BEFORE the next row's state is read (the row after r may belong
+                // to the target whose segment is parked here -- in the next relation)
+                if (dlC != cur_dl) {
                     const bool same_target = (dlC == prev_dl);
                     flush();
                     U0 = U1 = U2 = U3 = 0.0f;
-                    l_seg = 0.0f;
                     cur_dl = dlC;
                     if (!same_target) {      // (same target in the next relation: its state is in m_ref / l_old already)
                         m_ref = (mtC == HGT_NEG) ? slC : mtC;
@@ -326,20 +363,14 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_ring(
                     }
                     prev_dl = dlC;
                 }
-                issue_row();      // (the slot of the row fetched one iteration ago is free: its data sits in registers)
-                float4 rowN;
-                float slN, mtN, loN;
-                int dlN;
-                fetch_row(rowN, slN, dlN, mtN, loN);
-                ++since_frag;
-                if (have_cur) {
+                const float mtN = p_state[dlN * 8], loN = p_state[dlN * 8 + 128];
+                issue_row();      // (the slot of row r is free: its data sits in registers)
+                i_slot = n_slot;
+                {
                     float dlt = slC - m_ref;
-#ifndef RG_X
-#define RG_X 0
-#endif
-                    if (RG_X != 1 && __builtin_amdgcn_ballot_w64(dlt > 40.0f) != 0) {
+                    if (__builtin_amdgcn_ballot_w64(dlt > 40.0f) != 0) {
                         // Rare: move the reference of the heads that were exceeded; everything this target has accumulated so far is
-                        // rescaled (see k_edge_aggregate_update_mfma)
+                        // rescaled (see k_edge_aggregate_update_mfma) ...
                         const float m_new = (dlt > 40.0f) ? slC : m_ref;
                         const float sc = __expf(m_ref - m_new);
                         U0 *= sc; U1 *= sc; U2 *= sc; U3 *= sc;
@@ -354,26 +385,28 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_ring(
                         m_ref = m_new;
                         dlt = slC - m_ref;
                     }
-                    const float pe = __expf(dlt);
-                    if (con_rel < R) {
+                    const float pe = (RG_OFF & 64) ? dlt : __expf(dlt);
+                    // (rows of the unclaimed bucket are gathered too and their sums never parked: no condition here)
+                    if (!(RG_OFF & 64)) {
                         U0 = fmaf(pe, rowC.x, U0);
                         U1 = fmaf(pe, rowC.y, U1);
                         U2 = fmaf(pe, rowC.z, U2);
                         U3 = fmaf(pe, rowC.w, U3);
+                    } else {
+                        U0 += rowC.x + rowC.y + rowC.z + rowC.w;
                     }
                     l_seg += pe;
                     --con_left;
                     --rows_left;
                 }
-                have_cur = true;
                 rowC = rowN; slC = slN; dlC = dlN; mtC = mtN; loC = loN;
             }
+#undef RG_FETCH
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the re-requested rows behind the end of the stream)
 #undef RG_BOUNDARY
 #undef RG_TIE8
 #undef RG_FRAG_HALF
 #undef RG_MUL_HALF
-#undef started_frag_ok
         }
         // normalise (PyG softmax denominator, conv.py:108) + exact-erf gelu (conv.py:119), in the accumulator layout
 #pragma unroll
@@ -406,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_ring(
             *reinterpret_cast<uint2*>(prow + A_PLANE + c * 32) = mid;
         }
     }
-#if RG_LAB != 7      // (7: no node update: the walk's own register need)
+#if RG_LAB != 7 && !(RG_OFF & 1)      // (no node update: the walk's own register need)
     fused_update_tail<4, HGT_FU_NSTG, true, false>(smem, smem + RG_FRONT, row0, NQ, fu, type_pre);
 #endif
 }

@@ -38,7 +38,7 @@ struct HgtFusedUpdate {
     int use_norm, n_types, n_out;
     float* out;                      // [NQ][n_out]
     int64_t q_lo;                    // first target row of the launch (a multiple of 64): workgroup b owns rows q_lo + 64 b ..
-    int no_ring;                     // HGT_FLAG_ROUND4_AGGREGATE: keep k_edge_aggregate_update_mfma where the ring form would run
+    int ring;                        // HGT_FLAG_RING_AGGREGATE: k_edge_aggregate_update_ring where it is instantiated
 };
 
 

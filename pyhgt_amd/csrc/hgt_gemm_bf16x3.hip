@@ -957,7 +957,10 @@ static int typed_linear_split_impl(const float* x, int64_t ldx, const int32_t* r
         return HGT_ERR_INVALID_ARG;
     const int n_blocks_out = (n_out + block_cols - 1) / block_cols;
     if (n_blocks_out > 3 || (n_blocks_out > 1 && !out1) || (n_blocks_out > 2 && !out2)) return HGT_ERR_INVALID_ARG;
-    if (prologue < 0 || prologue > 2) return HGT_ERR_INVALID_ARG;
+    const int32_t prologue_arg = prologue;      // (with the kernel-selection bits HGT_LINEAR_FORCE_XS / HGT_LINEAR_NO_XS)
+    if (prologue < 0 || (prologue & ~(0xff | HGT_LINEAR_FORCE_XS | HGT_LINEAR_NO_XS)) != 0) return HGT_ERR_INVALID_ARG;
+    prologue &= 0xff;
+    if (prologue > 2) return HGT_ERR_INVALID_ARG;
     if (prologue == 2 && (k > KP || (k & 3) != 0 || ldx != 3 * (int64_t)(k / 4))) return HGT_ERR_UNSUPPORTED;   // 24-bit wire rows: the persistent kernel only
     if (((n_out | block_cols) & 3) != 0) return HGT_ERR_UNSUPPORTED;   // 16-byte epilogue stores; use hgt_typed_linear (fp32) instead
     if (n_rows == 0) return HGT_OK;
@@ -971,7 +974,7 @@ static int typed_linear_split_impl(const float* x, int64_t ldx, const int32_t* r
     const int pass_split = (n_pass > 1 && row_tiles * 2 <= pc_grid()) ? n_pass : 1;
     {   // millions of rows: the x-stationary kernel (hgt_gemm_xs.hip: W through LDS once per 256 rows; K = 64 / 128 / 256 / 512)
         const int xs = hgt_typed_linear_xs_try(F16, x, ldx, rows, group_off, n_groups, n_rows, k, n_out, w_split, bias, b_group_stride, out0, out1,
-                                               out2, block_cols, out_by_position, prologue, stream_);
+                                               out2, block_cols, out_by_position, prologue_arg, stream_);
         if (xs != 0) return xs < 0 ? xs : HGT_OK;
     }
     if (k <= KP) {

@@ -31,7 +31,6 @@
 #include "hgt_common.h"
 #include "hgt_split_common.h"
 #include <algorithm>
-#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -238,103 +237,10 @@ __device__ __forceinline__ void xs_store_tile(const f32x16& acc, int col, int la
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// "Trickled" output (TR forms of the kernel).  A burst of 8 output stores per wavefront and step = 64 KB per CU that the CU's memory
-// pipe accepts at ~10-13 B/clk: the wavefronts sit at the store instructions (in-order issue) while the matrix cores idle, and the
-// barrier makes everyone wait for the last one -- which is why the stores cost 0.3 ms "on top" in every ordering of whole epilogues.
-// Here a step computes its two column tiles one after the other; a finished tile is finalised IN its accumulator registers
-// (transpose, scale, bias), and its four stores are issued one per NKC / 4 k-chunks inside the NEXT tile's k-loop, through
-// exec-masked stores the compiler does not see (straight-line k-loop, always exactly one store instruction per slot).
-struct XsPend {
-    f32x4s v[4];                 // row group q: 4 consecutive columns of one row per lane
-    float* p[4];                 // their addresses (any address in masked-off lanes)
-    unsigned long long m[4];     // lanes that really store
-    bool full;                   // every one of the four instructions has an active lane (counted waits may rely on them)
-};
-
-__device__ __forceinline__ void xs_store_masked(float* p, f32x4s v, unsigned long long lanes) {
-    unsigned long long saved;
-    asm volatile("s_and_saveexec_b64 %0, %3\n\tglobal_store_dwordx4 %1, %2, off\n\ts_nop 1\n\ts_mov_b64 exec, %0"
-                 : "=&s"(saved)
-                 : "v"(p), "v"(v), "s"(lanes)
-                 : "memory");
-}
-
-__device__ __forceinline__ void xs_pend_clear(XsPend& pd, float* any) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { pd.v[q] = f32x4s{0.f, 0.f, 0.f, 0.f}; pd.p[q] = any; pd.m[q] = 0ull; }
-    pd.full = false;
-}
-
-__device__ __forceinline__ void xs_pend_flush(const XsPend& pd) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) xs_store_masked(pd.p[q], pd.v[q], pd.m[q]);
-}
-
-// a finished 32 x 32 tile -> pending stores (the epilogue arithmetic of xs_store_tile, results kept in registers)
-template <bool F16>
-__device__ __forceinline__ void xs_finalize_tile(const f32x16& acc, int col, int tile_col0, int lane, int n_out, const float* s_bias,
-                                                 float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2, int block_cols,
-                                                 const int* s_orow_w, const float* s_inv_w, float winv, int inrows, XsPend& pd) {
-    const bool col_ok = col < n_out;
-    const bool b1 = col >= block_cols, b2 = col >= 2 * block_cols;
-    const int cc = col - (b2 ? 2 * block_cols : (b1 ? block_cols : 0));
-    float* __restrict__ ob = b2 ? out2 : (b1 ? out1 : out0);
-    const bool o1 = lane & 1, o2 = lane & 2;
-    const float4 b4 = *reinterpret_cast<const float4*>(s_bias + col);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float v0 = acc[4 * q], v1 = acc[4 * q + 1], v2 = acc[4 * q + 2], v3 = acc[4 * q + 3];
-        quad_transpose(v0, v1, v2, v3, o1, o2);
-        const int rt = (lane & 3) + 8 * q + 4 * (lane >> 5);
-        const int orow = s_orow_w[rt];
-        float sc = 1.0f;
-        if constexpr (F16) sc = s_inv_w[rt] * winv;
-        const bool ok = col_ok && orow >= 0;
-        pd.v[q] = f32x4s{v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w};
-        pd.m[q] = __builtin_amdgcn_ballot_w64(ok);
-        pd.p[q] = ob + (int64_t)(ok ? orow : 0) * block_cols + (col_ok ? cc : 0);
-    }
-    pd.full = inrows > 24 && tile_col0 < n_out;
-}
-
-// the k-loop of ONE column tile (WHICH = 0 / 1 of the step's two), with the pending stores of the tile before it
-template <int PROLOGUE, bool F16, int NKC, int WHICH, bool PREFETCH>
-__device__ __forceinline__ void xs_kloop_half(const unsigned char* slot_lane, const bf16x8 (&ah)[NKC], const bf16x8 (&am)[NKC], f32x16& acc,
-                                              float4 (&xr)[NKC][2], const float* __restrict__ px_next, const XsPend& pd) {
-    bf16x8 bh[2], bm[2];
-#define XS_LOAD_B1(BUF, KCX)                                                                          \
-    {                                                                                                 \
-        const unsigned char* b_ = slot_lane + (KCX) * (4 * XS_PIECE) + WHICH * XS_PIECE;              \
-        bh[BUF] = *reinterpret_cast<const bf16x8*>(b_);                                               \
-        bm[BUF] = *reinterpret_cast<const bf16x8*>(b_ + 2 * XS_PIECE);                                \
-    }
-    XS_LOAD_B1(0, 0)
-    constexpr int EVERY = NKC / 4;
-#pragma unroll
-    for (int kc = 0; kc < NKC; ++kc) {
-        const int cur = kc & 1;
-        if (kc + 1 < NKC) XS_LOAD_B1(cur ^ 1, kc + 1)
-        acc = mfma32_t<F16>(am[kc], bh[cur], acc);      // (the order of k_typed_linear_pc: bit-identical results)
-        acc = mfma32_t<F16>(ah[kc], bm[cur], acc);
-        acc = mfma32_t<F16>(ah[kc], bh[cur], acc);
-        if constexpr (PREFETCH) xs_issue_chunk<PROLOGUE>(xr[kc], px_next, kc);
-        if (kc + 1 < NKC) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        if constexpr (PREFETCH) __builtin_amdgcn_sched_group_barrier(0x020, PROLOGUE == 2 ? 3 : 2, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kc % EVERY == EVERY - 1) {
-            xs_store_masked(pd.p[kc / EVERY], pd.v[kc / EVERY], pd.m[kc / EVERY]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#undef XS_LOAD_B1
-}
-
 // NW wavefronts of 32 rows each, NT column tiles per step:  <8, 2> for K <= 256 (two wavefronts per SIMD, 256 registers each, 64
 // columns per step);  <4, 1> for K = 512 (the 256 fragment registers of a row tile need the 512-register budget of ONE wavefront per
 // SIMD; 32 columns per step keep a ring slot at 64 KB).
-template <int PROLOGUE, bool F16, int NKC, int NW, int NT, bool TR = false>
+template <int PROLOGUE, bool F16, int NKC, int NW, int NT>
 __global__ __launch_bounds__(64 * NW) void k_typed_linear_xs(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off, int n_groups,
     int n_out, const unsigned short* __restrict__ wsplit, const float* __restrict__ bias, int64_t bgs, float* __restrict__ out0,
@@ -448,9 +354,6 @@ __global__ __launch_bounds__(64 * NW) void k_typed_linear_xs(
     int t = 0;
     int rpar = 0;      // parity of the round: its bias table
     bool full8 = false;
-    XsPend pd0, pd1;      // (TR) the two column tiles' pending stores
-    xs_pend_clear(pd0, out0);
-    xs_pend_clear(pd1, out0);
     while (true) {
         bf16x8 ah[NKC], am[NKC];
         out_rows(irow0, inrows);
@@ -518,49 +421,6 @@ __global__ __launch_bounds__(64 * NW) void k_typed_linear_xs(
             }
             ++t;
         };
-      if constexpr (TR) {
-        static_assert(!TR || (NW == 8 && NT == 2), "the trickled form walks the two column tiles of a 64-column step");
-        auto step_tr = [&](int s, auto pf_tag) {
-            constexpr bool PF = decltype(pf_tag)::value;
-            constexpr int NX = NKC * (PROLOGUE == 2 ? 3 : 2);
-            int lane_e = lane;
-            asm volatile("" : "+v"(lane_e));
-            const unsigned char* slot_lane = smem + (t & 1) * SLOT + lane_e * 16;
-            const int col = s * CW + ((lane_e & 31) >> 2) * 4;
-            const int n_eff = (dbg_nostore || dbg_noepi) ? 0 : n_out;
-            const bool counted_in = pd1.full;
-            f32x16 acc;
-            if (inrows > 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                xs_kloop_half<PROLOGUE, F16, NKC, 0, false>(slot_lane, ah, am, acc, xr, nullptr, pd1);      // (+ the stores of step s - 1, tile 1)
-                xs_finalize_tile<F16>(acc, col, s * CW, lane_e, n_eff, s_bias, out0, out1, out2, block_cols, s_orow_w, s_inv_w, winv, inrows, pd0);
-            } else {
-                xs_pend_flush(pd1);
-                xs_pend_clear(pd0, out0);
-            }
-            if (inrows > 0 || PF) {      // (the last step's second half also requests the next rows: every wavefront runs it)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                xs_kloop_half<PROLOGUE, F16, NKC, 1, PF>(slot_lane, ah, am, acc, xr, dbg_noswitch ? x : pn, pd0);   // (+ the stores of tile 0)
-            }
-            const bool counted = counted_in && pd0.full && inrows > 0;
-            if (inrows > 0) xs_finalize_tile<F16>(acc, col + 32, s * CW + 32, lane_e, n_eff, s_bias, out0, out1, out2, block_cols, s_orow_w, s_inv_w, winv, inrows, pd1);
-            else xs_pend_clear(pd1, out0);
-            // outstanding, oldest first: this wavefront's DMA pieces of step t + 1 (issued behind the barrier that ended step t - 1),
-            // then the step's 8 trickled stores and, in a last step, the NX row loads.  vmcnt retires in order.
-            if (counted && 8 + (PF ? NX : 0) <= 63) {
-                if (PF) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 + NX <= 63 ? 8 + NX : 0) : "memory");
-                else asm volatile("s_waitcnt vmcnt(8)" : : : "memory");
-            } else {
-                xs_wait_vm();
-            }
-            front(s);
-            ++t;
-        };
-        for (int s = 0; s + 1 < n_steps; ++s) step_tr(s, std::false_type{});
-        step_tr(n_steps - 1, std::true_type{});
-      } else {
         for (int s = 0; s + 1 < n_steps; ++s) {
             f32x16 acc[NT];
 #pragma unroll
@@ -579,14 +439,12 @@ __global__ __launch_bounds__(64 * NW) void k_typed_linear_xs(
             xs_kloop<PROLOGUE, F16, NKC, NT, true>(smem + (t & 1) * SLOT + lane * 16, ah, am, acc, xr, dbg_noswitch ? x : pn);
             tail(n_steps - 1, acc, std::true_type{});
         }
-      }
         if (!nxt.valid) break;
         cur = nxt;
         irow0 = nrow0;
         inrows = nnrows;
         rpar ^= 1;
     }
-    if constexpr (TR) xs_pend_flush(pd1);      // the last tile of the last step
 }
 
 static int xs_grid() {
@@ -605,7 +463,6 @@ static void xs_launch_nkc(int nkc, unsigned grid, hipStream_t stream, const floa
                           float* out2, int block_cols, int by_pos, int stagger) {
 #define XS_ARGS x, ldx, rows, group_off, n_groups, n_out, w, bias, bgs, out0, out1, out2, block_cols, by_pos
     if (nkc == 32) k_typed_linear_xs<PROLOGUE, F16, 32, 4, 1><<<grid, 256, 0, stream>>>(XS_ARGS, stagger & ~7);      // (one wavefront per SIMD: no pairs)
-    else if (nkc == 16 && (stagger & 128)) k_typed_linear_xs<PROLOGUE, F16, 16, 8, 2, true><<<grid, 512, 0, stream>>>(XS_ARGS, stagger & ~7);
     else if (nkc == 16) k_typed_linear_xs<PROLOGUE, F16, 16, 8, 2><<<grid, 512, 0, stream>>>(XS_ARGS, stagger);
     else if (nkc == 8) k_typed_linear_xs<PROLOGUE, F16, 8, 8, 2><<<grid, 512, 0, stream>>>(XS_ARGS, stagger);
     else k_typed_linear_xs<PROLOGUE, F16, 4, 8, 2><<<grid, 512, 0, stream>>>(XS_ARGS, stagger);
@@ -655,22 +512,23 @@ extern "C" int hgt_typed_linear_xs_schedule(const int32_t* group_off, int32_t n_
 }
 
 // 1 = launched, 0 = shape / size outside this kernel's domain (the caller falls back to k_typed_linear_pc), < 0 = error.
-// HGT_GEMM_XS=0 switches it off, =1 takes it for every eligible shape whatever the row count (tests, tools/bench_linear.py).
 // In a wire-format call (prologue 2) ldx / x follow hgt_typed_linear_bf16x3: dwords per row, 8-byte aligned.
 int hgt_typed_linear_xs_try(bool f16, const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
                             int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias, int64_t bgs, float* out0,
                             float* out1, float* out2, int32_t block_cols, int32_t by_pos, int32_t prologue, void* stream_) {
-    const char* env = getenv("HGT_GEMM_XS");
-    const int mode = env ? atoi(env) : -1;
+    // kernel selection travels in the prologue argument like every other switch of the C ABI (include/hgt_hip.h): bit 8 takes this kernel
+    // for every eligible shape whatever the row count (tests, tools/bench_xs.py), bit 9 never takes it
+    const int mode = (prologue & HGT_LINEAR_NO_XS) ? 0 : ((prologue & HGT_LINEAR_FORCE_XS) ? 1 : -1);
+    prologue &= 0xff;
     if (mode == 0) return 0;
     if (prologue != 0 && prologue != 2) return 0;
     if (prologue == 2 && k > KP) return 0;
     const int n_kc = k / KC;
     if (n_out > XS_MAXCOL || n_out <= 64 || (k != 64 && k != 128 && k != 256 && k != 512)) return 0;   // K = NKC * 16 exactly (see xs_issue_chunk)
-    // wavefront order: see the kernel.  Default 3 (wavefronts 4-7 staggered): Q|K|V at c2 1.28 ms against 1.31 in lock-step and 1.45
-    // for the slab kernel; the counted-wait forms (5-7) measure the same and are kept as experiments only
-    const char* env_st = getenv("HGT_GEMM_XS_STAGGER");
-    const int stagger = env_st ? atoi(env_st) : 3;
+    // wavefront order: wavefronts 4-7 staggered (3: see the kernel): Q|K|V at c2 1.28 ms against 1.31 in lock-step and 1.45 for the slab
+    // kernel.  The other orders measured in round 4 (counted-wait forms, trickled stores: all within +-3 %) live in HISTORY.md section 10
+    // and tools/lab/hgt_gemm_xs_trickled.txt, not in the library.
+    const int stagger = 3;
     if (prologue == 0 && ((ldx & 3) != 0 || ((uintptr_t)x & 15) != 0)) return 0;
     if (prologue == 2 && (((uintptr_t)x & 7) != 0)) return 0;
     // measured crossover against the slab kernels (tools/bench_xs.py --threshold, profiles/r04_xs_threshold.txt): K <= 256 even at

@@ -465,6 +465,15 @@ class PartitionedGraph:
             self.halo = halo
             if mode == "blocked" and halo.n_chunks != n_chunks:
                 raise ValueError("a prebuilt HaloPlan for the blocked schedule must be built with edge_block / n_chunks = blocks")
+            if mode == "blocked" and halo.n_halo > 0:
+                # ... and with THESE blocks: block b's in-edges may only reference own rows and halo chunks 0..b (the K|V of a later
+                # chunk are not projected yet when the block runs -- the kernels would read stale workspace rows without any error)
+                off = torch.tensor(list(halo.recv_chunk_off[1:]), dtype=torch.int64, device=dst_local.device)
+                src_chunk = torch.searchsorted(off, (halo.src_local.to(torch.int64) - halo.n_own).clamp(min=0), right=True)
+                late = (halo.src_local >= halo.n_own) & (src_chunk > edge_block)
+                if bool(late.any()):
+                    raise ValueError("the prebuilt HaloPlan was built for other target blocks (edge_block / block_shape / alignment): "
+                                     "%d edges reference a halo chunk later than their own block" % int(late.sum()))
         else:
             self.halo = HaloPlan(node_type_own, src_global, node_offsets, rank, world, group, n_chunks=n_chunks, edge_block=edge_block)
         self.compress = bool(compress)     # 24-bit halo rows on the links (exchange_chunk); off: exact fp32 rows
@@ -514,7 +523,10 @@ class PartitionedGraph:
         hgt = getattr(layer, "_UPDATE_MODE", 0) == 0
         if self.mode == "blocked" and split and hgt and not getattr(layer, "keep_att", False):
             lay = _lib.layout_for(layer.out_dim, layer.n_heads)
-            if lay.d_pad <= 256 and layer.out_dim % 4 == 0 and not (layer.kernel_flags & _lib.HGT_FLAG_VALU_AGGREGATE):
+            # (everything hgt_conv_forward stage 5 / the fused matrix-core aggregation require: a layer outside it would fail with
+            #  HGT_ERR_UNSUPPORTED after stages 1 and 2 and the all-to-alls are in flight)
+            if (lay.d_pad <= 256 and layer.out_dim % 4 == 0 and layer.in_dim % 4 == 0 and self.num_relations < 64 and
+                    not (layer.kernel_flags & _lib.HGT_FLAG_VALU_AGGREGATE)):
                 return "blocked"
         if self.mode == "bucketed" and split and hgt:
             return "bucketed"

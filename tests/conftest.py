@@ -15,6 +15,13 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # HGT_TEST_KERNEL_FLAGS=<HGT_FLAG_* bits>: the whole suite once more with a kernel forced onto every layer, e.g. 1024 = the
+    # x-stationary split GEMM on the small graphs its size threshold keeps it off, 512 = the LDS-ring aggregation (tools/gpu.sh).
+    # A switch of the TEST SUITE: the library itself reads no environment variable.
+    extra = int(os.environ.get("HGT_TEST_KERNEL_FLAGS", "0"))
+    if extra:
+        from pyhgt_amd import HGTConv
+        HGTConv.EXTRA_KERNEL_FLAGS = extra
 
 
 def golden_names():

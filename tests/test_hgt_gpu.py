@@ -1032,10 +1032,10 @@ RING_CASES = [
 
 
 @pytest.mark.parametrize("case", RING_CASES, ids=[str(i) for i in range(len(RING_CASES))])
-def test_ring_aggregation_is_bit_identical_to_the_round4_kernel(case):
-    """csrc/hgt_edge_agg_ring.h (round 5: gathered rows through an LDS ring by LDS-DMA, U tile in registers, fragments requested a
-    relation ahead, hand-counted vmcnt waits) performs the arithmetic of k_edge_aggregate_update_mfma in the same order: at
-    d = 256 / 8 heads the two must agree to the BIT (HGT_FLAG_ROUND4_AGGREGATE selects the old kernel), and with the fp64 oracle to
+def test_ring_aggregation_is_bit_identical_to_the_default_kernel(case):
+    """csrc/hgt_edge_agg_ring.h (round 5, opt-in through HGT_FLAG_RING_AGGREGATE: gathered rows through an LDS ring by LDS-DMA, U
+    tile in registers, fragments requested a relation ahead, hand-counted vmcnt waits) performs the arithmetic of
+    k_edge_aggregate_update_mfma in the same order: at d = 256 / 8 heads the two must agree to the BIT, and with the fp64 oracle to
     the split-bf16 bound."""
     N, E, T, R, gk, edit = case
     d, H = 256, 8
@@ -1054,7 +1054,7 @@ def test_ring_aggregation_is_bit_identical_to_the_round4_kernel(case):
     layer = _layer_from(sd, d, T, R, H, True, False, keep_att=False, precision="bf16x3")
     outs = []
     det = _lib.HGT_FLAG_DETERMINISTIC_HUBS if edit == "hubs" else 0      # (hub rows: atomics by default, not run-to-run reproducible)
-    for flags in (0, _lib.HGT_FLAG_ROUND4_AGGREGATE, 0):
+    for flags in (_lib.HGT_FLAG_RING_AGGREGATE, 0, _lib.HGT_FLAG_RING_AGGREGATE):
         layer.kernel_flags = flags | det
         out, _ = _run(layer, x, nt, ei, et, None)
         outs.append(out.clone())
@@ -1062,7 +1062,7 @@ def test_ring_aggregation_is_bit_identical_to_the_round4_kernel(case):
     same = torch.equal(outs[0], outs[1])
     if not same:
         bad = (outs[0] != outs[1]).any(dim=1).nonzero().flatten()
-        print("ring vs round-4 kernel: %d differing rows, first %s, max |d| %.3e" % (
+        print("ring vs default kernel: %d differing rows, first %s, max |d| %.3e" % (
             bad.numel(), bad[:8].tolist(), (outs[0] - outs[1]).abs().max().item()))
     assert same
     if N * E <= 70_000 * 700_000:
@@ -1096,6 +1096,32 @@ def test_f16_split_rows_of_very_different_size_per_relation(N, order):
     assert torch.isfinite(out).all()
     rel = ((out.double() - ref).abs().amax(dim=1) / ref.abs().amax(dim=1).clamp_min(1e-30)).max().item()
     print("f16x3 rows 1e-3 / 1e+3 (%s, N=%d): max row-relative err %.2e" % (order, N, rel))
+    assert rel < 1e-5
+
+
+def test_f16_split_first_row_thirty_five_decades_below_a_later_one():
+    """The optimistic fp16 row scale of the aggregation (round 4) takes sigma_t from the target's first non-zero row and walks the
+    sub-tile again with 2^14 more headroom per attempt when a later row overflows.  Round-4 advisor finding: the attempts were capped
+    at 4, and a target whose first row was more than ~2^70 smaller than a later one got NaN.  Here the sources of relation 0 are
+    1e-25 in size and the others 1e+10: the walk must retry ~9 times and still deliver finite, accurate rows."""
+    d, H, T, R, N = 64, 4, 2, 4, 70_000
+    E = 6 * N
+    sd = O.make_state_dict(d, d, T, R, H, False, False, seed=33)
+    for t in range(T):
+        sd["v_linears.%d.bias" % t].zero_()
+        sd["q_linears.%d.weight" % t].zero_()
+        sd["k_linears.%d.weight" % t].zero_()
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=78)
+    et = torch.where(ei[0] < N // 2, torch.zeros_like(et), 1 + et % (R - 1))
+    x = x.clone()
+    x[:N // 2] *= 1e-25
+    x[N // 2:] *= 1e10
+    ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, None, use_norm=False, use_RTE=False, dtype=torch.float64)
+    layer = _layer_from(sd, d, T, R, H, False, False, keep_att=False, precision="f16x3")
+    out, _ = _run(layer, x, nt, ei, et, None)
+    assert torch.isfinite(out).all()
+    rel = ((out.double() - ref).abs().amax(dim=1) / ref.abs().amax(dim=1).clamp_min(1e-300)).max().item()
+    print("f16x3 rows 1e-25 / 1e+10: max row-relative err %.2e" % rel)
     assert rel < 1e-5
 
 
@@ -1805,21 +1831,13 @@ def test_xs_gemm_against_fp64_at_its_dispatch_sizes(N, k, n_out, T, prologue, pr
 ])
 def test_xs_gemm_is_bit_identical_to_the_slab_kernel(N, k, n_out, T, f16, c24, bypos):
     """csrc/hgt_gemm_xs.hip (x rows stationary in registers, W through an LDS ring by LDS-DMA) accumulates every output element in
-    the order of k_typed_linear_pc: on ragged, permuted inputs with an empty and a tiny group the two kernels must agree to the
-    bit, in every wavefront order (lock-step, staggered pairings, DMA owned by the staggered wavefronts with counted waits, non-temporal
-    stores), and untouched output rows must stay untouched."""
+    the order of k_typed_linear_pc: on ragged, permuted inputs with an empty and a tiny group the two kernels (selected through the
+    prologue bits HGT_LINEAR_NO_XS / HGT_LINEAR_FORCE_XS of the C ABI) must agree to the bit, and untouched output rows must stay
+    untouched."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import bench_xs
     lib = _lib.load()
-    saved = {v: os.environ.get(v) for v in ("HGT_GEMM_XS", "HGT_GEMM_XS_STAGGER")}
-    try:
-        for stagger in ("3", "0", "14"):      # default order; lock-step; DMA owned by the staggered wavefronts + counted waits + nt stores
-            os.environ["HGT_GEMM_XS_STAGGER"] = stagger
-            assert bench_xs.check(lib, N, k, n_out, T, f16, c24, bypos, ragged=1, seed=N % 97)
-    finally:
-        for v, old in saved.items():
-            if old is None:
-                os.environ.pop(v, None)
-            else:
-                os.environ[v] = old
+    assert bench_xs.check(lib, N, k, n_out, T, f16, c24, bypos, ragged=1, seed=N % 97)
+
+

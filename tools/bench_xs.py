@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """The x-stationary split typed linear (csrc/hgt_gemm_xs.hip) against the persistent slab kernel it replaces on large inputs:
 bit-identity on ragged / permuted / multi-group inputs in every instantiated form, then timings at the c2 Q|K|V shape and the
-halo K|V shape (development aid, not the judged bench).   python tools/bench_xs.py [--quick]"""
+halo K|V shape (development aid, not the judged bench).  The kernel is selected through the prologue bits of the C ABI
+(HGT_LINEAR_FORCE_XS / HGT_LINEAR_NO_XS), not through the environment.   python tools/bench_xs.py [--quick]"""
 import argparse
 import ctypes as C
 import os
@@ -42,7 +43,9 @@ def setup(lib, N, k, n_out, T, f16, seed, ragged):
     return x, W, b, rows, off, ws
 
 
-def run(lib, f16, xptr, ldx, rows, off, T, N, k, n_out, ws, b, outs, bc, bypos, prologue):
+def run(lib, f16, xptr, ldx, rows, off, T, N, k, n_out, ws, b, outs, bc, bypos, prologue, sel=0):
+    """sel: 0 = the library's own choice, _lib.HGT_LINEAR_FORCE_XS / HGT_LINEAR_NO_XS (bits of the prologue argument)"""
+    prologue = prologue | sel
     lin = lib.hgt_typed_linear_f16x3 if f16 else lib.hgt_typed_linear_bf16x3
     st = torch.cuda.current_stream().cuda_stream
     optr = [o.data_ptr() for o in outs] + [None, None]
@@ -64,10 +67,9 @@ def check(lib, N, k, n_out, T, f16, c24, bypos, ragged, seed=1):
     else:
         xptr, ldx, prologue = x.data_ptr(), k, 0
     res = []
-    for mode in ("0", "1"):
-        os.environ["HGT_GEMM_XS"] = mode
+    for sel in (_lib.HGT_LINEAR_NO_XS, _lib.HGT_LINEAR_FORCE_XS):
         outs = [torch.full((N, bc), float("nan"), device=DEV) for _ in range(nblk)]
-        run(lib, f16, xptr, ldx, rows, off, T, N, k, n_out, ws, b, outs, bc, bypos, prologue)
+        run(lib, f16, xptr, ldx, rows, off, T, N, k, n_out, ws, b, outs, bc, bypos, prologue, sel)
         torch.cuda.synchronize()
         res.append(torch.cat(outs, 1))
     same = torch.equal(res[0].nan_to_num(nan=12345.0), res[1].nan_to_num(nan=12345.0))
@@ -90,7 +92,7 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def bench(lib, N, k, n_out, T, f16, c24, modes, iters=5, reps=4):
+def bench(lib, N, k, n_out, T, f16, c24, iters=5, reps=4):
     x, W, b, rows, off, ws = setup(lib, N, k, n_out, T, f16, 3, False)
     nblk = 3 if n_out % 3 == 0 else 2
     bc = n_out // nblk
@@ -103,16 +105,14 @@ def bench(lib, N, k, n_out, T, f16, c24, modes, iters=5, reps=4):
         xptr, ldx, prologue = wire.data_ptr(), 3 * k // 4, 2
     else:
         xptr, ldx, prologue = x.data_ptr(), k, 0
-    variants = [("slab", {"HGT_GEMM_XS": "0"})] + [("xs%d" % m, {"HGT_GEMM_XS": "1", "HGT_GEMM_XS_STAGGER": str(m)}) for m in modes]
+    variants = [("slab", _lib.HGT_LINEAR_NO_XS), ("xs", _lib.HGT_LINEAR_FORCE_XS)]
     best = {n: 1e9 for n, _ in variants}
     for rep in range(reps):      # interleaved repetitions, minimum per variant (the order of the variants and the clocks matter)
-        for name, env in (variants if rep % 2 == 0 else variants[::-1]):
-            os.environ.update(env)
-            best[name] = min(best[name], timeit(lambda: run(lib, f16, xptr, ldx, rows, off, T, N, k, n_out, ws, b, outs, bc, 0, prologue), iters))
+        for name, sel in (variants if rep % 2 == 0 else variants[::-1]):
+            best[name] = min(best[name], timeit(lambda: run(lib, f16, xptr, ldx, rows, off, T, N, k, n_out, ws, b, outs, bc, 0, prologue, sel), iters))
     gb = (N * k * (3 if c24 else 4) + N * n_out * 4) / 1e9
     print("time  N=%d k=%d n_out=%d f16=%d c24=%d :" % (N, k, n_out, f16, c24) + "".join("  %s %.3f" % (n, best[n]) for n, _ in variants) +
           "   [ms; %.2f GB]" % gb, flush=True)
-    os.environ.pop("HGT_GEMM_XS_STAGGER", None)
 
 
 def main():
@@ -125,10 +125,10 @@ def main():
     ok = True
     if args.threshold:
         for N in (40000, 66000, 100000, 131072, 160000, 200000, 262144, 330000, 400000, 524288):
-            bench(lib, N, 256, 768, 4, 0, 0, [3], iters=8, reps=3)
+            bench(lib, N, 256, 768, 4, 0, 0, iters=8, reps=3)
         for N in (66000, 131072, 200000, 330000):
-            bench(lib, N, 256, 512, 4, 0, 1, [3], iters=8, reps=3)
-            bench(lib, N, 512, 1536, 4, 0, 0, [0], iters=8, reps=3)
+            bench(lib, N, 256, 512, 4, 0, 1, iters=8, reps=3)
+            bench(lib, N, 512, 1536, 4, 0, 0, iters=8, reps=3)
         return
     if not args.no_check:
         # one round per workgroup, several rounds, ragged groups with an empty and a tiny group, both output addressings, both formats
@@ -139,20 +139,11 @@ def main():
             (1000000, 256, 768, 4, 0, 0, 0, 0), (1000000, 256, 768, 4, 1, 0, 0, 0),
             (200003, 512, 1536, 3, 0, 0, 0, 1), (200003, 512, 1536, 4, 1, 0, 1, 1), (120001, 512, 512, 3, 0, 0, 0, 1), (3000, 512, 1536, 3, 0, 0, 0, 0),
         ]:
-            for st in ("0", "3", "7", "15", "128"):
-                os.environ["HGT_GEMM_XS_STAGGER"] = st
-                ok &= check(lib, N, k, n_out, T, f16, c24, bypos, ragged)
-                if args.quick:
-                    break
-        os.environ.pop("HGT_GEMM_XS_STAGGER", None)
+            ok &= check(lib, N, k, n_out, T, f16, c24, bypos, ragged)
         print("ALL BIT-IDENTICAL" if ok else "MISMATCH", flush=True)
     for (N, k, n_out, f16, c24) in [(500000, 512, 1536, 0, 0), (500000, 512, 1536, 1, 0), (500000, 512, 512, 0, 0), (1000000, 256, 768, 0, 0), (1000000, 256, 768, 1, 0), (1000000, 256, 512, 0, 1), (1000000, 256, 512, 0, 0),
                                     (625000, 256, 512, 0, 1), (1000000, 128, 384, 0, 0)]:
-        full = n_out == 768 and not f16
-        # wavefront orders (see the kernel: 1-3 staggered pairings, +4 DMA owned by the staggered four with counted waits, +8
-        # non-temporal stores), then timing-only eliminations on the default (16 no stores, 32 no epilogue, 64 no row loads)
-        bench(lib, N, k, n_out, 4, f16, c24, [0, 3, 128, 6, 16, 32, 64, 96, 128 + 16, 128 + 64] if full else ([0, 16, 32, 64, 96] if k == 512 and n_out == 1536 and not f16 else [0, 3, 128]))
-    os.environ.pop("HGT_GEMM_XS", None)
+        bench(lib, N, k, n_out, 4, f16, c24)
     sys.exit(0 if ok else 1)
 
 

@@ -79,7 +79,7 @@ final)
     python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/pytest_$TAG.log
     grep -E "^FAILED|^ERROR| passed| failed" gpurun_out/pytest_$TAG.log | tail -10
     # the x-stationary GEMM forced onto the small graphs of the backward / staged tests (its size threshold keeps it off them otherwise)
-    HGT_GEMM_XS=1 timeout 600 python -m pytest tests -m gpu -q -k "backward or staged or two_rank or matches_oracle" 2>&1 | tail -3
+    HGT_TEST_KERNEL_FLAGS=1024 timeout 600 python -m pytest tests -m gpu -q -k "backward or staged or two_rank or matches_oracle" 2>&1 | tail -3
     timeout 300 python tools/bench_xs.py > gpurun_out/${TAG}_xs_check.log 2>&1; grep -v "BIT-IDENTICAL (" gpurun_out/${TAG}_xs_check.log | tail -12
     tools/profile_pmc.sh $TAG > gpurun_out/prof_$TAG.log 2>&1
     cp gpurun_out/prof_$TAG/${TAG}_pmc_summary.json profiles/${TAG}_pmc_summary.json      # the line below is judged against THIS build's counters
@@ -97,8 +97,8 @@ xs)
     timeout 420 python tools/bench_xs.py > gpurun_out/xs_check_$TAG.log 2>&1; echo "bench_xs rc=$?"
     grep -v "BIT-IDENTICAL (" gpurun_out/xs_check_$TAG.log | tail -30
     for m in 0 1; do
-        HGT_GEMM_XS=$m timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 40 > gpurun_out/xs_c2_$m.json 2> gpurun_out/xs_c2_$m.err
-        HGT_GEMM_XS=$m timeout 300 python bench.py --dim 512 --nodes-per-gpu 500000 --edges-per-gpu 5000000 --no-secondary --no-cpu-baseline > gpurun_out/xs_d512_$m.json 2> gpurun_out/xs_d512_$m.err
+        timeout 300 python bench.py --kernel-flags $((m ? 1024 : 2048)) --no-secondary --no-cpu-baseline --steps 40 > gpurun_out/xs_c2_$m.json 2> gpurun_out/xs_c2_$m.err
+        timeout 300 python bench.py --kernel-flags $((m ? 1024 : 2048)) --dim 512 --nodes-per-gpu 500000 --edges-per-gpu 5000000 --no-secondary --no-cpu-baseline > gpurun_out/xs_d512_$m.json 2> gpurun_out/xs_d512_$m.err
     done
     summ gpurun_out/xs_c2_0.json gpurun_out/xs_c2_1.json gpurun_out/xs_d512_0.json gpurun_out/xs_d512_1.json
     ;;
