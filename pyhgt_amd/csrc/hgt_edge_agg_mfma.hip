@@ -917,14 +917,14 @@ __device__ __attribute__((noinline)) void agg_mfma_hub_workgroup(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
     const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, float* __restrict__ agg, int R, int64_t NQ, int HT,
-    unsigned hub_mask, int64_t wrow0, unsigned char* utile, float* s_m, float* s_l, float* s_sc, float* s_sig) {
+    unsigned hub_mask, int64_t wrow0, int sub, unsigned char* utile, float* s_m, float* s_l, float* s_sc, float* s_sig) {
     using G = MG<VEC, LPH>;
     f32x4 acc[G::NCT];
-    agg_mfma_subtile<VEC, LPH, RTE, true, F16>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, 0, R + 1, HT, hub_mask, 16, wrow0, utile,
+    agg_mfma_subtile<VEC, LPH, RTE, true, F16>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, 0, R + 1, HT, hub_mask, sub, wrow0, utile,
                                                s_m, s_l, s_sc, s_sig, 0, acc);
     if constexpr (F16) agg_mfma_finish<VEC, LPH>(s_l, 1, acc, s_sig, msg_frag_inv_scale<VEC, LPH>(msgF, R, HT));
     else agg_mfma_finish<VEC, LPH>(s_l, 1, acc);
-    agg_mfma_store<VEC, LPH>(agg, wrow0, 16, NQ, (int64_t)HT * G::DKP, 0, hub_mask, acc);
+    agg_mfma_store<VEC, LPH>(agg, wrow0, sub, NQ, (int64_t)HT * G::DKP, 0, hub_mask, acc);
 }
 
 // Aggregation + fused node update (see hgt_fused_update.h).  Workgroups that contain a hub target cannot finish their rows
@@ -1008,9 +1008,14 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
     fused_update_tail<VEC, HGT_FU_NSTG, true, F16>(smem, smem + FRONT, row0, NQ, fu, type_pre);
 }
 
-// The workgroups of the fused kernels that contain a hub target (pending[workgroup] != 0): their non-hub targets are walked run by
+// The 64-target tiles of the fused kernels that contain a hub target (pending[tile] != 0): their non-hub targets are walked run by
 // run here, agg is written, and k_update_pending finishes the rows after the hub kernels.  Its own kernel since round 5: as an
-// out-of-line call inside the fused kernels it gave every launch of them a 504-byte scratch frame (rocprofv3 Scratch_Size).
+// out-of-line call inside the fused kernels it gave every launch of them a 504-byte scratch frame (rocprofv3 Scratch_Size) -- and the
+// neighbours of hubs are themselves heavy targets (Zipf(0.8): ~1000 in-edges each), so a tile's walk is cut into wavefronts of
+// HGT_HUBWG_SUB targets (32 wavefronts per tile instead of 4: 16 targets of 1000 edges per wavefront were 2.8 ms on their own).
+#ifndef HGT_HUBWG_SUB
+#define HGT_HUBWG_SUB 2
+#endif
 template <int VEC, int LPH, bool RTE, bool F16>
 __global__ __launch_bounds__(256, 2) void k_edge_aggregate_hub_workgroups(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
@@ -1018,20 +1023,22 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_hub_workgroups(
     const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, float* __restrict__ agg, int R, int64_t NQ, int HT,
     const int32_t* __restrict__ hub_slot, const int32_t* __restrict__ pending, int64_t q_lo) {
     using G = MG<VEC, LPH>;
+    constexpr int SUB = HGT_HUBWG_SUB, BPT = 16 / SUB;      // blocks (of 4 wavefronts) per 64-target tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 2 * G::PLANE + 4 * 2 * 256 * 4 + 4 * 16 * 4 + (F16 ? 4 * 16 * 4 : 0)];
-    if (pending[q_lo / 64 + blockIdx.x] == 0) return;
+    const int64_t tile = blockIdx.x / BPT;
+    if (pending[q_lo / 64 + tile] == 0) return;
     float* s_ml = reinterpret_cast<float*>(smem + 4 * 2 * G::PLANE);
     float* s_scale = s_ml + 4 * 2 * 256;
     float* s_sig = s_scale + (F16 ? 4 * 16 : 0);
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t wrow0 = q_lo + (int64_t)blockIdx.x * 64 + wib * 16;
+    const int64_t wrow0 = q_lo + tile * 64 + (int64_t)(blockIdx.x % BPT) * (4 * SUB) + wib * SUB;
     if (wrow0 >= NQ) return;
     const int64_t rr = wrow0 + (lane & 15);
-    const bool is_hub = (lane < 16) && (rr < NQ) && (hub_slot[rr] >= 0);
+    const bool is_hub = (lane < SUB) && (rr < NQ) && (hub_slot[rr] >= 0);
     const unsigned hub_mask = (unsigned)(__builtin_amdgcn_ballot_w64(is_hub) & 0xFFFFull);
     float* s_m = s_ml + wib * 512;
-    agg_mfma_hub_workgroup<VEC, LPH, RTE, F16>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, agg, R, NQ, HT, hub_mask, wrow0,
+    agg_mfma_hub_workgroup<VEC, LPH, RTE, F16>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, agg, R, NQ, HT, hub_mask, wrow0, SUB,
                                                smem + wib * 2 * G::PLANE, s_m, s_m + 256, s_scale + wib * 16, s_sig + wib * 16);
 }
 
@@ -1102,7 +1109,7 @@ static int launch_aggupd_mfma(HGT_MFMA_AGGUPD_ARGS) {
         k_edge_aggregate_update_mfma<VEC, LPH, RTE, F16><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
                                                                                   agg, R, NQ, HT, hub_slot, pending, fu);
     if (hb.mx) {   // workgroups with a hub target: their other targets, then the hub path + the update of those workgroups
-        k_edge_aggregate_hub_workgroups<VEC, LPH, RTE, F16><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
+        k_edge_aggregate_hub_workgroups<VEC, LPH, RTE, F16><<<dim3((unsigned)tiles * (16 / HGT_HUBWG_SUB), 1), 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
                                                                                      agg, R, NQ, HT, hub_slot, pending, fu.q_lo);
         int rc = hgt_launch_hub(VEC, LPH, pv, logits, V, rteV, msgP, agg, R, NQ, 1, HT, hb, 1u, (int64_t)HT * (VEC * LPH), stream);
         if (rc != HGT_OK) return rc;

@@ -491,6 +491,23 @@ def test_partitioned_graph_on_gpu_single_rank():
             with torch.no_grad():
                 out = pg.forward(layer, xs)
             assert (out.cpu().double() - ref).abs().max().item() < TOL
+        # The blocked schedule (the default of an 8-rank run) on RCCL itself, with the collectives REALLY entered: on one rank every
+        # chunk is dead (no rank moves a row) and would be skipped, so the chunks are declared live -- async all_to_all_single calls
+        # with zero-length splits and empty buffers, back to back, in both wire formats, then wait() on each: exactly what a rank
+        # without halo rows does in an 8-rank step.  (The first real multi-rank run must not die on an RCCL argument check.)
+        layer_b = _layer_from(sd, d, T, R, H, True, True, keep_att=False, precision="bf16x3")
+        for mode, compress in (("blocked", False), ("blocked", True), ("bucketed", True), ("pipelined", False)):
+            pg = PartitionedGraph(nts, eis[0].contiguous(), eis[1].contiguous(), ets, tms, T, R, N, 0, 1, n_chunks=4, mode=mode,
+                                  compress=compress)
+            assert pg.halo.n_halo == 0 and not any(pg.halo.chunk_live)
+            pg.halo.chunk_live = [True] * pg.halo.n_chunks
+            assert pg.layer_mode(layer_b) == mode
+            with torch.no_grad():
+                out = pg.forward(layer_b, xs)
+                out2 = pg.forward(layer_b, xs)
+            torch.cuda.synchronize()
+            assert (out.cpu().double() - ref).abs().max().item() < TOL
+            assert torch.equal(out, out2)
     finally:
         dist.destroy_process_group()
 
