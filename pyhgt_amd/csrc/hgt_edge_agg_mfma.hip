@@ -405,11 +405,14 @@ __device__ __forceinline__ void agg_mfma_subtile(
 //   * the relation-end work (zero rows, fragment loads, 48 MFMAs) runs BETWEEN batches, with the next batch's rows already
 //     on their way.
 // ---------------------------------------------------------------------------------------------
-template <int VEC, int LPH, bool RTE, bool F16>
+// FULL: the wavefront covers whole rows (HT == H, no head-group split: the fused kernels) -- row and logit strides are then compile-time
+// powers of two; as run-time values every gathered row paid a 64-bit scalar multiply (7 SALU instructions, round-5 ISA audit of a
+// kernel that is bound by instruction issue: profiles/r05_agg_counters.txt)
+template <int VEC, int LPH, bool RTE, bool F16, bool FULL = false>
 __device__ __forceinline__ void agg_mfma_stream(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
-    const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, int R, int rel_lo, int rel_hi, int HT, int SUBR,
+    const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, int R, int rel_lo, int rel_hi, int HT_, int SUBR,
     int64_t row0, unsigned char* utile, float* s_m, float* s_l, float* s_sc, float* s_sig, int raw,
     f32x4 (&acc)[MG<VEC, LPH>::NCT]) {
     using G = MG<VEC, LPH>;
@@ -433,10 +436,11 @@ __device__ __forceinline__ void agg_mfma_stream(
 #define HGT_AGG_UN_RTE 3
 #endif
     constexpr int UN = RTE ? HGT_AGG_UN_RTE : HGT_AGG_UN;    // rows per batch; two batches (register buffers A / B) are in flight
-    const int hg = blockIdx.y;
-    const int64_t ld = (int64_t)HT * DKP;
+    const int hg = FULL ? 0 : blockIdx.y;
+    const int HTx = FULL ? H : HT_;      // heads per row
+    const int64_t ld = FULL ? (int64_t)DP : (int64_t)HT_ * DKP;
     const int co = hg * DP;
-    const int NY = HT / H;
+    const int NY = FULL ? 1 : HT_ / H;
 
     const int lane = threadIdx.x & 63;
     const int h = lane / LPH, p = lane % LPH;
@@ -513,7 +517,7 @@ __device__ __forceinline__ void agg_mfma_stream(
         if (cur_dl >= 0) {
             const int dl = cur_dl;
             if (p == 0) {
-                s_l[dl * 16 + h] += l_seg;
+                s_l[dl * 16 + h] += l_seg;      // (as ds_add_f32 without return -- one instruction, no round trip -- measured the same: r05)
                 s_m[dl * 16 + h] = m_ref;
             }
             if (seg_claimed) {
@@ -642,7 +646,7 @@ __device__ __forceinline__ void agg_mfma_stream(
         const int p_ = __builtin_amdgcn_readlane(c_pos, idx);                                      \
         KY[u] = __builtin_amdgcn_readlane(c_key, idx);                                             \
         AGG_LOAD(VR[u], V + (int64_t)s_ * ld + co + lane * VEC)                                    \
-        AGG_LOAD(SL[u], logits + (int64_t)p_ * HT + hg * H + h)                                    \
+        AGG_LOAD(SL[u], logits + (int64_t)p_ * HTx + hg * H + h)                                    \
         if constexpr (RTE) {                                                                       \
             const int ri = __builtin_amdgcn_readlane(c_rte, idx);                                  \
             AGG_LOAD(TR[u], rteV + (int64_t)ri * ld + co + lane * VEC)                             \
@@ -670,6 +674,8 @@ __device__ __forceinline__ void agg_mfma_stream(
                     l_seg = 0.0f;                                                                  \
                     cur_dl = KY[u] & 255;                                                          \
                     seg_claimed = claimed_;                                                        \
+                    /* (requested here, behind the parking's own exp-sum round trip: requested before it -- one wait for both -- */ \
+                    /*  it measured 0.8 % slower, r05) */                                           \
                     const float m_t = s_m[cur_dl * 16 + h];                                        \
                     m_ref = (m_t == HGT_NEG) ? SL[u] : m_t;                                        \
                 }                                                                                  \
@@ -964,8 +970,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
     if (any_hub) return;      // k_edge_aggregate_hub_workgroups walks the 64 targets of such a workgroup (same launcher)
     f32x4 acc[G::NCT];
     if (wrow0 < NQ) {
-        agg_mfma_stream<VEC, LPH, RTE, F16>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, 0, R + 1, HT, 16, wrow0, utile, s_m, s_l,
-                                            s_scale + wib * 16, s_sig + wib * 16, 0, acc);
+        agg_mfma_stream<VEC, LPH, RTE, F16, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, 0, R + 1, HT, 16, wrow0, utile, s_m, s_l,
+                                                  s_scale + wib * 16, s_sig + wib * 16, 0, acc);
         if constexpr (F16) agg_mfma_finish<VEC, LPH>(s_l, 1, acc, s_sig + wib * 16, msg_frag_inv_scale<VEC, LPH>(msgF, R, HT));
         else agg_mfma_finish<VEC, LPH>(s_l, 1, acc);
     } else {

@@ -1,32 +1,35 @@
 // Ring form of the fused aggregation + node-update kernel (round 5): d = 256 / 8 heads (VEC = 4, LPH = 8), no temporal rows, bf16 split.
-// Included by hgt_edge_agg_mfma.hip (part VEC = 4 / RTE = 0 / F16 = 0) inside its anonymous namespace.
+// Included by hgt_edge_agg_mfma.hip (part VEC = 4 / RTE = 0 / F16 = 0) inside its anonymous namespace.  OPT-IN (HGT_FLAG_RING_AGGREGATE):
+// bit-identical to k_edge_aggregate_update_mfma, measured 3.57 ms against 3.27 at the benchmark size -- kept as the record of the
+// experiment the round-4 review asked for and as the A/B partner of the default kernel (counters: profiles/r05_agg_counters.txt).
 //
-// Why.  k_edge_aggregate_update_mfma is bound by CONCURRENCY, not by bytes or instructions (profiles/r05_agg_lab_switches.txt: one
-// workgroup per CU instead of two doubles its time; HBM traffic is 1.05x algorithmic).  A wavefront of that kernel keeps 2 x 4 gathered rows
-// in flight -- all its registers allow next to 64 accumulators, 64 fragment registers and the row buffers (256 VGPRs, 2 waves per SIMD) --
-// and every relation end stops its gather pipeline for two dependent L2 round trips (the fragments are requested when they are needed,
-// behind the rows already in flight: vmcnt retires in order).  Both limits are on-chip capacity, so the capacity is re-assigned:
-//   * gathered rows never touch registers: a wavefront owns an LDS RING of RG_D slots of 1 KB, a row arrives by LDS-DMA
-//     (global_load_lds_dwordx4: one instruction, scalar row base + lane offset, no VGPR) and is read back with one ds_read_b128 when it
-//     is consumed; the slot is refilled at once with the row RG_D positions ahead -- RG_D rows in flight per wavefront, all the time,
-//     across segment, relation and chunk boundaries;
-//   * the LDS for the ring comes from the U tile: a finished segment row (bf16 hi / mid) goes through ONE 1 KB bounce row straight into the
-//     REGISTERS of the four lanes that hold its target's column of the MFMA B operand (exec-masked ds_read_b128: 64 VGPRs per lane hold the
-//     16 x 256 tile; they take the place of the old row buffers + half the fragment stage);
-//   * the fragments of a relation are requested when the walk ENTERS it and sit in 64 VGPRs until its end, so a relation end waits for
-//     nothing: they are older than (nearly) every row in flight;
-//   * edge ids and logits of the next 64 stream entries also arrive by LDS-DMA (4 instructions per chunk).
-// Nothing in the walk is a compiler-visible vector-memory access, so hipcc emits no vmcnt wait inside it; the kernel counts its own
-// operations (vm_issued) and waits with exact, dynamic s_waitcnt vmcnt(n) (rg_wait_vm).  Arithmetic, summation order and softmax
-// references are those of k_edge_aggregate_update_mfma: the two kernels are bit-identical (tests/test_hgt_gpu.py).
+// The idea.  A wavefront of the default kernel keeps 2 x 4 gathered rows in flight -- all its registers allow next to 64 accumulators, 64
+// fragment registers and the row buffers -- and every relation end fetches 32 KB of fragments behind the rows in flight.  Here the on-chip
+// capacity is re-assigned:
+//   * gathered rows never touch registers before they are used: a wavefront owns an LDS RING of RG_D slots of 1 KB, a row arrives by
+//     LDS-DMA (global_load_lds_dwordx4: scalar base + one lane offset, no VGPR) and is read back with one ds_read_b128 one row ahead of
+//     its use; the slot is refilled at once -- RG_D - 1 rows in flight per wavefront across segment, relation and chunk boundaries, and
+//     past the end of the stream (the last row is re-requested), so that every wait for a row is the SAME s_waitcnt immediate;
+//   * the LDS for the ring comes from the U tile: finished segment rows (bf16 hi / mid) wait in a 4-row park buffer and reach the
+//     REGISTERS of the lanes that hold their targets' columns of the MFMA B operand through exec-masked ds_read_b128 (64 VGPRs per lane
+//     hold the 16 x 256 tile);
+//   * half of a relation's fragments (64 VGPRs: all 32 would be 128, the whole file next to accumulators and U tile) is requested when
+//     the walk ENTERS the relation; the other half after the first half's products: one exposed round trip that also drains the ring
+//     (measured: hidden by the other wavefronts);
+//   * edge ids and logits of 64 stream entries arrive by LDS-DMA as well (4 instructions per chunk).
+// Nothing in the walk is a compiler-visible vector-memory access: hipcc emits no vmcnt wait inside it, the waits are the kernel's own.
+//
+// What was learnt (the reason it is not the default): neither kernel is bound by memory latency or by the fragment traffic.  Both are
+// bound by INSTRUCTION ISSUE -- two wavefronts per SIMD retire about one instruction per 5 cycles whatever the mix, and the time follows
+// the instruction count (ring v1: 190 instructions per row, 4.55 ms; this form: 127, 3.57 ms; default kernel: 113, 3.27 ms).  The ring
+// removes the waits it was built to remove and pays for it with per-row bookkeeping: a single-row loop has no instruction-level
+// parallelism across rows and ~60 instructions of fetch / issue / index work per row (1.85 ms with everything else switched off), where
+// the default kernel's batches of four amortise theirs.
 #pragma once
 
-#ifndef RG_LAB
-#define RG_LAB 0      // timing-only experiment switches (wrong results): see the uses
-#endif
 #ifndef RG_OFF
 #define RG_OFF 0      // timing-only: bit mask of parts left out -- 1 node update, 2 register fills of parked rows, 4 parking (split + LDS
-#endif                // writes + fills), 8 relation transforms, 16 waits for rows, 32 the row DMA instruction, 64 exp + fma
+#endif                // writes + fills), 8 relation transforms, 16 waits for rows, 32 the row DMA instruction, 64 exp + fma, 128 gathers hit row 0
 #ifndef RG_DEPTH
 #define RG_DEPTH 8
 #endif
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_ring(
 
             // one row issued: entry at the issue pointer -> slot i_slot; the pointer advances
             auto issue_row = [&]() {
-                const int src = (RG_LAB == 5) ? 0 : __builtin_amdgcn_readlane(v_src, i_idx);      // (5: every gather reads row 0: cache hits)
+                const int src = (RG_OFF & 128) ? 0 : __builtin_amdgcn_readlane(v_src, i_idx);      // (128: every gather reads row 0)
                 if (RG_OFF & 32) asm volatile("" ::"v"(((unsigned)src << 10) + voff), "s"(lds_w + (unsigned)i_slot));
                 else if constexpr (WIDE) rg_dma16_s(V + (int64_t)src * 256, voff, lds_w + (unsigned)i_slot);
                 else rg_dma16_s(V, ((unsigned)src << 10) + voff, lds_w + (unsigned)i_slot);
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_ring(
 #define RG_FETCH(row, sl, dl, WAIT)                                                                                                \
     {                                                                                                                              \
         if (skip > 0) --skip;                                                                                                      \
-        else if (RG_LAB != 6 && !(RG_OFF & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");                                          \
+        else if (!(RG_OFF & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");                                          \
         row = *reinterpret_cast<const float4*>(p_ring + f_slot);                                                                   \
         sl = *reinterpret_cast<const float*>(p_log + f_par * 2048 + f_idx * 16);                                                   \
         dl = __builtin_amdgcn_readlane(v_dst, f_idx);                                                                              \
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_ring(
                     l_seg = 0.0f;
                     s_m[dl * 8 + h] = m_ref;      // (every lane of a head writes the same pair: no exec mask)
                     s_l[dl * 8 + h] = l_old;
-                    if (con_rel < R && RG_LAB != 4 && !(RG_OFF & 4)) {
+                    if (con_rel < R && !(RG_OFF & 4)) {
                         uint2 hi, mid;
                         split4(make_float4(U0, U1, U2, U3), hi, mid);
                         unsigned char* w = bnc + pk * 1024 + lane * 8;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_ring(
                         slotv = mine ? pk * 1024 : slotv;
                         pmask |= __builtin_amdgcn_ballot_w64(mine);
                         rowmask |= 1u << dl;
-                        if (++pk == RG_PARK && RG_LAB != 2 && !(RG_OFF & 2)) fill();
+                        if (++pk == RG_PARK && !(RG_OFF & 2)) fill();
                     }
                 }
             };
@@ -278,10 +281,10 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_ring(
 #define RG_BOUNDARY()                                                                                                              \
     {                                                                                                                              \
         flush();                                                                                                                   \
-        if (RG_LAB != 2 && !(RG_OFF & 2)) fill();                                                                                  \
+        if (!(RG_OFF & 2)) fill();                                                                                                  \
         cur_dl = -1;                                                                                                               \
         bool drained = false;                                                                                                      \
-        if (rowmask != 0 && RG_LAB != 3 && !(RG_OFF & 8)) {   /* Z^T += M_r^T . U_r^T for the rows parked during relation con_rel */                  \
+        if (rowmask != 0 && !(RG_OFF & 8)) {             /* Z^T += M_r^T . U_r^T for the rows parked during relation con_rel */                  \
             const unsigned short* fb_cur = msgF + (int64_t)con_rel * (NCT * 2 * 512);                                              \
             if (rel_len < RG_D) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* (a relation shorter than the ring) */        \
             float pf[8];      /* pending scales of this lane's target, head by head (1.0 unless a softmax reference moved) */      \
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_ring(
             *reinterpret_cast<uint2*>(prow + A_PLANE + c * 32) = mid;
         }
     }
-#if RG_LAB != 7 && !(RG_OFF & 1)      // (no node update: the walk's own register need)
+#if !(RG_OFF & 1)      // (no node update: the walk's own register need)
     fused_update_tail<4, HGT_FU_NSTG, true, false>(smem, smem + RG_FRONT, row0, NQ, fu, type_pre);
 #endif
 }

@@ -12,7 +12,7 @@
 #   xs        the x-stationary typed linear (csrc/hgt_gemm_xs.hip): bit-identity against the slab kernel in every wavefront order,
 #             timings with the elimination switches (tools/bench_xs.py), the c2 / d = 512 layers with and without it
 # Everything lands in gpurun_out/; summaries to be judged are copied to profiles/ by hand (or by `final`).
-MODE=${1:-quick}; TAG=${2:-r04}
+MODE=${1:-quick}; TAG=${2:-r05}
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
 ulimit -c 0      # a faulting kernel must not fill the scratch disk with core files (every later command of the call then fails)
