@@ -954,6 +954,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "median_ms_per_step": median_ms,
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
+            # said plainly (round-4 review): the builder's development loop has ONE GPU -- no step of the dst-partitioned path has been
+            # timed on more than one device by the builder; `secondary.rank_of_8_*` is one GPU playing rank 0 of 8 (GPU side only)
+            "multi_gpu_measured_by_builder": False if world == 1 else None,
             "dtype": prec_note[args.precision],
             "data": "synthetic",
             "config": {"workload": "%s: synthetic %d-type/%d-relation graph, %d nodes / %d edges per GPU, "

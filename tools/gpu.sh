@@ -11,7 +11,13 @@
 #   judged    rocprofv3 passes of the judged command + the judged line (what `final` ends with)
 #   xs        the x-stationary typed linear (csrc/hgt_gemm_xs.hip): bit-identity against the slab kernel in every wavefront order,
 #             timings with the elimination switches (tools/bench_xs.py), the c2 / d = 512 layers with and without it
+#   suite     pytest -m gpu, whole suite ($3 = HGT_FLAG_* bits forced onto every layer through HGT_TEST_KERNEL_FLAGS, e.g. 1024 = the
+#             x-stationary GEMM on every eligible typed linear, 512 = the LDS-ring aggregation)
+#   sanity    smoke(), the judged layer without secondaries, a handful of tests: the first call after a kernel change
+#   ceiling   plain streaming kernels of the part (tools/lab/stream_ceiling.py): fill / copy / 1:3 read:write rates
+#   xsthr     slab vs x-stationary GEMM around the dispatch threshold (tools/bench_xs.py --threshold)
 # Everything lands in gpurun_out/; summaries to be judged are copied to profiles/ by hand (or by `final`).
+# Kernel experiments: tools/lab/build_lab.sh (lab libraries), lab_run.sh (phase times), pmc_quick.sh (counters), isa.sh (ISA + resources).
 MODE=${1:-quick}; TAG=${2:-r05}
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
@@ -78,8 +84,9 @@ final)
     timeout 300 python examples/train_synthetic.py --steps 6 2>&1 | tail -3
     python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/pytest_$TAG.log
     grep -E "^FAILED|^ERROR| passed| failed" gpurun_out/pytest_$TAG.log | tail -10
-    # the x-stationary GEMM forced onto the small graphs of the backward / staged tests (its size threshold keeps it off them otherwise)
-    HGT_TEST_KERNEL_FLAGS=1024 timeout 600 python -m pytest tests -m gpu -q -k "backward or staged or two_rank or matches_oracle" 2>&1 | tail -3
+    # the x-stationary GEMM (1024) and the LDS-ring aggregation (512) forced onto every layer of the backward / staged / oracle tests
+    # (the GEMM's size threshold keeps it off small graphs otherwise; the ring form is opt-in)
+    HGT_TEST_KERNEL_FLAGS=$((1024 + 512 + 64)) timeout 900 python -m pytest tests -m gpu -q -k "backward or staged or two_rank or matches_oracle or fused or golden" 2>&1 | tail -3
     timeout 300 python tools/bench_xs.py > gpurun_out/${TAG}_xs_check.log 2>&1; grep -v "BIT-IDENTICAL (" gpurun_out/${TAG}_xs_check.log | tail -12
     tools/profile_pmc.sh $TAG > gpurun_out/prof_$TAG.log 2>&1
     cp gpurun_out/prof_$TAG/${TAG}_pmc_summary.json profiles/${TAG}_pmc_summary.json      # the line below is judged against THIS build's counters
@@ -108,6 +115,21 @@ judged)
     cp gpurun_out/prof_$TAG/${TAG}_pmc_summary.json profiles/${TAG}_pmc_summary.json
     ( time timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err ) 2>&1 | grep real
     summ gpurun_out/${TAG}_bench.json
+    ;;
+suite)
+    HGT_TEST_KERNEL_FLAGS=${3:-0} timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 | tee gpurun_out/suite_${TAG}_flags${3:-0}.txt
+    ;;
+sanity)
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+    timeout 300 python bench.py --no-secondary --no-cpu-baseline > gpurun_out/sanity_bench.json 2> gpurun_out/sanity_bench.err; echo "bench rc=$?"
+    summ gpurun_out/sanity_bench.json
+    timeout 300 python -m pytest tests -m gpu -q -x -k "golden or xs_gemm or reference_call or ring_aggregation" 2>&1 | tail -2
+    ;;
+ceiling)
+    timeout 200 python tools/lab/stream_ceiling.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/stream_ceiling.txt
+    ;;
+xsthr)
+    timeout 300 python tools/bench_xs.py --threshold 2>&1 | grep -v amdgpu.ids | tee gpurun_out/xs_threshold.txt
     ;;
 emuprof)
     export TMPDIR=/tmp; ROOT=$(pwd); cd /tmp
