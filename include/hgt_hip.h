@@ -40,6 +40,11 @@ extern "C" {
 
 const char* hgt_strerror(int code);
 int hgt_abi_version(void);
+/* Bit mask of optional parts compiled into this library.  Bit 0 (HGT_FEATURE_LAB_KERNELS): the measured-and-not-adopted kernels of
+ * csrc/lab/ (make LAB=1) -- only then do HGT_FLAG_RING_AGGREGATE / HGT_FLAG_SINGLE_PASS select anything; the shipped library is
+ * built without them and ignores both flags. */
+#define HGT_FEATURE_LAB_KERNELS 1
+int hgt_build_features(void);
 
 /* ----------------------------------------------------------------------------------------------
  * Internal "head-padded" feature layout.  Q/K/V/agg rows hold n_heads blocks of dk_pad floats
@@ -280,7 +285,8 @@ int hgt_edge_aggregate_items(const void* plan, int64_t n_nodes, int64_t n_edges,
  * gathered together, the logit, the run's online softmax and the weighted sum, then the message transform (msg_frag) -- no [E][H]
  * logits array, one launch less per layer.  Same scratch, same fixed-order merge and (up to the fp32 summation order of the
  * logits) the same result as hgt_edge_logits_mfma + hgt_edge_aggregate_items.  rte_k / rte_v: both tables or both NULL.
- * HGT_ERR_UNSUPPORTED for layouts it is not instantiated for (the caller takes the two-kernel form). */
+ * HGT_ERR_UNSUPPORTED for layouts it is not instantiated for (the caller takes the two-kernel form) -- and ALWAYS in the shipped
+ * library: the kernel (csrc/lab/hgt_edge_single_pass.hip, measured not faster) is compiled into LAB builds only (hgt_build_features). */
 int hgt_edge_single_pass_items(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                                int32_t n_heads, int32_t dk_pad, const float* Q, const float* K, const float* V, const float* rte_k,
                                const float* rte_v, const void* att_frag, const void* msg_frag, int32_t frag_f16, float* agg,
@@ -564,15 +570,15 @@ typedef struct hgt_conv_args {
 #define HGT_FLAG_ITEM_AGGREGATE 16   /* hgt_edge_aggregate_items wherever it applies (the default below 65536 nodes when its scratch is at most 1 GB) */
 #define HGT_FLAG_NO_ITEM_AGGREGATE 32 /* never hgt_edge_aggregate_items */
 #define HGT_FLAG_FUSED_ANY_SIZE 64   /* hgt_edge_aggregate_update below its default size too (>= 16384 targets) */
-#define HGT_FLAG_SINGLE_PASS 256     /* ABI 6: hgt_edge_single_pass_items instead of logits + item-parallel aggregation where it applies (sampled
+#define HGT_FLAG_SINGLE_PASS 256     /* LAB builds only (ignored otherwise: the two-kernel form runs).  ABI 6: hgt_edge_single_pass_items instead of logits + item-parallel aggregation where it applies (sampled
                                       * sub-graphs, attention weights not exported).  Off by default: measured equal at c3 and 5 % slower at c5
                                       * (its two LDS tiles cap it at 4 wavefronts per CU) */
 #define HGT_FLAG_XS_GEMM_ALWAYS 1024 /* ABI 6: the x-stationary split GEMM (hgt_gemm_xs.hip) for every typed linear of the layer it covers, whatever
                                       * the row count (HGT_LINEAR_FORCE_XS); */
 #define HGT_FLAG_XS_GEMM_NEVER 2048  /* ... never (HGT_LINEAR_NO_XS): the slab kernels.  Bit-identical results either way: tests / A/B timings */
-#define HGT_FLAG_RING_AGGREGATE 512 /* ABI 6: the LDS-ring form of the fused aggregation kernel (round 5, csrc/hgt_edge_agg_ring.h: rows by LDS-DMA,
-                                     * U tile in registers) where it exists (d = 256 / 8 heads, no temporal rows, bf16 split) instead of the
-                                     * default kernel: bit-identical, measured 4 % slower at c2 -- kept for A/B runs */
+#define HGT_FLAG_RING_AGGREGATE 512 /* LAB builds only (hgt_build_features() & HGT_FEATURE_LAB_KERNELS; ignored otherwise): the LDS-ring form of the fused
+                                     * aggregation kernel (round 5, csrc/lab/hgt_edge_agg_ring.h: rows by LDS-DMA, U tile in registers) where it exists
+                                     * (d = 256 / 8 heads, no temporal rows, bf16 split): bit-identical, measured 9 % slower at c2 */
 #define HGT_FLAG_DETERMINISTIC_HUBS 128 /* ABI 6: targets with more than 1024 in-edges ("hubs") are aggregated WITHOUT atomics: every piece of a
                                       * (hub, relation) range writes its partial row / exp-sum to its own slot and the finalize kernel sums
                                       * the slots in (relation, piece) order, so two forwards are bit-identical on every row (the default

@@ -26,6 +26,7 @@ HGT_FLAG_XS_GEMM_ALWAYS = 1024
 HGT_FLAG_XS_GEMM_NEVER = 2048
 HGT_LINEAR_FORCE_XS = 0x100
 HGT_LINEAR_NO_XS = 0x200
+HGT_FEATURE_LAB_KERNELS = 1
 
 
 class HgtLayout(C.Structure):
@@ -78,6 +79,7 @@ _i32, _i64, _u64, _vp = C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
 SIGNATURES = {
     "hgt_strerror": (C.c_char_p, [C.c_int]),
     "hgt_abi_version": (C.c_int, []),
+    "hgt_build_features": (C.c_int, []),
     "hgt_layout_for": (C.c_int, [_i32, _i32, C.POINTER(HgtLayout)]),
     "hgt_plan_sizes_for": (C.c_int, [_i64, _i64, _i32, _i32, C.POINTER(HgtPlanSizes)]),
     "hgt_plan_constants": (C.c_int, [C.POINTER(_i32), C.POINTER(_i32)]),

@@ -137,6 +137,13 @@ extern "C" const char* hgt_strerror(int code) {
 }
 
 extern "C" int hgt_abi_version(void) { return HGT_ABI_VERSION; }
+extern "C" int hgt_build_features(void) {
+#ifdef HGT_LAB_KERNELS
+    return HGT_FEATURE_LAB_KERNELS;
+#else
+    return 0;
+#endif
+}
 
 extern "C" int hgt_layout_for(int32_t d_out, int32_t n_heads, hgt_layout* out) {
     if (!out) return HGT_ERR_INVALID_ARG;
@@ -429,7 +436,7 @@ edge_phase:
                            !(a->flags & HGT_FLAG_NO_ITEM_AGGREGATE) &&
                            (NQ < HGT_ITEM_AGG_DEFAULT_NODES || (a->flags & HGT_FLAG_ITEM_AGGREGATE));
     // ... and, on request (HGT_FLAG_SINGLE_PASS) and when nobody asks for the attention weights, logits + runs in ONE walk
-    // (hgt_edge_single_pass.hip): one kernel and the [E][H] logits array less; not the default -- measured equal at c3, 5 % slower at c5
+    // (lab/hgt_edge_single_pass.hip, LAB builds only): one kernel and the [E][H] logits array less; measured equal at c3, 5 % slower at c5
     bool agg_done = false;
     if (items_agg && !fuse_all && !a->want_att && have_frags && E > 0 && (a->flags & HGT_FLAG_SINGLE_PASS)) {
         rc = hgt_edge_single_pass_items(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, V, rte_k, rte_v, att_f_buf, msg_f, f16 ? 1 : 0, agg, NQ,

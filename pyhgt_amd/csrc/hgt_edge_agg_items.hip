@@ -363,10 +363,18 @@ extern "C" int hgt_edge_aggregate_items_bytes(int64_t n_edges, int32_t n_heads, 
     return HGT_OK;
 }
 
-// hgt_edge_single_pass.hip
+// lab/hgt_edge_single_pass.hip (logits inside the runs kernel: correct, not faster -- DESIGN.md section 10): part of LAB builds only
+// (make LAB=1); the shipped library answers HGT_ERR_UNSUPPORTED and the caller takes the two-kernel form
+#ifdef HGT_LAB_KERNELS
 int hgt_launch_single_pass_runs(int vec, int lph, bool f16, const HgtPlanView& pv, const float* Q, const float* K, const float* V,
                                 const float* rteK, const float* rteV, const unsigned short* attF, const unsigned short* msgF, float* zrows,
                                 float* zstat, unsigned char* zflag, int R, int HT, hipStream_t stream);
+#else
+static int hgt_launch_single_pass_runs(int, int, bool, const HgtPlanView&, const float*, const float*, const float*, const float*, const float*,
+                                       const unsigned short*, const unsigned short*, float*, float*, unsigned char*, int, int, hipStream_t) {
+    return HGT_ERR_UNSUPPORTED;
+}
+#endif
 
 // sp != nullptr: the single-pass form (logits computed inside the runs kernel from Q, K and the attention fragments)
 struct SinglePassArgs {

@@ -1048,12 +1048,10 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_hub_workgroups(
                                                smem + wib * 2 * G::PLANE, s_m, s_m + 256, s_scale + wib * 16, s_sig + wib * 16);
 }
 
-#ifndef HGT_AGG_RING
-#define HGT_AGG_RING 1      // 0: the ring form is not built
-#endif
-#if defined(HGT_MFMA_PART_VEC) && HGT_MFMA_PART_VEC == 4 && HGT_MFMA_PART_RTE == 0 && HGT_MFMA_PART_F16 == 0 && HGT_AGG_RING
+// the LDS-ring form of the fused kernel (lab/hgt_edge_agg_ring.h: bit-identical, measured slower -- DESIGN.md section 10): LAB builds only
+#if defined(HGT_LAB_KERNELS) && defined(HGT_MFMA_PART_VEC) && HGT_MFMA_PART_VEC == 4 && HGT_MFMA_PART_RTE == 0 && HGT_MFMA_PART_F16 == 0
 #define HGT_HAVE_RING 1
-#include "hgt_edge_agg_ring.h"
+#include "lab/hgt_edge_agg_ring.h"
 #endif
 
 // ---------------------------------------------------------------------------------------------

@@ -18,8 +18,8 @@
 // [E][H] logits array), tested on every layout it is instantiated for, and the answer to "would one walk over the edges be
 // faster?" for the latency regime; for the million-node graph the same question is answered on paper in DESIGN.md section 10.
 // No atomics, fixed order: bit-reproducible like its two-kernel form.
-#include "hgt_edge_common.h"
-#include "hgt_split_common.h"
+#include "../hgt_edge_common.h"
+#include "../hgt_split_common.h"
 
 #ifndef HGT_LOGITS_XCD
 #define HGT_LOGITS_XCD 1

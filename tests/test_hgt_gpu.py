@@ -1050,10 +1050,12 @@ RING_CASES = [
 
 @pytest.mark.parametrize("case", RING_CASES, ids=[str(i) for i in range(len(RING_CASES))])
 def test_ring_aggregation_is_bit_identical_to_the_default_kernel(case):
-    """csrc/hgt_edge_agg_ring.h (round 5, opt-in through HGT_FLAG_RING_AGGREGATE: gathered rows through an LDS ring by LDS-DMA, U
+    """csrc/lab/hgt_edge_agg_ring.h (round 5, LAB builds, selected by HGT_FLAG_RING_AGGREGATE: gathered rows through an LDS ring by LDS-DMA, U
     tile in registers, fragments requested a relation ahead, hand-counted vmcnt waits) performs the arithmetic of
     k_edge_aggregate_update_mfma in the same order: at d = 256 / 8 heads the two must agree to the BIT, and with the fp64 oracle to
     the split-bf16 bound."""
+    if not (_lib.load().hgt_build_features() & _lib.HGT_FEATURE_LAB_KERNELS):
+        pytest.skip("the ring kernel is part of LAB builds only (make -C pyhgt_amd/csrc LAB=1; profiles/r05_forced_kernels_suite.txt)")
     N, E, T, R, gk, edit = case
     d, H = 256, 8
     sd = O.make_state_dict(d, d, T, R, H, True, False, seed=N % 1000 + R)

@@ -5,10 +5,10 @@
 set -e
 NAME=$1; FLAGS=$2; PART=${3:-400}
 cd "$(dirname "$0")/../../pyhgt_amd/csrc"
-make BUILD=build_lab LIBDIR=../lib_lab EXTRA=-DHGT_DEV_LAYOUTS -j8 > /dev/null
+make BUILD=build_lab LIBDIR=../lib_lab LAB=1 EXTRA=-DHGT_DEV_LAYOUTS -j8 > /dev/null
 V=$(echo $PART | cut -c1); R=$(echo $PART | cut -c2); F=$(echo $PART | cut -c3)
 OBJ=build_lab/lab_${NAME}_p$PART.o
-/opt/rocm/bin/hipcc -DHGT_DEV_LAYOUTS $FLAGS --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function \
+/opt/rocm/bin/hipcc -DHGT_DEV_LAYOUTS -DHGT_LAB_KERNELS $FLAGS --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function \
     -I../../include -DHGT_MFMA_PART_VEC=$V -DHGT_MFMA_PART_RTE=$R -DHGT_MFMA_PART_F16=$F -c hgt_edge_agg_mfma.hip -o $OBJ \
     -Rpass-analysis=kernel-resource-usage 2> build_lab/lab_${NAME}_p$PART.rpass || { tail -30 build_lab/lab_${NAME}_p$PART.rpass; exit 1; }
 mkdir -p ../lib_lab_$NAME
