@@ -1,5 +1,6 @@
 // Ring form of the fused aggregation + node-update kernel (round 5): d = 256 / 8 heads (VEC = 4, LPH = 8), no temporal rows, bf16 split.
-// Included by hgt_edge_agg_mfma.hip (part VEC = 4 / RTE = 0 / F16 = 0) inside its anonymous namespace.  OPT-IN (HGT_FLAG_RING_AGGREGATE):
+// Included by hgt_edge_agg_mfma.hip (part VEC = 4 / RTE = 0 / F16 = 0) inside its anonymous namespace in LAB builds only (make LAB=1;
+// selected by HGT_FLAG_RING_AGGREGATE):
 // bit-identical to k_edge_aggregate_update_mfma, measured 3.57 ms against 3.27 at the benchmark size -- kept as the record of the
 // experiment the round-4 review asked for and as the A/B partner of the default kernel (counters: profiles/r05_agg_counters.txt).
 //
