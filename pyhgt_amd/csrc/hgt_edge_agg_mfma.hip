@@ -408,7 +408,9 @@ __device__ __forceinline__ void agg_mfma_subtile(
 // FULL: the wavefront covers whole rows (HT == H, no head-group split: the fused kernels) -- row and logit strides are then compile-time
 // powers of two; as run-time values every gathered row paid a 64-bit scalar multiply (7 SALU instructions, round-5 ISA audit of a
 // kernel that is bound by instruction issue: profiles/r05_agg_counters.txt)
-template <int VEC, int LPH, bool RTE, bool F16, bool FULL = false>
+// S32 (fused kernels, chosen by the launcher): every gathered row / logit / temporal row lies below 4 GiB from its base -> 32-bit
+// unsigned lane offsets, one VALU instruction per address instead of a 64-bit scalar shift + a 64-bit vector add (r05: 3.22 -> 3.14 ms)
+template <int VEC, int LPH, bool RTE, bool F16, bool FULL = false, bool S32 = false>
 __device__ __forceinline__ void agg_mfma_stream(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
@@ -516,7 +518,7 @@ __device__ __forceinline__ void agg_mfma_stream(
     auto flush = [&]() {
         if (cur_dl >= 0) {
             const int dl = cur_dl;
-            if (p == 0) {
+            {      // (every lane of the head writes the same pair: no exec mask around it -- r05: 3.22 -> 3.19 ms)
                 s_l[dl * 16 + h] += l_seg;      // (as ds_add_f32 without return -- one instruction, no round trip -- measured the same: r05)
                 s_m[dl * 16 + h] = m_ref;
             }
@@ -575,8 +577,8 @@ __device__ __forceinline__ void agg_mfma_stream(
         rowmask = 0;
         return;
 #endif
-        for (int r = 0; r < SUBR; ++r) {
-            if ((rowmask >> r) & 1u) continue;
+        for (unsigned zm_ = ~rowmask & ((1u << SUBR) - 1u); zm_ != 0; zm_ &= zm_ - 1) {      // (only the absent rows are visited)
+            const int r = __builtin_ctz(zm_);
             unsigned char* w = utile + r * ROWB + ((((wb >> 4) ^ (r & (NS - 1)))) << 4) + (wb & 15);
             if constexpr (VEC == 1) {
                 *reinterpret_cast<unsigned short*>(w) = 0;
@@ -645,11 +647,20 @@ __device__ __forceinline__ void agg_mfma_stream(
         const int s_ = __builtin_amdgcn_readlane(c_src, idx);                                      \
         const int p_ = __builtin_amdgcn_readlane(c_pos, idx);                                      \
         KY[u] = __builtin_amdgcn_readlane(c_key, idx);                                             \
-        AGG_LOAD(VR[u], V + (int64_t)s_ * ld + co + lane * VEC)                                    \
-        AGG_LOAD(SL[u], logits + (int64_t)p_ * HTx + hg * H + h)                                    \
-        if constexpr (RTE) {                                                                       \
-            const int ri = __builtin_amdgcn_readlane(c_rte, idx);                                  \
-            AGG_LOAD(TR[u], rteV + (int64_t)ri * ld + co + lane * VEC)                             \
+        if constexpr (FULL && S32) {                                                               \
+            AGG_LOAD(VR[u], reinterpret_cast<const char*>(V) + (unsigned)((unsigned)s_ * (unsigned)(DP * 4) + (unsigned)(lane * VEC * 4))) \
+            AGG_LOAD(SL[u], reinterpret_cast<const char*>(logits) + (unsigned)((unsigned)p_ * (unsigned)(H * 4) + (unsigned)(h * 4)))       \
+            if constexpr (RTE) {                                                                   \
+                const int ri = __builtin_amdgcn_readlane(c_rte, idx);                              \
+                AGG_LOAD(TR[u], reinterpret_cast<const char*>(rteV) + (unsigned)((unsigned)ri * (unsigned)(DP * 4) + (unsigned)(lane * VEC * 4))) \
+            }                                                                                      \
+        } else {                                                                                   \
+            AGG_LOAD(VR[u], V + (int64_t)s_ * ld + co + lane * VEC)                                \
+            AGG_LOAD(SL[u], logits + (int64_t)p_ * HTx + hg * H + h)                               \
+            if constexpr (RTE) {                                                                   \
+                const int ri = __builtin_amdgcn_readlane(c_rte, idx);                              \
+                AGG_LOAD(TR[u], rteV + (int64_t)ri * ld + co + lane * VEC)                         \
+            }                                                                                      \
         }                                                                                          \
     }
 #define AGG_LOAD(D, P) D = *reinterpret_cast<const __typeof__(D)*>(P);
@@ -685,7 +696,8 @@ __device__ __forceinline__ void agg_mfma_stream(
                     const float sc = __expf(m_ref - m_new);                                        \
                     _Pragma("unroll") for (int i = 0; i < VEC; ++i) U[i] *= sc;                    \
                     l_seg *= sc;                                                                   \
-                    const int dl = cur_dl;                                                         \
+                    int dl = cur_dl;                                                               \
+                    asm volatile("" : "+s"(dl));   /* (keeps the lane masks of this rare path out of every batch: hipcc hoisted four v_cmp per batch) */ \
                     if (p == 0) {                                                                  \
                         s_l[dl * 16 + h] *= sc;                                                    \
                         s_sc[h] = sc;                                                              \
@@ -935,7 +947,7 @@ __device__ __attribute__((noinline)) void agg_mfma_hub_workgroup(
 
 // Aggregation + fused node update (see hgt_fused_update.h).  Workgroups that contain a hub target cannot finish their rows
 // here: they write agg, raise pending[workgroup], and k_update_pending runs the same epilogue from agg after the hub kernels.
-template <int VEC, int LPH, bool RTE, bool F16>
+template <int VEC, int LPH, bool RTE, bool F16, bool S32>
 __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ esrc, const int32_t* __restrict__ edst,
     const uint16_t* __restrict__ ertei, const float* __restrict__ logits, const float* __restrict__ V,
@@ -970,8 +982,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
     if (any_hub) return;      // k_edge_aggregate_hub_workgroups walks the 64 targets of such a workgroup (same launcher)
     f32x4 acc[G::NCT];
     if (wrow0 < NQ) {
-        agg_mfma_stream<VEC, LPH, RTE, F16, true>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, 0, R + 1, HT, 16, wrow0, utile, s_m, s_l,
-                                                  s_scale + wib * 16, s_sig + wib * 16, 0, acc);
+        agg_mfma_stream<VEC, LPH, RTE, F16, true, S32>(segptr, esrc, edst, ertei, logits, V, rteV, msgF, R, 0, R + 1, HT, 16, wrow0, utile, s_m, s_l,
+                                                       s_scale + wib * 16, s_sig + wib * 16, 0, acc);
         if constexpr (F16) agg_mfma_finish<VEC, LPH>(s_l, 1, acc, s_sig + wib * 16, msg_frag_inv_scale<VEC, LPH>(msgF, R, HT));
         else agg_mfma_finish<VEC, LPH>(s_l, 1, acc);
     } else {
@@ -1109,9 +1121,14 @@ static int launch_aggupd_mfma(HGT_MFMA_AGGUPD_ARGS) {
       }
     }
 #endif
-    if (!ring)
-        k_edge_aggregate_update_mfma<VEC, LPH, RTE, F16><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
-                                                                                  agg, R, NQ, HT, hub_slot, pending, fu);
+    if (!ring) {
+        if (fu.small32)
+            k_edge_aggregate_update_mfma<VEC, LPH, RTE, F16, true><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
+                                                                                            agg, R, NQ, HT, hub_slot, pending, fu);
+        else
+            k_edge_aggregate_update_mfma<VEC, LPH, RTE, F16, false><<<grid, 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
+                                                                                             agg, R, NQ, HT, hub_slot, pending, fu);
+    }
     if (hb.mx) {   // workgroups with a hub target: their other targets, then the hub path + the update of those workgroups
         k_edge_aggregate_hub_workgroups<VEC, LPH, RTE, F16><<<dim3((unsigned)tiles * (16 / HGT_HUBWG_SUB), 1), 256, 0, stream>>>(pv.segptr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF,
                                                                                      agg, R, NQ, HT, hub_slot, pending, fu.q_lo);
@@ -1371,7 +1388,10 @@ static int edge_aggregate_update_impl(bool f16, const void* plan, int64_t N, int
     HgtPlanView pv = hgt_plan_view(plan, N, E, T, R);
     HgtHubBuffers hb = carve_hub(hub_ws, pv, H, E, dk_pad, R, det_hubs);
     HgtFusedUpdate fu = {node_type, (const unsigned short*)w_a_split, b_a, x_skip, ld_skip, skip, ln_w, ln_b, use_norm, T, n_out, out,
-                         ranged ? q_begin : 0, use_ring ? 1 : 0};
+                         ranged ? q_begin : 0, use_ring ? 1 : 0,
+                         // every gathered row / logit / temporal row sits below 4 GiB from its base: the fused kernels address them
+                         // with 32-bit lane offsets
+                         ((uint64_t)N * (uint64_t)dp * 4u < (1ull << 32) && (uint64_t)E * (uint64_t)H * 4u < (1ull << 32)) ? 1 : 0};
     if (ranged) { hb.q_lo = q_begin; hb.q_hi = q_end; }
     int rc = HGT_ERR_UNSUPPORTED;
     if (msg_frag && mfma_split_for(dk_pad / lph, lph) == 1)

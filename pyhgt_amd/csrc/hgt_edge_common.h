@@ -39,6 +39,7 @@ struct HgtFusedUpdate {
     float* out;                      // [NQ][n_out]
     int64_t q_lo;                    // first target row of the launch (a multiple of 64): workgroup b owns rows q_lo + 64 b ..
     int ring;                        // HGT_FLAG_RING_AGGREGATE: k_edge_aggregate_update_ring where it is instantiated
+    int small32;                     // V / logits / temporal rows lie below 4 GiB from their bases (launcher: the S32 instantiation, 32-bit lane offsets)
 };
 
 

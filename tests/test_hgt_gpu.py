@@ -1860,3 +1860,61 @@ def test_xs_gemm_is_bit_identical_to_the_slab_kernel(N, k, n_out, T, f16, c24, b
     assert bench_xs.check(lib, N, k, n_out, T, f16, c24, bypos, ragged=1, seed=N % 97)
 
 
+
+
+# ------------------------------------------------------------------ rows / logits beyond 4 GiB from their bases
+def _fused_vs_unfused(layer, x, nt, ei, et, rows=None):
+    """The fused aggregation + update kernel (32-bit lane offsets when every row sits below 4 GiB, 64-bit addresses otherwise)
+    against the unfused kernels (always 64-bit addresses) on the same inputs."""
+    outs = []
+    for fl in (_lib.HGT_FLAG_DETERMINISTIC_HUBS | _lib.HGT_FLAG_NO_ITEM_AGGREGATE | _lib.HGT_FLAG_FUSED_ANY_SIZE,
+               _lib.HGT_FLAG_DETERMINISTIC_HUBS | _lib.HGT_FLAG_NO_ITEM_AGGREGATE | _lib.HGT_FLAG_NO_FUSED_UPDATE):
+        layer.kernel_flags = fl
+        GraphPlan.clear_cache()
+        with torch.no_grad():
+            o = layer(x, nt, ei, et, None)
+        torch.cuda.synchronize()
+        outs.append(o if rows is None else o[rows].clone())
+        del o
+    return outs
+
+
+def test_gathered_rows_beyond_four_gib_from_the_table_base():
+    """4.3 M rows of 256 floats: the V rows of the last nodes sit above 2^32 bytes, where the fused kernel must drop its 32-bit lane
+    offsets (hgt_edge_agg_mfma.hip: HgtFusedUpdate::small32).  All edges live among the last 4096 nodes."""
+    if torch.cuda.get_device_properties(0).total_memory < 64 << 30:
+        pytest.skip("needs ~30 GB of device memory")
+    N, n_act, E, d, H, T, R = 4_300_000, 4096, 60_000, 256, 8, 3, 5
+    assert (N - n_act) * d * 4 > 1 << 32
+    g = torch.Generator().manual_seed(11)
+    layer = HGTConv(d, d, T, R, H, 0.2, True, False, precision="bf16x3").eval().to(DEV)
+    x = torch.zeros(N, d, device=DEV)
+    x[N - n_act:] = torch.randn(n_act, d, generator=g).to(DEV)
+    nt = torch.randint(0, T, (N,), generator=g).to(DEV)
+    ei = (torch.randint(0, n_act, (2, E), generator=g) + (N - n_act)).to(DEV)
+    et = torch.randint(0, R, (E,), generator=g).to(DEV)
+    rows = torch.arange(N - n_act, N, device=DEV)
+    fused, unfused = _fused_vs_unfused(layer, x, nt, ei, et, rows)
+    # the same graph renumbered to 4096 nodes: everything below 4 GiB
+    with torch.no_grad():
+        small = layer(x[N - n_act:].contiguous(), nt[N - n_act:].contiguous(), ei - (N - n_act), et, None)
+    assert torch.isfinite(fused).all()
+    assert (fused - unfused).abs().max().item() < 2e-5
+    assert (fused - small).abs().max().item() < 2e-5
+
+
+def test_logits_beyond_four_gib_from_their_base():
+    """135 M edges x 8 heads: the logit rows of the last edges sit above 2^32 bytes (the other half of the small32 condition)."""
+    if torch.cuda.get_device_properties(0).total_memory < 64 << 30:
+        pytest.skip("needs ~30 GB of device memory")
+    N, E, d, H, T, R = 200_000, 135_000_000, 32, 8, 2, 3
+    assert E * H * 4 > 1 << 32
+    g = torch.Generator(device=DEV).manual_seed(12)
+    layer = HGTConv(d, d, T, R, H, 0.2, True, False, precision="bf16x3").eval().to(DEV)
+    x = torch.randn(N, d, device=DEV, generator=g)
+    nt = torch.randint(0, T, (N,), device=DEV, generator=g)
+    ei = torch.randint(0, N, (2, E), device=DEV, generator=g)
+    et = torch.randint(0, R, (E,), device=DEV, generator=g)
+    fused, unfused = _fused_vs_unfused(layer, x, nt, ei, et)
+    assert torch.isfinite(fused).all()
+    assert (fused - unfused).abs().max().item() < 2e-5

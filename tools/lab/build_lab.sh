@@ -12,6 +12,6 @@ OBJ=build_lab/lab_${NAME}_p$PART.o
     -I../../include -DHGT_MFMA_PART_VEC=$V -DHGT_MFMA_PART_RTE=$R -DHGT_MFMA_PART_F16=$F -c hgt_edge_agg_mfma.hip -o $OBJ \
     -Rpass-analysis=kernel-resource-usage 2> build_lab/lab_${NAME}_p$PART.rpass || { tail -30 build_lab/lab_${NAME}_p$PART.rpass; exit 1; }
 mkdir -p ../lib_lab_$NAME
-OBJS=$(ls build_lab/hgt_*.o | grep -v "hgt_edge_agg_mfma_p$PART.o")
+OBJS=$(ls build_lab/hgt_*.o build_lab/lab_hgt_*.o | grep -v "hgt_edge_agg_mfma_p$PART.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib_lab_$NAME/libhgt_hip.so $OBJS $OBJ
 grep -A12 "Function Name: .*k_edge_aggregate_update_mfma.*Li4ELi8E" build_lab/lab_${NAME}_p$PART.rpass | grep -E "Function Name|VGPRs:|SGPRs:|ScratchSize|Occupancy|LDS Size" | head -12
