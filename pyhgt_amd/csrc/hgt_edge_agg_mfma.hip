@@ -665,20 +665,9 @@ __device__ __forceinline__ void agg_mfma_stream(
     }
 #define AGG_LOAD(D, P) D = *reinterpret_cast<const __typeof__(D)*>(P);
 #define AGG_WAIT(VR, SL, TR)
-    // Consume a batch: runs [lo, hi) of one relation; the relation-end work sits between the runs (one call site per buffer)
-#define AGG_PROCESS(VR, SL, TR, KY, CNT)                                                           \
-    for (int lo = 0; lo < (CNT);) {                                                                \
-        int rel_run = KY[0] >> 8, hi = (CNT);                                                      \
-        _Pragma("unroll") for (int u = 1; u < UN; ++u) if (u <= lo) rel_run = KY[u] >> 8;          \
-        _Pragma("unroll") for (int u = UN - 1; u >= 1; --u) if (u > lo && u < (CNT) && (KY[u] >> 8) != rel_run) hi = u; \
-        if (rel_run != cur_rel) {                                                                  \
-            flush();                                                                               \
-            relation_end(cur_rel);                                                                 \
-            cur_rel = rel_run;                                                                     \
-        }                                                                                          \
-        const bool claimed_ = rel_run < R;                                                         \
-        _Pragma("unroll") for (int u = 0; u < UN; ++u) {                                           \
-            if (u >= lo && u < hi) {                                                               \
+    // One gathered row of the current relation in three pieces: segment change (parking of the previous segment, state of the new
+    // one), the rare re-reference of the softmax, the accumulation
+#define AGG_ROW_SEG(SL, KY, u)                                                                     \
                 if ((KY[u] & 255) != cur_dl) {                                                     \
                     flush();                                                                       \
                     _Pragma("unroll") for (int i = 0; i < VEC; ++i) U[i] = 0.0f;                   \
@@ -689,9 +678,8 @@ __device__ __forceinline__ void agg_mfma_stream(
                     /*  it measured 0.8 % slower, r05) */                                           \
                     const float m_t = s_m[cur_dl * 16 + h];                                        \
                     m_ref = (m_t == HGT_NEG) ? SL[u] : m_t;                                        \
-                }                                                                                  \
-                float dlt = SL[u] - m_ref;                                                         \
-                if (!raw && __builtin_amdgcn_ballot_w64(dlt > 40.0f) != 0) {                       \
+                }
+#define AGG_ROW_RESCALE(SL, u)                                                                     \
                     const float m_new = (dlt > 40.0f) ? SL[u] : m_ref;                             \
                     const float sc = __expf(m_ref - m_new);                                        \
                     _Pragma("unroll") for (int i = 0; i < VEC; ++i) U[i] *= sc;                    \
@@ -711,8 +699,8 @@ __device__ __forceinline__ void agg_mfma_stream(
                     }                                                                              \
                     __builtin_amdgcn_wave_barrier();                                               \
                     m_ref = m_new;                                                                 \
-                    dlt = SL[u] - m_ref;                                                           \
-                }                                                                                  \
+                    dlt = SL[u] - m_ref;
+#define AGG_ROW_ACC(VR, SL, TR, u)                                                                 \
                 const float pe = raw ? SL[u] : __expf(dlt);   /* raw: the array holds the edge weights themselves */ \
                 /* (no `if (claimed_)`: the rows of the unclaimed bucket are gathered too -- valid addresses -- and their sums are */ \
                 /*  never parked (seg_claimed); as a condition it compiled to four v_cndmask per row, round-5 ISA audit) */          \
@@ -721,10 +709,50 @@ __device__ __forceinline__ void agg_mfma_stream(
                     if constexpr (RTE) vv += row_elem(TR[u], i);                                   \
                     U[i] = fmaf(pe, vv, U[i]);                                                     \
                 }                                                                                  \
-                l_seg += pe;                                                                       \
+                l_seg += pe;
+    // Consume a batch.  Ordinary case -- a full batch inside the current relation (at config 2 four of five batches): the rows one after
+    // the other, nothing to decide (r05 ISA audit: the run bookkeeping of the general form was ~35 scalar instructions per batch in a
+    // kernel bound by instruction issue).  General case: runs [lo, hi) of one relation, the relation-end work between the runs.
+#define AGG_PROCESS(VR, SL, TR, KY, CNT)                                                           \
+    {                                                                                              \
+        int lo = 0;                                                                                \
+        bool plain_ = (CNT) == UN && (KY[UN - 1] >> 8) == cur_rel;                                 \
+        const bool claimed_p = cur_rel < R;                                                        \
+        _Pragma("unroll") for (int u = 0; u < UN; ++u) {                                           \
+            if (plain_) {                                                                          \
+                const bool claimed_ = claimed_p;                                                   \
+                AGG_ROW_SEG(SL, KY, u)                                                             \
+                float dlt = SL[u] - m_ref;                                                         \
+                if (!raw && __builtin_amdgcn_ballot_w64(dlt > 40.0f) != 0) {                       \
+                    plain_ = false;      /* (the re-reference writes the accumulators: the general form takes over at this row) */ \
+                } else {                                                                           \
+                    AGG_ROW_ACC(VR, SL, TR, u)                                                     \
+                    lo = u + 1;                                                                    \
+                }                                                                                  \
             }                                                                                      \
         }                                                                                          \
-        lo = hi;                                                                                   \
+        while (lo < (CNT)) {                                                                       \
+            int rel_run = KY[0] >> 8, hi = (CNT);                                                  \
+            _Pragma("unroll") for (int u = 1; u < UN; ++u) if (u <= lo) rel_run = KY[u] >> 8;      \
+            _Pragma("unroll") for (int u = UN - 1; u >= 1; --u) if (u > lo && u < (CNT) && (KY[u] >> 8) != rel_run) hi = u; \
+            if (rel_run != cur_rel) {                                                              \
+                flush();                                                                           \
+                relation_end(cur_rel);                                                             \
+                cur_rel = rel_run;                                                                 \
+            }                                                                                      \
+            const bool claimed_ = rel_run < R;                                                     \
+            _Pragma("unroll") for (int u = 0; u < UN; ++u) {                                       \
+                if (u >= lo && u < hi) {                                                           \
+                    AGG_ROW_SEG(SL, KY, u)                                                         \
+                    float dlt = SL[u] - m_ref;                                                     \
+                    if (!raw && __builtin_amdgcn_ballot_w64(dlt > 40.0f) != 0) {                   \
+                        AGG_ROW_RESCALE(SL, u)                                                     \
+                    }                                                                              \
+                    AGG_ROW_ACC(VR, SL, TR, u)                                                     \
+                }                                                                                  \
+            }                                                                                      \
+            lo = hi;                                                                               \
+        }                                                                                          \
     }
     // batch after (I0, CNT); rotates the chunk registers at a chunk end; CNTN = 0: the stream is over (the issue that
     // follows then re-requests the last edge: unconditional, fixed size)
@@ -788,6 +816,9 @@ __device__ __forceinline__ void agg_mfma_stream(
 #undef AGG_META_WAIT
 #undef load_meta_next
 #undef AGG_PROCESS
+#undef AGG_ROW_SEG
+#undef AGG_ROW_RESCALE
+#undef AGG_ROW_ACC
 #undef AGG_NEXT
 }
 
