@@ -203,8 +203,9 @@ int hgt_typed_linear_xs_schedule(const int32_t* group_off_host, int32_t n_groups
 
 /* a_linear (conv.py:125) with the node update (conv.py:129-133, see hgt_node_update) fused into its epilogue:
  *   out[n] = LN_t( (agg[n] @ W_a[t]^T + b_a[t]) * sigmoid(skip[t]) + x_skip[n] * (1 - sigmoid(skip[t])) )
- * for the rows of every group; split-bf16 x3 MFMA; needs n_out <= 256 and n_out % 4 == 0 (HGT_ERR_UNSUPPORTED
- * otherwise -> use hgt_typed_linear[_bf16x3] + hgt_node_update).  Rows of no group are not written: hgt_zero_rows. */
+ * for the rows of every group; split-bf16 x3 MFMA; needs n_out % 4 == 0 and n_out <= 256, or n_out <= 512 with k <= 512 (round 5:
+ * both 256-column passes of a row tile stay in registers, LayerNorm over the two together) -- HGT_ERR_UNSUPPORTED otherwise -> use
+ * hgt_typed_linear[_bf16x3] + hgt_node_update.  Rows of no group are not written: hgt_zero_rows. */
 int hgt_linear_update_bf16x3(const float* agg, int64_t ld_agg, const int32_t* rows, const int32_t* group_off,
                              int32_t n_groups, int64_t n_rows, int32_t k, int32_t n_out, const void* w_split,
                              const float* bias, int64_t b_group_stride, const float* x_skip, int64_t ld_skip,

@@ -506,7 +506,8 @@ edge_phase:
     }
     mark(4);
     // (6) update: a_linear(gelu(agg)) -> gated skip -> LayerNorm (conv.py:119-133)
-    const bool fuse_update = !dense && split && dout <= 256 && (dout & 3) == 0 && (din & 3) == 0;
+    // (257..512 columns, e.g. n_hid 400 / 512: k_typed_linear_update_wide, round 5)
+    const bool fuse_update = !dense && split && (dout <= 256 || (dout <= 512 && dp <= 512)) && (dout & 3) == 0 && (din & 3) == 0;
     if (dense) {
         // DenseHGTConv.update (conv.py:250-274): no gelu on the aggregate, plain residual, then the shared dense layer
         rc = linear(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, a->w_a, (int64_t)dout * dp, a->b_a, dout, trans, nullptr, nullptr, dout,

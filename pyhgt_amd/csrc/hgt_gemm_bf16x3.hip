@@ -429,6 +429,225 @@ __global__ __launch_bounds__(512, (UPD || NSTG == 4) ? 2 : 4) void k_typed_linea
 }
 
 // =============================================================================================
+// a_linear + gated skip + LayerNorm for rows of 257..512 output columns and K <= 512 (n_hid 400 / 512: the reference's published
+// ogbn-mag width, ogbn-mag/train_ogbn_mag.py:36-40) in ONE kernel (round 5).  Before: k_typed_linear_split wrote the 512-column
+// product (2 passes x 2 K panels, the A panels loaded once per pass) and hgt_node_update read it back -- 4 d bytes per node written
+// and read for nothing and a second K-panel load per tile (d512_h8: 0.98 + 0.78 ms).
+// Here both 256-column passes keep their accumulators (64 registers), the K panels are the OUTER loop (each loaded once), and
+// the LayerNorm statistics run over the two passes' columns together in the epilogue.  The B fragments of the (panel, pass) segments
+// are not contiguous in the image: a prefetch cursor walks them in the order they are used, so a segment's first k-chunk is as
+// much in flight as any other.
+// =============================================================================================
+__device__ __forceinline__ void store_update_wide(f32x16 (&acc)[2][2], int wave, int lane, int g, int n_out, int nrows, const int* s_rid,
+                                                  const float* __restrict__ bias, int64_t bgs, float* __restrict__ out,
+                                                  const UpdateArgs& u, float* s_red, const float* s_inv, float winv) {
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));      // (the address arithmetic of this section stays out of the MFMA loop's register budget)
+    const int col0 = wave * 32 + ((lane_e & 31) >> 2) * 4;      // pass p: col0 + 256 p
+    const float alpha = 1.0f / (1.0f + expf(-u.skip[g]));
+    const bool o1 = lane_e & 1, o2 = lane_e & 2;
+    const float inv_n = 1.0f / (float)n_out;
+    float4 b4[2], w4[2], c4[2];
+    bool col_ok[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int col = col0 + p * BNP;
+        col_ok[p] = col < n_out;
+        b4[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        w4[p] = make_float4(1.f, 1.f, 1.f, 1.f);
+        c4[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col_ok[p] && bias) b4[p] = *reinterpret_cast<const float4*>(bias + (int64_t)g * bgs + col);
+        if (u.use_norm && col_ok[p]) {
+            w4[p] = *reinterpret_cast<const float4*>(u.lnw + (int64_t)g * n_out + col);
+            c4[p] = *reinterpret_cast<const float4*>(u.lnb + (int64_t)g * n_out + col);
+        }
+    }
+    // the two 32-row halves one after the other (half the live registers)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float y[2][4][4];
+        int64_t orow[4];
+        int rts[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rt = j * 32 + (lane_e & 3) + 8 * q + 4 * (lane_e >> 5);
+            rts[q] = rt;
+            orow[q] = (rt < nrows) ? (int64_t)s_rid[rt] : -1;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v0 = acc[p][j][4 * q], v1 = acc[p][j][4 * q + 1], v2 = acc[p][j][4 * q + 2], v3 = acc[p][j][4 * q + 3];
+                quad_transpose(v0, v1, v2, v3, o1, o2);
+                float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (col_ok[p] && orow[q] >= 0) xv = *reinterpret_cast<const float4*>(u.xs + orow[q] * u.ldxs + col0 + p * BNP);
+                const float sc = s_inv ? s_inv[rts[q]] * winv : 1.0f;
+                y[p][q][0] = col_ok[p] ? (v0 * sc + b4[p].x) * alpha + xv.x * (1.0f - alpha) : 0.0f;
+                y[p][q][1] = col_ok[p] ? (v1 * sc + b4[p].y) * alpha + xv.y * (1.0f - alpha) : 0.0f;
+                y[p][q][2] = col_ok[p] ? (v2 * sc + b4[p].z) * alpha + xv.z * (1.0f - alpha) : 0.0f;
+                y[p][q][3] = col_ok[p] ? (v3 * sc + b4[p].w) * alpha + xv.w * (1.0f - alpha) : 0.0f;
+            }
+        }
+        if (u.use_norm) {
+            // mean: a row's columns live in 8 waves x 2 passes x 8 lanes
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float ps = strided8_sum(y[0][q][0] + y[0][q][1] + y[0][q][2] + y[0][q][3] + y[1][q][0] + y[1][q][1] + y[1][q][2] + y[1][q][3]);
+                if (((lane_e & 31) >> 2) == 0) s_red[rts[q] * 8 + wave] = ps;
+            }
+            __syncthreads();
+            float mean[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = *reinterpret_cast<const float4*>(&s_red[rts[q] * 8]);
+                const float4 b = *reinterpret_cast<const float4*>(&s_red[rts[q] * 8 + 4]);
+                mean[q] = (a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w) * inv_n;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float ss = 0.0f;
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        y[p][q][e] -= mean[q];      // centred from here on
+                        if (col_ok[p]) ss += y[p][q][e] * y[p][q][e];
+                    }
+                const float ps = strided8_sum(ss);
+                if (((lane_e & 31) >> 2) == 0) s_red[rts[q] * 8 + wave] = ps;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = *reinterpret_cast<const float4*>(&s_red[rts[q] * 8]);
+                const float4 b = *reinterpret_cast<const float4*>(&s_red[rts[q] * 8 + 4]);
+                const float rstd = rsqrtf((a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w) * inv_n + 1e-5f);
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    if (col_ok[p] && orow[q] >= 0)
+                        *reinterpret_cast<float4*>(out + orow[q] * n_out + col0 + p * BNP) =
+                            make_float4(y[p][q][0] * rstd * w4[p].x + c4[p].x, y[p][q][1] * rstd * w4[p].y + c4[p].y,
+                                        y[p][q][2] * rstd * w4[p].z + c4[p].z, y[p][q][3] * rstd * w4[p].w + c4[p].w);
+            }
+            __syncthreads();   // s_red is reused by the second half
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    if (col_ok[p] && orow[q] >= 0)
+                        *reinterpret_cast<float4*>(out + orow[q] * n_out + col0 + p * BNP) = make_float4(y[p][q][0], y[p][q][1], y[p][q][2], y[p][q][3]);
+        }
+    }
+}
+
+template <bool F16>
+__global__ __launch_bounds__(512, 1) void k_typed_linear_update_wide(
+    const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off, int n_groups, int k,
+    int n_out, const unsigned short* __restrict__ wsplit, const float* __restrict__ bias, int64_t bgs, float* __restrict__ out, int vec_ok,
+    UpdateArgs upd) {
+    __shared__ __attribute__((aligned(16))) unsigned char sA[2 * A_PLANE];        // [plane][64][528]
+    __shared__ int s_rid[BM];
+    __shared__ float s_scale[F16 ? BM : 1], s_inv[F16 ? BM : 1];
+
+    const int slot = blockIdx.x;
+    int g = 0, gbeg = 0, gend = 0, tiles_before = 0;
+    for (; g < n_groups; ++g) {
+        gbeg = group_off[g];
+        gend = group_off[g + 1];
+        int nt = (gend - gbeg + BM - 1) / BM;
+        if (slot < tiles_before + nt) break;
+        tiles_before += nt;
+    }
+    if (g >= n_groups) return;
+    const int row0 = gbeg + (slot - tiles_before) * BM;
+    const int nrows = min(BM, gend - row0);
+    const int tid = threadIdx.x;
+    if (tid < BM) s_rid[tid] = (tid < nrows) ? rows[row0 + tid] : -1;
+    __syncthreads();
+
+    const int n_kc = ((k + KC - 1) / KC + 3) & ~3;      // k-chunks of the image (a multiple of 4), <= 32 here
+    const int n_panel = (k + KP - 1) / KP;              // 1 or 2
+    const int total = 2 * n_kc;                         // two passes
+    const int lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 31, khalf = lane >> 5;
+    const unsigned short* __restrict__ wfrag = wsplit + (int64_t)g * total * 2 * W_PLANE_ELEMS + (wave * 64 + lane) * 8;
+    float winv = 1.0f;
+    if constexpr (F16) {
+        winv = reinterpret_cast<const float*>(wsplit + (int64_t)n_groups * total * 2 * W_PLANE_ELEMS)[g];
+        if (n_panel > 1) row_scales_all_panels<0>(tid, s_rid, x, ldx, k, vec_ok, s_scale, s_inv);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][j][r] = 0.0f;
+
+    // prefetch cursor over the (panel, pass, k-chunk) order of use; beyond the end it re-requests the last tile
+    int pf_pass = 0, pf_kc = 0, pf_beg = 0, pf_end = min(KP / KC, n_kc);
+    // (two k-chunks of B fragments in flight; four measured SLOWER, 1.36 vs 1.27 ms at d512_h8: every tile streams the whole 1 MB image
+    //  of its type through the L2 -- 8 GB per launch next to 3 GB of HBM traffic -- and more requests in flight only queue)
+    bf16x8 s0h, s0m, s1h, s1m;
+#define HGT_WLOAD(S)                                                                                  \
+    {                                                                                                 \
+        const unsigned short* t_ = wfrag + (int64_t)(pf_pass * n_kc + min(pf_kc, n_kc - 1)) * 2 * W_PLANE_ELEMS; \
+        s##S##h = *reinterpret_cast<const bf16x8*>(t_);                                               \
+        s##S##m = *reinterpret_cast<const bf16x8*>(t_ + W_PLANE_ELEMS);                               \
+        /* (selects, not branches: the cursor is scalar state between the MFMA groups) */             \
+        ++pf_kc;                                                                                      \
+        const bool wrap_ = pf_kc == pf_end, p0_ = pf_pass == 0, more_ = pf_end < n_kc;                \
+        const int nbeg_ = (wrap_ && !p0_ && more_) ? pf_end : pf_beg;                                 \
+        pf_kc = wrap_ ? ((p0_ || more_) ? nbeg_ : n_kc) : pf_kc;                                      \
+        pf_end = (wrap_ && !p0_ && more_) ? n_kc : pf_end;                                            \
+        pf_pass = wrap_ ? (p0_ ? 1 : (more_ ? 0 : 1)) : pf_pass;                                      \
+        pf_beg = nbeg_;                                                                               \
+    }
+#define HGT_WSTEP(S, P, KCP)                                                                                       \
+    {                                                                                                              \
+        const int ao = frow * A_STRIDE + ((KCP) * KC + khalf * 8) * 2;                                             \
+        const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(sA + ao);                                              \
+        const bf16x8 am0 = *reinterpret_cast<const bf16x8*>(sA + A_PLANE + ao);                                    \
+        const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(sA + ao + 32 * A_STRIDE);                              \
+        const bf16x8 am1 = *reinterpret_cast<const bf16x8*>(sA + A_PLANE + ao + 32 * A_STRIDE);                    \
+        const bf16x8 bh = s##S##h, bm = s##S##m;                                                                   \
+        HGT_WLOAD(S)                                                                                               \
+        acc[P][0] = mfma32_t<F16>(am0, bh, acc[P][0]);                          \
+        acc[P][1] = mfma32_t<F16>(am1, bh, acc[P][1]);                          \
+        acc[P][0] = mfma32_t<F16>(ah0, bm, acc[P][0]);                          \
+        acc[P][1] = mfma32_t<F16>(ah1, bm, acc[P][1]);                          \
+        acc[P][0] = mfma32_t<F16>(ah0, bh, acc[P][0]);                          \
+        acc[P][1] = mfma32_t<F16>(ah1, bh, acc[P][1]);                          \
+    }
+    HGT_WLOAD(0)
+    HGT_WLOAD(1)
+    for (int panel = 0; panel < n_panel; ++panel) {
+        load_a_panel<0, F16>(panel * KP, tid, s_rid, x, ldx, k, vec_ok, sA, panel > 0, s_scale, s_inv, n_panel == 1);
+        const int nkc_p = min(KP / KC, n_kc - panel * (KP / KC));
+        for (int kq = 0; kq < nkc_p; kq += 4) {
+            HGT_WSTEP(0, 0, kq)
+            HGT_WSTEP(1, 0, kq + 1)
+            HGT_WSTEP(0, 0, kq + 2)
+            HGT_WSTEP(1, 0, kq + 3)
+        }
+        for (int kq = 0; kq < nkc_p; kq += 4) {
+            HGT_WSTEP(0, 1, kq)
+            HGT_WSTEP(1, 1, kq + 1)
+            HGT_WSTEP(0, 1, kq + 2)
+            HGT_WSTEP(1, 1, kq + 3)
+        }
+    }
+#undef HGT_WSTEP
+#undef HGT_WLOAD
+    __syncthreads();   // every wave left the MFMA loops: the A slab is reused as the reduction table
+    store_update_wide(acc, wave, lane, g, n_out, nrows, s_rid, bias, bgs, out, upd, reinterpret_cast<float*>(sA), F16 ? s_inv : nullptr, winv);
+}
+
+// =============================================================================================
 // Persistent producer / consumer variant (k <= 256: the whole K extent is one LDS slab).
 //
 // Why: the kernel above has at most two workgroups per CU and every one of them runs its phases
@@ -1024,7 +1243,8 @@ extern "C" int hgt_typed_linear_f16x3(const float* x, int64_t ldx, const int32_t
                                          block_cols, out_by_position, prologue, stream);
 }
 
-// a_linear + gated skip + LayerNorm in one kernel (n_out <= 256, n_out % 4 == 0): see store_pass_update.
+// a_linear + gated skip + LayerNorm in one kernel (n_out <= 256, or n_out <= 512 with k <= 512; n_out % 4 == 0): see store_pass_update /
+// store_update_wide.
 template <bool F16>
 static int linear_update_split_impl(const float* agg, int64_t ld_agg, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
                                     int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias,
@@ -1033,13 +1253,21 @@ static int linear_update_split_impl(const float* agg, int64_t ld_agg, const int3
     if (!agg || !rows || !group_off || !w_split || !x_skip || !skip || !out || n_groups <= 0 || n_rows < 0 || k <= 0 || n_out <= 0)
         return HGT_ERR_INVALID_ARG;
     if (use_norm && (!ln_w || !ln_b)) return HGT_ERR_INVALID_ARG;
-    if (n_out > BNP || (n_out & 3) != 0 || (ld_skip & 3) != 0 || ((uintptr_t)x_skip & 15) != 0) return HGT_ERR_UNSUPPORTED;
+    if (n_out > 2 * BNP || (n_out > BNP && k > 2 * KP) || (n_out & 3) != 0 || (ld_skip & 3) != 0 || ((uintptr_t)x_skip & 15) != 0)
+        return HGT_ERR_UNSUPPORTED;
     if (n_rows == 0) return HGT_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t row_tiles = (n_rows + BM - 1) / BM + n_groups;
     if (row_tiles > 0x7fffffffLL) return HGT_ERR_TOO_LARGE;
     const int vec_ok = (ld_agg % 4 == 0) && (k % 4 == 0) && (((uintptr_t)agg & 15) == 0);
     UpdateArgs u = {x_skip, ld_skip, skip, ln_w, ln_b, use_norm};
+    if (n_out > BNP) {      // 257..512 columns: both passes' accumulators stay in registers (k_typed_linear_update_wide)
+        k_typed_linear_update_wide<F16><<<(unsigned)row_tiles, 512, 0, stream>>>(agg, ld_agg, rows, group_off, n_groups, k, n_out,
+                                                                               (const unsigned short*)w_split, bias, b_group_stride, out,
+                                                                               vec_ok, u);
+        HGT_CHECK_LAUNCH();
+        return HGT_OK;
+    }
     if (k <= KP) {
         const unsigned grid = (unsigned)std::min<int64_t>(row_tiles, pc_grid());
         k_typed_linear_pc<0, true, F16><<<grid, PC_THREADS, 0, stream>>>(agg, ld_agg, rows, group_off, n_groups, k, n_out,

@@ -1918,3 +1918,60 @@ def test_logits_beyond_four_gib_from_their_base():
     fused, unfused = _fused_vs_unfused(layer, x, nt, ei, et)
     assert torch.isfinite(fused).all()
     assert (fused - unfused).abs().max().item() < 2e-5
+
+
+# ------------------------------------------------------------------ a_linear + gated skip + LayerNorm in one kernel, up to 512 columns
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("n,k,n_out,use_norm", [
+    (1000, 256, 256, 1),      # one pass, persistent kernel
+    (1000, 512, 512, 1),      # n_hid 512: two passes x two K panels in registers (k_typed_linear_update_wide)
+    (777, 512, 400, 1),       # n_hid 400 (OAG): 8 heads x 50 padded to 64 -> K = 512, 400 columns, the second pass partly masked
+    (300, 320, 512, 0),       # K not a multiple of the panel, no LayerNorm
+    (70_000, 512, 512, 1),    # more row tiles than CUs
+])
+def test_linear_update_against_float64(precision, n, k, n_out, use_norm):
+    """hgt_linear_update_{bf16x3,f16x3} (conv.py:125-133: a_linear, gated skip, LayerNorm) against the float64 closed form, at the
+    column counts of its three kernels; ragged groups incl. an empty one, rows through a shuffled row list, rows of no group untouched."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5 + n_out)
+    G = 4
+    agg = torch.randn(n, k, generator=g).to(DEV)
+    xs = torch.randn(n, n_out, generator=g).to(DEV)
+    W = (torch.randn(G, n_out, k, generator=g) / k ** 0.5).to(DEV)
+    bias = torch.randn(G, n_out, generator=g).to(DEV)
+    skip = torch.tensor([0.3, -1.2, 2.0, 0.0]).to(DEV)
+    lnw = (1.0 + 0.1 * torch.randn(G, n_out, generator=g)).to(DEV)
+    lnb = (0.1 * torch.randn(G, n_out, generator=g)).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    n_used = n - 37
+    perm = torch.randperm(n, generator=g)
+    rows = perm[:n_used].to(torch.int32).to(DEV).contiguous()
+    c1 = n_used // 3
+    off = torch.tensor([0, c1, c1, c1 + 65, n_used], dtype=torch.int32, device=DEV)      # group 1 is empty
+    nb = C.c_uint64()
+    assert lib.hgt_split_weights_bytes(G, k, n_out, C.byref(nb)) == 0
+    wsplit = torch.empty(int(nb.value), dtype=torch.uint8, device=DEV)
+    split = lib.hgt_split_weights_f16 if precision == "f16x3" else lib.hgt_split_weights
+    upd = lib.hgt_linear_update_f16x3 if precision == "f16x3" else lib.hgt_linear_update_bf16x3
+    assert split(W.data_ptr(), n_out * k, G, k, n_out, wsplit.data_ptr(), st) == 0
+    out = torch.full((n, n_out), 7.0, device=DEV)
+    assert upd(agg.data_ptr(), k, rows.data_ptr(), off.data_ptr(), G, n_used, k, n_out, wsplit.data_ptr(), bias.data_ptr(), n_out,
+               xs.data_ptr(), n_out, skip.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), use_norm, out.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    ref = torch.full((n, n_out), 7.0, dtype=torch.float64)
+    offl = off.tolist()
+    for gi in range(G):
+        r = rows[offl[gi]:offl[gi + 1]].long().cpu()
+        if r.numel() == 0:
+            continue
+        a = torch.sigmoid(skip[gi].cpu().double())
+        y = (agg.cpu().double()[r] @ W[gi].cpu().double().T + bias[gi].cpu().double()) * a + xs.cpu().double()[r] * (1 - a)
+        if use_norm:
+            y = torch.nn.functional.layer_norm(y, (n_out,), lnw[gi].cpu().double(), lnb[gi].cpu().double(), 1e-5)
+        ref[r] = y
+    err = (out.cpu().double() - ref).abs().max().item()
+    print("linear_update %s n_out %d k %d: max|err| %.2e" % (precision, n_out, k, err))
+    assert err < (4e-6 if precision == "f16x3" else 5e-5)
+    # beyond 512 columns (or K beyond two panels with more than one pass): unsupported, the caller takes the two-kernel form
+    assert upd(agg.data_ptr(), k, rows.data_ptr(), off.data_ptr(), G, n_used, k, 516, wsplit.data_ptr(), bias.data_ptr(), n_out,
+               xs.data_ptr(), n_out, skip.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), use_norm, out.data_ptr(), st) == -2
