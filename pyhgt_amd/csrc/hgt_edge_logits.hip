@@ -26,7 +26,10 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // pass 1: logits
 // ---------------------------------------------------------------------------------------------
-template <int VEC, int LPH, bool RTE>
+// S32 (chosen by the launcher: one head group and every Q / K / temporal row below 4 GiB from its base): compile-time row strides and
+// 32-bit unsigned lane offsets -- as run-time 64-bit products every gathered row paid seven scalar multiplies / adds (r05 ISA audit,
+// like the aggregation kernel's)
+template <int VEC, int LPH, bool RTE, bool S32 = false>
 __global__ __launch_bounds__(256) void k_edge_logits(
     const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
     const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ Q,
@@ -37,8 +40,9 @@ __global__ __launch_bounds__(256) void k_edge_logits(
     // not fit in registers (d = 512: 512 floats) -- narrower slices keep it register-resident.
     // With temporal encoding the table rows get their own slots (added at use), so the batch is 3/4 as deep (full depth needs 270 registers).
     constexpr int DKP = VEC * LPH, DP = 64 * VEC, H = 64 / LPH, UN = RTE ? (unroll_for<VEC>() * 3) / 4 : unroll_for<VEC>();
-    const int hg = blockIdx.y;
-    const int64_t ld = (int64_t)HT * DKP;   // row stride of Q/K/V/rte tables in floats
+    const int hg = S32 ? 0 : blockIdx.y;
+    if constexpr (S32) HT = H;
+    const int64_t ld = S32 ? (int64_t)DP : (int64_t)HT * DKP;   // row stride of Q/K/V/rte tables in floats
     const int co = hg * DP;                 // first column of this head group
     constexpr bool HOIST = (DKP * VEC <= 128);
     __shared__ __attribute__((aligned(16))) float s_bounce[4][DP + 4 * (64 / LPH)];
@@ -102,12 +106,21 @@ __global__ __launch_bounds__(256) void k_edge_logits(
         const int idx = min((I0) + u, nb - 1);                                                     \
         const int s_ = __builtin_amdgcn_readlane(my_src, idx);                                     \
         const int d_ = __builtin_amdgcn_readlane(my_dst, idx);                                     \
-        load_vec<VEC>(K + (int64_t)s_ * ld + co + lane * VEC, KR[u]);                              \
-        if constexpr (RTE) {                                                                       \
-            const int ri = __builtin_amdgcn_readlane(my_rte, idx);                                 \
-            load_vec<VEC>(rteK + (int64_t)ri * ld + co + lane * VEC, TR[u]);                       \
+        if constexpr (S32) {                                                                       \
+            load_vec<VEC>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(K) + (unsigned)((unsigned)s_ * (unsigned)(DP * 4) + (unsigned)(lane * VEC * 4))), KR[u]); \
+            if constexpr (RTE) {                                                                   \
+                const int ri = __builtin_amdgcn_readlane(my_rte, idx);                             \
+                load_vec<VEC>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(rteK) + (unsigned)((unsigned)ri * (unsigned)(DP * 4) + (unsigned)(lane * VEC * 4))), TR[u]); \
+            }                                                                                      \
+            load_vec<VEC>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(Q) + (unsigned)((unsigned)d_ * (unsigned)(DP * 4) + (unsigned)(lane * VEC * 4))), QR[u]); \
+        } else {                                                                                   \
+            load_vec<VEC>(K + (int64_t)s_ * ld + co + lane * VEC, KR[u]);                          \
+            if constexpr (RTE) {                                                                   \
+                const int ri = __builtin_amdgcn_readlane(my_rte, idx);                             \
+                load_vec<VEC>(rteK + (int64_t)ri * ld + co + lane * VEC, TR[u]);                   \
+            }                                                                                      \
+            load_vec<VEC>(Q + (int64_t)d_ * ld + co + lane * VEC, QR[u]);                          \
         }                                                                                          \
-        load_vec<VEC>(Q + (int64_t)d_ * ld + co + lane * VEC, QR[u]);                              \
     }
 #define HGT_PROCESS(KR, QR, TR, I0)                                                                \
     _Pragma("unroll") for (int u = 0; u < HB; ++u) {                                               \
@@ -204,11 +217,16 @@ __global__ void k_relation_pack(const float* __restrict__ ratt, const float* __r
 template <int VEC, int LPH>
 struct LaunchLogits {
     static int run(const HgtPlanView& pv, const float* Q, const float* K, const float* rteK, const float* attT, float* logits,
-                   int R, int HT, int rel_lo, int rel_hi, int item_lo, int item_hi, hipStream_t stream) {
+                   int R, int HT, int rel_lo, int rel_hi, int item_lo, int item_hi, int small32, hipStream_t stream) {
         const int64_t n_launch = item_hi >= 0 ? (int64_t)(item_hi - item_lo) : pv.L.max_items;
         const unsigned blocks = ((unsigned)((n_launch + 3) / 4) + 127u) & ~127u;      // (a multiple of 8 XCDs x 16: XCD-aware item order)
         dim3 grid(blocks, (unsigned)(HT / (64 / LPH)));
-        if (rteK)
+        if (small32 && grid.y == 1) {
+            if (rteK)
+                k_edge_logits<VEC, LPH, true, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi, item_lo, item_hi);
+            else
+                k_edge_logits<VEC, LPH, false, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi, item_lo, item_hi);
+        } else if (rteK)
             k_edge_logits<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi, item_lo, item_hi);
         else
             k_edge_logits<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi, item_lo, item_hi);
@@ -259,8 +277,10 @@ static int edge_logits_impl(const void* plan, int64_t N, int64_t E, int32_t T, i
         }
     }
     const int sp = head_split_for(dk_pad / lph, lph, dk_pad);
+    // (every row of Q / K -- and of the 240-row temporal table -- below 4 GiB from its base: the 32-bit-offset instantiation)
+    const int small32 = ((uint64_t)N * (uint64_t)H * (uint64_t)dk_pad * 4u < (1ull << 32)) ? 1 : 0;
     int rc = dispatch_layout<LaunchLogits>(dk_pad / lph / sp, lph * sp, pv, Q, K, rte_k, att_t, logits, (int)R, (int)H, rel_lo, rel_hi,
-                                           item_lo, item_hi, (hipStream_t)stream);
+                                           item_lo, item_hi, small32, (hipStream_t)stream);
     if (rc != HGT_OK) return rc;
     HGT_CHECK_LAUNCH();
     return HGT_OK;
