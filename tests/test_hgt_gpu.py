@@ -1975,3 +1975,27 @@ def test_linear_update_against_float64(precision, n, k, n_out, use_norm):
     # beyond 512 columns (or K beyond two panels with more than one pass): unsupported, the caller takes the two-kernel form
     assert upd(agg.data_ptr(), k, rows.data_ptr(), off.data_ptr(), G, n_used, k, 516, wsplit.data_ptr(), bias.data_ptr(), n_out,
                xs.data_ptr(), n_out, skip.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), use_norm, out.data_ptr(), st) == -2
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 1000, 100_003])
+def test_c24_pack_of_256_column_rows_is_bit_exact(n):
+    """hgt_gather_rows_c24 at the benchmark width against the format's definition computed with torch integer ops (little-endian 3-byte
+    groups of (bits + 0x80) >> 8) -- random row indices with repeats, ragged counts, the bytes behind the last row untouched."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n)
+    d, n_src = 256, 5000
+    x = (torch.randn(n_src, d, generator=g) * torch.logspace(-5, 5, d)).to(DEV)
+    idx = torch.randint(0, n_src, (n,), generator=g).to(torch.int32).to(DEV)
+    wire = torch.full((n + 1, 3 * d), 0xAB, dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.hgt_gather_rows_c24(x.data_ptr(), d, idx.data_ptr(), n, d, wire.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    bits = x[idx.long()].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    v = ((bits + 0x80) >> 8) & 0xFFFFFF                                   # 24-bit codes, [n, 256]
+    ref = torch.stack([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF], dim=2).reshape(n, 3 * d).to(torch.uint8)   # little-endian 3-byte groups
+    assert torch.equal(wire[:n], ref)
+    assert bool((wire[n] == 0xAB).all())
+    back = torch.empty(n, d, device=DEV)
+    assert lib.hgt_unpack_rows_c24(wire.data_ptr(), n, d, back.data_ptr(), d, st) == 0
+    torch.cuda.synchronize()
+    assert ((back - x[idx.long()]).abs() <= x[idx.long()].abs() * 2.0 ** -16 * 1.0001).all()

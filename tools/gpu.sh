@@ -38,7 +38,7 @@ for f in sys.argv[1:]:
     for k, v in (j.get("secondary") or {}).items():
         if isinstance(v, dict):
             print("   ", k, {kk: (float("%.4g" % vv) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk in
-                             ("ms_per_step", "parity_max_abs_err", "layer_frac", "gpu_ms_per_step", "stage_ms", "halo_rows", "link_ms_at_70pct_of_7x76.8GBs", "phase_ms")})
+                             ("ms_per_step", "parity_max_abs_err", "layer_frac", "gpu_ms_per_step", "emulated_copy_ms", "gpu_ms_per_step_minus_emulated_copy", "stage_ms", "halo_rows", "link_ms_at_70pct_of_7x76.8GBs", "phase_ms")})
 PY
 }
 case $MODE in
