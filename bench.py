@@ -650,6 +650,8 @@ def main():
                     help="c2 (default): BASELINE.json configs[1] at N=1, the configs[3] recipe (dst partition + RCCL halo all-to-all) at N>1.  "
                          "c5: configs[4] surrogate in REPLICAS mode -- every GPU runs the 2-layer GNN forward on its own independent sampled "
                          "batches (OAG/train_paper_field.py:145-153 prepares n_batch independent sub-graphs), no collective in the data path")
+    ap.add_argument("--small-only", action="store_true", help="tool mode: only the latency-regime measurements of the line (c1, c3, script-default "
+                    "batch, c5, published 4-layer model), printed as one JSON object")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also run the CPU port ONCE at the full c2 size (about a minute; needs >= 64 GB "
                     "of free RAM); the default on hosts with >= 96 GB of RAM available")
     ap.add_argument("--cpu-baseline-sample-only", action="store_true", help="never run the full-size CPU forward")
@@ -699,6 +701,9 @@ def main():
     d, H, T, R = args.dim, args.heads, args.types, args.relations
     Nl, El = args.nodes_per_gpu, args.edges_per_gpu
     use_rte = bool(args.rte)
+    if world == 1 and args.small_only:
+        print(json.dumps(small_regime(dev)))
+        return
     if world == 1 and args.emulate_world > 1:      # tool mode: the GPU side of one rank's multi-GPU step, on one GPU
         print(json.dumps(emulate_rank(dev, args.emulate_world, Nl, El, d, H, T, R, args.locality, args.blocks, not args.halo_fp32,
                                       args.steps, args.precision if args.precision != "fp32" else "bf16x3", args.block_shape)))

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HGT_ABI_VERSION 6
+#define HGT_ABI_VERSION 7
 
 /* error codes */
 #define HGT_OK 0
@@ -161,6 +161,8 @@ int hgt_plan_from_sorted(const int32_t* src, const int32_t* dst, const int32_t* 
  * ---------------------------------------------------------------------------------------------- */
 #define HGT_LINEAR_FORCE_XS 0x100
 #define HGT_LINEAR_NO_XS 0x200
+#define HGT_LINEAR_NO_TILE 0x400   /* ABI 7: never the latency-regime tile kernel (hgt_gemm_tile.hip; the default below 49 152 rows) -- it is
+                                    * bit-identical to the slab kernels; the bit exists for tests and A/B timings */
 int hgt_typed_linear(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off,
                      int32_t n_groups, int64_t n_rows, int32_t k, int32_t n_out,
                      const float* W, int64_t w_group_stride, const float* bias, int64_t b_group_stride,
@@ -281,6 +283,19 @@ int hgt_edge_aggregate_items(const void* plan, int64_t n_nodes, int64_t n_edges,
                              int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
                              const void* msg_frag, int32_t frag_f16, float* agg, int64_t n_q_rows, int32_t apply_gelu,
                              void* scratch, uint64_t scratch_bytes, void* stream);
+/* ABI 7: hgt_edge_aggregate_items whose merge pass IS the node update (sampled batches: one of the layer's five dependent kernels less and the
+ * merged rows never written): per target the runs are merged exactly like hgt_edge_aggregate_items merges them (apply_gelu = 1), the row is
+ * multiplied with W_a[type] on the matrix cores (split x3 like hgt_linear_update_*; w_a_split = hgt_split_weights[_f16](W_a) with
+ * k = n_heads * dk_pad; frag_f16 selects the fp16 images of BOTH msg_frag and w_a_split) and the gated skip + LayerNorm of conv.py:129-133
+ * is applied: out[n] for every row n of rows[] (rows / group_off: target rows grouped by node type, hgt_plan_row_lists rows_q / off_q).
+ * Output identical to hgt_edge_aggregate_items + hgt_linear_update_*.  HGT_ERR_UNSUPPORTED: rows wider than 512 padded columns,
+ * n_out > 512 or > the padded row, n_out % 4 != 0, ld_skip % 4 != 0 -> use the two-call form. */
+int hgt_edge_aggregate_items_update(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
+                                    int32_t n_heads, int32_t dk_pad, const float* logits, const float* V, const float* rte_v,
+                                    const void* msg_frag, int32_t frag_f16, int64_t n_q_rows, void* scratch, uint64_t scratch_bytes,
+                                    const int32_t* rows, const int32_t* group_off, int32_t n_groups, const void* w_a_split,
+                                    const float* b_a, const float* x_skip, int64_t ld_skip, const float* skip, const float* ln_w,
+                                    const float* ln_b, int32_t use_norm, int32_t n_out, float* out, void* stream);
 /* ABI 6: logits AND the item-parallel aggregation in one walk over the edges (sampled sub-graphs): per group of <= 16 runs the
  * target-side transform q~ = q A'[r] on the matrix cores (att_frag = hgt_relation_frag_pack[_f16](att_t)), then per edge K and V
  * gathered together, the logit, the run's online softmax and the weighted sum, then the message transform (msg_frag) -- no [E][H]
@@ -577,6 +592,10 @@ typedef struct hgt_conv_args {
 #define HGT_FLAG_XS_GEMM_ALWAYS 1024 /* ABI 6: the x-stationary split GEMM (hgt_gemm_xs.hip) for every typed linear of the layer it covers, whatever
                                       * the row count (HGT_LINEAR_FORCE_XS); */
 #define HGT_FLAG_XS_GEMM_NEVER 2048  /* ... never (HGT_LINEAR_NO_XS): the slab kernels.  Bit-identical results either way: tests / A/B timings */
+#define HGT_FLAG_NO_TILE_GEMM 4096   /* ABI 7: the typed linears of a small layer on the persistent / slab kernels instead of the latency-regime tile
+                                      * kernel (HGT_LINEAR_NO_TILE): bit-identical results; tests / A/B timings */
+#define HGT_FLAG_NO_MERGE_UPDATE 8192 /* ABI 7: sampled batches: hgt_edge_aggregate_items + hgt_linear_update_* as two calls instead of
+                                      * hgt_edge_aggregate_items_update (identical output; tests / A/B timings) */
 #define HGT_FLAG_RING_AGGREGATE 512 /* LAB builds only (hgt_build_features() & HGT_FEATURE_LAB_KERNELS; ignored otherwise): the LDS-ring form of the fused
                                      * aggregation kernel (round 5, csrc/lab/hgt_edge_agg_ring.h: rows by LDS-DMA, U tile in registers) where it exists
                                      * (d = 256 / 8 heads, no temporal rows, bf16 split): bit-identical, measured 9 % slower at c2 */

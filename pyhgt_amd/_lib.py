@@ -24,8 +24,11 @@ HGT_FLAG_SINGLE_PASS = 256
 HGT_FLAG_RING_AGGREGATE = 512
 HGT_FLAG_XS_GEMM_ALWAYS = 1024
 HGT_FLAG_XS_GEMM_NEVER = 2048
+HGT_FLAG_NO_TILE_GEMM = 4096
+HGT_FLAG_NO_MERGE_UPDATE = 8192
 HGT_LINEAR_FORCE_XS = 0x100
 HGT_LINEAR_NO_XS = 0x200
+HGT_LINEAR_NO_TILE = 0x400
 HGT_FEATURE_LAB_KERNELS = 1
 
 
@@ -71,7 +74,7 @@ class HgtConvArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 6          # HGT_ABI_VERSION of include/hgt_hip.h this binding was written against
+ABI_VERSION = 7          # HGT_ABI_VERSION of include/hgt_hip.h this binding was written against
 
 _i32, _i64, _u64, _vp = C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
 
@@ -119,6 +122,8 @@ SIGNATURES = {
     "hgt_edge_aggregate_f16x3": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "hgt_relation_frag_pack_f16": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "hgt_edge_aggregate_items_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_u64)]),
+    "hgt_edge_aggregate_items_update": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _u64, _vp, _vp, _i32,
+                                                  _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "hgt_edge_aggregate_items": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _u64, _vp]),
     "hgt_edge_single_pass_items": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32,
                                              _vp, _u64, _vp]),

@@ -321,7 +321,8 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
             if (r2 != HGT_OK) return r2;
         }
         // (kernel-selection bits of the split linears: HGT_FLAG_XS_GEMM_ALWAYS / _NEVER -- tests and A/B runs)
-        const int sel = (a->flags & HGT_FLAG_XS_GEMM_NEVER) ? HGT_LINEAR_NO_XS : ((a->flags & HGT_FLAG_XS_GEMM_ALWAYS) ? HGT_LINEAR_FORCE_XS : 0);
+        const int sel = ((a->flags & HGT_FLAG_XS_GEMM_NEVER) ? HGT_LINEAR_NO_XS : ((a->flags & HGT_FLAG_XS_GEMM_ALWAYS) ? HGT_LINEAR_FORCE_XS : 0)) |
+                        ((a->flags & HGT_FLAG_NO_TILE_GEMM) ? HGT_LINEAR_NO_TILE : 0);
         return f16 ? hgt_typed_linear_f16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos, prologue | sel, stream)
                    : hgt_typed_linear_bf16x3(xin, ldx, rws, goff, ng, nrows, kk, nout, wsplit, bp, bgs, o0, o1, o2, bcols, by_pos, prologue | sel,
                                              stream);
@@ -484,6 +485,32 @@ edge_phase:
     // latency regime: the item-parallel form (hgt_edge_agg_items.hip), where a sub-tile wavefront's chain of edge batches and
     // relation ends is the kernel time (c3: 80 -> 66 us per layer, c5: 195 -> 147 us); flags force / forbid it
     rc = agg_done ? HGT_OK : HGT_ERR_UNSUPPORTED;
+    // sampled batches (round 6): the merge pass of the item-parallel aggregation IS the node update (k_merge_update) -- two of the
+    // layer's five dependent kernels become one and `agg` is never written
+    if (items_agg && !agg_done && !dense && !(a->flags & HGT_FLAG_NO_MERGE_UPDATE) && dp <= 512 && dout <= 512 && dout <= dp &&
+        (dout & 3) == 0 && (din & 3) == 0) {
+        if (fresh || !pb) {
+            rc = split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
+            if (rc != HGT_OK) return rc;
+        }
+        rc = hgt_edge_aggregate_items_update(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_f, f16 ? 1 : 0, NQ, wb + w.off_zitems,
+                                             w.zitems_bytes, pr.rows_q, pr.off_q, T, ws_upd, a->b_a, a->x, din, a->skip, a->ln_w, a->ln_b,
+                                             a->use_norm, dout, a->out, stream);
+        if (rc == HGT_OK) {
+            if (a->want_att && E > 0) {
+                rc = hgt_edge_softmax(a->plan, N, E, T, R, H, logits, stream);
+                if (rc != HGT_OK) return rc;
+                rc = hgt_att_export(a->plan, N, E, T, R, H, logits, a->att_out, Hreal, stream);
+                if (rc != HGT_OK) return rc;
+            }
+            mark(4);
+            mark(5);
+            if (!no_unknown_rows) rc = hgt_zero_rows(pr.rows_q, pr.off_q + T, dout, a->out, stream);   // nodes of unknown type -> 0 (conv.py:120)
+            mark(6);
+            return rc;
+        }
+        if (rc != HGT_ERR_UNSUPPORTED) return rc;
+    }
     if (items_agg && !agg_done)
         rc = hgt_edge_aggregate_items(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_f, f16 ? 1 : 0, agg, NQ, dense ? 0 : 1,
                                       wb + w.off_zitems, w.zitems_bytes, stream);
@@ -536,7 +563,7 @@ edge_phase:
             if (rc != HGT_OK) return rc;
         }
         rc = (f16 ? hgt_linear_update_f16x3 : hgt_linear_update_bf16x3)(agg, dp, pr.rows_q, pr.off_q, T, NQ, dp, dout, ws_upd, a->b_a, dout, a->x, din, a->skip, a->ln_w,
-                                      a->ln_b, a->use_norm, a->out, stream);
+                                      a->ln_b, (a->use_norm ? 1 : 0) | ((a->flags & HGT_FLAG_NO_TILE_GEMM) ? 2 : 0), a->out, stream);
         if (rc != HGT_OK) return rc;
         mark(5);
         if (!no_unknown_rows) rc = hgt_zero_rows(pr.rows_q, pr.off_q + T, dout, a->out, stream);   // nodes of unknown type -> 0 (conv.py:120)

@@ -31,6 +31,15 @@ int hgt_typed_linear_xs_try(bool f16, const float* x, int64_t ldx, const int32_t
                             int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias, int64_t bgs, float* out0,
                             float* out1, float* out2, int32_t block_cols, int32_t by_pos, int32_t prologue, void* stream);
 
+// hgt_gemm_tile.hip: the latency-regime form of the split typed linear and of the fused update (1 = launched, 0 = not its domain, < 0 = error)
+struct HgtTileUpdate {
+    const float* x_skip; int64_t ld_skip; const float* skip; const float* ln_w; const float* ln_b; int use_norm;
+};
+int hgt_typed_linear_tile_try(bool f16, const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
+                              int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias, int64_t bgs, float* out0,
+                              float* out1, float* out2, int32_t block_cols, int32_t by_pos, int32_t prologue, const HgtTileUpdate* upd,
+                              void* stream);
+
 // hgt_edge_aggregate_update / _f16x3 / _range with the kernel-selection flags of hgt_conv_forward (q_end < 0: the whole graph)
 int hgt_edge_aggregate_update_sel(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad, const float* logits,
                                   const float* V, const float* rte_v, const float* msg_p, const void* msg_frag, float* agg, int64_t n_q_rows,

@@ -236,15 +236,12 @@ __global__ __launch_bounds__(256, 2) void k_edge_runs_mfma(
 }
 
 // One wavefront per target: the runs of all its segments, in (relation, position) order.  Lane l holds VECF consecutive columns
-// of the full row (d = 64 * VECF); DKP >= VECF, so a lane's columns belong to one head.
-template <int VECF>
-__global__ __launch_bounds__(256) void k_merge_runs(const int32_t* __restrict__ segptr, const float* __restrict__ zrows,
-                                                    const float* __restrict__ zstat, const unsigned char* __restrict__ zflag,
-                                                    float* __restrict__ agg, int R, int64_t NQ, int HT, int DKP, int apply_gelu,
-                                                    int64_t ld_out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= NQ) return;
+// of the full row (d = 64 * VECF); DKP >= VECF, so a lane's columns belong to one head.  NB = run rows requested together.
+// Returns the finished row of target i (normalised, gelu applied when asked for) in o[].
+template <int VECF, int NB>
+__device__ __forceinline__ void merge_target(int64_t i, int lane, const int32_t* __restrict__ segptr, const float* __restrict__ zrows,
+                                             const float* __restrict__ zstat, const unsigned char* __restrict__ zflag, int R, int HT, int DKP,
+                                             int apply_gelu, float (&o)[VECF]) {
     const int64_t ld = (int64_t)HT * DKP;
     const int hd = (lane * VECF) / DKP;
     const int64_t tile = i / HGT_TD;
@@ -259,9 +256,9 @@ __global__ __launch_bounds__(256) void k_merge_runs(const int32_t* __restrict__ 
     if (lane >= R) len = 0;
     int incl = len;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
+    for (int o_ = 1; o_ < 64; o_ <<= 1) {
+        const int t = __shfl_up(incl, o_);
+        if (lane >= o_) incl += t;
     }
     const int total = __builtin_amdgcn_readlane(incl, 63);
     float M = HGT_NEG, L = 0.0f, X[VECF];
@@ -279,11 +276,11 @@ __global__ __launch_bounds__(256) void k_merge_runs(const int32_t* __restrict__ 
         const bool start = live && zflag[live ? pos : 0] != 0;
         unsigned long long runs = __builtin_amdgcn_ballot_w64(start);
         while (runs != 0ull) {
-            // up to four runs per round: their rows and statistics are requested together
-            int pz[4];
+            // up to NB runs per round: their rows and statistics are requested together
+            int pz[NB];
             int nr = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NB; ++u) {
                 if (runs != 0ull) {
                     const int k = __builtin_ctzll(runs);
                     runs &= runs - 1ull;
@@ -293,15 +290,15 @@ __global__ __launch_bounds__(256) void k_merge_runs(const int32_t* __restrict__ 
                     pz[u] = pz[u > 0 ? u - 1 : 0];
                 }
             }
-            float rows[4][VECF];
-            float2 st[4];
+            float rows[NB][VECF];
+            float2 st[NB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NB; ++u) {
                 load_vec<VECF>(zrows + (int64_t)pz[u] * ld + lane * VECF, rows[u]);
                 st[u] = *reinterpret_cast<const float2*>(zstat + ((int64_t)pz[u] * HT + hd) * 2);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NB; ++u) {
                 if (u < nr) {
                     const float m_new = fmaxf(M, st[u].x);
                     const float sa = __expf(M - m_new), sb = __expf(st[u].x - m_new);
@@ -321,13 +318,24 @@ __global__ __launch_bounds__(256) void k_merge_runs(const int32_t* __restrict__ 
         L = fmaf(L, sa, (float)n_unclaimed * sb);
     }
     const float inv = 1.0f / (L + 1e-16f);
-    float o[VECF];
 #pragma unroll
     for (int k = 0; k < VECF; ++k) {
         float v = X[k] * inv;
         if (apply_gelu == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
         o[k] = v;
     }
+}
+
+template <int VECF>
+__global__ __launch_bounds__(256) void k_merge_runs(const int32_t* __restrict__ segptr, const float* __restrict__ zrows,
+                                                    const float* __restrict__ zstat, const unsigned char* __restrict__ zflag,
+                                                    float* __restrict__ agg, int R, int64_t NQ, int HT, int DKP, int apply_gelu,
+                                                    int64_t ld_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= NQ) return;
+    float o[VECF];
+    merge_target<VECF, 4>(i, lane, segptr, zrows, zstat, zflag, R, HT, DKP, apply_gelu, o);
     float* g = agg + i * ld_out + lane * VECF;
     if constexpr (VECF == 1) {
         g[0] = o[0];
@@ -336,6 +344,216 @@ __global__ __launch_bounds__(256) void k_merge_runs(const int32_t* __restrict__ 
     } else {
 #pragma unroll
         for (int k = 0; k < VECF / 4; ++k) *reinterpret_cast<float4*>(g + 4 * k) = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Merge + node update in ONE kernel (round 6; sampled batches).  k_merge_runs + the update GEMM were two of the layer's five dependent
+// kernels (6.7 + 12 us at c3, 14 + 24 us at c5), with the merged rows written to `agg` and read back in between.  Here a workgroup of
+// SIXTEEN wavefronts owns 16 targets of one node type: every wavefront merges ONE target exactly like k_merge_runs (same order, same
+// arithmetic: the same row bit for bit), splits the row into bf16 (fp16) hi / mid terms and parks it in an LDS slab; then the sixteen
+// wavefronts are the 16 x 32 output columns of a_linear: the slab's rows 0..15 are the upper half of a 32-row MFMA tile (the lower half
+// is never stored -- matrix-core time is not what a 3 000-target batch waits for), W_a's fragments stream through an eight-stage
+// register ring that is already requested while the merge runs, and the gated skip + LayerNorm epilogue (conv.py:129-133) is the tile
+// kernel's.  Same products in the same order as hgt_linear_update_*: identical output.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct MergeUpdateArgs {
+    const int32_t* segptr; const float* zrows; const float* zstat; const unsigned char* zflag; int R; int HT; int DKP; int apply_gelu;
+    const int32_t* rows; const int32_t* group_off; int n_groups; int n_out;
+    const unsigned short* wsplit; const float* bias; const float* xs; int64_t ldxs; const float* skip; const float* lnw; const float* lnb;
+    int use_norm; float* out;
+};
+
+constexpr int MU_ROWS = 16, MU_NW = 16, MU_STG = 8;
+
+template <int VECF, bool F16, int TPW>
+__global__ __launch_bounds__(64 * MU_NW, 4) void k_merge_update(const MergeUpdateArgs a) {
+    constexpr int MU_R = MU_ROWS * TPW;      // targets per workgroup: wavefront w merges rows w (and w + 16)
+    constexpr int DP = 64 * VECF, ASTRK = DP * 2 + 16, NKC = (DP / 16 + 3) & ~3, NB = VECF >= 8 ? 2 : 4;
+    constexpr int STG = NKC < MU_STG ? NKC : MU_STG;
+    __shared__ __attribute__((aligned(16))) unsigned char sA[2][32 * ASTRK];      // [plane][row][k] (rows 16..31: never written, never stored)
+    __shared__ int s_rid[MU_R];
+    __shared__ float s_rinv[F16 ? MU_R : 1];
+    __shared__ __attribute__((aligned(16))) float s_red[2][MU_R * MU_NW];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int g = 0, row0 = 0, nrows = 0;
+    {
+        int before = 0, t = (int)blockIdx.x;
+        bool found = false;
+        for (g = 0; g < a.n_groups; ++g) {
+            const int gb = a.group_off[g], ge = a.group_off[g + 1];
+            const int nt = (ge - gb + MU_R - 1) / MU_R;
+            if (t < before + nt) {
+                row0 = gb + (t - before) * MU_R;
+                nrows = min(MU_R, ge - row0);
+                found = true;
+                break;
+            }
+            before += nt;
+        }
+        if (!found) return;
+    }
+    const int n_out = a.n_out;
+    const int n_pass = (n_out + BNP - 1) / BNP;
+    const bool live = (wave >> 3) < n_pass;
+    const unsigned short* wp = a.wsplit + ((int64_t)g * n_pass + (live ? (wave >> 3) : 0)) * NKC * 2 * W_PLANE_ELEMS + ((wave & 7) * 64 + lane) * 8;
+    float winv = 1.0f;
+    if constexpr (F16) winv = reinterpret_cast<const float*>(a.wsplit + (int64_t)a.n_groups * n_pass * NKC * 2 * W_PLANE_ELEMS)[g];
+    // the first STG k-chunks of this wavefront's column block: in flight while the merge runs
+    bf16x8 wh[STG], wm[STG];
+    if (live) {      // (rows of at most 256 columns: wavefronts 8..15 only merge)
+#pragma unroll
+        for (int s_ = 0; s_ < STG; ++s_) {
+            wh[s_] = *reinterpret_cast<const bf16x8*>(wp + (int64_t)s_ * 2 * W_PLANE_ELEMS);
+            wm[s_] = *reinterpret_cast<const bf16x8*>(wp + (int64_t)s_ * 2 * W_PLANE_ELEMS + W_PLANE_ELEMS);
+        }
+    }
+    // ---- phase 1: wavefront w merges target rows[row0 + w] (and rows[row0 + 16 + w])
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+        const int r = tp * MU_ROWS + wave;
+        const int rid = (r < nrows) ? a.rows[row0 + r] : -1;
+        if (lane == 0) s_rid[r] = rid;
+        float o[VECF];
+        if (rid >= 0) {
+            merge_target<VECF, NB>((int64_t)rid, lane, a.segptr, a.zrows, a.zstat, a.zflag, a.R, a.HT, a.DKP, a.apply_gelu, o);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VECF; ++k) o[k] = 0.0f;
+        }
+        float scale = 1.0f;
+        if constexpr (F16) {
+            float inv;
+            f16_row_scale(wave_max_bits(abs_bits_v<VECF>(o)), scale, inv);
+            if (lane == 0) s_rinv[r] = inv;
+        }
+        unsigned char* w_ = sA[0] + r * ASTRK + lane * VECF * 2;
+        if constexpr (VECF == 1) {
+            unsigned short hi, mid;
+            split1_t<F16>(o[0], scale, hi, mid);
+            *reinterpret_cast<unsigned short*>(w_) = hi;
+            *reinterpret_cast<unsigned short*>(w_ + 32 * ASTRK) = mid;
+        } else if constexpr (VECF == 2) {
+            unsigned hi, mid;
+            split2_t<F16>(o[0], o[1], scale, hi, mid);
+            *reinterpret_cast<unsigned*>(w_) = hi;
+            *reinterpret_cast<unsigned*>(w_ + 32 * ASTRK) = mid;
+        } else {
+#pragma unroll
+            for (int q = 0; q < VECF / 4; ++q) {
+                uint2 hi, mid;
+                split4_t<F16>(make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]), scale, hi, mid);
+                *reinterpret_cast<uint2*>(w_ + 8 * q) = hi;
+                *reinterpret_cast<uint2*>(w_ + 8 * q + 32 * ASTRK) = mid;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: out[rows x n_out] = slab x W_a^T; the skip rows are requested first, used after the k loop
+    constexpr int NQR = 2 * TPW;        // a lane's rows of the 32-row MFMA tile: rt0 + 8 q, q < NQR
+    const int col_l = ((lane & 31) >> 2) * 4, rt0 = (lane & 3) + 4 * (lane >> 5);
+    const int col = wave * 32 + col_l;
+    const bool col_ok = live && col < n_out;
+    float y[NQR][4];
+    if (live) {
+        float4 xv[NQR];
+#pragma unroll
+        for (int q = 0; q < NQR; ++q) {
+            const int orow = s_rid[rt0 + 8 * q];
+            xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (orow >= 0 && col_ok) xv[q] = *reinterpret_cast<const float4*>(a.xs + (int64_t)orow * a.ldxs + col);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        const unsigned char* sl_ = sA[0] + (lane & 31) * ASTRK + (lane >> 5) * 16;
+#pragma unroll
+        for (int kc0 = 0; kc0 < NKC; kc0 += STG) {
+#pragma unroll
+            for (int s_ = 0; s_ < STG; ++s_) {
+                const int kc = kc0 + s_;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(sl_ + kc * 32);
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(sl_ + kc * 32 + 32 * ASTRK);
+                acc = mfma32_t<F16>(am, wh[s_], acc);
+                acc = mfma32_t<F16>(ah, wm[s_], acc);
+                acc = mfma32_t<F16>(ah, wh[s_], acc);
+                if (kc + STG < NKC) {
+                    wh[s_] = *reinterpret_cast<const bf16x8*>(wp + (int64_t)(kc + STG) * 2 * W_PLANE_ELEMS);
+                    wm[s_] = *reinterpret_cast<const bf16x8*>(wp + (int64_t)(kc + STG) * 2 * W_PLANE_ELEMS + W_PLANE_ELEMS);
+                }
+            }
+        }
+        // ---- epilogue (hgt_gemm_tile.hip's)
+        const bool o1 = lane & 1, o2 = lane & 2;
+        const float alpha = 1.0f / (1.0f + expf(-a.skip[g]));
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col_ok && a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + (int64_t)g * n_out + col);
+#pragma unroll
+        for (int q = 0; q < NQR; ++q) {
+            float v0 = acc[4 * q], v1 = acc[4 * q + 1], v2 = acc[4 * q + 2], v3 = acc[4 * q + 3];
+            quad_transpose(v0, v1, v2, v3, o1, o2);
+            const float sc = F16 ? s_rinv[F16 ? (rt0 + 8 * q) : 0] * winv : 1.0f;
+            y[q][0] = col_ok ? (v0 * sc + b4.x) * alpha + xv[q].x * (1.0f - alpha) : 0.0f;
+            y[q][1] = col_ok ? (v1 * sc + b4.y) * alpha + xv[q].y * (1.0f - alpha) : 0.0f;
+            y[q][2] = col_ok ? (v2 * sc + b4.z) * alpha + xv[q].z * (1.0f - alpha) : 0.0f;
+            y[q][3] = col_ok ? (v3 * sc + b4.w) * alpha + xv[q].w * (1.0f - alpha) : 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NQR; ++q) y[q][0] = y[q][1] = y[q][2] = y[q][3] = 0.0f;
+    }
+    const float inv_n = 1.0f / (float)n_out;
+    float rstd[NQR];
+#pragma unroll
+    for (int q = 0; q < NQR; ++q) rstd[q] = 1.0f;
+    if (a.use_norm) {
+#pragma unroll
+        for (int q = 0; q < NQR; ++q) {
+            const float ps = strided8_sum(y[q][0] + y[q][1] + y[q][2] + y[q][3]);
+            if (((lane & 31) >> 2) == 0) s_red[0][(rt0 + 8 * q) * MU_NW + wave] = ps;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQR; ++q) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < MU_NW; ++w) s += s_red[0][(rt0 + 8 * q) * MU_NW + w];
+            const float mean = s * inv_n;
+            float ps = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                y[q][i] -= mean;
+                const float d = col_ok ? y[q][i] : 0.0f;
+                ps = fmaf(d, d, ps);
+            }
+            ps = strided8_sum(ps);
+            if (((lane & 31) >> 2) == 0) s_red[1][(rt0 + 8 * q) * MU_NW + wave] = ps;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQR; ++q) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < MU_NW; ++w) s += s_red[1][(rt0 + 8 * q) * MU_NW + w];
+            rstd[q] = rsqrtf(s * inv_n + 1e-5f);
+        }
+    }
+    if (col_ok) {
+        float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f), c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.use_norm) {
+            w4 = *reinterpret_cast<const float4*>(a.lnw + (int64_t)g * n_out + col);
+            c4 = *reinterpret_cast<const float4*>(a.lnb + (int64_t)g * n_out + col);
+        }
+#pragma unroll
+        for (int q = 0; q < NQR; ++q) {
+            const int rt = rt0 + 8 * q;
+            if (rt < nrows)
+                *reinterpret_cast<float4*>(a.out + (int64_t)s_rid[rt] * n_out + col) =
+                    make_float4(y[q][0] * rstd[q] * w4.x + c4.x, y[q][1] * rstd[q] * w4.y + c4.y, y[q][2] * rstd[q] * w4.z + c4.z,
+                                y[q][3] * rstd[q] * w4.w + c4.w);
+        }
     }
 }
 
@@ -387,8 +605,8 @@ struct SinglePassArgs {
 static int aggregate_items_impl(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
                                 const float* logits, const float* V, const float* rte_v, const void* msg_frag, int32_t frag_f16,
                                 float* agg, int64_t n_q_rows, int32_t apply_gelu, void* scratch, uint64_t scratch_bytes,
-                                void* stream_, const SinglePassArgs* spa) {
-    if (!plan || !V || !msg_frag || !agg || (E > 0 && ((!spa && !logits) || !scratch)) || H <= 0 || 64 % H != 0 || dk_pad <= 0)
+                                void* stream_, const SinglePassArgs* spa, const MergeUpdateArgs* mu = nullptr) {
+    if (!plan || !V || !msg_frag || (!agg && !mu) || (E > 0 && ((!spa && !logits) || !scratch)) || H <= 0 || 64 % H != 0 || dk_pad <= 0)
         return HGT_ERR_INVALID_ARG;
     if (spa && (!spa->Q || !spa->K || !spa->att_frag || ((spa->rte_k == nullptr) != (rte_v == nullptr)))) return HGT_ERR_INVALID_ARG;
     if (apply_gelu != 0 && apply_gelu != 1) return HGT_ERR_INVALID_ARG;
@@ -428,8 +646,31 @@ static int aggregate_items_impl(const void* plan, int64_t N, int64_t E, int32_t 
 #undef AGI_CASE
         if (rc != HGT_OK) return rc;
     }
-    const unsigned mgrid = (unsigned)((NQ + 3) / 4);
     const int vf = (int)(d / 64);
+    if (mu) {      // merge + a_linear + gated skip + LayerNorm in one kernel (k_merge_update)
+        MergeUpdateArgs m = *mu;
+        m.segptr = pv.segptr; m.zrows = zrows; m.zstat = zstat; m.zflag = zflag; m.R = (int)R; m.HT = (int)H; m.DKP = (int)dk_pad;
+        m.apply_gelu = (int)apply_gelu;
+        // 16 targets per workgroup (one per wavefront) while that is at most ~one workgroup per CU; 32 (two per wavefront: half the
+        // passes over W_a) beyond
+        const int tpw = NQ <= 16 * 288 ? 1 : 2;
+        const unsigned ugrid = (unsigned)((NQ + MU_ROWS * tpw - 1) / (MU_ROWS * tpw) + m.n_groups);      // device-side group sizes: the upper bound
+#define AGI_MU(VF)                                                                                      \
+        do {                                                                                            \
+            if (tpw == 1) {                                                                             \
+                if (frag_f16) k_merge_update<VF, true, 1><<<ugrid, 64 * MU_NW, 0, stream>>>(m);         \
+                else k_merge_update<VF, false, 1><<<ugrid, 64 * MU_NW, 0, stream>>>(m);                 \
+            } else {                                                                                    \
+                if (frag_f16) k_merge_update<VF, true, 2><<<ugrid, 64 * MU_NW, 0, stream>>>(m);         \
+                else k_merge_update<VF, false, 2><<<ugrid, 64 * MU_NW, 0, stream>>>(m);                 \
+            }                                                                                           \
+        } while (0)
+        if (vf == 1) AGI_MU(1); else if (vf == 2) AGI_MU(2); else if (vf == 4) AGI_MU(4); else AGI_MU(8);
+#undef AGI_MU
+        HGT_CHECK_LAUNCH();
+        return HGT_OK;
+    }
+    const unsigned mgrid = (unsigned)((NQ + 3) / 4);
 #define AGI_MERGE(VF) \
     k_merge_runs<VF><<<mgrid, 256, 0, stream>>>(pv.segptr, zrows, zstat, zflag, agg, (int)R, NQ, (int)H, (int)dk_pad, (int)apply_gelu, d)
     if (vf == 1) AGI_MERGE(1); else if (vf == 2) AGI_MERGE(2); else if (vf == 4) AGI_MERGE(4); else AGI_MERGE(8);
@@ -457,4 +698,29 @@ extern "C" int hgt_edge_single_pass_items(const void* plan, int64_t N, int64_t E
     const SinglePassArgs spa = {Q, K, rte_k, att_frag};
     return aggregate_items_impl(plan, N, E, T, R, H, dk_pad, nullptr, V, rte_v, msg_frag, frag_f16, agg, n_q_rows, apply_gelu, scratch,
                                 scratch_bytes, stream_, &spa);
+}
+
+// ABI 7: item-parallel aggregation whose merge pass IS the node update: hgt_edge_aggregate_items followed by hgt_linear_update_* (a_linear +
+// gated skip + LayerNorm, conv.py:119-133) with the merged rows never written to memory (k_merge_update: 16 targets per workgroup).
+// rows / group_off: the target rows grouped by node type (hgt_plan_row_lists: rows_q / off_q); w_a_split: hgt_split_weights[_f16] of W_a
+// with k = n_heads * dk_pad; frag_f16 selects the fp16 images of BOTH msg_frag and w_a_split.  Same output as the two-call form.
+// HGT_ERR_UNSUPPORTED: rows wider than 512 padded columns, n_out > 512, n_out % 4 != 0, ld_skip % 4 != 0.
+extern "C" int hgt_edge_aggregate_items_update(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                               const float* logits, const float* V, const float* rte_v, const void* msg_frag, int32_t frag_f16,
+                                               int64_t n_q_rows, void* scratch, uint64_t scratch_bytes, const int32_t* rows,
+                                               const int32_t* group_off, int32_t n_groups, const void* w_a_split, const float* b_a,
+                                               const float* x_skip, int64_t ld_skip, const float* skip, const float* ln_w, const float* ln_b,
+                                               int32_t use_norm, int32_t n_out, float* out, void* stream_) {
+    if (!rows || !group_off || n_groups <= 0 || !w_a_split || !x_skip || !skip || !out || n_out <= 0) return HGT_ERR_INVALID_ARG;
+    if (use_norm && (!ln_w || !ln_b)) return HGT_ERR_INVALID_ARG;
+    const int64_t d = (int64_t)H * dk_pad;
+    if (d > 512 || d % 64 != 0 || n_out > 512 || (n_out & 3) != 0 || (ld_skip & 3) != 0 || ((uintptr_t)x_skip & 15) != 0 || n_out > d)
+        return HGT_ERR_UNSUPPORTED;
+    MergeUpdateArgs m;
+    m.segptr = nullptr; m.zrows = nullptr; m.zstat = nullptr; m.zflag = nullptr; m.R = 0; m.HT = 0; m.DKP = 0; m.apply_gelu = 1;
+    m.rows = rows; m.group_off = group_off; m.n_groups = n_groups; m.n_out = n_out;
+    m.wsplit = (const unsigned short*)w_a_split; m.bias = b_a; m.xs = x_skip; m.ldxs = ld_skip; m.skip = skip; m.lnw = ln_w; m.lnb = ln_b;
+    m.use_norm = use_norm; m.out = out;
+    return aggregate_items_impl(plan, N, E, T, R, H, dk_pad, logits, V, rte_v, msg_frag, frag_f16, nullptr, n_q_rows, 1, scratch, scratch_bytes,
+                                stream_, nullptr, &m);
 }

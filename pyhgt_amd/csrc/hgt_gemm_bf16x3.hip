@@ -1175,7 +1175,7 @@ static int typed_linear_split_impl(const float* x, int64_t ldx, const int32_t* r
     const int n_blocks_out = (n_out + block_cols - 1) / block_cols;
     if (n_blocks_out > 3 || (n_blocks_out > 1 && !out1) || (n_blocks_out > 2 && !out2)) return HGT_ERR_INVALID_ARG;
     const int32_t prologue_arg = prologue;      // (with the kernel-selection bits HGT_LINEAR_FORCE_XS / HGT_LINEAR_NO_XS)
-    if (prologue < 0 || (prologue & ~(0xff | HGT_LINEAR_FORCE_XS | HGT_LINEAR_NO_XS)) != 0) return HGT_ERR_INVALID_ARG;
+    if (prologue < 0 || (prologue & ~(0xff | HGT_LINEAR_FORCE_XS | HGT_LINEAR_NO_XS | HGT_LINEAR_NO_TILE)) != 0) return HGT_ERR_INVALID_ARG;
     prologue &= 0xff;
     if (prologue > 2) return HGT_ERR_INVALID_ARG;
     if (prologue == 2 && (k > KP || (k & 3) != 0 || ldx != 3 * (int64_t)(k / 4))) return HGT_ERR_UNSUPPORTED;   // 24-bit wire rows: the persistent kernel only
@@ -1189,6 +1189,12 @@ static int typed_linear_split_impl(const float* x, int64_t ldx, const int32_t* r
     // latency regime (sampled sub-graphs: fewer row tiles than CUs): one workgroup per (row tile, 256-column pass)
     const int n_pass = (n_out + BNP - 1) / BNP;
     const int pass_split = (n_pass > 1 && row_tiles * 2 <= pc_grid()) ? n_pass : 1;
+    if (!(prologue_arg & (HGT_LINEAR_NO_TILE | HGT_LINEAR_FORCE_XS)) && prologue <= 1) {
+        // sampled batches (a few thousand rows): the tile kernel (hgt_gemm_tile.hip), laid out for a short dependent chain
+        const int tl = hgt_typed_linear_tile_try(F16, x, ldx, rows, group_off, n_groups, n_rows, k, n_out, w_split, bias, b_group_stride, out0, out1,
+                                                 out2, block_cols, out_by_position, prologue, nullptr, stream_);
+        if (tl != 0) return tl < 0 ? tl : HGT_OK;
+    }
     {   // millions of rows: the x-stationary kernel (hgt_gemm_xs.hip: W through LDS once per 256 rows; K = 64 / 128 / 256 / 512)
         const int xs = hgt_typed_linear_xs_try(F16, x, ldx, rows, group_off, n_groups, n_rows, k, n_out, w_split, bias, b_group_stride, out0, out1,
                                                out2, block_cols, out_by_position, prologue_arg, stream_);
@@ -1250,7 +1256,7 @@ static int linear_update_split_impl(const float* agg, int64_t ld_agg, const int3
                                     const float* ln_w, const float* ln_b, int32_t use_norm, float* out, void* stream_) {
     if (!agg || !rows || !group_off || !w_split || !x_skip || !skip || !out || n_groups <= 0 || n_rows < 0 || k <= 0 || n_out <= 0)
         return HGT_ERR_INVALID_ARG;
-    if (use_norm && (!ln_w || !ln_b)) return HGT_ERR_INVALID_ARG;
+    if ((use_norm & 1) && (!ln_w || !ln_b)) return HGT_ERR_INVALID_ARG;
     if (n_out > 2 * BNP || (n_out > BNP && k > 2 * KP) || (n_out & 3) != 0 || (ld_skip & 3) != 0 || ((uintptr_t)x_skip & 15) != 0)
         return HGT_ERR_UNSUPPORTED;
     if (n_rows == 0) return HGT_OK;
@@ -1258,7 +1264,13 @@ static int linear_update_split_impl(const float* agg, int64_t ld_agg, const int3
     const int64_t row_tiles = (n_rows + BM - 1) / BM + n_groups;
     if (row_tiles > 0x7fffffffLL) return HGT_ERR_TOO_LARGE;
     const int vec_ok = (ld_agg % 4 == 0) && (k % 4 == 0) && (((uintptr_t)agg & 15) == 0);
-    UpdateArgs u = {x_skip, ld_skip, skip, ln_w, ln_b, use_norm};
+    UpdateArgs u = {x_skip, ld_skip, skip, ln_w, ln_b, use_norm & 1};
+    if (!(use_norm & 2)) {      // (bit 1 of use_norm: HGT_LINEAR_NO_TILE of this entry point -- tests / A/B timings)
+        const HgtTileUpdate tu = {x_skip, ld_skip, skip, ln_w, ln_b, use_norm & 1};
+        const int tl = hgt_typed_linear_tile_try(F16, agg, ld_agg, rows, group_off, n_groups, n_rows, k, n_out, w_split, bias, b_group_stride, out,
+                                                 nullptr, nullptr, n_out, 0, 0, &tu, stream_);
+        if (tl != 0) return tl < 0 ? tl : HGT_OK;
+    }
     if (n_out > BNP) {      // 257..512 columns: both passes' accumulators stay in registers (k_typed_linear_update_wide)
         k_typed_linear_update_wide<F16><<<(unsigned)row_tiles, 512, 0, stream>>>(agg, ld_agg, rows, group_off, n_groups, k, n_out,
                                                                                (const unsigned short*)w_split, bias, b_group_stride, out,

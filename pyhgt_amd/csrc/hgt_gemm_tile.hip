@@ -1,0 +1,439 @@
+// Typed (grouped) linear layer for the LATENCY regime: sampled batches of a few thousand rows (BASELINE.json configs[2] / [4],
+// the only workload the reference's scripts run: pyHGT/model.py:77-79, train_ogbn_mag.py:44-46, train_paper_field.py:35-41).
+//
+//   y[n, :] = x[n, :] @ W[type(n)]^T + b[type(n)]          (conv.py:96-97,103: Q | K | V;  conv.py:119-133: a_linear + update)
+//
+// The persistent kernels of hgt_gemm_bf16x3.hip are built for millions of rows: one workgroup per CU, a producer / consumer split
+// that overlaps tile i + 1's rows with tile i's MFMAs.  On a 3 200-row batch a workgroup sees ONE tile and nothing overlaps: 14 us
+// for Q | K | V and 19 us for the update at c3 (profiles/r06_latency_base_c3.txt) against 1 - 3 us of matrix-core work.  Here the
+// same arithmetic (same split, same k order, same three products per k-chunk: results are bit-identical to the slab kernels) is
+// laid out for many small workgroups and a short dependent chain:
+//   * a workgroup owns one (row tile, column tile) pair: 32 x 128 outputs for the plain linear (a 3 200 x 768 problem is 624
+//     workgroups of four wavefronts, up to four per CU), 32 whole rows for the update form (8 wavefronts x 32 or 64 columns);
+//   * K is walked in panels of 64 or 128: a wavefront's B fragments of the first two panels and the first two A panels are
+//     requested before anything is waited for, later panels one panel of MFMAs ahead;
+//   * the x rows go global -> registers -> (split hi / mid) -> LDS, double buffered: one workgroup barrier per panel;
+//   * the update form (a_linear + gated skip + LayerNorm, conv.py:129-133) requests its skip rows while the MFMAs run.
+// What the time of such a kernel is made of (r6 eliminations at c3, 64 x 128 tiles, 13.9 us warm: no stores 10.8, no fragment loads
+// 11.4, no row loads 12.8, none of the three 8.6): dispatch + the id chain + one round of MFMAs + a store burst that a CU retires
+// at ~10 B / clk -- every phase short, none overlapped with another inside ONE round of workgroups.  Smaller tiles (more, lighter
+// workgroups per CU) were worth 2.7 us; the sampled-batch layer's update now runs inside the merge pass instead
+// (hgt_edge_agg_items.hip: k_merge_update), this file's update form serves the two-call path.
+// fp16 split (precision "f16x3"): the power-of-two row scales need the maximum of the WHOLE row before its first panel is split:
+// one extra pass over the tile's rows (L2 hits: the panels read them again right after).
+#include "hgt_common.h"
+#include "hgt_split_common.h"
+#include <algorithm>
+
+#ifndef HGT_TILE_MAX_ROWS
+#define HGT_TILE_MAX_ROWS 8192      // typed linears below this many rows take the tile kernels (measured against the persistent kernel)
+#endif
+
+namespace {
+
+struct TileArgs {
+    const float* x; int64_t ldx; const int32_t* rows; const int32_t* group_off; int n_groups; int k; int n_out;
+    const unsigned short* wsplit; const float* bias; int64_t bgs; float* out0; float* out1; float* out2; int block_cols; int by_pos;
+    int vec_ok; int prologue;
+    // update form
+    const float* xs; int64_t ldxs; const float* skip; const float* lnw; const float* lnb; int use_norm;
+};
+
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void tile_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NW, int RT, int CT, int KPAN, bool UPD, bool F16, bool GELU>
+__global__ __launch_bounds__(64 * NW, (KPAN == 64 && RT == 1 && CT == 1) ? 4 : 2) void k_tile_linear(const TileArgs a) {
+    constexpr int BMT = 32 * RT, KCP = KPAN / 16, LPR = KPAN / 4, RPI = 64 / LPR, NL = BMT / (RPI * NW);
+    constexpr int ASTR = KPAN * 2 + 16, APLANE = BMT * ASTR;
+    static_assert(NL >= 1 && NL * RPI * NW == BMT, "row tile / wavefront geometry");
+    __shared__ __attribute__((aligned(16))) unsigned char sA[2][2 * APLANE];
+    __shared__ int s_rid[BMT];
+    __shared__ float s_rinv[F16 ? BMT : 1];
+    __shared__ float s_rscale[F16 ? BMT : 1];      // (written and read by the same wavefront: LDS operations of a wavefront stay in order)
+    __shared__ __attribute__((aligned(16))) float s_red[UPD ? 2 * BMT * NW : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- which (group, rows) is this row tile?  (device-side group sizes: the launcher starts an upper bound of row tiles)
+    int g = 0, row0 = 0, nrows = 0;
+    {
+        int before = 0, t = (int)blockIdx.x;
+        bool found = false;
+        for (g = 0; g < a.n_groups; ++g) {
+            const int gb = a.group_off[g], ge = a.group_off[g + 1];
+            const int nt = (ge - gb + BMT - 1) / BMT;
+            if (t < before + nt) {
+                row0 = gb + (t - before) * BMT;
+                nrows = min(BMT, ge - row0);
+                found = true;
+                break;
+            }
+            before += nt;
+        }
+        if (!found) return;
+    }
+    const int k = a.k, n_out = a.n_out;
+    const int n_pass = (n_out + BNP - 1) / BNP;
+    const int n_kc = ((k + KC - 1) / KC + 3) & ~3;
+    const int total = n_pass * n_kc;
+    const int n_pan = (n_kc + KCP - 1) / KCP;
+
+    // ---- this wavefront's column blocks (32 columns each) and their fragment streams
+    int cb[CT];
+    bool live[CT];
+    const unsigned short* wp[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        cb[c] = ((int)blockIdx.y * NW + wave) * CT + c;
+        live[c] = (cb[c] >> 3) < n_pass;
+        const int pass = live[c] ? (cb[c] >> 3) : 0;
+        wp[c] = a.wsplit + ((int64_t)g * total + (int64_t)pass * n_kc) * 2 * W_PLANE_ELEMS + ((cb[c] & 7) * 64 + lane) * 8;
+    }
+    float winv = 1.0f;
+    if constexpr (F16) winv = reinterpret_cast<const float*>(a.wsplit + (int64_t)a.n_groups * total * 2 * W_PLANE_ELEMS)[g];
+
+    // ---- row ids: every lane keeps the ids of the NL rows it loads; the table in LDS serves the epilogue
+    const int lrow = lane / LPR, lk = (lane % LPR) * 4;
+    int myrid[NL];
+    const int rid_safe = a.rows[row0];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int r = (j * NW + wave) * RPI + lrow;
+        myrid[j] = (r < nrows) ? a.rows[row0 + r] : -1;
+    }
+    if (tid < BMT) s_rid[tid] = (tid < nrows) ? a.rows[row0 + tid] : -1;
+
+    bf16x8 wh[2][CT][KCP], wm[2][CT][KCP];
+    float4 areg[NL];
+
+#define TILE_WLOAD(D, PTR) D = *reinterpret_cast<const bf16x8*>(PTR);
+#define TILE_LOAD_W(B, P)                                                                                  \
+    _Pragma("unroll") for (int c = 0; c < CT; ++c) {                                                       \
+        _Pragma("unroll") for (int kc = 0; kc < KCP; ++kc) {                                               \
+            const int kidx = min((P) * KCP + kc, n_kc - 1);                                                \
+            const unsigned short* t_ = wp[c] + (int64_t)kidx * 2 * W_PLANE_ELEMS;                          \
+            TILE_WLOAD(wh[B][c][kc], t_)                                                                   \
+            TILE_WLOAD(wm[B][c][kc], t_ + W_PLANE_ELEMS)                                                   \
+        }                                                                                                  \
+    }
+    // a lane's 16 bytes of row myrid[j], k = P * KPAN + lk ..: always an in-bounds address (absent rows re-read the tile's first row,
+    // columns past k the row's last ones); what must read as zero is zeroed in tile_commit
+    auto load_a = [&](int P, float4 (&dst)[NL]) {
+        const int kk = P * KPAN + lk;
+        if (a.vec_ok) {
+            const int kc_ = min(kk, k - 4);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const int rid = myrid[j] < 0 ? rid_safe : myrid[j];
+                dst[j] = *reinterpret_cast<const float4*>(a.x + (int64_t)rid * a.ldx + kc_);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const int rid = myrid[j] < 0 ? rid_safe : myrid[j];
+                const float* px = a.x + (int64_t)rid * a.ldx;
+                dst[j] = make_float4(px[min(kk, k - 1)], px[min(kk + 1, k - 1)], px[min(kk + 2, k - 1)], px[min(kk + 3, k - 1)]);
+            }
+        }
+    };
+    auto masked = [&](int P, int j, float4 v) -> float4 {      // (selects, no branches: the loads behind it stay counted)
+        const int kk = P * KPAN + lk;
+        const bool row_ok = myrid[j] >= 0;
+        v.x = (row_ok && kk < k) ? v.x : 0.f;
+        v.y = (row_ok && kk + 1 < k) ? v.y : 0.f;
+        v.z = (row_ok && kk + 2 < k) ? v.z : 0.f;
+        v.w = (row_ok && kk + 3 < k) ? v.w : 0.f;
+        return v;
+    };
+    auto gelu_all = [&](float4 (&t)[NL]) {      // prologue 1 (conv.py:119 / DenseHGTConv's out_linear): one uniform branch per panel
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { t[j].x = gelu_erf_(t[j].x); t[j].y = gelu_erf_(t[j].y); t[j].z = gelu_erf_(t[j].z); t[j].w = gelu_erf_(t[j].w); }
+    };
+    auto commit_a = [&](int P, float4 (&src)[NL], unsigned char* buf) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) src[j] = masked(P, j, src[j]);
+        if constexpr (GELU) gelu_all(src);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int r = (j * NW + wave) * RPI + lrow;
+            uint2 hi, mid;
+            split4_t<F16>(src[j], F16 ? s_rscale[F16 ? r : 0] : 1.0f, hi, mid);
+            unsigned char* p_ = buf + r * ASTR + lk * 2;
+            *reinterpret_cast<uint2*>(p_) = hi;
+            *reinterpret_cast<uint2*>(p_ + APLANE) = mid;
+        }
+    };
+
+    // ---- everything that does not depend on anything else is requested first
+    TILE_LOAD_W(0, 0)
+    if constexpr (F16) {
+        // row maxima over the whole row (all panels), then the panels are read again (L2 hits)
+        unsigned mb[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) mb[j] = 0u;
+        for (int P = 0; P < n_pan; ++P) {
+            float4 t[NL];
+            load_a(P, t);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) t[j] = masked(P, j, t[j]);
+            if constexpr (GELU) gelu_all(t);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) mb[j] = max(mb[j], abs_bits4(t[j]));
+        }
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+#pragma unroll
+            for (int o = 1; o < LPR; o <<= 1) mb[j] = max(mb[j], (unsigned)__shfl_xor((int)mb[j], o));
+            float sc, inv;
+            f16_row_scale(mb[j], sc, inv);
+            const int r = (j * NW + wave) * RPI + lrow;
+            if ((lane % LPR) == 0) { s_rinv[r] = inv; s_rscale[r] = sc; }
+        }
+    }
+    load_a(0, areg);
+    if (n_pan > 1) TILE_LOAD_W(1, 1)
+    commit_a(0, areg, sA[0]);
+    if (n_pan > 1) load_a(1, areg);
+
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.0f;
+
+    const int frow = lane & 31, khalf = lane >> 5;
+    // One panel: KCP k-chunks x (RT x CT) x 3 MFMAs; the A fragments of k-chunk kc + 1 are read while kc's MFMAs run.  No branch
+    // inside: the k-chunks past n_kc (K not a multiple of the panel) multiply zero columns of the slab by a finite fragment.
+#define TILE_LOAD_AF(SET, KCI)                                                                                          \
+    _Pragma("unroll") for (int r = 0; r < RT; ++r) {                                                                    \
+        fah[SET][r] = *reinterpret_cast<const bf16x8*>(sl_ + r * 32 * ASTR + (KCI) * 32);                               \
+        fam[SET][r] = *reinterpret_cast<const bf16x8*>(sl_ + r * 32 * ASTR + (KCI) * 32 + APLANE);                      \
+    }
+#define TILE_COMPUTE(B, P)                                                                                              \
+    {                                                                                                                   \
+        const unsigned char* sl_ = sA[B] + frow * ASTR + khalf * 16;                                                    \
+        bf16x8 fah[2][RT], fam[2][RT];                                                                                  \
+        TILE_LOAD_AF(0, 0)                                                                                              \
+        _Pragma("unroll") for (int kc = 0; kc < KCP; ++kc) {                                                            \
+            if (kc + 1 < KCP) { TILE_LOAD_AF((kc + 1) & 1, kc + 1) }                                                    \
+            _Pragma("unroll") for (int c = 0; c < CT; ++c) {                                                            \
+                _Pragma("unroll") for (int r = 0; r < RT; ++r) acc[r][c] = mfma32_t<F16>(fam[kc & 1][r], wh[B][c][kc], acc[r][c]); \
+                _Pragma("unroll") for (int r = 0; r < RT; ++r) acc[r][c] = mfma32_t<F16>(fah[kc & 1][r], wm[B][c][kc], acc[r][c]); \
+                _Pragma("unroll") for (int r = 0; r < RT; ++r) acc[r][c] = mfma32_t<F16>(fah[kc & 1][r], wh[B][c][kc], acc[r][c]); \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
+
+    tile_barrier();
+    // ---- the skip rows / LayerNorm vectors of the update form: requested here, used after the last panel
+    const int col_l = ((lane & 31) >> 2) * 4;           // this lane's 4 consecutive columns inside a column block (after the quad transpose)
+    const int rt0 = (lane & 3) + 4 * (lane >> 5);       // ... and its rows: rt0 + 8 q (+ 32 per row tile)
+    // (two column blocks per wavefront: 32 more registers than the file has next to both fragment buffers -- requested after the
+    //  last panel instead, one exposed L2 round trip)
+    float4 xv[UPD ? RT : 1][UPD ? CT : 1][4];
+#define TILE_LOAD_SKIP()                                                                                                \
+    _Pragma("unroll") for (int r = 0; r < RT; ++r)                                                                      \
+        _Pragma("unroll") for (int c = 0; c < CT; ++c)                                                                  \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                             \
+                const int orow = s_rid[r * 32 + rt0 + 8 * q];                                                           \
+                const int col = cb[c] * 32 + col_l;                                                                     \
+                xv[r][c][q] = make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
+                if (orow >= 0 && col < n_out) xv[r][c][q] = *reinterpret_cast<const float4*>(a.xs + (int64_t)orow * a.ldxs + col); \
+            }
+    if constexpr (UPD && CT == 1) { TILE_LOAD_SKIP() }
+
+    for (int P = 0; P < n_pan; P += 2) {
+        TILE_COMPUTE(0, P)
+        if (P + 1 < n_pan) commit_a(P + 1, areg, sA[1]);
+        if (P + 2 < n_pan) {
+            TILE_LOAD_W(0, P + 2)
+            load_a(P + 2, areg);
+        }
+        if (P + 1 < n_pan) {
+            tile_barrier();
+            TILE_COMPUTE(1, P + 1)
+            if (P + 2 < n_pan) commit_a(P + 2, areg, sA[0]);
+            if (P + 3 < n_pan) {
+                TILE_LOAD_W(1, P + 3)
+                load_a(P + 3, areg);
+            }
+            if (P + 2 < n_pan) tile_barrier();
+        }
+    }
+#undef TILE_COMPUTE
+#undef TILE_LOAD_AF
+#undef TILE_LOAD_W
+#undef TILE_WLOAD
+    if constexpr (UPD && CT > 1) { TILE_LOAD_SKIP() }
+#undef TILE_LOAD_SKIP
+
+    // ---- epilogue
+    const bool o1 = lane & 1, o2 = lane & 2;
+    if constexpr (!UPD) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int col = cb[c] * 32 + col_l;
+            if (!live[c] || col >= n_out) continue;
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + (int64_t)g * a.bgs + col);
+            const int blk = col / a.block_cols, cc = col - blk * a.block_cols;
+            float* __restrict__ ob = (blk == 0) ? a.out0 : ((blk == 1) ? a.out1 : a.out2);
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v0 = acc[r][c][4 * q], v1 = acc[r][c][4 * q + 1], v2 = acc[r][c][4 * q + 2], v3 = acc[r][c][4 * q + 3];
+                    quad_transpose(v0, v1, v2, v3, o1, o2);
+                    const int rt = r * 32 + rt0 + 8 * q;
+                    if (rt < nrows) {
+                        const float sc = F16 ? s_rinv[F16 ? rt : 0] * winv : 1.0f;
+                        const int64_t orow = a.by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
+                        *reinterpret_cast<float4*>(ob + orow * a.block_cols + cc) = make_float4(v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w);
+                    }
+                }
+        }
+    } else {
+        // y = (acc + b) * sigmoid(skip[t]) + x * (1 - sigmoid(skip[t]));  out = LayerNorm_t(y), two-pass mean / variance (conv.py:129-133).
+        // A row's columns live in NW wavefronts x CT column blocks x 8 lanes: lane-strided sums, then one LDS table entry per (row, wave).
+        const float alpha = 1.0f / (1.0f + expf(-a.skip[g]));
+        const float inv_n = 1.0f / (float)n_out;
+        float y[RT][CT][4][4];
+        float* s_sum = s_red;
+        float* s_var = s_red + BMT * NW;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int col = cb[c] * 32 + col_l;
+            const bool col_ok = live[c] && col < n_out;
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col_ok && a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + (int64_t)g * a.bgs + col);
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v0 = acc[r][c][4 * q], v1 = acc[r][c][4 * q + 1], v2 = acc[r][c][4 * q + 2], v3 = acc[r][c][4 * q + 3];
+                    quad_transpose(v0, v1, v2, v3, o1, o2);
+                    const float sc = F16 ? s_rinv[F16 ? (r * 32 + rt0 + 8 * q) : 0] * winv : 1.0f;
+                    const float4 x4 = xv[r][c][q];
+                    y[r][c][q][0] = col_ok ? (v0 * sc + b4.x) * alpha + x4.x * (1.0f - alpha) : 0.0f;
+                    y[r][c][q][1] = col_ok ? (v1 * sc + b4.y) * alpha + x4.y * (1.0f - alpha) : 0.0f;
+                    y[r][c][q][2] = col_ok ? (v2 * sc + b4.z) * alpha + x4.z * (1.0f - alpha) : 0.0f;
+                    y[r][c][q][3] = col_ok ? (v3 * sc + b4.w) * alpha + x4.w * (1.0f - alpha) : 0.0f;
+                }
+        }
+        if (a.use_norm) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float ps = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) ps += y[r][c][q][0] + y[r][c][q][1] + y[r][c][q][2] + y[r][c][q][3];
+                    ps = strided8_sum(ps);
+                    if (((lane & 31) >> 2) == 0) s_sum[(r * 32 + rt0 + 8 * q) * NW + wave] = ps;
+                }
+            tile_barrier();
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rt = r * 32 + rt0 + 8 * q;
+                    float s = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) s += s_sum[rt * NW + w];
+                    const float mean = s * inv_n;
+                    float ps = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        const bool col_ok = live[c] && (cb[c] * 32 + col_l) < n_out;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            y[r][c][q][i] -= mean;      // y is centred from here on
+                            const float d = col_ok ? y[r][c][q][i] : 0.0f;
+                            ps = fmaf(d, d, ps);
+                        }
+                    }
+                    ps = strided8_sum(ps);
+                    if (((lane & 31) >> 2) == 0) s_var[rt * NW + wave] = ps;
+                }
+            tile_barrier();
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int col = cb[c] * 32 + col_l;
+            if (!live[c] || col >= n_out) continue;
+            float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f), c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.use_norm) {
+                w4 = *reinterpret_cast<const float4*>(a.lnw + (int64_t)g * n_out + col);
+                c4 = *reinterpret_cast<const float4*>(a.lnb + (int64_t)g * n_out + col);
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rt = r * 32 + rt0 + 8 * q;
+                    if (rt >= nrows) continue;
+                    float rstd = 1.0f;
+                    if (a.use_norm) {
+                        float s = 0.0f;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) s += s_var[rt * NW + w];
+                        rstd = rsqrtf(s * inv_n + 1e-5f);
+                    }
+                    const int64_t orow = (int64_t)s_rid[rt];
+                    *reinterpret_cast<float4*>(a.out0 + orow * n_out + col) =
+                        make_float4(y[r][c][q][0] * rstd * w4.x + c4.x, y[r][c][q][1] * rstd * w4.y + c4.y, y[r][c][q][2] * rstd * w4.z + c4.z,
+                                    y[r][c][q][3] * rstd * w4.w + c4.w);
+                }
+        }
+    }
+}
+
+template <int NW, int RT, int CT, int KPAN, bool UPD>
+static void launch_tile(bool f16, const TileArgs& a, int64_t n_rows, hipStream_t stream) {
+    constexpr int BMT = 32 * RT, BNT = 32 * CT * NW;
+    const int64_t row_tiles = (n_rows + BMT - 1) / BMT + a.n_groups;      // device-side group sizes: the upper bound
+    dim3 grid((unsigned)row_tiles, (unsigned)((a.n_out + BNT - 1) / BNT));
+    if (f16) k_tile_linear<NW, RT, CT, KPAN, UPD, true, false><<<grid, 64 * NW, 0, stream>>>(a);
+    else k_tile_linear<NW, RT, CT, KPAN, UPD, false, false><<<grid, 64 * NW, 0, stream>>>(a);
+}
+
+}  // namespace
+
+// 1 = launched, 0 = not this kernel's domain (the caller takes the persistent / slab kernels), < 0 = error.
+// `upd` = nullptr: the plain typed linear; otherwise {x_skip, ld_skip, skip, ln_w, ln_b, use_norm} of the fused update (n_out <= 512).
+int hgt_typed_linear_tile_try(bool f16, const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off, int32_t n_groups,
+                              int64_t n_rows, int32_t k, int32_t n_out, const void* w_split, const float* bias, int64_t bgs, float* out0,
+                              float* out1, float* out2, int32_t block_cols, int32_t by_pos, int32_t prologue, const HgtTileUpdate* upd,
+                              void* stream_) {
+    // (prologue 1 = gelu on load -- DenseHGTConv's out_linear, the unfused wide update -- stays on the slab kernels: the inlined erf next
+    //  to both fragment buffers spills (4.7 KB of scratch per lane in the fp16 form))
+    if (n_rows > HGT_TILE_MAX_ROWS || prologue != 0 || n_groups > 64) return 0;
+    if (((n_out | block_cols) & 3) != 0) return 0;
+    if (upd && (n_out > 512 || (upd->ld_skip & 3) != 0 || ((uintptr_t)upd->x_skip & 15) != 0)) return 0;
+    TileArgs a;
+    a.x = x; a.ldx = ldx; a.rows = rows; a.group_off = group_off; a.n_groups = n_groups; a.k = k; a.n_out = n_out;
+    a.wsplit = (const unsigned short*)w_split; a.bias = bias; a.bgs = bgs; a.out0 = out0; a.out1 = out1; a.out2 = out2;
+    a.block_cols = block_cols; a.by_pos = by_pos; a.prologue = prologue;
+    a.vec_ok = (ldx % 4 == 0) && (k % 4 == 0) && (((uintptr_t)x & 15) == 0) ? 1 : 0;
+    a.xs = nullptr; a.ldxs = 0; a.skip = nullptr; a.lnw = nullptr; a.lnb = nullptr; a.use_norm = 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (upd) {
+        a.xs = upd->x_skip; a.ldxs = upd->ld_skip; a.skip = upd->skip; a.lnw = upd->ln_w; a.lnb = upd->ln_b; a.use_norm = upd->use_norm;
+        if (n_out <= 256) launch_tile<8, 1, 1, 128, true>(f16, a, n_rows, stream);      // (c3: 11.9 us against 19.2 on the persistent kernel)
+        else launch_tile<8, 1, 2, 64, true>(f16, a, n_rows, stream);
+    } else {
+        // plain linear: 32 x 128 tiles of four wavefronts, four workgroups per CU (K panels of 64: 120 registers) -- measured at c3
+        // (3 200 x 256 -> 768): 11.3 us against 14.0 (64 x 128 tiles) and 13.9 (persistent kernel).  Beyond K = 256 or ~1 000 workgroups
+        // the slab kernels are as fast or faster (K = 512: 36 vs 31 us at 3 200 rows): not this kernel's domain
+        const int64_t wgs = ((n_rows + 31) / 32 + n_groups) * ((n_out + 127) / 128);
+        if (k > 256 || wgs > 1024) return 0;
+        launch_tile<4, 1, 1, 64, false>(f16, a, n_rows, stream);
+    }
+    if (hipGetLastError() != hipSuccess) return HGT_ERR_LAUNCH;
+    return 1;
+}

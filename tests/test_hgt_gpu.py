@@ -1977,6 +1977,96 @@ def test_linear_update_against_float64(precision, n, k, n_out, use_norm):
                xs.data_ptr(), n_out, skip.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), use_norm, out.data_ptr(), st) == -2
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("n,k,n_out,prologue", [(3200, 256, 768, 0), (1000, 512, 1536, 0), (777, 200, 1200, 0), (300, 1169, 400, 0),
+                                                  (5000, 64, 192, 0), (4000, 256, 512, 0), (70, 129, 96, 0), (2000, 250, 96, 0)])
+def test_tile_linear_is_bit_identical_to_the_slab_kernels(precision, n, k, n_out, prologue):
+    """The latency-regime typed linear (csrc/hgt_gemm_tile.hip, round 6: K <= 256 and at most ~1 000 workgroups of 32 x 128 outputs)
+    keeps the slab kernels' split, k order and product order: bit-identical output on ragged shuffled groups (incl. an empty one), K
+    that is not a multiple of a panel / of 4 (scalar row loads), both output modes; shapes outside its domain fall through to the
+    slab kernels (the comparison is then trivially equal, the float64 bound still checked)."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + k)
+    G = 4
+    x = (torch.randn(n + 9, k, generator=g) * torch.pow(10.0, torch.rand(n + 9, 1, generator=g) * 4 - 2)).to(DEV)
+    W = (torch.randn(G, n_out, k, generator=g) / k ** 0.5).to(DEV)
+    bias = torch.randn(G, n_out, generator=g).to(DEV)
+    rows = torch.randperm(n + 9, generator=g)[:n].to(torch.int32).to(DEV).contiguous()
+    c1 = n // 3
+    off = torch.tensor([0, c1, c1, min(n, c1 + 65), n], dtype=torch.int32, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = C.c_uint64()
+    assert lib.hgt_split_weights_bytes(G, k, n_out, C.byref(nb)) == 0
+    ws = torch.empty(int(nb.value), dtype=torch.uint8, device=DEV)
+    split, linear = ((lib.hgt_split_weights_f16, lib.hgt_typed_linear_f16x3) if precision == "f16x3" else
+                     (lib.hgt_split_weights, lib.hgt_typed_linear_bf16x3))
+    assert split(W.data_ptr(), n_out * k, G, k, n_out, ws.data_ptr(), st) == 0
+    nblk = 3 if n_out % 3 == 0 and (n_out // 3) % 4 == 0 else 1
+    bc = n_out // nblk
+    for by_pos in (0, 1):
+        res = []
+        for sel in (0, _lib.HGT_LINEAR_NO_TILE | _lib.HGT_LINEAR_NO_XS):
+            outs = [torch.full((n + 9, bc), 3.0, device=DEV) for _ in range(nblk)]
+            optr = [o.data_ptr() for o in outs] + [0, 0]
+            assert linear(x.data_ptr(), k, rows.data_ptr(), off.data_ptr(), G, n, k, n_out, ws.data_ptr(), bias.data_ptr(), n_out,
+                          optr[0], optr[1], optr[2], bc, by_pos, prologue | sel, st) == 0
+            torch.cuda.synchronize()
+            res.append(torch.cat(outs, dim=1))
+        assert torch.equal(res[0], res[1]), "tile kernel differs from the slab kernel: max %.3e" % (res[0] - res[1]).abs().max().item()
+    # and against float64 (the slab kernel's own bound)
+    xin = torch.nn.functional.gelu(x.cpu().double()) if prologue else x.cpu().double()
+    offl = off.tolist()
+    worst = 0.0
+    for gi in range(G):
+        r = rows[offl[gi]:offl[gi + 1]].long().cpu()
+        if r.numel() == 0:
+            continue
+        ref = xin[r] @ W[gi].cpu().double().T + bias[gi].cpu().double()
+        got = res[0][offl[gi]:offl[gi + 1]].cpu().double()          # (the by_pos = 1 run: position order)
+        scale = xin[r].abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+        worst = max(worst, ((got - ref).abs() / scale).max().item())
+    print("tile linear %s n=%d k=%d n_out=%d: max|err| / row scale %.2e" % (precision, n, k, n_out, worst))
+    assert worst < (8e-6 if precision == "f16x3" else 6e-5)      # (rows spanning four decades: the slab kernel's own figure)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("n,k,n_out,use_norm", [(3200, 256, 256, 1), (1000, 512, 512, 1), (777, 512, 400, 0), (333, 256, 64, 1), (4096, 512, 400, 1)])
+def test_tile_linear_update_is_bit_identical_to_the_slab_kernels(precision, n, k, n_out, use_norm):
+    """The fused update of the latency regime (32 whole rows per workgroup, hgt_gemm_tile.hip) against the persistent / wide kernels
+    (bit 1 of `use_norm` keeps the call off the tile kernel): same sums, same LayerNorm order -> bit-identical rows."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11 + n_out + n)
+    G = 4
+    agg = torch.randn(n, k, generator=g).to(DEV)
+    xs = torch.randn(n, n_out, generator=g).to(DEV)
+    W = (torch.randn(G, n_out, k, generator=g) / k ** 0.5).to(DEV)
+    bias = torch.randn(G, n_out, generator=g).to(DEV)
+    skip = torch.tensor([0.3, -1.2, 2.0, 0.0]).to(DEV)
+    lnw = (1.0 + 0.1 * torch.randn(G, n_out, generator=g)).to(DEV)
+    lnb = (0.1 * torch.randn(G, n_out, generator=g)).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    n_used = n - 37
+    rows = torch.randperm(n, generator=g)[:n_used].to(torch.int32).to(DEV).contiguous()
+    c1 = n_used // 3
+    off = torch.tensor([0, c1, c1, c1 + 65, n_used], dtype=torch.int32, device=DEV)
+    nb = C.c_uint64()
+    assert lib.hgt_split_weights_bytes(G, k, n_out, C.byref(nb)) == 0
+    wsplit = torch.empty(int(nb.value), dtype=torch.uint8, device=DEV)
+    split = lib.hgt_split_weights_f16 if precision == "f16x3" else lib.hgt_split_weights
+    upd = lib.hgt_linear_update_f16x3 if precision == "f16x3" else lib.hgt_linear_update_bf16x3
+    assert split(W.data_ptr(), n_out * k, G, k, n_out, wsplit.data_ptr(), st) == 0
+    res = []
+    for no_tile in (0, 2):
+        out = torch.full((n, n_out), 7.0, device=DEV)
+        assert upd(agg.data_ptr(), k, rows.data_ptr(), off.data_ptr(), G, n_used, k, n_out, wsplit.data_ptr(), bias.data_ptr(), n_out,
+                   xs.data_ptr(), n_out, skip.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), use_norm | no_tile, out.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        res.append(out)
+    d = (res[0] - res[1]).abs().max().item()
+    print("tile update %s n=%d k=%d n_out=%d: max|tile - slab| %.3e" % (precision, n, k, n_out, d))
+    assert d <= 2e-6      # (same products; the LayerNorm sums meet in a different order: last-bit differences)
+
+
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 1000, 100_003])
 def test_c24_pack_of_256_column_rows_is_bit_exact(n):
     """hgt_gather_rows_c24 at the benchmark width against the format's definition computed with torch integer ops (little-endian 3-byte

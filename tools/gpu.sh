@@ -16,6 +16,9 @@
 #   sanity    smoke(), the judged layer without secondaries, a handful of tests: the first call after a kernel change
 #   ceiling   plain streaming kernels of the part (tools/lab/stream_ceiling.py): fill / copy / 1:3 read:write rates
 #   xsthr     slab vs x-stationary GEMM around the dispatch threshold (tools/bench_xs.py --threshold)
+#   latency   kernel timelines of the latency-regime workloads (c3, script-default batch, c5, published 4-layer model, c1; $3 = precision):
+#             per-kernel us and gaps of a steady-state forward (tools/trace_latency.py) -> gpurun_out/<tag>_latency_<workload>.txt
+#   small     the latency-regime part of the judged line only (bench.py --small-only): wall-clock us per layer / forward + parity
 # Everything lands in gpurun_out/; summaries to be judged are copied to profiles/ by hand (or by `final`).
 # Kernel experiments: tools/lab/build_lab.sh (lab libraries), lab_run.sh (phase times), pmc_quick.sh (counters), isa.sh (ISA + resources).
 MODE=${1:-quick}; TAG=${2:-r05}
@@ -130,6 +133,29 @@ ceiling)
     ;;
 xsthr)
     timeout 300 python tools/bench_xs.py --threshold 2>&1 | grep -v amdgpu.ids | tee gpurun_out/xs_threshold.txt
+    ;;
+latency)
+    export TMPDIR=/tmp; ROOT=$(pwd); PREC=${3:-bf16x3}; cd /tmp
+    for wl in c3:1 c3w520:1 c5:2 mag4:4 c1:1; do
+        w=${wl%%:*}; nl=${wl##*:}
+        rm -rf /tmp/pl_$w
+        timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/pl_$w -o t -- python $ROOT/tools/trace_latency.py run $w $PREC > /tmp/pl_$w.log 2>&1
+        { echo "# tools/trace_latency.py $w $PREC  ($(grep -E '^N ' /tmp/pl_$w.log | tail -1))  commit $HGT_COMMIT"; python $ROOT/tools/trace_latency.py show /tmp/pl_$w $nl; } > $ROOT/gpurun_out/${TAG}_latency_${w}_$PREC.txt 2>&1
+        tail -1 $ROOT/gpurun_out/${TAG}_latency_${w}_$PREC.txt
+    done
+    cd $ROOT
+    ;;
+small)
+    timeout 600 python bench.py --small-only > gpurun_out/${TAG}_small.json 2> gpurun_out/${TAG}_small.err; echo "rc=$?"; tail -3 gpurun_out/${TAG}_small.err
+    python - gpurun_out/${TAG}_small.json <<'PY'
+import json, sys
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+for k, v in j.items():
+    if not isinstance(v, dict): continue
+    print(k, {kk: vv for kk, vv in v.items() if kk != "workload" and not isinstance(vv, dict)})
+    for p, e in v.items():
+        if isinstance(e, dict): print("    ", p, {kk: (float("%.4g" % vv) if isinstance(vv, float) else vv) for kk, vv in e.items()})
+PY
     ;;
 emuprof)
     export TMPDIR=/tmp; ROOT=$(pwd); cd /tmp
