@@ -271,7 +271,7 @@ def small_regime(dev):
     from oracle.gen_golden_gnn import GNN_CASES, build_batch
     from pyhgt_amd import HGTConv, GNN, GraphPlan
     from pyhgt_amd.sampled import synthetic_sampled_batch, to_torch_layout, to_device_graph
-    res = {}
+    res = {"timing": "host wall time per call, fastest of 3 timed loops (wall_us; rounds 1-4 reported the mean of one loop)"}
     graph_cases = []      # (entry, divisor, fn): measured at the very end, see graph_replay_us
     gold = os.path.join(ROOT, "tests", "golden")
     # ---- c1
@@ -326,7 +326,7 @@ def small_regime(dev):
         res["c3"][prec] = {"us_per_layer": us, "edges_per_s": E / (us * 1e-6),
                            "parity_max_abs_err": float((out.cpu().double() - ref).abs().max()),
                            "layer_frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
-        if prec == "bf16x3":
+        if prec == "f16x3":      # (the default precision)
             # every sampled batch of the reference's training loop is a NEW graph (round-3 advisor note): one layer with the plan
             # of the sampler-ordered hand-off built inside the timed call
             def new_graph_layer():
@@ -341,7 +341,7 @@ def small_regime(dev):
     N, E = int(ntc.numel()), int(etc_.numel())
     ref = O.forward_closed_form(sd, T, R, H, xc, ntc, eic, etc_, tmc, use_norm=True, use_RTE=True, dtype=torch.float64)
     x, nt, tm, ei, et = [t.to(dev) for t in (xc, ntc, tmc, eic, etc_)]
-    layer = HGTConv(d, d, T, R, H, 0.2, True, True, precision="bf16x3").eval()
+    layer = HGTConv(d, d, T, R, H, 0.2, True, True, precision="f16x3").eval()
     layer.load_state_dict(sd)
     layer = layer.to(dev)
     plan = GraphPlan(nt, ei, et, tm, T, R)
@@ -351,7 +351,7 @@ def small_regime(dev):
     res["c3_width520"] = {"workload": "ogbn-mag script default batch (sample_depth 6, sample_width 520; train_ogbn_mag.py:44-46), surrogate: "
                                       "T=%d R=%d N=%d E=%d d=%d H=%d use_RTE=True, one layer" % (T, R, N, E, d, H),
                           "plan_build_us": wall_us(lambda: GraphPlan(nt, ei, et, tm, T, R), 30, 5),
-                          "bf16x3": {"us_per_layer": us, "edges_per_s": E / (us * 1e-6),
+                          "f16x3": {"us_per_layer": us, "edges_per_s": E / (us * 1e-6),
                                      "parity_max_abs_err": float((out.cpu().double() - ref).abs().max()),
                                      "layer_frac": round(algorithmic_bytes(N, E, d, True)["layer"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
     # ---- c5 and the published 4-layer model: whole GNN forwards against rows of the verbatim reference GNN
@@ -380,7 +380,7 @@ def small_regime(dev):
                 us = wall_us(lambda: gnn(*args), 100, 10)
             res[key][prec] = {"us_per_forward": us, "us_per_layer": us / c["n_layers"], "edges_per_s_per_layer": etc_.numel() * c["n_layers"] / (us * 1e-6),
                               "parity_max_abs_err": float((out[rows.to(dev)].cpu() - want).abs().max())}
-            if prec == "bf16x3":      # a new graph per forward (plan cache emptied inside the timed call: radix plan build included)
+            if prec == "f16x3":      # a new graph per forward (plan cache emptied inside the timed call: radix plan build included)
                 def new_graph_forward():
                     GraphPlan.clear_cache()
                     return gnn(*args)
@@ -640,11 +640,11 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0, help="N = 1 only: ONE GPU plays rank 0 of a W-rank partition of the configs[3] "
                     "recipe (exchange replaced by device copies of the same size): the per-rank GPU work of a multi-GPU step, measured")
     ap.add_argument("--precision", default=None, choices=["bf16x3", "f16x3", "fp32"],
-                    help="typed linears / relation transforms.  Default bf16x3 = 3-term split-bf16 MFMA, fp32 accumulation: the layer's "
-                         "default, the split SURVEY.md 7.2 prescribes, <= 3.5e-5 from the fp64 oracle (north-star bound 1e-4) and the "
-                         "mode of the round 1-3 lines (like-for-like tracking).  f16x3 = 3-term fp16 hi/lo MFMA with power-of-two row "
-                         "scales: the reference's own fp32 accuracy (<= 2e-6), ~4 %% slower -- measured in EVERY default run and "
-                         "reported at the top level of the line as `fp32_accurate` (and under `secondary`, with exact fp32)")
+                    help="typed linears / relation transforms.  Default (round 6, N = 1) f16x3 = 3-term fp16 hi/lo MFMA with power-of-two "
+                         "row scales, fp32 accumulation: the layer's default, the reference's own fp32 accuracy (<= 2e-6 from the fp64 "
+                         "oracle).  bf16x3 = 3-term split-bf16 MFMA (the split SURVEY.md 7.2 prescribes, <= 3.5e-5, north-star bound 1e-4; "
+                         "the judged mode of rounds 1-5, ~5 %% faster): measured in EVERY default run and reported at the top level of the "
+                         "line as `fast_mode` (and under `secondary`, with exact fp32).  N > 1 defaults to bf16x3: the staged calls run it")
     ap.add_argument("--kernel-flags", type=int, default=0, help="hgt_conv_args.flags (HGT_FLAG_*), A/B runs")
     ap.add_argument("--workload", default="c2", choices=["c2", "c5"],
                     help="c2 (default): BASELINE.json configs[1] at N=1, the configs[3] recipe (dst partition + RCCL halo all-to-all) at N>1.  "
@@ -669,7 +669,9 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.precision is None:      # (see --precision)
-        args.precision = "bf16x3"
+        # round 6: the reference-accurate split is the layer's default and the judged mode at N = 1; the staged multi-GPU calls run the
+        # bf16 split whatever the layer says (include/hgt_hip.h: precision 2 is whole-layer only), so N > 1 is labelled with what runs
+        args.precision = "f16x3" if world == 1 else "bf16x3"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
@@ -1067,6 +1069,30 @@ def main():
         if f16:      # the same layer, same graph, same run in the reference's own accuracy (see --precision)
             line["fp32_accurate"] = {"precision": "f16x3", "ms_per_step": f16["ms_per_step"], "edges_per_s": f16["edges_per_s"],
                                      "layer_frac": f16["layer_frac"], "parity_max_abs_err": f16["parity_max_abs_err"]}
+        elif args.precision == "f16x3":      # (round 6: the headline IS the reference-accurate mode)
+            line["fp32_accurate"] = {"precision": "f16x3", "ms_per_step": ms_per_step, "edges_per_s": value,
+                                     "layer_frac": roofline.get("layer_frac") if roofline else None,
+                                     "parity_max_abs_err": None if parity is None else parity["max_abs_err"]}
+        fast = secondary.get("precision_bf16x3")
+        if fast:     # the opt-in fast mode (rounds 1-5's judged mode) on the same graph in the same run
+            line["fast_mode"] = {"precision": "bf16x3", "ms_per_step": fast["ms_per_step"], "edges_per_s": fast["edges_per_s"],
+                                 "layer_frac": fast["layer_frac"], "parity_max_abs_err": fast["parity_max_abs_err"]}
+        # scalar copies of figures that live in nested objects (the driver's `parsed` view flattens those away: round-5 review)
+        if plan_ms is not None:
+            line["plan_included_ms"] = ms_per_step + plan_ms
+            line["plan_included_frac"] = round(alg["layer"] / ((ms_per_step + plan_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if isinstance(cpu, dict):
+            full = cpu.get("full_c2")
+            line["cpu_full_c2_edges_per_s"] = full.get("edges_per_s") if isinstance(full, dict) else None
+            line["cpu_sample_edges_per_s"] = cpu.get("value")
+        lat = secondary.get("latency_regime")
+        if isinstance(lat, dict):
+            try:
+                line["c3_us_per_layer"] = lat["c3"][args.precision]["us_per_layer"]
+                line["c5_us_per_forward"] = lat["c5"][args.precision]["us_per_forward"]
+                line["mag4_us_per_layer"] = lat["mag4"][args.precision]["us_per_layer"]
+            except KeyError:
+                pass
         print(json.dumps(line))
         def parities(prefix, node):
             if isinstance(node, dict):

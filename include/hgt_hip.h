@@ -161,6 +161,9 @@ int hgt_plan_from_sorted(const int32_t* src, const int32_t* dst, const int32_t* 
  * ---------------------------------------------------------------------------------------------- */
 #define HGT_LINEAR_FORCE_XS 0x100
 #define HGT_LINEAR_NO_XS 0x200
+#define HGT_LINEAR_TANH 0x1000     /* ABI 7, split variants: tanh applied to the output (model.py:70-76: the GNN's typed adapter + tanh in one kernel).
+                                    * Only the latency-regime tile kernel and the K > 256 slab kernel carry it: HGT_ERR_UNSUPPORTED otherwise (and
+                                    * nothing launched) -> plain call + hgt_tanh_inplace */
 #define HGT_LINEAR_NO_TILE 0x400   /* ABI 7: never the latency-regime tile kernel (hgt_gemm_tile.hip; the default below 49 152 rows) -- it is
                                     * bit-identical to the slab kernels; the bit exists for tests and A/B timings */
 int hgt_typed_linear(const float* x, int64_t ldx, const int32_t* rows, const int32_t* group_off,
@@ -301,8 +304,9 @@ int hgt_edge_aggregate_items_update(const void* plan, int64_t n_nodes, int64_t n
  * gathered together, the logit, the run's online softmax and the weighted sum, then the message transform (msg_frag) -- no [E][H]
  * logits array, one launch less per layer.  Same scratch, same fixed-order merge and (up to the fp32 summation order of the
  * logits) the same result as hgt_edge_logits_mfma + hgt_edge_aggregate_items.  rte_k / rte_v: both tables or both NULL.
- * HGT_ERR_UNSUPPORTED for layouts it is not instantiated for (the caller takes the two-kernel form) -- and ALWAYS in the shipped
- * library: the kernel (csrc/lab/hgt_edge_single_pass.hip, measured not faster) is compiled into LAB builds only (hgt_build_features). */
+ * HGT_ERR_UNSUPPORTED for layouts it is not instantiated for (the caller takes the two-kernel form) -- and, in the shipped library,
+ * for every call that has work to do (n_edges > 0 and target rows > 0; an empty call returns HGT_OK like every entry point): the
+ * kernel (csrc/lab/hgt_edge_single_pass.hip, measured not faster) is compiled into LAB builds only (hgt_build_features). */
 int hgt_edge_single_pass_items(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                                int32_t n_heads, int32_t dk_pad, const float* Q, const float* K, const float* V, const float* rte_k,
                                const float* rte_v, const void* att_frag, const void* msg_frag, int32_t frag_f16, float* agg,

@@ -29,6 +29,7 @@ HGT_FLAG_NO_MERGE_UPDATE = 8192
 HGT_LINEAR_FORCE_XS = 0x100
 HGT_LINEAR_NO_XS = 0x200
 HGT_LINEAR_NO_TILE = 0x400
+HGT_LINEAR_TANH = 0x1000
 HGT_FEATURE_LAB_KERNELS = 1
 
 

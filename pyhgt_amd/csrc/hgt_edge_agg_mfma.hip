@@ -31,9 +31,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef HGT_FU_NSTG
 #define HGT_FU_NSTG 2     // W_a fragment stages of the fused epilogue (hgt_fused_update.h)
 #endif
-#ifndef HGT_AGG_LAB
-#define HGT_AGG_LAB 0     // timing-only experiment switches of the streaming walk (tools/lab): 0 = product build
-#endif
 #ifndef HGT_AGG_GS
 #define HGT_AGG_GS 8      // column-tile steps whose fragments are requested together at a relation end (16 loads in flight)
 #endif
@@ -515,6 +512,13 @@ __device__ __forceinline__ void agg_mfma_stream(
     for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
     bool seg_claimed = false;      // relation of the running segment is a real one (its rows go into the U tile)
 
+    // INVARIANTS of flush() and of the row path (round-5 advisor):
+    //  * the exp-sum write-back `s_l[..] += l_seg` is a plain read-modify-write executed by EVERY lane of a head with the SAME l_seg
+    //    (l_seg is updated from head-uniform logits only): it must stay non-atomic and lane-uniform -- a ds_add_f32 here would add
+    //    l_seg once per lane of the head (LPH times);
+    //  * U is parked in the tile ONLY under seg_claimed, and U is zeroed at every segment change: the rows of the bucket of unclaimed
+    //    edges (rel == R) are accumulated into U unconditionally by AGG_ROW_ACC (no branch on the row path) and then dropped here --
+    //    an unclaimed segment's U must never reach the tile.
     auto flush = [&]() {
         if (cur_dl >= 0) {
             const int dl = cur_dl;
@@ -573,10 +577,6 @@ __device__ __forceinline__ void agg_mfma_stream(
     static_assert(STEPS % GS == 0, "column-tile steps come in multiples of 4 (DP is a multiple of 64)");
     auto relation_end = [&](int rel) {
         if (rowmask == 0) return;
-#if HGT_AGG_LAB == 2      // no relation-end work at all (wrong results): what the transforms cost in total
-        rowmask = 0;
-        return;
-#endif
         for (unsigned zm_ = ~rowmask & ((1u << SUBR) - 1u); zm_ != 0; zm_ &= zm_ - 1) {      // (only the absent rows are visited)
             const int r = __builtin_ctz(zm_);
             unsigned char* w = utile + r * ROWB + ((((wb >> 4) ^ (r & (NS - 1)))) << 4) + (wb & 15);
@@ -595,17 +595,11 @@ __device__ __forceinline__ void agg_mfma_stream(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#if HGT_AGG_LAB == 1      // every relation end reads the same 8 KB of fragments (wrong results): L1-resident, a quarter of the loads
-        const unsigned short* __restrict__ mf = msgF + lane * 8;
-#define LAB_STEP(x) ((x) & 3)
-#else
         const unsigned short* __restrict__ mf = msgF + (((int64_t)rel * NY + hg) * NCT) * NKS * 2 * 512 + lane * 8;
-#define LAB_STEP(x) (x)
-#endif
         bf16x8 f0h[GS], f0m[GS];     // one group in flight: a second register buffer would push the kernel over 256 VGPRs
 #define FRAG_ISSUE(FH, FM, G_)                                                                     \
     _Pragma("unroll") for (int j = 0; j < GS; ++j) {                                               \
-        const unsigned short* t_ = mf + (int64_t)(LAB_STEP((G_) * GS + j) * 2) * 512;            \
+        const unsigned short* t_ = mf + (int64_t)(((G_) * GS + j) * 2) * 512;            \
         FH[j] = *reinterpret_cast<const bf16x8*>(t_);                                              \
         FM[j] = *reinterpret_cast<const bf16x8*>(t_ + 512);                                        \
     }                                                                                              \
@@ -630,7 +624,6 @@ __device__ __forceinline__ void agg_mfma_stream(
         }
 #undef FRAG_ISSUE
 #undef FRAG_MUL
-#undef LAB_STEP
         __builtin_amdgcn_wave_barrier();
     };
 
@@ -988,8 +981,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_aggregate_update_mfma(
     static_assert(G::DP <= KP, "the fused epilogue keeps the whole K extent in one LDS slab");
     constexpr int TILES = 4 * 2 * G::PLANE;
     constexpr int FRONT = TILES > 2 * A_PLANE ? TILES : 2 * A_PLANE;
-    // (HGT_AGG_LAB == 6: 16 KB of padding -> ONE workgroup per CU: how much of the kernel is occupancy)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[FRONT + 4 * 2 * 256 * 4 + 4 * 16 * 4 + (F16 ? 4 * 16 * 4 : 0) + (HGT_AGG_LAB == 6 ? 16384 : 0)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[FRONT + 4 * 2 * 256 * 4 + 4 * 16 * 4 + (F16 ? 4 * 16 * 4 : 0)];
     float* s_ml = reinterpret_cast<float*>(smem + FRONT);                 // [4][2][256]; later: the epilogue's tables
     float* s_scale = reinterpret_cast<float*>(smem + FRONT + 4 * 2 * 256 * 4);
     float* s_sig = s_scale + (F16 ? 4 * 16 : 0);                           // fp16 split: row scales of the targets, [4][16]

@@ -87,48 +87,19 @@ __global__ __launch_bounds__(1024) void k_group_scale(const float* __restrict__ 
     }
 }
 
-// Row scales of the fp16 split for the kernels that walk K in several LDS panels (k_typed_linear_split): the scale of a row
-// must be the same for all its panels, so the row maximum is taken over the whole row first (one more pass over x; K > 256 only).
-template <int PROLOGUE>
-__device__ __forceinline__ void row_scales_all_panels(int tid, const int* s_rid, const float* __restrict__ x, int64_t ldx, int k,
-                                                      int vec_ok, float* s_scale, float* s_inv) {
-    // wave w owns rows w, w + 8, ... (the mapping of load_a_panel): the 64 lanes walk the row 16 B each, one wave reduction
-    // per row (the first version: scalar loads + an LDS atomicMax per lane -- 22 us on a 3000-row sampled batch)
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int j = 0; j < BM / 8; ++j) {
-        const int r = wave + 8 * j, rid = s_rid[r];
-        unsigned mb = 0u;
-        if (rid >= 0) {
-            for (int kk = lane * 4; kk < k; kk += 256) {
-                const float* px = x + (int64_t)rid * ldx + kk;
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (vec_ok && kk + 3 < k) {
-                    a = *reinterpret_cast<const float4*>(px);
-                } else {
-                    a.x = px[0];
-                    if (kk + 1 < k) a.y = px[1];
-                    if (kk + 2 < k) a.z = px[2];
-                    if (kk + 3 < k) a.w = px[3];
-                }
-                if (PROLOGUE == 1) { a.x = gelu_erf_(a.x); a.y = gelu_erf_(a.y); a.z = gelu_erf_(a.z); a.w = gelu_erf_(a.w); }
-                mb = max(mb, abs_bits4(a));
-            }
-        }
-        mb = wave_max_bits(mb);
-        if (lane == 0) f16_row_scale(mb, s_scale[r], s_inv[r]);
-    }
-    __syncthreads();
-}
-
 // Load one K panel of the 64-row x slab: whole rows, split into bf16 hi/mid planes ONCE, stored to LDS.
 // Done in two halves of 4 float4 per thread to keep the live register set small (the kernel is capped at 128 VGPRs
 // so that two workgroups fit a CU; an 8-deep version spilled ~230 B per lane to scratch = +2.9 GB of HBM traffic at c2).
 template <int PROLOGUE, bool F16>
 __device__ __forceinline__ void load_a_panel(int kp0, int tid, const int* s_rid, const float* __restrict__ x, int64_t ldx, int k,
                                              int vec_ok, unsigned char* sA, bool wait_readers, float* s_scale, float* s_inv,
-                                             bool single) {      // single (F16): K fits one panel, the row scales are found here
+                                             float* s_ratio, int* s_flag, bool first) {      // first: the row's first panel (F16: its scale starts here)
     if (wait_readers) __syncthreads();   // every wave is done reading the previous panel
+    const int par = (kp0 / KP) & 1;
+    if constexpr (F16) {
+        if (tid == 0) s_flag[par] = 0;      // (the flag of the panel before last: its readers passed a barrier since)
+        if (!first) __syncthreads();
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         float4 av[4];
@@ -142,11 +113,13 @@ __device__ __forceinline__ void load_a_panel(int kp0, int tid, const int* s_rid,
                 const float* px = x + (int64_t)rid * ldx + kk;
                 if (vec_ok && kk + 3 < k) {
                     a = *reinterpret_cast<const float4*>(px);
-                } else {
+                } else {      // (four loads in flight, no branch between them: rows of 1169 floats are not 16-byte aligned)
+                    const int rem = k - 1 - kk;
+                    const float t1 = px[min(1, rem)], t2 = px[min(2, rem)], t3 = px[min(3, rem)];
                     a.x = px[0];
-                    if (kk + 1 < k) a.y = px[1];
-                    if (kk + 2 < k) a.z = px[2];
-                    if (kk + 3 < k) a.w = px[3];
+                    a.y = rem >= 1 ? t1 : 0.f;
+                    a.z = rem >= 2 ? t2 : 0.f;
+                    a.w = rem >= 3 ? t3 : 0.f;
                 }
                 if (PROLOGUE == 1) { a.x = gelu_erf_(a.x); a.y = gelu_erf_(a.y); a.z = gelu_erf_(a.z); a.w = gelu_erf_(a.w); }
             }
@@ -158,14 +131,20 @@ __device__ __forceinline__ void load_a_panel(int kp0, int tid, const int* s_rid,
             const int r = f >> 6, cb = (f & 63) * 8;
             uint2 hi, mid;
             float scale = 1.0f;
-            if constexpr (F16) {
-                if (single) {      // the wavefront holds the whole row (64 lanes x 4 columns)
-                    float inv;
-                    f16_row_scale(wave_max_bits(abs_bits4(av[j])), scale, inv);
-                    if ((tid & 63) == 0) s_inv[r] = inv;
-                } else {
-                    scale = s_scale[r];
+            if constexpr (F16) {      // the wavefront holds the row's whole panel (64 lanes x 4 columns): running scale (see the kernel)
+                float inv;
+                f16_row_scale(wave_max_bits(abs_bits4(av[j])), scale, inv);
+                if (!first) {
+                    const float cur = s_scale[r];
+                    if (scale < cur) {      // (wave-uniform) this panel is larger than everything before it
+                        if ((tid & 63) == 0) { s_ratio[r] = scale / cur; s_flag[par] = 1; }
+                    } else {
+                        scale = cur;
+                        inv = s_inv[r];
+                        if ((tid & 63) == 0) s_ratio[r] = 1.0f;
+                    }
                 }
+                if ((tid & 63) == 0) { s_scale[r] = scale; s_inv[r] = inv; }
             }
             split4_t<F16>(av[j], scale, hi, mid);
             *reinterpret_cast<uint2*>(sA + r * A_STRIDE + cb) = hi;
@@ -182,7 +161,7 @@ __device__ __forceinline__ void load_a_panel(int kp0, int tid, const int* s_rid,
 __device__ __forceinline__ void store_pass(f32x16 (&acc)[2], int pass, int wave, int lane, int g, int n_out, int nrows, int row0,
                                            const int* s_rid, const float* __restrict__ bias, int64_t bgs, float* __restrict__ out0,
                                            float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos,
-                                           const float* s_inv, float winv) {      // s_inv == nullptr: no operand scales (bf16 split)
+                                           const float* s_inv, float winv, int act_tanh = 0) {      // s_inv == nullptr: no operand scales (bf16 split)
     const int col = pass * BNP + wave * 32 + ((lane & 31) >> 2) * 4;      // first of this lane's 4 columns after the transpose
     const bool col_ok = col < n_out;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -200,8 +179,9 @@ __device__ __forceinline__ void store_pass(f32x16 (&acc)[2], int pass, int wave,
             if (col_ok && rt < nrows) {
                 const int64_t orow = by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
                 const float sc = s_inv ? s_inv[rt] * winv : 1.0f;
-                *reinterpret_cast<float4*>(ob + orow * block_cols + cc) =
-                    make_float4(v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w);
+                float4 o4 = make_float4(v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w);
+                if (act_tanh) o4 = make_float4(tanhf(o4.x), tanhf(o4.y), tanhf(o4.z), tanhf(o4.w));
+                *reinterpret_cast<float4*>(ob + orow * block_cols + cc) = o4;
             }
         }
     }
@@ -305,14 +285,17 @@ __device__ __forceinline__ void store_pass_update(f32x16 (&acc)[2], int wave, in
 }
 
 template <int PROLOGUE, bool UPD, bool F16, int NSTG = 2>
-__global__ __launch_bounds__(512, (UPD || NSTG == 4) ? 2 : 4) void k_typed_linear_split(
+__global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rows, const int32_t* __restrict__ group_off,
     int n_groups, int k, int n_out, const unsigned short* __restrict__ wsplit, const float* __restrict__ bias, int64_t bgs,
     float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2, int block_cols, int by_pos, int vec_ok,
-    UpdateArgs upd, int pass_split) {
+    UpdateArgs upd, int pass_split_act) {
+    const int pass_split = pass_split_act & 0xffff, act_tanh = pass_split_act >> 16;      // (bit 16: tanh on the output, the GNN's adapter)
     __shared__ __attribute__((aligned(16))) unsigned char sA[2 * A_PLANE];        // [plane][64][528]
     __shared__ int s_rid[BM];
     __shared__ float s_scale[F16 ? BM : 1], s_inv[F16 ? BM : 1];                   // fp16 split: row scales and their inverses
+    __shared__ __attribute__((aligned(16))) float s_ratio[F16 ? BM : 1];          // ... the factor a panel lowered a row's scale by
+    __shared__ int s_flag[2];                                                      // ... "some row was lowered", by panel parity
 
     // pass_split = n_pass (small problems: fewer row tiles than CUs): a workgroup owns ONE 256-column pass of a row tile, so that
     // tiles x passes workgroups share the work (sampled sub-graphs of a few thousand nodes: 50-64 row tiles for 256 CUs);
@@ -346,7 +329,11 @@ __global__ __launch_bounds__(512, (UPD || NSTG == 4) ? 2 : 4) void k_typed_linea
     float winv = 1.0f;                               // inverse of the group's weight scale: the image's tail (hgt_split_weights_f16)
     if constexpr (F16) {
         winv = reinterpret_cast<const float*>(wsplit + (int64_t)n_groups * total * 2 * W_PLANE_ELEMS)[g];
-        if (n_panel > 1) row_scales_all_panels<PROLOGUE>(tid, s_rid, x, ldx, k, vec_ok, s_scale, s_inv);
+        // several K panels: ONE scale per row without a second pass over x (round 6; rounds 3-5 took the row maximum in a pre-pass:
+        // +8 us at K = 512, +21 us at K = 1169 on a 4 000-row batch) -- RUNNING scales: a panel is split with the scale its row has
+        // so far, lowered first when the panel's own maximum needs it; the accumulators of a row whose scale was lowered are multiplied
+        // by the (power-of-two, exact) ratio before the panel's products are added.  Absolute resolution = that of the row's maximum so
+        // far: the whole-row scale's accuracy when the largest panel comes first, better otherwise.
     }
 
     f32x16 acc[2];
@@ -376,7 +363,7 @@ __global__ __launch_bounds__(512, (UPD || NSTG == 4) ? 2 : 4) void k_typed_linea
         HGT_LOAD_STAGE(3, pass_lo * n_kc + 3)
     }
 
-    load_a_panel<PROLOGUE, F16>(0, tid, s_rid, x, ldx, k, vec_ok, sA, false, s_scale, s_inv, n_panel == 1);
+    load_a_panel<PROLOGUE, F16>(0, tid, s_rid, x, ldx, k, vec_ok, sA, false, s_scale, s_inv, s_ratio, s_flag, true);
 
 #define HGT_STEP(S, T, KCP)                                                                                        \
     {                                                                                                              \
@@ -398,7 +385,18 @@ __global__ __launch_bounds__(512, (UPD || NSTG == 4) ? 2 : 4) void k_typed_linea
 
     for (int pass = pass_lo; pass < pass_hi; ++pass) {
         for (int panel = 0; panel < n_panel; ++panel) {
-            if (n_panel > 1 && (pass != pass_lo || panel != 0)) load_a_panel<PROLOGUE, F16>(panel * KP, tid, s_rid, x, ldx, k, vec_ok, sA, true, s_scale, s_inv, false);
+            if (n_panel > 1 && (pass != pass_lo || panel != 0)) load_a_panel<PROLOGUE, F16>(panel * KP, tid, s_rid, x, ldx, k, vec_ok, sA, true, s_scale, s_inv, s_ratio, s_flag, panel == 0);
+            if constexpr (F16) {
+                if (panel > 0 && s_flag[panel & 1] != 0) {      // (workgroup-uniform) some row's scale was lowered by this panel
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {      // C/D layout: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+                            const float4 rv = *reinterpret_cast<const float4*>(&s_ratio[j * 32 + 8 * q + 4 * khalf]);
+                            acc[j][4 * q] *= rv.x; acc[j][4 * q + 1] *= rv.y; acc[j][4 * q + 2] *= rv.z; acc[j][4 * q + 3] *= rv.w;
+                        }
+                }
+            }
             const int nkc_p = min(KP / KC, n_kc - panel * (KP / KC));
             const int tbase = pass * n_kc + panel * (KP / KC);
             for (int kq = 0; kq < nkc_p; kq += 4) {
@@ -421,7 +419,7 @@ __global__ __launch_bounds__(512, (UPD || NSTG == 4) ? 2 : 4) void k_typed_linea
                               F16 ? s_inv : nullptr, winv);
         } else {
             store_pass(acc, pass, wave, lane, g, n_out, nrows, row0, s_rid, bias, bgs, out0, out1, out2, block_cols, by_pos,
-                       F16 ? s_inv : nullptr, winv);
+                       F16 ? s_inv : nullptr, winv, act_tanh);
         }
     }
 #undef HGT_STEP
@@ -551,6 +549,8 @@ __global__ __launch_bounds__(512, 1) void k_typed_linear_update_wide(
     __shared__ __attribute__((aligned(16))) unsigned char sA[2 * A_PLANE];        // [plane][64][528]
     __shared__ int s_rid[BM];
     __shared__ float s_scale[F16 ? BM : 1], s_inv[F16 ? BM : 1];
+    __shared__ __attribute__((aligned(16))) float s_ratio[F16 ? BM : 1];          // running row scales: see k_typed_linear_split
+    __shared__ int s_flag[2];
 
     const int slot = blockIdx.x;
     int g = 0, gbeg = 0, gend = 0, tiles_before = 0;
@@ -577,7 +577,6 @@ __global__ __launch_bounds__(512, 1) void k_typed_linear_update_wide(
     float winv = 1.0f;
     if constexpr (F16) {
         winv = reinterpret_cast<const float*>(wsplit + (int64_t)n_groups * total * 2 * W_PLANE_ELEMS)[g];
-        if (n_panel > 1) row_scales_all_panels<0>(tid, s_rid, x, ldx, k, vec_ok, s_scale, s_inv);
     }
 
     f32x16 acc[2][2];
@@ -624,7 +623,20 @@ __global__ __launch_bounds__(512, 1) void k_typed_linear_update_wide(
     HGT_WLOAD(0)
     HGT_WLOAD(1)
     for (int panel = 0; panel < n_panel; ++panel) {
-        load_a_panel<0, F16>(panel * KP, tid, s_rid, x, ldx, k, vec_ok, sA, panel > 0, s_scale, s_inv, n_panel == 1);
+        load_a_panel<0, F16>(panel * KP, tid, s_rid, x, ldx, k, vec_ok, sA, panel > 0, s_scale, s_inv, s_ratio, s_flag, panel == 0);
+        if constexpr (F16) {
+            if (panel > 0 && s_flag[panel & 1] != 0) {      // (workgroup-uniform) the second panel lowered some row's scale
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 rv = *reinterpret_cast<const float4*>(&s_ratio[j * 32 + 8 * q + 4 * khalf]);
+                            acc[p][j][4 * q] *= rv.x; acc[p][j][4 * q + 1] *= rv.y; acc[p][j][4 * q + 2] *= rv.z; acc[p][j][4 * q + 3] *= rv.w;
+                        }
+            }
+        }
         const int nkc_p = min(KP / KC, n_kc - panel * (KP / KC));
         for (int kq = 0; kq < nkc_p; kq += 4) {
             HGT_WSTEP(0, 0, kq)
@@ -1175,7 +1187,8 @@ static int typed_linear_split_impl(const float* x, int64_t ldx, const int32_t* r
     const int n_blocks_out = (n_out + block_cols - 1) / block_cols;
     if (n_blocks_out > 3 || (n_blocks_out > 1 && !out1) || (n_blocks_out > 2 && !out2)) return HGT_ERR_INVALID_ARG;
     const int32_t prologue_arg = prologue;      // (with the kernel-selection bits HGT_LINEAR_FORCE_XS / HGT_LINEAR_NO_XS)
-    if (prologue < 0 || (prologue & ~(0xff | HGT_LINEAR_FORCE_XS | HGT_LINEAR_NO_XS | HGT_LINEAR_NO_TILE)) != 0) return HGT_ERR_INVALID_ARG;
+    if (prologue < 0 || (prologue & ~(0xff | HGT_LINEAR_FORCE_XS | HGT_LINEAR_NO_XS | HGT_LINEAR_NO_TILE | HGT_LINEAR_TANH)) != 0) return HGT_ERR_INVALID_ARG;
+    const int act_tanh = (prologue & HGT_LINEAR_TANH) ? 1 : 0;      // tanh on the output: the tile kernel / the K > 256 slab kernel only
     prologue &= 0xff;
     if (prologue > 2) return HGT_ERR_INVALID_ARG;
     if (prologue == 2 && (k > KP || (k & 3) != 0 || ldx != 3 * (int64_t)(k / 4))) return HGT_ERR_UNSUPPORTED;   // 24-bit wire rows: the persistent kernel only
@@ -1192,10 +1205,11 @@ static int typed_linear_split_impl(const float* x, int64_t ldx, const int32_t* r
     if (!(prologue_arg & (HGT_LINEAR_NO_TILE | HGT_LINEAR_FORCE_XS)) && prologue <= 1) {
         // sampled batches (a few thousand rows): the tile kernel (hgt_gemm_tile.hip), laid out for a short dependent chain
         const int tl = hgt_typed_linear_tile_try(F16, x, ldx, rows, group_off, n_groups, n_rows, k, n_out, w_split, bias, b_group_stride, out0, out1,
-                                                 out2, block_cols, out_by_position, prologue, nullptr, stream_);
+                                                 out2, block_cols, out_by_position, prologue | (act_tanh ? HGT_LINEAR_TANH : 0), nullptr, stream_);
         if (tl != 0) return tl < 0 ? tl : HGT_OK;
     }
-    {   // millions of rows: the x-stationary kernel (hgt_gemm_xs.hip: W through LDS once per 256 rows; K = 64 / 128 / 256 / 512)
+    if (act_tanh && k <= KP) return HGT_ERR_UNSUPPORTED;      // (the persistent / x-stationary kernels have no activation epilogue: the caller runs hgt_tanh_inplace)
+    if (!act_tanh) {   // millions of rows: the x-stationary kernel (hgt_gemm_xs.hip: W through LDS once per 256 rows; K = 64 / 128 / 256 / 512)
         const int xs = hgt_typed_linear_xs_try(F16, x, ldx, rows, group_off, n_groups, n_rows, k, n_out, w_split, bias, b_group_stride, out0, out1,
                                                out2, block_cols, out_by_position, prologue_arg, stream_);
         if (xs != 0) return xs < 0 ? xs : HGT_OK;
@@ -1223,7 +1237,7 @@ static int typed_linear_split_impl(const float* x, int64_t ldx, const int32_t* r
 #define HGT_SPLIT_LAUNCH(P, NS)                                                                                                        \
     k_typed_linear_split<P, false, F16, NS><<<grid_s, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,                   \
                                                                         (const unsigned short*)w_split, bias, b_group_stride, out0, out1, \
-                                                                        out2, block_cols, out_by_position, vec_ok, noupd, pass_split)
+                                                                        out2, block_cols, out_by_position, vec_ok, noupd, pass_split | (act_tanh << 16))
     if (prologue == 0) { if (deep) HGT_SPLIT_LAUNCH(0, 4); else HGT_SPLIT_LAUNCH(0, 2); }
     else               { if (deep) HGT_SPLIT_LAUNCH(1, 4); else HGT_SPLIT_LAUNCH(1, 2); }
 #undef HGT_SPLIT_LAUNCH

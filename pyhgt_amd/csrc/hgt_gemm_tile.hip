@@ -10,17 +10,17 @@
 // laid out for many small workgroups and a short dependent chain:
 //   * a workgroup owns one (row tile, column tile) pair: 32 x 128 outputs for the plain linear (a 3 200 x 768 problem is 624
 //     workgroups of four wavefronts, up to four per CU), 32 whole rows for the update form (8 wavefronts x 32 or 64 columns);
-//   * K is walked in panels of 64 or 128: a wavefront's B fragments of the first two panels and the first two A panels are
-//     requested before anything is waited for, later panels one panel of MFMAs ahead;
-//   * the x rows go global -> registers -> (split hi / mid) -> LDS, double buffered: one workgroup barrier per panel;
+//   * the tile's x rows are requested WHOLE (all K panels, K <= 256 / 512) together with a wavefront's B fragments of the first two
+//     panels before anything is waited for; they go registers -> (split hi / mid) -> an LDS slab that holds every panel: ONE
+//     workgroup barrier, then a k loop of ds_read + MFMA with the later panels' fragments requested one panel of MFMAs ahead;
 //   * the update form (a_linear + gated skip + LayerNorm, conv.py:129-133) requests its skip rows while the MFMAs run.
 // What the time of such a kernel is made of (r6 eliminations at c3, 64 x 128 tiles, 13.9 us warm: no stores 10.8, no fragment loads
 // 11.4, no row loads 12.8, none of the three 8.6): dispatch + the id chain + one round of MFMAs + a store burst that a CU retires
 // at ~10 B / clk -- every phase short, none overlapped with another inside ONE round of workgroups.  Smaller tiles (more, lighter
 // workgroups per CU) were worth 2.7 us; the sampled-batch layer's update now runs inside the merge pass instead
 // (hgt_edge_agg_items.hip: k_merge_update), this file's update form serves the two-call path.
-// fp16 split (precision "f16x3"): the power-of-two row scales need the maximum of the WHOLE row before its first panel is split:
-// one extra pass over the tile's rows (L2 hits: the panels read them again right after).
+// fp16 split (precision "f16x3"): the power-of-two row scale needs the maximum of the WHOLE row before its first panel is split --
+// the row is in the registers of 16 or 32 lanes of one wavefront by then: four or five lane exchanges, no second pass over x.
 #include "hgt_common.h"
 #include "hgt_split_common.h"
 #include <algorithm>
@@ -43,15 +43,15 @@ typedef float f32x4t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void tile_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NW, int RT, int CT, int KPAN, bool UPD, bool F16, bool GELU>
+// NPM = K panels the LDS slab holds (K <= NPM * KPAN: the launcher's domain check)
+template <int NW, int RT, int CT, int KPAN, int NPM, bool UPD, bool F16>
 __global__ __launch_bounds__(64 * NW, (KPAN == 64 && RT == 1 && CT == 1) ? 4 : 2) void k_tile_linear(const TileArgs a) {
     constexpr int BMT = 32 * RT, KCP = KPAN / 16, LPR = KPAN / 4, RPI = 64 / LPR, NL = BMT / (RPI * NW);
     constexpr int ASTR = KPAN * 2 + 16, APLANE = BMT * ASTR;
     static_assert(NL >= 1 && NL * RPI * NW == BMT, "row tile / wavefront geometry");
-    __shared__ __attribute__((aligned(16))) unsigned char sA[2][2 * APLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char sA[NPM][2 * APLANE];      // the tile's rows, all K panels: [panel][plane][row][k]
     __shared__ int s_rid[BMT];
     __shared__ float s_rinv[F16 ? BMT : 1];
-    __shared__ float s_rscale[F16 ? BMT : 1];      // (written and read by the same wavefront: LDS operations of a wavefront stay in order)
     __shared__ __attribute__((aligned(16))) float s_red[UPD ? 2 * BMT * NW : 1];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64 * NW, (KPAN == 64 && RT == 1 && CT == 1) ? 4 : 2
     const int n_pass = (n_out + BNP - 1) / BNP;
     const int n_kc = ((k + KC - 1) / KC + 3) & ~3;
     const int total = n_pass * n_kc;
-    const int n_pan = (n_kc + KCP - 1) / KCP;
+    const int n_pan = (n_kc + KCP - 1) / KCP;       // <= NPM
 
     // ---- this wavefront's column blocks (32 columns each) and their fragment streams
     int cb[CT];
@@ -107,96 +107,89 @@ __global__ __launch_bounds__(64 * NW, (KPAN == 64 && RT == 1 && CT == 1) ? 4 : 2
     if (tid < BMT) s_rid[tid] = (tid < nrows) ? a.rows[row0 + tid] : -1;
 
     bf16x8 wh[2][CT][KCP], wm[2][CT][KCP];
-    float4 areg[NL];
-
-#define TILE_WLOAD(D, PTR) D = *reinterpret_cast<const bf16x8*>(PTR);
 #define TILE_LOAD_W(B, P)                                                                                  \
     _Pragma("unroll") for (int c = 0; c < CT; ++c) {                                                       \
         _Pragma("unroll") for (int kc = 0; kc < KCP; ++kc) {                                               \
             const int kidx = min((P) * KCP + kc, n_kc - 1);                                                \
             const unsigned short* t_ = wp[c] + (int64_t)kidx * 2 * W_PLANE_ELEMS;                          \
-            TILE_WLOAD(wh[B][c][kc], t_)                                                                   \
-            TILE_WLOAD(wm[B][c][kc], t_ + W_PLANE_ELEMS)                                                   \
+            wh[B][c][kc] = *reinterpret_cast<const bf16x8*>(t_);                                           \
+            wm[B][c][kc] = *reinterpret_cast<const bf16x8*>(t_ + W_PLANE_ELEMS);                           \
         }                                                                                                  \
     }
-    // a lane's 16 bytes of row myrid[j], k = P * KPAN + lk ..: always an in-bounds address (absent rows re-read the tile's first row,
-    // columns past k the row's last ones); what must read as zero is zeroed in tile_commit
-    auto load_a = [&](int P, float4 (&dst)[NL]) {
-        const int kk = P * KPAN + lk;
-        if (a.vec_ok) {
-            const int kc_ = min(kk, k - 4);
-#pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                const int rid = myrid[j] < 0 ? rid_safe : myrid[j];
-                dst[j] = *reinterpret_cast<const float4*>(a.x + (int64_t)rid * a.ldx + kc_);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                const int rid = myrid[j] < 0 ? rid_safe : myrid[j];
-                const float* px = a.x + (int64_t)rid * a.ldx;
-                dst[j] = make_float4(px[min(kk, k - 1)], px[min(kk + 1, k - 1)], px[min(kk + 2, k - 1)], px[min(kk + 3, k - 1)]);
-            }
-        }
-    };
-    auto masked = [&](int P, int j, float4 v) -> float4 {      // (selects, no branches: the loads behind it stay counted)
-        const int kk = P * KPAN + lk;
-        const bool row_ok = myrid[j] >= 0;
-        v.x = (row_ok && kk < k) ? v.x : 0.f;
-        v.y = (row_ok && kk + 1 < k) ? v.y : 0.f;
-        v.z = (row_ok && kk + 2 < k) ? v.z : 0.f;
-        v.w = (row_ok && kk + 3 < k) ? v.w : 0.f;
-        return v;
-    };
-    auto gelu_all = [&](float4 (&t)[NL]) {      // prologue 1 (conv.py:119 / DenseHGTConv's out_linear): one uniform branch per panel
-#pragma unroll
-        for (int j = 0; j < NL; ++j) { t[j].x = gelu_erf_(t[j].x); t[j].y = gelu_erf_(t[j].y); t[j].z = gelu_erf_(t[j].z); t[j].w = gelu_erf_(t[j].w); }
-    };
-    auto commit_a = [&](int P, float4 (&src)[NL], unsigned char* buf) {
-#pragma unroll
-        for (int j = 0; j < NL; ++j) src[j] = masked(P, j, src[j]);
-        if constexpr (GELU) gelu_all(src);
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const int r = (j * NW + wave) * RPI + lrow;
-            uint2 hi, mid;
-            split4_t<F16>(src[j], F16 ? s_rscale[F16 ? r : 0] : 1.0f, hi, mid);
-            unsigned char* p_ = buf + r * ASTR + lk * 2;
-            *reinterpret_cast<uint2*>(p_) = hi;
-            *reinterpret_cast<uint2*>(p_ + APLANE) = mid;
-        }
-    };
-
-    // ---- everything that does not depend on anything else is requested first
+    // ---- everything is requested before anything is waited for: the fragments of the first two panels, then ALL panels of the
+    //      tile's rows (a lane: NL rows x NPM panels x 16 bytes; always an in-bounds address -- absent rows re-read the tile's
+    //      first row, columns past k the row's last ones -- and zeroed below where they must read as zero)
     TILE_LOAD_W(0, 0)
-    if constexpr (F16) {
-        // row maxima over the whole row (all panels), then the panels are read again (L2 hits)
-        unsigned mb[NL];
+    float4 areg[NPM][NL];
 #pragma unroll
-        for (int j = 0; j < NL; ++j) mb[j] = 0u;
-        for (int P = 0; P < n_pan; ++P) {
-            float4 t[NL];
-            load_a(P, t);
+    for (int P = 0; P < NPM; ++P) {
+        if (P < n_pan) {
+            const int kk = P * KPAN + lk;
+            if (a.vec_ok) {
+                const int kc_ = min(kk, k - 4);
 #pragma unroll
-            for (int j = 0; j < NL; ++j) t[j] = masked(P, j, t[j]);
-            if constexpr (GELU) gelu_all(t);
+                for (int j = 0; j < NL; ++j) {
+                    const int rid = myrid[j] < 0 ? rid_safe : myrid[j];
+                    areg[P][j] = *reinterpret_cast<const float4*>(a.x + (int64_t)rid * a.ldx + kc_);
+                }
+            } else {
 #pragma unroll
-            for (int j = 0; j < NL; ++j) mb[j] = max(mb[j], abs_bits4(t[j]));
-        }
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-#pragma unroll
-            for (int o = 1; o < LPR; o <<= 1) mb[j] = max(mb[j], (unsigned)__shfl_xor((int)mb[j], o));
-            float sc, inv;
-            f16_row_scale(mb[j], sc, inv);
-            const int r = (j * NW + wave) * RPI + lrow;
-            if ((lane % LPR) == 0) { s_rinv[r] = inv; s_rscale[r] = sc; }
+                for (int j = 0; j < NL; ++j) {
+                    const int rid = myrid[j] < 0 ? rid_safe : myrid[j];
+                    const float* px = a.x + (int64_t)rid * a.ldx;
+                    areg[P][j] = make_float4(px[min(kk, k - 1)], px[min(kk + 1, k - 1)], px[min(kk + 2, k - 1)], px[min(kk + 3, k - 1)]);
+                }
+            }
         }
     }
-    load_a(0, areg);
     if (n_pan > 1) TILE_LOAD_W(1, 1)
-    commit_a(0, areg, sA[0]);
-    if (n_pan > 1) load_a(1, areg);
+    // ---- zero what lies outside the matrix, fp16 split: the rows' power-of-two scales (the whole row is in this wavefront's registers)
+    unsigned mb[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) mb[j] = 0u;
+#pragma unroll
+    for (int P = 0; P < NPM; ++P) {
+        if (P < n_pan) {
+            const int kk = P * KPAN + lk;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const bool row_ok = myrid[j] >= 0;
+                float4 v = areg[P][j];
+                v.x = (row_ok && kk < k) ? v.x : 0.f;
+                v.y = (row_ok && kk + 1 < k) ? v.y : 0.f;
+                v.z = (row_ok && kk + 2 < k) ? v.z : 0.f;
+                v.w = (row_ok && kk + 3 < k) ? v.w : 0.f;
+                areg[P][j] = v;
+                if constexpr (F16) mb[j] = max(mb[j], abs_bits4(v));
+            }
+        }
+    }
+    float rscale[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        rscale[j] = 1.0f;
+        if constexpr (F16) {
+#pragma unroll
+            for (int o = 1; o < LPR; o <<= 1) mb[j] = max(mb[j], (unsigned)__shfl_xor((int)mb[j], o));
+            float inv;
+            f16_row_scale(mb[j], rscale[j], inv);
+            if ((lane % LPR) == 0) s_rinv[(j * NW + wave) * RPI + lrow] = inv;
+        }
+    }
+#pragma unroll
+    for (int P = 0; P < NPM; ++P) {
+        if (P < n_pan) {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const int r = (j * NW + wave) * RPI + lrow;
+                uint2 hi, mid;
+                split4_t<F16>(areg[P][j], rscale[j], hi, mid);
+                unsigned char* p_ = sA[P] + r * ASTR + lk * 2;
+                *reinterpret_cast<uint2*>(p_) = hi;
+                *reinterpret_cast<uint2*>(p_ + APLANE) = mid;
+            }
+        }
+    }
 
     f32x16 acc[RT][CT];
 #pragma unroll
@@ -216,7 +209,7 @@ __global__ __launch_bounds__(64 * NW, (KPAN == 64 && RT == 1 && CT == 1) ? 4 : 2
     }
 #define TILE_COMPUTE(B, P)                                                                                              \
     {                                                                                                                   \
-        const unsigned char* sl_ = sA[B] + frow * ASTR + khalf * 16;                                                    \
+        const unsigned char* sl_ = sA[P] + frow * ASTR + khalf * 16;                                                    \
         bf16x8 fah[2][RT], fam[2][RT];                                                                                  \
         TILE_LOAD_AF(0, 0)                                                                                              \
         _Pragma("unroll") for (int kc = 0; kc < KCP; ++kc) {                                                            \
@@ -229,8 +222,8 @@ __global__ __launch_bounds__(64 * NW, (KPAN == 64 && RT == 1 && CT == 1) ? 4 : 2
         }                                                                                                               \
     }
 
-    tile_barrier();
-    // ---- the skip rows / LayerNorm vectors of the update form: requested here, used after the last panel
+    tile_barrier();        // the ONE barrier of the k loop: the slab is complete
+    // ---- the skip rows of the update form: requested here, used after the last panel
     const int col_l = ((lane & 31) >> 2) * 4;           // this lane's 4 consecutive columns inside a column block (after the quad transpose)
     const int rt0 = (lane & 3) + 4 * (lane >> 5);       // ... and its rows: rt0 + 8 q (+ 32 per row tile)
     // (two column blocks per wavefront: 32 more registers than the file has next to both fragment buffers -- requested after the
@@ -249,26 +242,15 @@ __global__ __launch_bounds__(64 * NW, (KPAN == 64 && RT == 1 && CT == 1) ? 4 : 2
 
     for (int P = 0; P < n_pan; P += 2) {
         TILE_COMPUTE(0, P)
-        if (P + 1 < n_pan) commit_a(P + 1, areg, sA[1]);
-        if (P + 2 < n_pan) {
-            TILE_LOAD_W(0, P + 2)
-            load_a(P + 2, areg);
-        }
+        if (P + 2 < n_pan) TILE_LOAD_W(0, P + 2)
         if (P + 1 < n_pan) {
-            tile_barrier();
             TILE_COMPUTE(1, P + 1)
-            if (P + 2 < n_pan) commit_a(P + 2, areg, sA[0]);
-            if (P + 3 < n_pan) {
-                TILE_LOAD_W(1, P + 3)
-                load_a(P + 3, areg);
-            }
-            if (P + 2 < n_pan) tile_barrier();
+            if (P + 3 < n_pan) TILE_LOAD_W(1, P + 3)
         }
     }
 #undef TILE_COMPUTE
 #undef TILE_LOAD_AF
 #undef TILE_LOAD_W
-#undef TILE_WLOAD
     if constexpr (UPD && CT > 1) { TILE_LOAD_SKIP() }
 #undef TILE_LOAD_SKIP
 
@@ -293,7 +275,9 @@ __global__ __launch_bounds__(64 * NW, (KPAN == 64 && RT == 1 && CT == 1) ? 4 : 2
                     if (rt < nrows) {
                         const float sc = F16 ? s_rinv[F16 ? rt : 0] * winv : 1.0f;
                         const int64_t orow = a.by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
-                        *reinterpret_cast<float4*>(ob + orow * a.block_cols + cc) = make_float4(v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w);
+                        float4 o4 = make_float4(v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w);
+                        if (a.prologue) o4 = make_float4(tanhf(o4.x), tanhf(o4.y), tanhf(o4.z), tanhf(o4.w));
+                        *reinterpret_cast<float4*>(ob + orow * a.block_cols + cc) = o4;
                     }
                 }
         }
@@ -393,13 +377,13 @@ __global__ __launch_bounds__(64 * NW, (KPAN == 64 && RT == 1 && CT == 1) ? 4 : 2
     }
 }
 
-template <int NW, int RT, int CT, int KPAN, bool UPD>
+template <int NW, int RT, int CT, int KPAN, int NPM, bool UPD>
 static void launch_tile(bool f16, const TileArgs& a, int64_t n_rows, hipStream_t stream) {
     constexpr int BMT = 32 * RT, BNT = 32 * CT * NW;
     const int64_t row_tiles = (n_rows + BMT - 1) / BMT + a.n_groups;      // device-side group sizes: the upper bound
     dim3 grid((unsigned)row_tiles, (unsigned)((a.n_out + BNT - 1) / BNT));
-    if (f16) k_tile_linear<NW, RT, CT, KPAN, UPD, true, false><<<grid, 64 * NW, 0, stream>>>(a);
-    else k_tile_linear<NW, RT, CT, KPAN, UPD, false, false><<<grid, 64 * NW, 0, stream>>>(a);
+    if (f16) k_tile_linear<NW, RT, CT, KPAN, NPM, UPD, true><<<grid, 64 * NW, 0, stream>>>(a);
+    else k_tile_linear<NW, RT, CT, KPAN, NPM, UPD, false><<<grid, 64 * NW, 0, stream>>>(a);
 }
 
 }  // namespace
@@ -412,27 +396,29 @@ int hgt_typed_linear_tile_try(bool f16, const float* x, int64_t ldx, const int32
                               void* stream_) {
     // (prologue 1 = gelu on load -- DenseHGTConv's out_linear, the unfused wide update -- stays on the slab kernels: the inlined erf next
     //  to both fragment buffers spills (4.7 KB of scratch per lane in the fp16 form))
-    if (n_rows > HGT_TILE_MAX_ROWS || prologue != 0 || n_groups > 64) return 0;
+    const int act_tanh = (prologue & HGT_LINEAR_TANH) ? 1 : 0;      // tanh on the output (the GNN's typed adapter, model.py:70-76)
+    prologue &= ~HGT_LINEAR_TANH;
+    if (n_rows > HGT_TILE_MAX_ROWS || prologue != 0 || n_groups > 64 || (upd && act_tanh)) return 0;
     if (((n_out | block_cols) & 3) != 0) return 0;
-    if (upd && (n_out > 512 || (upd->ld_skip & 3) != 0 || ((uintptr_t)upd->x_skip & 15) != 0)) return 0;
+    if (upd && (n_out > 512 || k > (n_out <= 256 ? 256 : 512) || (upd->ld_skip & 3) != 0 || ((uintptr_t)upd->x_skip & 15) != 0)) return 0;
     TileArgs a;
     a.x = x; a.ldx = ldx; a.rows = rows; a.group_off = group_off; a.n_groups = n_groups; a.k = k; a.n_out = n_out;
     a.wsplit = (const unsigned short*)w_split; a.bias = bias; a.bgs = bgs; a.out0 = out0; a.out1 = out1; a.out2 = out2;
-    a.block_cols = block_cols; a.by_pos = by_pos; a.prologue = prologue;
-    a.vec_ok = (ldx % 4 == 0) && (k % 4 == 0) && (((uintptr_t)x & 15) == 0) ? 1 : 0;
+    a.block_cols = block_cols; a.by_pos = by_pos; a.prologue = act_tanh;      // (the field carries the output activation: gelu-on-load is not this kernel's)
+    a.vec_ok = (ldx % 4 == 0) && (k % 4 == 0) && k >= 4 && (((uintptr_t)x & 15) == 0) ? 1 : 0;
     a.xs = nullptr; a.ldxs = 0; a.skip = nullptr; a.lnw = nullptr; a.lnb = nullptr; a.use_norm = 0;
     hipStream_t stream = (hipStream_t)stream_;
     if (upd) {
         a.xs = upd->x_skip; a.ldxs = upd->ld_skip; a.skip = upd->skip; a.lnw = upd->ln_w; a.lnb = upd->ln_b; a.use_norm = upd->use_norm;
-        if (n_out <= 256) launch_tile<8, 1, 1, 128, true>(f16, a, n_rows, stream);      // (c3: 11.9 us against 19.2 on the persistent kernel)
-        else launch_tile<8, 1, 2, 64, true>(f16, a, n_rows, stream);
+        if (n_out <= 256) launch_tile<8, 1, 1, 128, 2, true>(f16, a, n_rows, stream);      // (c3: 11.9 us against 19.2 on the persistent kernel)
+        else launch_tile<8, 1, 2, 64, 8, true>(f16, a, n_rows, stream);
     } else {
         // plain linear: 32 x 128 tiles of four wavefronts, four workgroups per CU (K panels of 64: 120 registers) -- measured at c3
         // (3 200 x 256 -> 768): 11.3 us against 14.0 (64 x 128 tiles) and 13.9 (persistent kernel).  Beyond K = 256 or ~1 000 workgroups
         // the slab kernels are as fast or faster (K = 512: 36 vs 31 us at 3 200 rows): not this kernel's domain
         const int64_t wgs = ((n_rows + 31) / 32 + n_groups) * ((n_out + 127) / 128);
         if (k > 256 || wgs > 1024) return 0;
-        launch_tile<4, 1, 1, 64, false>(f16, a, n_rows, stream);
+        launch_tile<4, 1, 1, 64, 4, false>(f16, a, n_rows, stream);
     }
     if (hipGetLastError() != hipSuccess) return HGT_ERR_LAUNCH;
     return 1;

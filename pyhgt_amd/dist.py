@@ -468,9 +468,12 @@ class PartitionedGraph:
             if mode == "blocked" and halo.n_halo > 0:
                 # ... and with THESE blocks: block b's in-edges may only reference own rows and halo chunks 0..b (the K|V of a later
                 # chunk are not projected yet when the block runs -- the kernels would read stale workspace rows without any error)
-                off = torch.tensor(list(halo.recv_chunk_off[1:]), dtype=torch.int64, device=dst_local.device)
+                # (one pass over the edges and ONE host synchronisation per PartitionedGraph built on a prebuilt plan; everything on the
+                #  plan's device -- a plan built on another device than dst_local is compared there, not a device-mismatch RuntimeError)
+                hdev = halo.src_local.device
+                off = torch.tensor(list(halo.recv_chunk_off[1:]), dtype=torch.int64, device=hdev)
                 src_chunk = torch.searchsorted(off, (halo.src_local.to(torch.int64) - halo.n_own).clamp(min=0), right=True)
-                late = (halo.src_local >= halo.n_own) & (src_chunk > edge_block)
+                late = (halo.src_local >= halo.n_own) & (src_chunk > edge_block.to(hdev))
                 if bool(late.any()):
                     raise ValueError("the prebuilt HaloPlan was built for other target blocks (edge_block / block_shape / alignment): "
                                      "%d edges reference a halo chunk later than their own block" % int(late.sum()))

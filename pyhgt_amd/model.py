@@ -128,11 +128,20 @@ class GNN(nn.Module):
         st = _stream()
         # typed adapter (in_dim is arbitrary, e.g. 129 or 1169): the precision of the layers -- split-bf16 x3 MFMA (its row loader
         # takes any K) or the exact fp32 MFMA kernel
+        need_tanh = True
         if conv0.precision in ("bf16x3", "f16x3") and n_hid % 4 == 0:
             f16 = conv0.precision == "f16x3"
             tiles = self._adapter_tiles(w, in_dim, n_hid, st, f16)
-            _lib.check((lib.hgt_typed_linear_f16x3 if f16 else lib.hgt_typed_linear_bf16x3)(_ptr(x), in_dim, rows.rows_all, rows.off_all, T, N, in_dim, n_hid, _ptr(tiles),
-                                                   _ptr(b), n_hid, _ptr(h), 0, 0, n_hid, 0, 0, st), "hgt_typed_linear_bf16x3(adapter)")
+            fn = lib.hgt_typed_linear_f16x3 if f16 else lib.hgt_typed_linear_bf16x3
+            # adapter + tanh in one kernel where the kernel that takes the shape has the activation epilogue (sampled batches;
+            # HGT_ERR_UNSUPPORTED = nothing was launched)
+            rc = fn(_ptr(x), in_dim, rows.rows_all, rows.off_all, T, N, in_dim, n_hid, _ptr(tiles), _ptr(b), n_hid, _ptr(h), 0, 0, n_hid, 0,
+                    _lib.HGT_LINEAR_TANH, st)
+            if rc == 0:
+                need_tanh = False
+            else:
+                _lib.check(fn(_ptr(x), in_dim, rows.rows_all, rows.off_all, T, N, in_dim, n_hid, _ptr(tiles), _ptr(b), n_hid, _ptr(h), 0, 0, n_hid,
+                              0, 0, st), "hgt_typed_linear_bf16x3(adapter)")
         else:
             _lib.check(lib.hgt_typed_linear(_ptr(x), in_dim, rows.rows_all, rows.off_all, T, N, in_dim, n_hid, _ptr(w), n_hid * in_dim,
                                             _ptr(b), n_hid, _ptr(h), 0, 0, n_hid, 0, 0, 0, st), "hgt_typed_linear(adapter)")
@@ -140,7 +149,8 @@ class GNN(nn.Module):
         # rows_all[off_all[T] .. off_all[T+1]) are exactly those nodes
         if not (plan.NQ == plan.N and plan.no_unknown_rows):      # (skipped once the plan header says every row has a valid type)
             _lib.check(lib.hgt_zero_rows(rows.rows_all, rows.off_all + 4 * T, n_hid, _ptr(h), st), "hgt_zero_rows")
-        _lib.check(lib.hgt_tanh_inplace(_ptr(h), N * n_hid, st), "hgt_tanh_inplace")
+        if need_tanh:
+            _lib.check(lib.hgt_tanh_inplace(_ptr(h), N * n_hid, st), "hgt_tanh_inplace")
         for gc in self.gcs:
             h = gc.base_conv(h, node_type, edge_index, edge_type, edge_time, plan=plan)
         return h

@@ -59,7 +59,7 @@ def test_install_into_makes_the_reference_gnn_build_our_layers():
         for (k, a), (k2, b) in zip(gnn.state_dict().items(), back.state_dict().items()):
             assert k == k2 and torch.equal(a, b)
         for gc in back.gcs:
-            assert gc.base_conv._packed is None and gc.base_conv.precision == "bf16x3"
+            assert gc.base_conv._packed is None and gc.base_conv.precision == C.DEFAULT_PRECISION == "f16x3"
 
 
 @needs_ref
@@ -79,7 +79,7 @@ def test_modules_pickled_by_the_reference_class_load_into_ours():
         assert type(layer) is C.HGTConv
         for k in RUNTIME_KEYS:
             assert k in layer.__dict__, k
-        assert layer.precision == "bf16x3" and layer.keep_att is False and layer.d_k == 16
+        assert layer.precision == C.DEFAULT_PRECISION and layer.keep_att is False and layer.d_k == 16
         layer._pack_parameters()                                        # every attribute forward() reads exists
         assert layer._packed["w_qkv"].shape == (2, 3 * layer._packed["lay"].d_pad, 32)
     for (k, a), (k2, b) in zip(theirs.state_dict().items(), ours.state_dict().items()):
@@ -95,7 +95,7 @@ def test_setstate_fills_runtime_defaults_without_the_reference():
     clone.__setstate__(state)
     for k in RUNTIME_KEYS:
         assert k in clone.__dict__
-    assert clone.d_k == 8 and clone.precision == "bf16x3"
+    assert clone.d_k == 8 and clone.precision == C.DEFAULT_PRECISION
     assert repr(clone) == repr(layer)
     dense = C.DenseHGTConv(32, 32, 2, 3, 4)
     state = {k: v for k, v in dense.__dict__.items() if k not in RUNTIME_KEYS}

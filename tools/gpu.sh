@@ -87,9 +87,10 @@ final)
     timeout 300 python examples/train_synthetic.py --steps 6 2>&1 | tail -3
     python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/pytest_$TAG.log
     grep -E "^FAILED|^ERROR| passed| failed" gpurun_out/pytest_$TAG.log | tail -10
-    # the x-stationary GEMM (1024) and the LDS-ring aggregation (512) forced onto every layer of the backward / staged / oracle tests
-    # (the GEMM's size threshold keeps it off small graphs otherwise; the ring form is opt-in)
-    HGT_TEST_KERNEL_FLAGS=$((1024 + 512 + 64)) timeout 900 python -m pytest tests -m gpu -q -k "backward or staged or two_rank or matches_oracle or fused or golden" 2>&1 | tail -3
+    # the x-stationary GEMM (1024) and the fused sub-tile aggregation (64) forced onto every layer of the backward / staged / oracle tests
+    # (their size thresholds keep them off small graphs otherwise).  The LDS-ring aggregation / single-pass runs (512 / 256) exist in LAB
+    # builds only (make LAB=1: tools/lab/build_lab.sh compiles them; the shipped library ignores the bits)
+    HGT_TEST_KERNEL_FLAGS=$((1024 + 64)) timeout 900 python -m pytest tests -m gpu -q -k "backward or staged or two_rank or matches_oracle or fused or golden" 2>&1 | tail -3
     timeout 300 python tools/bench_xs.py > gpurun_out/${TAG}_xs_check.log 2>&1; grep -v "BIT-IDENTICAL (" gpurun_out/${TAG}_xs_check.log | tail -12
     tools/profile_pmc.sh $TAG > gpurun_out/prof_$TAG.log 2>&1
     cp gpurun_out/prof_$TAG/${TAG}_pmc_summary.json profiles/${TAG}_pmc_summary.json      # the line below is judged against THIS build's counters
@@ -135,7 +136,7 @@ xsthr)
     timeout 300 python tools/bench_xs.py --threshold 2>&1 | grep -v amdgpu.ids | tee gpurun_out/xs_threshold.txt
     ;;
 latency)
-    export TMPDIR=/tmp; ROOT=$(pwd); PREC=${3:-bf16x3}; cd /tmp
+    export TMPDIR=/tmp; ROOT=$(pwd); PREC=${3:-f16x3}; cd /tmp
     for wl in c3:1 c3w520:1 c5:2 mag4:4 c1:1; do
         w=${wl%%:*}; nl=${wl##*:}
         rm -rf /tmp/pl_$w
