@@ -95,11 +95,8 @@ __device__ __forceinline__ void load_a_panel(int kp0, int tid, const int* s_rid,
                                              int vec_ok, unsigned char* sA, bool wait_readers, float* s_scale, float* s_inv,
                                              float* s_ratio, int* s_flag, bool first) {      // first: the row's first panel (F16: its scale starts here)
     if (wait_readers) __syncthreads();   // every wave is done reading the previous panel
-    const int par = (kp0 / KP) & 1;
-    if constexpr (F16) {
-        if (tid == 0) s_flag[par] = 0;      // (the flag of the panel before last: its readers passed a barrier since)
-        if (!first) __syncthreads();
-    }
+    const int par = (kp0 / KP) & 1, epoch = kp0 / KP + 1;      // s_flag[par] == epoch: this panel lowered some row's scale (nothing to clear:
+                                                              // a stale match -- the same panel of an earlier pass -- rescales by ratios of 1)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         float4 av[4];
@@ -137,7 +134,7 @@ __device__ __forceinline__ void load_a_panel(int kp0, int tid, const int* s_rid,
                 if (!first) {
                     const float cur = s_scale[r];
                     if (scale < cur) {      // (wave-uniform) this panel is larger than everything before it
-                        if ((tid & 63) == 0) { s_ratio[r] = scale / cur; s_flag[par] = 1; }
+                        if ((tid & 63) == 0) { s_ratio[r] = scale / cur; s_flag[par] = epoch; }
                     } else {
                         scale = cur;
                         inv = s_inv[r];
@@ -300,19 +297,44 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     // pass_split = n_pass (small problems: fewer row tiles than CUs): a workgroup owns ONE 256-column pass of a row tile, so that
     // tiles x passes workgroups share the work (sampled sub-graphs of a few thousand nodes: 50-64 row tiles for 256 CUs);
     // pass_split = 1: a workgroup owns a row tile and walks all passes
-    const int slot = blockIdx.x / pass_split;
-    const int pass_only = (pass_split > 1) ? (int)(blockIdx.x % pass_split) : -1;
-    int g = 0, gbeg = 0, gend = 0, tiles_before = 0;
-    for (; g < n_groups; ++g) {
-        gbeg = group_off[g];
-        gend = group_off[g + 1];
-        int nt = (gend - gbeg + BM - 1) / BM;
-        if (slot < tiles_before + nt) break;
-        tiles_before += nt;
+    int g = 0, row0 = 0, nrows = 0, pass_only = -1;
+    if (pass_split > 1) {
+        // latency regime, XCD-aware work order (round 6): workgroup b runs on XCD b % 8 and every XCD has its own 4 MB L2 -- with the
+        // plain (row tile, pass) order every XCD walked all (type, pass) slabs of the fragment image (12.6 MB at n_hid = 512) and 74 %
+        // of its L2 requests missed.  The work list is ordered (type, pass, row tile) and cut into eight contiguous chunks, one per XCD.
+        int t_all = 0;
+        for (int gg = 0; gg < n_groups; ++gg) t_all += (group_off[gg + 1] - group_off[gg] + BM - 1) / BM;
+        const int total_work = t_all * pass_split, chunk = (total_work + 7) / 8;
+        const int b = (int)blockIdx.x, j = b >> 3, v = (b & 7) * chunk + j;
+        if (j >= chunk || v >= total_work) return;
+        int before = 0;
+        for (; g < n_groups; ++g) {
+            const int gb = group_off[g], ge = group_off[g + 1];
+            const int nt = (ge - gb + BM - 1) / BM;
+            if (v < (before + nt) * pass_split) {
+                const int local = v - before * pass_split;
+                pass_only = local / nt;
+                row0 = gb + (local - pass_only * nt) * BM;
+                nrows = min(BM, ge - row0);
+                break;
+            }
+            before += nt;
+        }
+        if (g >= n_groups) return;
+    } else {
+        const int slot = blockIdx.x;
+        int gbeg = 0, gend = 0, tiles_before = 0;
+        for (; g < n_groups; ++g) {
+            gbeg = group_off[g];
+            gend = group_off[g + 1];
+            int nt = (gend - gbeg + BM - 1) / BM;
+            if (slot < tiles_before + nt) break;
+            tiles_before += nt;
+        }
+        if (g >= n_groups) return;
+        row0 = gbeg + (slot - tiles_before) * BM;
+        nrows = min(BM, gend - row0);
     }
-    if (g >= n_groups) return;
-    const int row0 = gbeg + (slot - tiles_before) * BM;
-    const int nrows = min(BM, gend - row0);
 
     const int tid = threadIdx.x;
     if (tid < BM) s_rid[tid] = (tid < nrows) ? rows[row0 + tid] : -1;
@@ -387,7 +409,7 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
         for (int panel = 0; panel < n_panel; ++panel) {
             if (n_panel > 1 && (pass != pass_lo || panel != 0)) load_a_panel<PROLOGUE, F16>(panel * KP, tid, s_rid, x, ldx, k, vec_ok, sA, true, s_scale, s_inv, s_ratio, s_flag, panel == 0);
             if constexpr (F16) {
-                if (panel > 0 && s_flag[panel & 1] != 0) {      // (workgroup-uniform) some row's scale was lowered by this panel
+                if (panel > 0 && s_flag[panel & 1] == panel + 1) {      // (workgroup-uniform) some row's scale was lowered by this panel
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -625,7 +647,7 @@ __global__ __launch_bounds__(512, 1) void k_typed_linear_update_wide(
     for (int panel = 0; panel < n_panel; ++panel) {
         load_a_panel<0, F16>(panel * KP, tid, s_rid, x, ldx, k, vec_ok, sA, panel > 0, s_scale, s_inv, s_ratio, s_flag, panel == 0);
         if constexpr (F16) {
-            if (panel > 0 && s_flag[panel & 1] != 0) {      // (workgroup-uniform) the second panel lowered some row's scale
+            if (panel > 0 && s_flag[panel & 1] == panel + 1) {      // (workgroup-uniform) the second panel lowered some row's scale
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -1232,7 +1254,7 @@ static int typed_linear_split_impl(const float* x, int64_t ldx, const int32_t* r
         HGT_CHECK_LAUNCH();
         return HGT_OK;
     }
-    const unsigned grid_s = (unsigned)(row_tiles * pass_split);
+    const unsigned grid_s = (unsigned)((row_tiles * pass_split + 7) / 8 * 8);      // (a multiple of 8: the XCD-aware work order of the kernel)
     const bool deep = row_tiles * pass_split <= 2 * pc_grid();      // latency regime: four B-fragment stages (see the kernel)
 #define HGT_SPLIT_LAUNCH(P, NS)                                                                                                        \
     k_typed_linear_split<P, false, F16, NS><<<grid_s, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,                   \

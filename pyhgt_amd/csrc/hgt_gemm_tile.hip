@@ -377,6 +377,254 @@ __global__ __launch_bounds__(64 * NW, (KPAN == 64 && RT == 1 && CT == 1) ? 4 : 2
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// K > 256 (n_hid 400 / 512, the 1169-column OAG adapter) on a few thousand rows: tiles of (32 RT) x 256 outputs, eight wavefronts,
+// the x rows STREAMED through a double-buffered LDS panel of 64 columns (the whole-row slab above would be 130 - 330 KB).
+// Why its own shape (r6): at 3 200 - 4 096 rows x 1 536 columns the 64 x 256 tiles of the slab kernel are 324 - 414 workgroups on 256
+// CUs -- some CUs get two, i.e. the kernel takes two tiles' time -- and every workgroup pulls 640 KB through its CU's L1 four
+// k-chunks at a time: 30 us against ~6 us of matrix-core work.  Here RT is chosen by the launcher so that the tiles fit the chip in ONE
+// round where they can (3 200 rows: RT = 3 -> 216 tiles), a wavefront's B fragments of a whole panel (4 k-chunks) are requested
+// together one panel of MFMAs (4 x RT x 3) ahead, and the next panel's rows are in flight during the current panel's MFMAs: one
+// barrier per panel.  Same split, k order and product order as the slab kernels: bit-identical in the bf16 split.
+// fp16 split: RUNNING row scales like k_typed_linear_split (a panel is split with the scale its row has so far, lowered first when
+// the panel's own maximum needs it; accumulators of lowered rows are multiplied by the exact power-of-two ratio) -- no pass over x
+// for the row maxima.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int RT, bool F16>
+__global__ __launch_bounds__(512, 2) void k_tile_linear_stream(const TileArgs a) {
+    constexpr int NW = 8, KPAN = 64, BMT = 32 * RT, KCP = 4, LPR = 16, RPI = 4, NL = RT;      // a lane: RT rows x 16 bytes per panel
+    constexpr int ASTR = KPAN * 2 + 16, APLANE = BMT * ASTR;
+    __shared__ __attribute__((aligned(16))) unsigned char sA[2][2 * APLANE];
+    __shared__ int s_rid[BMT];
+    __shared__ float s_rscale[F16 ? BMT : 1], s_rinv[F16 ? BMT : 1];       // (a row's scale is read and written by ONE wavefront)
+    __shared__ __attribute__((aligned(16))) float s_ratio[2][F16 ? BMT : 1];      // by panel parity
+    __shared__ int s_flag[2];                                                      // = P + 1 when panel P lowered a row's scale (no clearing)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- XCD-aware work order.  Workgroup b runs on XCD b % 8 and every XCD has its own 4 MB L2: with the plain (row tile, pass) order
+    // every XCD walks ALL (type, pass) slabs of the fragment image -- 12.6 MB at n_hid = 512 -- and 74 % of its L2 requests miss
+    // (r6 counters: TCC_MISS 1.15 M of 1.55 M requests, 147 MB per launch through the fabric: that, not the matrix cores, was the
+    // 30 us).  Here the work list is ordered (type, pass, row tile) and cut into eight contiguous chunks, one per XCD: an XCD touches
+    // ~3 slabs of 512 KB and the rows of about one type.
+    int g = 0, row0 = 0, nrows = 0, pass = 0;
+    {
+        const int n_passes = (a.n_out + BNP - 1) / BNP;
+        int t_all = 0;
+        for (int gg = 0; gg < a.n_groups; ++gg) t_all += (a.group_off[gg + 1] - a.group_off[gg] + BMT - 1) / BMT;
+        const int total_work = t_all * n_passes, chunk = (total_work + 7) / 8;
+        const int b = (int)blockIdx.x, xcd = b & 7, j = b >> 3;
+        const int v = xcd * chunk + j;
+        if (j >= chunk || v >= total_work) return;
+        int before = 0;
+        bool found = false;
+        for (g = 0; g < a.n_groups; ++g) {
+            const int gb = a.group_off[g], ge = a.group_off[g + 1];
+            const int nt = (ge - gb + BMT - 1) / BMT;
+            if (v < (before + nt) * n_passes) {
+                const int local = v - before * n_passes;
+                pass = local / nt;
+                const int t = local - pass * nt;
+                row0 = gb + t * BMT;
+                nrows = min(BMT, ge - row0);
+                found = true;
+                break;
+            }
+            before += nt;
+        }
+        if (!found) return;
+    }
+    const int k = a.k, n_out = a.n_out;
+    const int n_pass = (n_out + BNP - 1) / BNP;
+    const int n_kc = ((k + KC - 1) / KC + 3) & ~3;
+    const int total = n_pass * n_kc;
+    const int n_pan = n_kc / KCP;                    // n_kc is a multiple of 4
+    const unsigned short* wp = a.wsplit + ((int64_t)g * total + (int64_t)pass * n_kc) * 2 * W_PLANE_ELEMS + (wave * 64 + lane) * 8;
+    float winv = 1.0f;
+    if constexpr (F16) winv = reinterpret_cast<const float*>(a.wsplit + (int64_t)a.n_groups * total * 2 * W_PLANE_ELEMS)[g];
+
+    const int lrow = lane / LPR, lk = (lane % LPR) * 4;
+    int myrid[NL];
+    const int rid_safe = a.rows[row0];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int r = (j * NW + wave) * RPI + lrow;
+        myrid[j] = (r < nrows) ? a.rows[row0 + r] : -1;
+    }
+    if (tid < BMT) s_rid[tid] = (tid < nrows) ? a.rows[row0 + tid] : -1;
+    if (tid < 2) s_flag[tid] = 0;
+
+    // Rings: the B fragments of THREE panels in registers (a panel is requested two panels of MFMAs before its use), the x rows of
+    // two panels in registers (requested two panels before they are split into the LDS panel that is free by then), two LDS panels.
+    // One panel ahead (r6, first form) left every wavefront waiting ~1.5 us per panel for its own requests: 26 us for 6 us of MFMAs.
+    bf16x8 wh[3][KCP], wm[3][KCP];
+    float4 areg[2][NL];
+#define TS_LOAD_W(B, P)                                                                                    \
+    _Pragma("unroll") for (int kc = 0; kc < KCP; ++kc) {                                                   \
+        const unsigned short* t_ = wp + (int64_t)((P) * KCP + kc) * 2 * W_PLANE_ELEMS;                     \
+        wh[B][kc] = *reinterpret_cast<const bf16x8*>(t_);                                                  \
+        wm[B][kc] = *reinterpret_cast<const bf16x8*>(t_ + W_PLANE_ELEMS);                                  \
+    }
+#define TS_LOAD_A(S, P)      /* (always an in-bounds address; zeroed in TS_COMMIT_A where it must read as zero) */      \
+    {                                                                                                                   \
+        const int kk_ = (P) * KPAN + lk;                                                                                \
+        if (a.vec_ok) {                                                                                                 \
+            const int kc_ = min(kk_, k - 4);                                                                            \
+            _Pragma("unroll") for (int j = 0; j < NL; ++j) {                                                            \
+                const int rid = myrid[j] < 0 ? rid_safe : myrid[j];                                                     \
+                areg[S][j] = *reinterpret_cast<const float4*>(a.x + (int64_t)rid * a.ldx + kc_);                        \
+            }                                                                                                           \
+        } else {                                                                                                        \
+            _Pragma("unroll") for (int j = 0; j < NL; ++j) {                                                            \
+                const int rid = myrid[j] < 0 ? rid_safe : myrid[j];                                                     \
+                const float* px = a.x + (int64_t)rid * a.ldx;                                                           \
+                areg[S][j] = make_float4(px[min(kk_, k - 1)], px[min(kk_ + 1, k - 1)], px[min(kk_ + 2, k - 1)], px[min(kk_ + 3, k - 1)]); \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
+#define TS_COMMIT_A(S, P, BUF)                                                                                          \
+    {                                                                                                                   \
+        const int kk_ = (P) * KPAN + lk;                                                                                \
+        _Pragma("unroll") for (int j = 0; j < NL; ++j) {                                                                \
+            const int r = (j * NW + wave) * RPI + lrow;                                                                 \
+            const bool row_ok = myrid[j] >= 0;                                                                          \
+            float4 v = areg[S][j];                                                                                      \
+            v.x = (row_ok && kk_ < k) ? v.x : 0.f;                                                                      \
+            v.y = (row_ok && kk_ + 1 < k) ? v.y : 0.f;                                                                  \
+            v.z = (row_ok && kk_ + 2 < k) ? v.z : 0.f;                                                                  \
+            v.w = (row_ok && kk_ + 3 < k) ? v.w : 0.f;                                                                  \
+            float scale = 1.0f;                                                                                         \
+            if constexpr (F16) {                                                                                        \
+                unsigned mb = abs_bits4(v);                                                                             \
+                _Pragma("unroll") for (int o = 1; o < LPR; o <<= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o));     \
+                float inv;                                                                                              \
+                f16_row_scale(mb, scale, inv);                                                                          \
+                if ((P) > 0) {                                                                                          \
+                    const float cur = s_rscale[r];                                                                      \
+                    if (scale < cur) {      /* this panel is larger than everything the row had so far */              \
+                        if ((lane % LPR) == 0) { s_ratio[(P) & 1][r] = scale / cur; s_flag[(P) & 1] = (P) + 1; }        \
+                    } else {                                                                                            \
+                        scale = cur;                                                                                    \
+                        inv = s_rinv[r];                                                                                \
+                        if ((lane % LPR) == 0) s_ratio[(P) & 1][r] = 1.0f;                                              \
+                    }                                                                                                   \
+                }                                                                                                       \
+                if ((lane % LPR) == 0) { s_rscale[r] = scale; s_rinv[r] = inv; }                                        \
+            }                                                                                                           \
+            uint2 hi, mid;                                                                                              \
+            split4_t<F16>(v, scale, hi, mid);                                                                           \
+            unsigned char* p_ = (BUF) + r * ASTR + lk * 2;                                                              \
+            *reinterpret_cast<uint2*>(p_) = hi;                                                                         \
+            *reinterpret_cast<uint2*>(p_ + APLANE) = mid;                                                               \
+        }                                                                                                               \
+    }
+
+    TS_LOAD_W(0, 0)
+    TS_LOAD_A(0, 0)
+    if (n_pan > 1) { TS_LOAD_W(1, 1) TS_LOAD_A(1, 1) }
+    if (n_pan > 2) TS_LOAD_W(2, 2)
+    TS_COMMIT_A(0, 0, sA[0])
+    if (n_pan > 2) TS_LOAD_A(0, 2)
+
+    f32x16 acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[r][i] = 0.0f;
+    const int frow = lane & 31, khalf = lane >> 5;
+#define TS_LOAD_AF(SET, KCI)                                                                                            \
+    _Pragma("unroll") for (int r = 0; r < RT; ++r) {                                                                    \
+        fah[SET][r] = *reinterpret_cast<const bf16x8*>(sl_ + r * 32 * ASTR + (KCI) * 32);                               \
+        fam[SET][r] = *reinterpret_cast<const bf16x8*>(sl_ + r * 32 * ASTR + (KCI) * 32 + APLANE);                      \
+    }
+#define TS_COMPUTE(WB, LB)                                                                                              \
+    {                                                                                                                   \
+        const unsigned char* sl_ = sA[LB] + frow * ASTR + khalf * 16;                                                   \
+        bf16x8 fah[2][RT], fam[2][RT];                                                                                  \
+        TS_LOAD_AF(0, 0)                                                                                                \
+        _Pragma("unroll") for (int kc = 0; kc < KCP; ++kc) {                                                            \
+            if (kc + 1 < KCP) { TS_LOAD_AF((kc + 1) & 1, kc + 1) }                                                      \
+            _Pragma("unroll") for (int r = 0; r < RT; ++r) acc[r] = mfma32_t<F16>(fam[kc & 1][r], wh[WB][kc], acc[r]);  \
+            _Pragma("unroll") for (int r = 0; r < RT; ++r) acc[r] = mfma32_t<F16>(fah[kc & 1][r], wm[WB][kc], acc[r]);  \
+            _Pragma("unroll") for (int r = 0; r < RT; ++r) acc[r] = mfma32_t<F16>(fah[kc & 1][r], wh[WB][kc], acc[r]);  \
+        }                                                                                                               \
+    }
+    // a panel whose rows were split with a LOWERED scale: the accumulators of those rows follow (C/D layout of the 32x32 MFMA:
+    // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)).  Flag = panel index + 1 and ratios by panel parity: nothing to clear, the
+    // slot of panel P is rewritten by panel P + 2 two barriers after its last reader.
+#define TS_RESCALE(P)                                                                                                   \
+    if constexpr (F16) {                                                                                                \
+        if ((P) > 0 && s_flag[(P) & 1] == (P) + 1) {                                                                    \
+            _Pragma("unroll") for (int r = 0; r < RT; ++r)                                                              \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
+                    const float4 rv = *reinterpret_cast<const float4*>(&s_ratio[(P) & 1][r * 32 + 8 * q + 4 * khalf]);  \
+                    acc[r][4 * q] *= rv.x; acc[r][4 * q + 1] *= rv.y; acc[r][4 * q + 2] *= rv.z; acc[r][4 * q + 3] *= rv.w; \
+                }                                                                                                       \
+        }                                                                                                               \
+    }
+    // panel P0 + I: fragments in ring slot I % 3, rows in LDS panel I & 1; afterwards panel + 1 is split into the other LDS panel out of
+    // register set (I + 1) & 1, which then takes the rows of panel + 3, and ring slot I % 3 takes the fragments of panel + 3
+#define TS_STEP(I)                                                                                                      \
+    if (P0 + (I) < n_pan) {                                                                                             \
+        const int P = P0 + (I);                                                                                         \
+        TS_RESCALE(P)                                                                                                   \
+        TS_COMPUTE((I) % 3, (I) & 1)                                                                                    \
+        if (P + 3 < n_pan) TS_LOAD_W((I) % 3, P + 3)                                                                    \
+        if (P + 1 < n_pan) {                                                                                            \
+            TS_COMMIT_A(((I) + 1) & 1, P + 1, sA[((I) + 1) & 1])                                                        \
+            if (P + 3 < n_pan) TS_LOAD_A(((I) + 1) & 1, P + 3)                                                          \
+            tile_barrier();                                                                                             \
+        }                                                                                                               \
+    }
+
+    tile_barrier();
+    for (int P0 = 0; P0 < n_pan; P0 += 6) {
+        TS_STEP(0) TS_STEP(1) TS_STEP(2) TS_STEP(3) TS_STEP(4) TS_STEP(5)
+    }
+#undef TS_STEP
+#undef TS_COMPUTE
+#undef TS_LOAD_AF
+#undef TS_LOAD_W
+#undef TS_LOAD_A
+#undef TS_COMMIT_A
+#undef TS_RESCALE
+
+    // ---- epilogue: bias, optional tanh, 16-byte stores after the quad transpose
+    const bool o1 = lane & 1, o2 = lane & 2;
+    const int col_l = ((lane & 31) >> 2) * 4, rt0 = (lane & 3) + 4 * (lane >> 5);
+    const int col = pass * BNP + wave * 32 + col_l;
+    if (col < n_out) {
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + (int64_t)g * a.bgs + col);
+        const int blk = col / a.block_cols, cc = col - blk * a.block_cols;
+        float* __restrict__ ob = (blk == 0) ? a.out0 : ((blk == 1) ? a.out1 : a.out2);
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v0 = acc[r][4 * q], v1 = acc[r][4 * q + 1], v2 = acc[r][4 * q + 2], v3 = acc[r][4 * q + 3];
+                quad_transpose(v0, v1, v2, v3, o1, o2);
+                const int rt = r * 32 + rt0 + 8 * q;
+                if (rt < nrows) {
+                    const float sc = F16 ? s_rinv[F16 ? rt : 0] * winv : 1.0f;
+                    const int64_t orow = a.by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
+                    float4 o4 = make_float4(v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w);
+                    if (a.prologue) o4 = make_float4(tanhf(o4.x), tanhf(o4.y), tanhf(o4.z), tanhf(o4.w));
+                    *reinterpret_cast<float4*>(ob + orow * a.block_cols + cc) = o4;
+                }
+            }
+    }
+}
+
+template <int RT>
+static void launch_stream(bool f16, const TileArgs& a, int64_t n_rows, hipStream_t stream) {
+    const int64_t row_tiles = (n_rows + 32 * RT - 1) / (32 * RT) + a.n_groups;      // device-side group sizes: the upper bound
+    const int64_t work = row_tiles * ((a.n_out + BNP - 1) / BNP);
+    dim3 grid((unsigned)((work + 7) / 8 * 8));                                       // (a multiple of 8: one chunk of the work list per XCD)
+    if (f16) k_tile_linear_stream<RT, true><<<grid, 512, 0, stream>>>(a);
+    else k_tile_linear_stream<RT, false><<<grid, 512, 0, stream>>>(a);
+}
+
 template <int NW, int RT, int CT, int KPAN, int NPM, bool UPD>
 static void launch_tile(bool f16, const TileArgs& a, int64_t n_rows, hipStream_t stream) {
     constexpr int BMT = 32 * RT, BNT = 32 * CT * NW;
@@ -417,8 +665,28 @@ int hgt_typed_linear_tile_try(bool f16, const float* x, int64_t ldx, const int32
         // (3 200 x 256 -> 768): 11.3 us against 14.0 (64 x 128 tiles) and 13.9 (persistent kernel).  Beyond K = 256 or ~1 000 workgroups
         // the slab kernels are as fast or faster (K = 512: 36 vs 31 us at 3 200 rows): not this kernel's domain
         const int64_t wgs = ((n_rows + 31) / 32 + n_groups) * ((n_out + 127) / 128);
-        if (k > 256 || wgs > 1024) return 0;
-        launch_tile<4, 1, 1, 64, 4, false>(f16, a, n_rows, stream);
+        if (k > 256) {
+            // (32 RT) x 256 tiles, RT <= 3, when they fit the chip in ONE round; among those the RT with the shortest workgroup under a
+            // two-term model -- matrix-core time ~ 6 RT, bytes through its CU's L1 ~ (RT + 8): whichever is larger -- ties: the larger
+            // tile (fewer passes over W).  Measured (r6, warm): 3 200 x 512 -> 1 536: RT = 3 (216 tiles) 25.8 us, slab kernel 31.7;
+            // 4 096 x 1 169 -> 400: RT = 2, 41.0 vs 46.7; 4 096 x 400 -> 1 536 needs two rounds at every RT (33.6 vs 31.3): the slab kernel
+            const int64_t passes = (n_out + BNP - 1) / BNP;
+            int best = 0;
+            int64_t best_cost = 0;
+            for (int rt = 1; rt <= 3; ++rt) {
+                const int64_t tiles = ((n_rows + 32 * rt - 1) / (32 * rt) + n_groups / 2) * passes;      // (about half the groups end in a partial tile)
+                if (tiles > 256) continue;
+                const int64_t cost = std::max<int64_t>(6 * rt, rt + 8);
+                if (best == 0 || cost <= best_cost) { best = rt; best_cost = cost; }
+            }
+            if (best == 0) return 0;
+            if (best == 1) launch_stream<1>(f16, a, n_rows, stream);
+            else if (best == 2) launch_stream<2>(f16, a, n_rows, stream);
+            else launch_stream<3>(f16, a, n_rows, stream);
+        } else {
+            if (wgs > 1024) return 0;
+            launch_tile<4, 1, 1, 64, 4, false>(f16, a, n_rows, stream);
+        }
     }
     if (hipGetLastError() != hipSuccess) return HGT_ERR_LAUNCH;
     return 1;
