@@ -380,13 +380,8 @@ __global__ __launch_bounds__(64 * MU_NW, 4) void k_merge_update(const MergeUpdat
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int g = 0, row0 = 0, nrows = 0;
     {
-        // XCD-aware order (workgroup b runs on XCD b % 8, one 4 MB L2 each): the row tiles -- grouped by node type -- are cut into eight
-        // contiguous chunks, so that an XCD streams the fragment image of about ONE type (1 MB at n_hid = 512) instead of all of them
-        int t_all = 0;
-        for (int gg = 0; gg < a.n_groups; ++gg) t_all += (a.group_off[gg + 1] - a.group_off[gg] + MU_R - 1) / MU_R;
-        const int chunk = (t_all + 7) / 8, b = (int)blockIdx.x, j = b >> 3;
-        const int t = (b & 7) * chunk + j;
-        if (j >= chunk || t >= t_all) return;
+        // (an XCD-aware order -- row tiles in eight contiguous chunks, one per XCD -- measured neutral to slower here, r6: c5 30.9 vs 28.3 us)
+        const int t = (int)blockIdx.x;
         int before = 0;
         bool found = false;
         for (g = 0; g < a.n_groups; ++g) {
@@ -660,8 +655,10 @@ static int aggregate_items_impl(const void* plan, int64_t N, int64_t E, int32_t 
         m.apply_gelu = (int)apply_gelu;
         // 16 targets per workgroup (one per wavefront) while that is at most ~one workgroup per CU; 32 (two per wavefront: half the
         // passes over W_a) beyond
+        // (two per wavefront also for 512-column rows from 2 048 targets on -- half the 1 MB fragment passes -- measured SLOWER: c5 36 vs
+        //  31 us, published 4-layer model 32 vs 25 us per layer: the second merge's chain costs more than the passes it saves)
         const int tpw = NQ <= 16 * 288 ? 1 : 2;
-        const unsigned ugrid = (unsigned)(((NQ + MU_ROWS * tpw - 1) / (MU_ROWS * tpw) + m.n_groups + 7) / 8 * 8);      // device-side group sizes: the upper bound (a multiple of 8: one chunk per XCD)
+        const unsigned ugrid = (unsigned)((NQ + MU_ROWS * tpw - 1) / (MU_ROWS * tpw) + m.n_groups);      // device-side group sizes: the upper bound
 #define AGI_MU(VF)                                                                                      \
         do {                                                                                            \
             if (tpw == 1) {                                                                             \

@@ -297,44 +297,21 @@ __global__ __launch_bounds__(512, UPD ? 2 : 4) void k_typed_linear_split(
     // pass_split = n_pass (small problems: fewer row tiles than CUs): a workgroup owns ONE 256-column pass of a row tile, so that
     // tiles x passes workgroups share the work (sampled sub-graphs of a few thousand nodes: 50-64 row tiles for 256 CUs);
     // pass_split = 1: a workgroup owns a row tile and walks all passes
-    int g = 0, row0 = 0, nrows = 0, pass_only = -1;
-    if (pass_split > 1) {
-        // latency regime, XCD-aware work order (round 6): workgroup b runs on XCD b % 8 and every XCD has its own 4 MB L2 -- with the
-        // plain (row tile, pass) order every XCD walked all (type, pass) slabs of the fragment image (12.6 MB at n_hid = 512) and 74 %
-        // of its L2 requests missed.  The work list is ordered (type, pass, row tile) and cut into eight contiguous chunks, one per XCD.
-        int t_all = 0;
-        for (int gg = 0; gg < n_groups; ++gg) t_all += (group_off[gg + 1] - group_off[gg] + BM - 1) / BM;
-        const int total_work = t_all * pass_split, chunk = (total_work + 7) / 8;
-        const int b = (int)blockIdx.x, j = b >> 3, v = (b & 7) * chunk + j;
-        if (j >= chunk || v >= total_work) return;
-        int before = 0;
-        for (; g < n_groups; ++g) {
-            const int gb = group_off[g], ge = group_off[g + 1];
-            const int nt = (ge - gb + BM - 1) / BM;
-            if (v < (before + nt) * pass_split) {
-                const int local = v - before * pass_split;
-                pass_only = local / nt;
-                row0 = gb + (local - pass_only * nt) * BM;
-                nrows = min(BM, ge - row0);
-                break;
-            }
-            before += nt;
-        }
-        if (g >= n_groups) return;
-    } else {
-        const int slot = blockIdx.x;
-        int gbeg = 0, gend = 0, tiles_before = 0;
-        for (; g < n_groups; ++g) {
-            gbeg = group_off[g];
-            gend = group_off[g + 1];
-            int nt = (gend - gbeg + BM - 1) / BM;
-            if (slot < tiles_before + nt) break;
-            tiles_before += nt;
-        }
-        if (g >= n_groups) return;
-        row0 = gbeg + (slot - tiles_before) * BM;
-        nrows = min(BM, gend - row0);
+    // (an XCD-aware work order like k_tile_linear_stream's -- (type, pass, row tile) in eight contiguous chunks -- measured neutral for
+    //  this kernel's 64 x 256 tiles, r6: 37.1 - 38.4 vs 37.5 us at 4 096 x 400 -> 1 536)
+    const int slot = blockIdx.x / pass_split;
+    const int pass_only = (pass_split > 1) ? (int)(blockIdx.x % pass_split) : -1;
+    int g = 0, gbeg = 0, gend = 0, tiles_before = 0;
+    for (; g < n_groups; ++g) {
+        gbeg = group_off[g];
+        gend = group_off[g + 1];
+        int nt = (gend - gbeg + BM - 1) / BM;
+        if (slot < tiles_before + nt) break;
+        tiles_before += nt;
     }
+    if (g >= n_groups) return;
+    const int row0 = gbeg + (slot - tiles_before) * BM;
+    const int nrows = min(BM, gend - row0);
 
     const int tid = threadIdx.x;
     if (tid < BM) s_rid[tid] = (tid < nrows) ? rows[row0 + tid] : -1;
@@ -574,6 +551,8 @@ __global__ __launch_bounds__(512, 1) void k_typed_linear_update_wide(
     __shared__ __attribute__((aligned(16))) float s_ratio[F16 ? BM : 1];          // running row scales: see k_typed_linear_split
     __shared__ int s_flag[2];
 
+    // (an XCD-aware order -- the row tiles cut into eight contiguous chunks, one per XCD, so that an XCD streams about one type's
+    //  1 MB image at a time -- measured slower at d512_h8: 1.34 vs 1.25 ms, r6)
     const int slot = blockIdx.x;
     int g = 0, gbeg = 0, gend = 0, tiles_before = 0;
     for (; g < n_groups; ++g) {
@@ -1254,7 +1233,7 @@ static int typed_linear_split_impl(const float* x, int64_t ldx, const int32_t* r
         HGT_CHECK_LAUNCH();
         return HGT_OK;
     }
-    const unsigned grid_s = (unsigned)((row_tiles * pass_split + 7) / 8 * 8);      // (a multiple of 8: the XCD-aware work order of the kernel)
+    const unsigned grid_s = (unsigned)(row_tiles * pass_split);
     const bool deep = row_tiles * pass_split <= 2 * pc_grid();      // latency regime: four B-fragment stages (see the kernel)
 #define HGT_SPLIT_LAUNCH(P, NS)                                                                                                        \
     k_typed_linear_split<P, false, F16, NS><<<grid_s, 512, 0, stream>>>(x, ldx, rows, group_off, n_groups, k, n_out,                   \
