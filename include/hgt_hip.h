@@ -453,6 +453,14 @@ int hgt_edge_aggregate_update_range(const void* plan, int64_t n_nodes, int64_t n
 int hgt_edge_spmm(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations, int32_t n_heads,
                   int32_t dk_pad, const float* weights, const float* rows, const float* rte_rows, const float* f_p,
                   const void* f_frag, float* out, int64_t ld_out, int64_t n_q_rows, void* hub_ws, void* stream);
+/* ABI 7: the same sums on the item-parallel kernels of the latency regime (hgt_edge_aggregate_items with the edge weights given): one
+ * wavefront per <= 16-edge work item + a fixed-order merge per target, no atomics; scratch = hgt_edge_aggregate_items_bytes().  What
+ * pyhgt_amd/autograd.py takes below 65 536 nodes (the sub-tile kernel's wavefronts walk sixteen targets' edges one after the other:
+ * 285 us per call on the transposed plan of a 3 200-node sampled batch against ~25 us).  HGT_ERR_UNSUPPORTED: > 63 relations, rows wider
+ * than 512 padded columns, ld_out % 4 != 0, out not 16-byte aligned -> hgt_edge_spmm. */
+int hgt_edge_spmm_items(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations, int32_t n_heads,
+                        int32_t dk_pad, const float* weights, const float* rows, const float* rte_rows, const void* f_frag, float* out,
+                        int64_t ld_out, int64_t n_q_rows, void* scratch, uint64_t scratch_bytes, void* stream);
 int hgt_edge_softmax_bwd(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations, int32_t n_heads,
                          const float* att, const float* d_att, const float* rho, int64_t ld_rho, float* d_logits, void* stream);
 int hgt_edge_gather_sorted(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations, int32_t n_heads,

@@ -123,6 +123,7 @@ SIGNATURES = {
     "hgt_edge_aggregate_f16x3": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "hgt_relation_frag_pack_f16": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "hgt_edge_aggregate_items_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_u64)]),
+    "hgt_edge_spmm_items": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _u64, _vp]),
     "hgt_edge_aggregate_items_update": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _u64, _vp, _vp, _i32,
                                                   _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "hgt_edge_aggregate_items": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _u64, _vp]),

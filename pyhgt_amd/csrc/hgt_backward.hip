@@ -651,7 +651,9 @@ struct LaunchOuter {
         if constexpr (VEC * LPH * VEC <= 128 && VEC * LPH >= 4) {
             // ~16 items of the selected relation per wavefront (items are ordered (tile, relation)): at c2 3 000 wavefronts for
             // 1 024 SIMDs (64 items left the chip with fewer wavefronts than SIMDs) against 25 M flush atomics
-            const int ipw = 16 * (R + 1);
+            // (sampled batches -- a few thousand 16-edge items: 16 (R + 1) items per wavefront left 13 x R wavefronts walking ~250 edges
+            //  each, 565 us per call at c3 (r6 timeline of a training step); 2 (R + 1) there)
+            const int ipw = (pv.L.max_items < 16384 ? 2 : 16) * (R + 1);
             const int64_t waves = (pv.L.max_items + ipw - 1) / ipw;
             dim3 grid((unsigned)((waves + 3) / 4), (unsigned)(HT / (64 / LPH)), (unsigned)R);
             if constexpr (VEC * LPH == 32 && VEC <= 4) {          // 32-wide heads: matrix-core form

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_runs_mfma(
     const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
     const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ logits,
     const float* __restrict__ V, const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, float* __restrict__ zrows,
-    float* __restrict__ zstat, unsigned char* __restrict__ zflag, int R, int HT) {
+    float* __restrict__ zstat, unsigned char* __restrict__ zflag, int R, int HT, int raw) {      // raw: `logits` ARE the edge weights (hgt_edge_spmm_items)
     using G = AG<VEC, LPH>;
     constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS;
     constexpr int UN = RTE ? (unroll_for<VEC>() * 3) / 4 : unroll_for<VEC>(), HB = UN / 2;
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_runs_mfma(
                 l_run = 0.0f;                                                                      \
                 _Pragma("unroll") for (int i = 0; i < VEC; ++i) U[i] = 0.0f;                       \
             }                                                                                      \
-            const float m_new = fmaxf(m_run, SL[u]);                                               \
-            const float sc = __expf(m_run - m_new), pe = __expf(SL[u] - m_new);                    \
+            const float m_new = raw ? 0.0f : fmaxf(m_run, SL[u]);                                  \
+            const float sc = raw ? 1.0f : __expf(m_run - m_new), pe = raw ? SL[u] : __expf(SL[u] - m_new); \
             _Pragma("unroll") for (int i = 0; i < VEC; ++i) {                                      \
                 float vv = VR[u][i];                                                               \
                 if constexpr (RTE) vv += TR[u][i];                                                 \
@@ -317,7 +317,7 @@ __device__ __forceinline__ void merge_target(int64_t i, int lane, const int32_t*
         for (int k = 0; k < VECF; ++k) X[k] *= sa;
         L = fmaf(L, sa, (float)n_unclaimed * sb);
     }
-    const float inv = 1.0f / (L + 1e-16f);
+    const float inv = apply_gelu == 2 ? 1.0f : 1.0f / (L + 1e-16f);      // (2: the plain weighted sum of hgt_edge_spmm_items)
 #pragma unroll
     for (int k = 0; k < VECF; ++k) {
         float v = X[k] * inv;
@@ -561,12 +561,12 @@ __global__ __launch_bounds__(64 * MU_NW, 4) void k_merge_update(const MergeUpdat
 
 template <int VEC, int LPH>
 static int launch_runs(bool f16, const HgtPlanView& pv, const float* logits, const float* V, const float* rteV, const unsigned short* msgF,
-                       float* zrows, float* zstat, unsigned char* zflag, int R, int HT, hipStream_t stream) {
+                       float* zrows, float* zstat, unsigned char* zflag, int R, int HT, hipStream_t stream, int raw = 0) {
     const unsigned blocks = ((unsigned)((pv.L.max_items + 3) / 4) + 127u) & ~127u;
     dim3 grid(blocks, (unsigned)(HT / (64 / LPH)));
 #define AGI_LAUNCH(RTE_, F16_)                                                                                                     \
     k_edge_runs_mfma<VEC, LPH, RTE_, F16_><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF, \
-                                                                     zrows, zstat, zflag, R, HT)
+                                                                     zrows, zstat, zflag, R, HT, raw)
     if (rteV) { if (f16) AGI_LAUNCH(true, true); else AGI_LAUNCH(true, false); }
     else      { if (f16) AGI_LAUNCH(false, true); else AGI_LAUNCH(false, false); }
 #undef AGI_LAUNCH
@@ -607,11 +607,11 @@ struct SinglePassArgs {
 static int aggregate_items_impl(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
                                 const float* logits, const float* V, const float* rte_v, const void* msg_frag, int32_t frag_f16,
                                 float* agg, int64_t n_q_rows, int32_t apply_gelu, void* scratch, uint64_t scratch_bytes,
-                                void* stream_, const SinglePassArgs* spa, const MergeUpdateArgs* mu = nullptr) {
+                                void* stream_, const SinglePassArgs* spa, const MergeUpdateArgs* mu = nullptr, int64_t ld_out = 0) {
     if (!plan || !V || !msg_frag || (!agg && !mu) || (E > 0 && ((!spa && !logits) || !scratch)) || H <= 0 || 64 % H != 0 || dk_pad <= 0)
         return HGT_ERR_INVALID_ARG;
     if (spa && (!spa->Q || !spa->K || !spa->att_frag || ((spa->rte_k == nullptr) != (rte_v == nullptr)))) return HGT_ERR_INVALID_ARG;
-    if (apply_gelu != 0 && apply_gelu != 1) return HGT_ERR_INVALID_ARG;
+    if (apply_gelu < 0 || apply_gelu > 2) return HGT_ERR_INVALID_ARG;
     const int64_t NQ = (n_q_rows > 0 && n_q_rows <= N) ? n_q_rows : N;
     if (NQ == 0) return HGT_OK;
     const int lph = 64 / H;
@@ -638,7 +638,7 @@ static int aggregate_items_impl(const void* plan, int64_t N, int64_t E, int32_t 
     } else if (E > 0) {
         int rc = HGT_ERR_UNSUPPORTED;
 #define AGI_CASE(V_, L_) \
-        if (vec == V_ && lphs == L_) rc = launch_runs<V_, L_>(frag_f16 != 0, pv, logits, V, rte_v, (const unsigned short*)msg_frag, zrows, zstat, zflag, (int)R, (int)H, stream);
+        if (vec == V_ && lphs == L_) rc = launch_runs<V_, L_>(frag_f16 != 0, pv, logits, V, rte_v, (const unsigned short*)msg_frag, zrows, zstat, zflag, (int)R, (int)H, stream, apply_gelu == 2 ? 1 : 0);
 #ifdef HGT_DEV_LAYOUTS
         AGI_CASE(4, 8) AGI_CASE(4, 16) AGI_CASE(1, 16)
 #else
@@ -676,7 +676,7 @@ static int aggregate_items_impl(const void* plan, int64_t N, int64_t E, int32_t 
     }
     const unsigned mgrid = (unsigned)((NQ + 3) / 4);
 #define AGI_MERGE(VF) \
-    k_merge_runs<VF><<<mgrid, 256, 0, stream>>>(pv.segptr, zrows, zstat, zflag, agg, (int)R, NQ, (int)H, (int)dk_pad, (int)apply_gelu, d)
+    k_merge_runs<VF><<<mgrid, 256, 0, stream>>>(pv.segptr, zrows, zstat, zflag, agg, (int)R, NQ, (int)H, (int)dk_pad, (int)apply_gelu, ld_out > 0 ? ld_out : d)
     if (vf == 1) AGI_MERGE(1); else if (vf == 2) AGI_MERGE(2); else if (vf == 4) AGI_MERGE(4); else AGI_MERGE(8);
 #undef AGI_MERGE
     HGT_CHECK_LAUNCH();
@@ -727,4 +727,17 @@ extern "C" int hgt_edge_aggregate_items_update(const void* plan, int64_t N, int6
     m.use_norm = use_norm; m.out = out;
     return aggregate_items_impl(plan, N, E, T, R, H, dk_pad, logits, V, rte_v, msg_frag, frag_f16, nullptr, n_q_rows, 1, scratch, scratch_bytes,
                                 stream_, nullptr, &m);
+}
+
+// ABI 7: hgt_edge_spmm (GIVEN edge weights, plain weighted sum: the gather passes of the backward) on the item-parallel kernels -- the
+// form for sampled batches, where the sub-tile kernel's wavefronts each walk sixteen targets' edges one after the other (285 us per
+// call on the transposed plan of the c3 batch against ~25 us here, r6).  scratch: hgt_edge_aggregate_items_bytes().  f_frag =
+// hgt_relation_frag_pack(f_p) (bf16 image).  Deterministic (no atomics).  HGT_ERR_UNSUPPORTED: more than 63 relations, rows wider than
+// 512 padded columns, ld_out % 4 != 0 -> hgt_edge_spmm.
+extern "C" int hgt_edge_spmm_items(const void* plan, int64_t N, int64_t E, int32_t T, int32_t R, int32_t H, int32_t dk_pad,
+                                   const float* weights, const float* rows, const float* rte_rows, const void* f_frag, float* out,
+                                   int64_t ld_out, int64_t n_q_rows, void* scratch, uint64_t scratch_bytes, void* stream_) {
+    if (!out || ld_out < (int64_t)H * dk_pad || (ld_out & 3) != 0 || (((uintptr_t)out) & 15) != 0) return HGT_ERR_UNSUPPORTED;
+    return aggregate_items_impl(plan, N, E, T, R, H, dk_pad, weights, rows, rte_rows, f_frag, 0, out, n_q_rows, 2, scratch, scratch_bytes, stream_,
+                                nullptr, nullptr, ld_out);
 }

@@ -291,3 +291,50 @@ def test_training_path_at_the_benchmark_size_sampled(precision):
     del out, xd, gout
     GraphPlan.clear_cache()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("d,H,R,rte", [(256, 8, 9, True), (512, 8, 5, False), (64, 4, 4, True), (400, 8, 33, True)])
+def test_item_parallel_spmm_matches_the_sub_tile_kernel(d, H, R, rte):
+    """hgt_edge_spmm_items (round 6: the gather passes of the backward on the item-parallel kernels, what autograd takes for sampled
+    batches) against hgt_edge_spmm on the same plan, weights and rows -- the same sums in another order (fp32 rounding), hub targets and
+    unclaimed relations included; two calls are bit-identical (no atomics)."""
+    lib = _lib.load()
+    T, N, E = 3, 3000, 30000
+    x, nt, ei, et, tm = [t.to(DEV) for t in synthetic_typed_graph(N, E, d, T, R, seed=d + R, dst_skew=1.1)]
+    et = et.clone()
+    et[::41] = R
+    plan = GraphPlan(nt, ei, et, tm if rte else None, T, R)
+    lay = _lib.HgtLayout()
+    assert lib.hgt_layout_for(d, H, C.byref(lay)) == 0
+    Hl, dkp, dp = lay.heads, lay.dk_pad, lay.d_pad
+    g = torch.Generator().manual_seed(7)
+    w = torch.randn(E, Hl, generator=g).to(DEV)
+    rows = torch.randn(N, dp, generator=g).to(DEV)
+    rte_rows = torch.randn(T * 240, dp, generator=g).to(DEV) if rte else None
+    f_p = (torch.randn(R, Hl, dkp, dkp, generator=g) / dkp ** 0.5).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = C.c_uint64()
+    assert lib.hgt_relation_frag_bytes(R, Hl, dkp, C.byref(nb)) == 0
+    frag = torch.empty(int(nb.value), dtype=torch.uint8, device=DEV)
+    assert lib.hgt_relation_frag_pack(f_p.data_ptr(), R, Hl, dkp, frag.data_ptr(), st) == 0
+    assert lib.hgt_hub_workspace_bytes(E, Hl, dkp, C.byref(nb)) == 0
+    hub = torch.empty(max(int(nb.value), 256), dtype=torch.uint8, device=DEV)
+    assert lib.hgt_edge_aggregate_items_bytes(E, Hl, dkp, C.byref(nb)) == 0
+    scratch = torch.empty(int(nb.value), dtype=torch.uint8, device=DEV)
+    rp = 0 if rte_rows is None else rte_rows.data_ptr()
+    ref = torch.zeros(N, dp, device=DEV)
+    assert lib.hgt_edge_spmm(plan.ptr, N, E, T, R, Hl, dkp, w.data_ptr(), rows.data_ptr(), rp, f_p.data_ptr(), frag.data_ptr(), ref.data_ptr(),
+                             dp, N, hub.data_ptr(), st) == 0
+    outs = []
+    for _ in range(2):
+        out = torch.full((N, 2 * dp), 5.0, device=DEV)      # (written into the second column block of a wider array: ld_out = 2 dp)
+        assert lib.hgt_edge_spmm_items(plan.ptr, N, E, T, R, Hl, dkp, w.data_ptr(), rows.data_ptr(), rp, frag.data_ptr(),
+                                       out.data_ptr() + 4 * dp, 2 * dp, N, scratch.data_ptr(), scratch.numel(), st) == 0
+        torch.cuda.synchronize()
+        assert bool((out[:, :dp] == 5.0).all())
+        outs.append(out[:, dp:].clone())
+    assert torch.equal(outs[0], outs[1])
+    scale = ref.abs().max().item()
+    err = (outs[0] - ref).abs().max().item() / scale
+    print("spmm_items d=%d R=%d: max|items - sub-tile| = %.2e of the largest entry" % (d, R, err))
+    assert err < 2e-5
