@@ -26,7 +26,7 @@
 #include <algorithm>
 
 #ifndef HGT_TILE_MAX_ROWS
-#define HGT_TILE_MAX_ROWS 8192      // typed linears below this many rows take the tile kernels (measured against the persistent kernel)
+#define HGT_TILE_MAX_ROWS 16384      // typed linears below this many rows take the tile kernels (measured against the persistent kernel)
 #endif
 
 namespace {
