@@ -1009,6 +1009,9 @@ def main():
         if d == 256 and H == 8:     # the reference's published ogbn-mag width (n_hid 512 = 8 heads x 64) at half the node count
             secondary["d512_h8"] = large_variant(Nl // 2, El // 2, 512, 8, False, 0.0, 4323)
             torch.cuda.empty_cache()
+            # ... and the OAG width (n_hid 400 = 8 heads x 50, padded to 64 columns per head: OAG/train_paper_field.py:31-32) on a large graph
+            secondary["d400_h8"] = large_variant(Nl // 2, El // 2, 400, 8, False, 0.0, 4324)
+            torch.cuda.empty_cache()
         secondary["latency_regime"] = small_regime(dev)
         if d == 256 and H == 8 and Nl == 1_000_000 and El == 10_000_000:
             # configs[3] on ONE GPU: rank 0 of an 8-rank partition, exchange emulated by device copies (what a rank's GPU does per step;

@@ -135,8 +135,10 @@ class GNN(nn.Module):
             fn = lib.hgt_typed_linear_f16x3 if f16 else lib.hgt_typed_linear_bf16x3
             # adapter + tanh in one kernel where the kernel that takes the shape has the activation epilogue (sampled batches;
             # HGT_ERR_UNSUPPORTED = nothing was launched)
-            rc = fn(_ptr(x), in_dim, rows.rows_all, rows.off_all, T, N, in_dim, n_hid, _ptr(tiles), _ptr(b), n_hid, _ptr(h), 0, 0, n_hid, 0,
-                    _lib.HGT_LINEAR_TANH, st)
+            # (asked for on sampled batches only: with the bit set a large input never takes the x-stationary kernel, which has no
+            #  activation epilogue)
+            rc = -2 if N >= 65536 else fn(_ptr(x), in_dim, rows.rows_all, rows.off_all, T, N, in_dim, n_hid, _ptr(tiles), _ptr(b), n_hid,
+                                          _ptr(h), 0, 0, n_hid, 0, _lib.HGT_LINEAR_TANH, st)
             if rc == 0:
                 need_tanh = False
             else:
