@@ -16,6 +16,7 @@
 // gelu and stores the row -- fixed order, no atomics: a forward is bit-reproducible.  Hub targets need no separate path.
 #include "hgt_edge_common.h"
 #include "hgt_split_common.h"
+#include "hgt_wt_store.h"
 
 #ifndef HGT_LOGITS_XCD
 #define HGT_LOGITS_XCD 1
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_runs_mfma(
                 float* zr = zrows + (int64_t)s_pos[wib][fi] * ld + co + 4 * fg;
 #pragma unroll
                 for (int c = 0; c < NCT; ++c)
-                    *reinterpret_cast<float4*>(zr + 16 * c) = make_float4(acc[c][0] * sc, acc[c][1] * sc, acc[c][2] * sc, acc[c][3] * sc);
+                    store_wt16(zr + 16 * c, acc[c][0] * sc, acc[c][1] * sc, acc[c][2] * sc, acc[c][3] * sc);      // (read by the merge kernel only)
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();         // the tile / position table are rewritten by the next group
@@ -551,10 +552,9 @@ __global__ __launch_bounds__(64 * MU_NW, 4) void k_merge_update(const MergeUpdat
 #pragma unroll
         for (int q = 0; q < NQR; ++q) {
             const int rt = rt0 + 8 * q;
-            if (rt < nrows)
-                *reinterpret_cast<float4*>(a.out + (int64_t)s_rid[rt] * n_out + col) =
-                    make_float4(y[q][0] * rstd[q] * w4.x + c4.x, y[q][1] * rstd[q] * w4.y + c4.y, y[q][2] * rstd[q] * w4.z + c4.z,
-                                y[q][3] * rstd[q] * w4.w + c4.w);
+            if (rt < nrows)      // (the layer's output: read by the next layer's projections -- another kernel)
+                store_wt16(a.out + (int64_t)s_rid[rt] * n_out + col, y[q][0] * rstd[q] * w4.x + c4.x, y[q][1] * rstd[q] * w4.y + c4.y,
+                           y[q][2] * rstd[q] * w4.z + c4.z, y[q][3] * rstd[q] * w4.w + c4.w);
         }
     }
 }

@@ -23,6 +23,7 @@
 // the row is in the registers of 16 or 32 lanes of one wavefront by then: four or five lane exchanges, no second pass over x.
 #include "hgt_common.h"
 #include "hgt_split_common.h"
+#include "hgt_wt_store.h"
 #include <algorithm>
 
 #ifndef HGT_TILE_MAX_ROWS
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, (KPAN == 64 && RT == 1 && CT == 1) ? 4 : 2
                         const int64_t orow = a.by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
                         float4 o4 = make_float4(v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w);
                         if (a.prologue) o4 = make_float4(tanhf(o4.x), tanhf(o4.y), tanhf(o4.z), tanhf(o4.w));
-                        *reinterpret_cast<float4*>(ob + orow * a.block_cols + cc) = o4;
+                        store_wt16(ob + orow * a.block_cols + cc, o4.x, o4.y, o4.z, o4.w);      // (read by the next kernel only)
                     }
                 }
         }
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(512, 2) void k_tile_linear_stream(const TileArgs a)
                     const int64_t orow = a.by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
                     float4 o4 = make_float4(v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w);
                     if (a.prologue) o4 = make_float4(tanhf(o4.x), tanhf(o4.y), tanhf(o4.z), tanhf(o4.w));
-                    *reinterpret_cast<float4*>(ob + orow * a.block_cols + cc) = o4;
+                    store_wt16(ob + orow * a.block_cols + cc, o4.x, o4.y, o4.z, o4.w);
                 }
             }
     }

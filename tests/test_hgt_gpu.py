@@ -2078,6 +2078,46 @@ def test_tile_linear_is_bit_identical_to_the_slab_kernels(precision, n, k, n_out
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("n,k,n_out", [(3000, 129, 512), (3200, 512, 400), (4096, 1169, 400), (300, 64, 64), (9000, 512, 1536)])
+def test_typed_linear_with_the_tanh_epilogue(precision, n, k, n_out):
+    """prologue | HGT_LINEAR_TANH (round 6: the GNN's typed adapter + tanh, model.py:70-76, in one kernel): tanh(x W^T + b) against
+    float64 wherever a latency-regime kernel takes the shape (tile kernel, streamed kernel, K > 256 slab kernel); where none does the
+    call answers HGT_ERR_UNSUPPORTED and has launched nothing (the output keeps its fill value)."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + k + n_out)
+    G = 3
+    x = torch.randn(n, k, generator=g).to(DEV)
+    W = (torch.randn(G, n_out, k, generator=g) / k ** 0.5).to(DEV)
+    bias = torch.randn(G, n_out, generator=g).to(DEV)
+    nt = torch.randint(0, G, (n,), generator=g).sort().values
+    rows = torch.arange(n, dtype=torch.int32).to(DEV)
+    off = torch.searchsorted(nt, torch.arange(G + 1)).int().to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = C.c_uint64()
+    assert lib.hgt_split_weights_bytes(G, k, n_out, C.byref(nb)) == 0
+    ws = torch.empty(int(nb.value), dtype=torch.uint8, device=DEV)
+    split, linear = ((lib.hgt_split_weights_f16, lib.hgt_typed_linear_f16x3) if precision == "f16x3" else
+                     (lib.hgt_split_weights, lib.hgt_typed_linear_bf16x3))
+    assert split(W.data_ptr(), n_out * k, G, k, n_out, ws.data_ptr(), st) == 0
+    out = torch.full((n, n_out), 9.0, device=DEV)
+    rc = linear(x.data_ptr(), k, rows.data_ptr(), off.data_ptr(), G, n, k, n_out, ws.data_ptr(), bias.data_ptr(), n_out, out.data_ptr(), 0, 0,
+                n_out, 0, _lib.HGT_LINEAR_TANH, st)
+    torch.cuda.synchronize()
+    if rc == -2:
+        assert k <= 256 and bool((out == 9.0).all())      # K <= 256 outside the tile kernel's domain: nothing launched
+        return
+    assert rc == 0
+    ref = torch.empty(n, n_out, dtype=torch.float64)
+    ntl = nt.tolist()
+    for gi in range(G):
+        m = nt == gi
+        ref[m] = torch.tanh(x.cpu().double()[m] @ W[gi].cpu().double().T + bias[gi].cpu().double())
+    err = (out.cpu().double() - ref).abs().max().item()
+    print("tanh epilogue %s n=%d k=%d n_out=%d: max|err| %.2e" % (precision, n, k, n_out, err))
+    assert err < (3e-6 if precision == "f16x3" else 5e-5)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
 @pytest.mark.parametrize("n,k,n_out,use_norm", [(3200, 256, 256, 1), (1000, 512, 512, 1), (777, 512, 400, 0), (333, 256, 64, 1), (4096, 512, 400, 1)])
 def test_tile_linear_update_is_bit_identical_to_the_slab_kernels(precision, n, k, n_out, use_norm):
     """The fused update of the latency regime (32 whole rows per workgroup, hgt_gemm_tile.hip) against the persistent / wide kernels

@@ -21,7 +21,7 @@
 #   small     the latency-regime part of the judged line only (bench.py --small-only): wall-clock us per layer / forward + parity
 # Everything lands in gpurun_out/; summaries to be judged are copied to profiles/ by hand (or by `final`).
 # Kernel experiments: tools/lab/build_lab.sh (lab libraries), lab_run.sh (phase times), pmc_quick.sh (counters), isa.sh (ISA + resources).
-MODE=${1:-quick}; TAG=${2:-r05}
+MODE=${1:-quick}; TAG=${2:-r06}
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
 ulimit -c 0      # a faulting kernel must not fill the scratch disk with core files (every later command of the call then fails)
@@ -80,7 +80,7 @@ import json
 j = json.load(open("gpurun_out/prof_$TAG/${TAG}_pmc_summary.json"))
 for k in ("avg_kernel_ms", "traffic_bytes", "mfma_busy_pct", "valu_busy_pct", "waves_per_simd_avg", "wait_pct", "lds_bank_conflict_pct"): print(k, j.get(k))
 PY
-    tools/profile_small.sh $TAG > gpurun_out/prof_small_$TAG.log 2>&1; tail -3 gpurun_out/prof_small_$TAG.log
+    $0 latency $TAG f16x3
     ;;
 final)
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
@@ -94,9 +94,11 @@ final)
     timeout 300 python tools/bench_xs.py > gpurun_out/${TAG}_xs_check.log 2>&1; grep -v "BIT-IDENTICAL (" gpurun_out/${TAG}_xs_check.log | tail -12
     tools/profile_pmc.sh $TAG > gpurun_out/prof_$TAG.log 2>&1
     cp gpurun_out/prof_$TAG/${TAG}_pmc_summary.json profiles/${TAG}_pmc_summary.json      # the line below is judged against THIS build's counters
-    tools/profile_small.sh $TAG > gpurun_out/prof_small_$TAG.log 2>&1
+    # per-kernel timelines of the sampled-batch workloads at this build, both split precisions (round-5 review, task 7b)
+    $0 latency $TAG f16x3 > gpurun_out/latency_$TAG.log 2>&1; $0 latency $TAG bf16x3 >> gpurun_out/latency_$TAG.log 2>&1
+    cp gpurun_out/${TAG}_latency_*.txt profiles/ 2>/dev/null
     tools/profile_train.sh $TAG > gpurun_out/prof_train_$TAG.log 2>&1
-    python tools/bench_train.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_training_step.json
+    python tools/bench_train.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_line.json
     for loc in 0 0.5 0.75 0.9; do
         timeout 300 python bench.py --emulate-world 8 --locality $loc --steps 7 > gpurun_out/${TAG}_emu8_loc$loc.json 2> gpurun_out/${TAG}_emu8_loc$loc.err
     done

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp
 rm -rf /tmp/pt
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -o s -- python $ROOT/tools/bench_train.py > /tmp/pt.log 2>&1
+HGT_TRAIN_NO_SMALL=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -o s -- python $ROOT/tools/bench_train.py > /tmp/pt.log 2>&1
 tail -2 /tmp/pt.log
 python - <<'PY' > $ROOT/gpurun_out/${TAG}_train_kernel_stats.txt
 import csv, glob
