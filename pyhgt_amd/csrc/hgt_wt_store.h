@@ -13,7 +13,9 @@ typedef float hgt_wt_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_wt16(float* p, float a, float b, float c, float d) {
 #if HGT_WT_STORES
     const hgt_wt_f4 v = {a, b, c, d};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    // (s_nop: a store of more than 64 bits followed by a VALU write of its data registers needs wait states hipcc inserts for its own
+    //  stores and cannot insert behind inline asm -- without them the first build of this header published corrupted rows)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 #else
     *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 #endif
