@@ -218,6 +218,8 @@ def test_merge_pass_fused_with_the_node_update_is_bit_identical(case, precision,
     hgt_linear_update_* as two calls (HGT_FLAG_NO_MERGE_UPDATE): the same merged row bit for bit, the same products in the same
     order; the epilogue's fused multiply-adds are contracted differently by the two kernels and the LayerNorm sums meet in a different
     wavefront order (16 wavefronts x 32 columns instead of 8): last-bit differences only.  Unclaimed relations, unknown node types, one / sixteen heads, 64 .. 512 columns; also against the fp64 closed form."""
+    if HGTConv.EXTRA_KERNEL_FLAGS & _lib.HGT_FLAG_FUSED_ANY_SIZE:
+        pytest.skip("the forced-kernel pass (tools/gpu.sh final) puts the fused sub-tile kernel on every layer: neither form under test runs")
     N, E, d, H, T, R, use_RTE, gk = case
     sd = O.make_state_dict(d, d, T, R, H, use_norm, use_RTE, seed=N + E + 5)
     x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=E + 13, **gk)
