@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_runs_mfma(
     const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
     const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ logits,
     const float* __restrict__ V, const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, float* __restrict__ zrows,
-    float* __restrict__ zstat, unsigned char* __restrict__ zflag, int R, int HT, int raw) {      // raw: `logits` ARE the edge weights (hgt_edge_spmm_items)
+    float* __restrict__ zstat, unsigned char* __restrict__ zflag, int R, int HT, int raw, int items_cap) {      // raw: `logits` ARE the edge weights (hgt_edge_spmm_items)
     using G = AG<VEC, LPH>;
     constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS;
     constexpr int UN = RTE ? (unroll_for<VEC>() * 3) / 4 : unroll_for<VEC>(), HB = UN / 2;
@@ -59,7 +59,6 @@ __global__ __launch_bounds__(256, 2) void k_edge_runs_mfma(
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n_items = hdr->n_items;
 #if HGT_LOGITS_XCD     // XCD-aware item order, see k_edge_logits
     constexpr int XC = 16;
     const int q8 = (int)(blockIdx.x >> 3), vblock = (q8 / XC) * (8 * XC) + (int)(blockIdx.x & 7u) * XC + (q8 % XC);
@@ -67,8 +66,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_runs_mfma(
     const int vblock = blockIdx.x;
 #endif
     const int item = vblock * 4 + wib;
+    const HgtItem it = items[min(item, items_cap - 1)];      // (requested together with the header's item count: see k_edge_logits)
+    const int n_items = hdr->n_items;
     if (item >= n_items) return;
-    const HgtItem it = items[item];
     const int beg = __builtin_amdgcn_readfirstlane(it.beg), end = __builtin_amdgcn_readfirstlane(it.end);
     const int rel = __builtin_amdgcn_readfirstlane(it.rel);
     if (rel >= R) return;                      // edges no meta relation claims carry no message: k_merge_runs counts them
@@ -413,6 +413,19 @@ __global__ __launch_bounds__(64 * MU_NW, 4) void k_merge_update(const MergeUpdat
             wm[s_] = *reinterpret_cast<const bf16x8*>(wp + (int64_t)s_ * 2 * W_PLANE_ELEMS + W_PLANE_ELEMS);
         }
     }
+    // the skip rows of this lane's outputs (rows rt0 + 8 q, 4 columns): requested here -- their ids straight from the row list --
+    // so that they travel while the merge runs (behind the slab barrier they cost the epilogue one more exposed round trip)
+    constexpr int NQR = 2 * TPW;        // a lane's rows of the 32-row MFMA tile: rt0 + 8 q, q < NQR
+    const int col_l = ((lane & 31) >> 2) * 4, rt0 = (lane & 3) + 4 * (lane >> 5);
+    const int col = wave * 32 + col_l;
+    const bool col_ok = live && col < n_out;
+    float4 xv[NQR];
+#pragma unroll
+    for (int q = 0; q < NQR; ++q) {
+        const int rt = rt0 + 8 * q;
+        xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col_ok && rt < nrows) xv[q] = *reinterpret_cast<const float4*>(a.xs + (int64_t)a.rows[row0 + rt] * a.ldxs + col);
+    }
     // ---- phase 1: wavefront w merges target rows[row0 + w] (and rows[row0 + 16 + w])
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp) {
@@ -454,20 +467,9 @@ __global__ __launch_bounds__(64 * MU_NW, 4) void k_merge_update(const MergeUpdat
         }
     }
     __syncthreads();
-    // ---- phase 2: out[rows x n_out] = slab x W_a^T; the skip rows are requested first, used after the k loop
-    constexpr int NQR = 2 * TPW;        // a lane's rows of the 32-row MFMA tile: rt0 + 8 q, q < NQR
-    const int col_l = ((lane & 31) >> 2) * 4, rt0 = (lane & 3) + 4 * (lane >> 5);
-    const int col = wave * 32 + col_l;
-    const bool col_ok = live && col < n_out;
+    // ---- phase 2: out[rows x n_out] = slab x W_a^T
     float y[NQR][4];
     if (live) {
-        float4 xv[NQR];
-#pragma unroll
-        for (int q = 0; q < NQR; ++q) {
-            const int orow = s_rid[rt0 + 8 * q];
-            xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (orow >= 0 && col_ok) xv[q] = *reinterpret_cast<const float4*>(a.xs + (int64_t)orow * a.ldxs + col);
-        }
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -566,7 +568,7 @@ static int launch_runs(bool f16, const HgtPlanView& pv, const float* logits, con
     dim3 grid(blocks, (unsigned)(HT / (64 / LPH)));
 #define AGI_LAUNCH(RTE_, F16_)                                                                                                     \
     k_edge_runs_mfma<VEC, LPH, RTE_, F16_><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF, \
-                                                                     zrows, zstat, zflag, R, HT, raw)
+                                                                     zrows, zstat, zflag, R, HT, raw, (int)pv.L.max_items)
     if (rteV) { if (f16) AGI_LAUNCH(true, true); else AGI_LAUNCH(true, false); }
     else      { if (f16) AGI_LAUNCH(false, true); else AGI_LAUNCH(false, false); }
 #undef AGI_LAUNCH

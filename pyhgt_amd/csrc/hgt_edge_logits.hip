@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_edge_logits(
     const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
     const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ Q,
     const float* __restrict__ K, const float* __restrict__ rteK, const float* __restrict__ attT, float* __restrict__ logits, int R,
-    int HT, int rel_lo, int rel_hi, int item_lo, int item_hi) {
+    int HT, int rel_lo, int rel_hi, int item_lo, int item_hi, int items_cap) {
     // A wave covers DP = 64*VEC consecutive floats of a row = H = 64/LPH heads.  When the row has more heads (HT > H),
     // blockIdx.y selects the head group: used when the full-width relation fragment (dk_pad*vec floats per lane) would
     // not fit in registers (d = 512: 512 floats) -- narrower slices keep it register-resident.
@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void k_edge_logits(
     // (adjacent in the item list) all read the tile's Q rows.  The XCDs take runs of 16 consecutive item groups in turn, so a
     // tile's items meet in one L2 at about the same time instead of pulling the tile through eight of them (HGT_LOGITS_XCD=0:
     // the plain order; gridDim.x is a multiple of 128)
-    const int n_items = item_hi >= 0 ? item_hi : hdr->n_items;      // (item_lo, item_hi): the items of a target block, or (0, -1)
+    // (the item is requested TOGETHER with the header's item count -- index clamped to the table -- not behind it: one dependent
+    //  round trip less in front of every wavefront's first row; sampled batches are a chain of such round trips, r6)
 #if HGT_LOGITS_XCD
     // (chunks of HGT_XCD_CHUNK workgroups, dealt to the XCDs in turn: contiguous EIGHTHS of the list put all the heavy items of a
     //  skewed graph -- its hub tiles come first -- on one XCD: Zipf(0.8) logits 2.2 -> 3.2 ms)
@@ -63,8 +64,9 @@ __global__ __launch_bounds__(256) void k_edge_logits(
     const int vblock = blockIdx.x;
 #endif
     const int item = item_lo + vblock * 4 + wib;
+    const HgtItem it = items[min(item, items_cap - 1)];
+    const int n_items = item_hi >= 0 ? item_hi : hdr->n_items;      // (item_lo, item_hi): the items of a target block, or (0, -1)
     if (item >= n_items) return;
-    const HgtItem it = items[item];
     const int beg = __builtin_amdgcn_readfirstlane(it.beg), end = __builtin_amdgcn_readfirstlane(it.end);
     const int rel = __builtin_amdgcn_readfirstlane(it.rel);
     const int h = lane / LPH, p = lane % LPH;
@@ -223,13 +225,13 @@ struct LaunchLogits {
         dim3 grid(blocks, (unsigned)(HT / (64 / LPH)));
         if (small32 && grid.y == 1) {
             if (rteK)
-                k_edge_logits<VEC, LPH, true, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi, item_lo, item_hi);
+                k_edge_logits<VEC, LPH, true, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi, item_lo, item_hi, (int)pv.L.max_items);
             else
-                k_edge_logits<VEC, LPH, false, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi, item_lo, item_hi);
+                k_edge_logits<VEC, LPH, false, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi, item_lo, item_hi, (int)pv.L.max_items);
         } else if (rteK)
-            k_edge_logits<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi, item_lo, item_hi);
+            k_edge_logits<VEC, LPH, true><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi, item_lo, item_hi, (int)pv.L.max_items);
         else
-            k_edge_logits<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi, item_lo, item_hi);
+            k_edge_logits<VEC, LPH, false><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attT, logits, R, HT, rel_lo, rel_hi, item_lo, item_hi, (int)pv.L.max_items);
         return HGT_OK;
     }
 };

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_logits_mfma(
     const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
     const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ Q,
     const float* __restrict__ K, const float* __restrict__ rteK, const unsigned short* __restrict__ attF, float* __restrict__ logits,
-    int R, int HT, int rel_lo, int rel_hi, int item_lo, int item_hi) {
+    int R, int HT, int rel_lo, int rel_hi, int item_lo, int item_hi, int items_cap) {
     using G = LG<VEC, LPH>;
     constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS, QS = G::QS;
     constexpr int UN = RTE ? (unroll_for<VEC>() * 3) / 4 : unroll_for<VEC>(), HB = UN / 2;
@@ -65,7 +65,6 @@ __global__ __launch_bounds__(256, 2) void k_edge_logits_mfma(
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n_items = item_hi >= 0 ? item_hi : hdr->n_items;      // (item_lo, item_hi): the items of a target block, or (0, -1)
 #if HGT_LOGITS_XCD     // XCD-aware item order, see k_edge_logits
     // (chunks of HGT_XCD_CHUNK workgroups, dealt to the XCDs in turn: contiguous EIGHTHS of the list put all the heavy items of a
     //  skewed graph -- its hub tiles come first -- on one XCD: Zipf(0.8) logits 2.2 -> 3.2 ms)
@@ -75,8 +74,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_logits_mfma(
     const int vblock = blockIdx.x;
 #endif
     const int item = item_lo + vblock * 4 + wib;
+    const HgtItem it = items[min(item, items_cap - 1)];              // (requested together with the header's item count: see k_edge_logits)
+    const int n_items = item_hi >= 0 ? item_hi : hdr->n_items;      // (item_lo, item_hi): the items of a target block, or (0, -1)
     if (item >= n_items) return;
-    const HgtItem it = items[item];
     const int beg = __builtin_amdgcn_readfirstlane(it.beg), end = __builtin_amdgcn_readfirstlane(it.end);
     const int rel = __builtin_amdgcn_readfirstlane(it.rel);
     if (rel < rel_lo || rel >= rel_hi) return;
@@ -267,7 +267,7 @@ static int launch_logits_mfma(bool f16, const HgtPlanView& pv, const float* Q, c
     dim3 grid(blocks, (unsigned)(HT / (64 / LPH)));
 #define LGM_LAUNCH(RTE_, F16_)                                                                                                   \
     k_edge_logits_mfma<VEC, LPH, RTE_, F16_><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, Q, K, rteK, attF, \
-                                                                       logits, R, HT, rel_lo, rel_hi, item_lo, item_hi)
+                                                                       logits, R, HT, rel_lo, rel_hi, item_lo, item_hi, (int)pv.L.max_items)
     if (rteK) { if (f16) LGM_LAUNCH(true, true); else LGM_LAUNCH(true, false); }
     else      { if (f16) LGM_LAUNCH(false, true); else LGM_LAUNCH(false, false); }
 #undef LGM_LAUNCH
