@@ -495,6 +495,90 @@ extern "C" int hgt_plan_tile_items_offset(int64_t n_nodes, int64_t n_edges, int3
     return HGT_OK;
 }
 
+// ---- small graphs through the wire format of the reference (hgt_plan_build on a sampled batch: every training batch is a NEW
+// graph, data.py:212-256 -> model.py:69): the radix build was 25 launches of ~4.8 us each at c3 (r6 timeline, tools/lab/trace_plan.py).
+// Two single-workgroup kernels take ten of them:
+// (a) the typed row lists (all nodes / target nodes) as a STABLE counting sort by node type -- bucket by bucket, a block scan per
+//     bucket: the same lists as the two stable radix sorts of (type, node id) pairs, for N <= 65 536 and T <= 30
+constexpr int SMALL_ROWS_N = 65536, SMALL_ROWS_T = 30;
+__global__ __launch_bounds__(1024) void k_node_rows_small(const int64_t* __restrict__ ntype, int64_t N, int64_t NQ, int T,
+                                                           int32_t* __restrict__ rows_all, int32_t* __restrict__ off_all,
+                                                           int32_t* __restrict__ rows_q, int32_t* __restrict__ off_q, HgtPlanHeader* hdr) {
+    __shared__ int s_a[16], s_b[16];
+    __shared__ unsigned char s_key[SMALL_ROWS_N];      // the nodes' buckets, read once (coalesced) from the int64 type array
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int64_t n = tid; n < N; n += 1024) {
+        const int64_t ty = ntype[n];
+        s_key[n] = (unsigned char)((ty >= 0 && ty < T) ? (int)ty : T);
+    }
+    __syncthreads();
+    const int64_t per = (N + 1023) / 1024;
+    const int64_t beg = min((int64_t)tid * per, N), end = min(beg + per, N);
+    int base_a = 0, base_q = 0;
+    for (int t = 0; t <= T; ++t) {      // bucket T = nodes whose type no layer knows
+        int ca = 0, cq = 0;
+        for (int64_t n = beg; n < end; ++n) {
+            const int key = s_key[n];
+            if (key == t) { ++ca; if (n < NQ) ++cq; }
+        }
+        // block exclusive scan of (ca, cq): wavefront scans + the sixteen wavefront totals
+        int ia = ca, iq = cq;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int va = __shfl_up(ia, o), vq = __shfl_up(iq, o);
+            if (lane >= o) { ia += va; iq += vq; }
+        }
+        if (lane == 63) { s_a[wave] = ia; s_b[wave] = iq; }
+        __syncthreads();
+        int wa = 0, wq = 0, tot_a = 0, tot_q = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int va = s_a[w], vq = s_b[w];
+            if (w < wave) { wa += va; wq += vq; }
+            tot_a += va; tot_q += vq;
+        }
+        int pa = base_a + wa + ia - ca, pq = base_q + wq + iq - cq;
+        for (int64_t n = beg; n < end; ++n) {
+            const int key = s_key[n];
+            if (key == t) { rows_all[pa++] = (int32_t)n; if (n < NQ) rows_q[pq++] = (int32_t)n; }
+        }
+        if (tid == 0) { off_all[t] = base_a; off_q[t] = base_q; }
+        base_a += tot_a; base_q += tot_q;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        off_all[T + 1] = base_a;
+        off_q[T + 1] = base_q;
+        hdr->n_unknown_q = off_q[T + 1] - off_q[T];
+    }
+}
+
+// (b) per-pair item counts + their exclusive scan in one workgroup (k_pair_counts + rocprim::exclusive_scan: three launches)
+__global__ __launch_bounds__(1024) void k_pair_scan_small(const int32_t* __restrict__ segptr, int64_t n_pairs, int ch,
+                                                           int32_t* __restrict__ pair_off) {
+    __shared__ int s_a[16];
+    const int tid = threadIdx.x;
+    const int64_t n = n_pairs + 1, per = (n + 1023) / 1024;
+    const int64_t beg = min((int64_t)tid * per, n), end = min(beg + per, n);
+    int tot = 0;
+    for (int64_t j = beg; j < end; ++j) tot += (j < n_pairs) ? (segptr[(j + 1) * HGT_TD] - segptr[j * HGT_TD] + ch - 1) / ch : 0;
+    int inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o);
+        if ((tid & 63) >= o) inc += v;
+    }
+    if ((tid & 63) == 63) s_a[tid >> 6] = inc;
+    __syncthreads();
+    int wsum = 0;
+    for (int w = 0; w < (tid >> 6); ++w) wsum += s_a[w];
+    int run = wsum + inc - tot;
+    for (int64_t j = beg; j < end; ++j) {
+        pair_off[j] = run;
+        run += (j < n_pairs) ? (segptr[(j + 1) * HGT_TD] - segptr[j * HGT_TD] + ch - 1) / ch : 0;
+    }
+}
+
 extern "C" int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int64_t stride_col,
                               const int64_t* edge_type, const int64_t* edge_time, const int64_t* node_type,
                               int64_t N, int64_t NQ, int64_t E, int32_t T, int32_t R,
@@ -549,27 +633,35 @@ extern "C" int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int
                                                    eid, esrc, edst, ertei, hdr);
     }
     k_segptr<<<nblk(L.n_bins + 1, BS), BS, 0, stream>>>(keys_out, E, L.n_bins, segptr);
-    k_pair_counts<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(segptr, L.n_pairs, hgt_item_edges(E), pair_cnt);
-    sort_bytes = (size_t)tl.sort_tmp_bytes;
-    if (rocprim::exclusive_scan(sort_tmp, sort_bytes, pair_cnt, pair_off, 0, (size_t)(L.n_pairs + 1),
-                                rocprim::plus<int32_t>(), stream) != hipSuccess) return HGT_ERR_LAUNCH;
+    if (L.n_pairs + 1 <= 65536) {      // sampled batches: counts + scan in one workgroup
+        k_pair_scan_small<<<1, 1024, 0, stream>>>(segptr, L.n_pairs, hgt_item_edges(E), pair_off);
+    } else {
+        k_pair_counts<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(segptr, L.n_pairs, hgt_item_edges(E), pair_cnt);
+        sort_bytes = (size_t)tl.sort_tmp_bytes;
+        if (rocprim::exclusive_scan(sort_tmp, sort_bytes, pair_cnt, pair_off, 0, (size_t)(L.n_pairs + 1),
+                                    rocprim::plus<int32_t>(), stream) != hipSuccess) return HGT_ERR_LAUNCH;
+    }
     k_items<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(segptr, pair_off, L.n_pairs, R, hgt_item_edges(E), items, tile_items, hdr);
     if (N > 0) k_hub_detect<<<nblk(N, BS), BS, 0, stream>>>(segptr, N, R, hub_slot, hub_list, hdr);
 
     // typed row lists: all nodes, and target nodes [0, NQ)
-    if (N > 0) {
-        k_node_keys<<<nblk(N, BS), BS, 0, stream>>>(node_type, N, T, nkeys_in, nvals_in);
-        sort_bytes = (size_t)tl.sort_tmp_bytes;
-        if (rocprim::radix_sort_pairs(sort_tmp, sort_bytes, nkeys_in, nkeys_out, nvals_in, rows_all, (size_t)N, 0,
-                                      key_bits((uint64_t)T + 1), stream) != hipSuccess) return HGT_ERR_LAUNCH;
+    if (N > 0 && N <= SMALL_ROWS_N && T <= SMALL_ROWS_T) {      // sampled batches: one workgroup (same lists as the stable sorts below)
+        k_node_rows_small<<<1, 1024, 0, stream>>>(node_type, N, NQ, T, rows_all, off_all, rows_q, off_q, hdr);
+    } else {
+        if (N > 0) {
+            k_node_keys<<<nblk(N, BS), BS, 0, stream>>>(node_type, N, T, nkeys_in, nvals_in);
+            sort_bytes = (size_t)tl.sort_tmp_bytes;
+            if (rocprim::radix_sort_pairs(sort_tmp, sort_bytes, nkeys_in, nkeys_out, nvals_in, rows_all, (size_t)N, 0,
+                                          key_bits((uint64_t)T + 1), stream) != hipSuccess) return HGT_ERR_LAUNCH;
+        }
+        k_type_offsets<<<1, 256, 0, stream>>>(nkeys_out, N, T, off_all, nullptr);
+        if (NQ > 0) {
+            sort_bytes = (size_t)tl.sort_tmp_bytes;
+            if (rocprim::radix_sort_pairs(sort_tmp, sort_bytes, nkeys_in, nkeys_out, nvals_in, rows_q, (size_t)NQ, 0,
+                                          key_bits((uint64_t)T + 1), stream) != hipSuccess) return HGT_ERR_LAUNCH;
+        }
+        k_type_offsets<<<1, 256, 0, stream>>>(nkeys_out, NQ, T, off_q, hdr);
     }
-    k_type_offsets<<<1, 256, 0, stream>>>(nkeys_out, N, T, off_all, nullptr);
-    if (NQ > 0) {
-        sort_bytes = (size_t)tl.sort_tmp_bytes;
-        if (rocprim::radix_sort_pairs(sort_tmp, sort_bytes, nkeys_in, nkeys_out, nvals_in, rows_q, (size_t)NQ, 0,
-                                      key_bits((uint64_t)T + 1), stream) != hipSuccess) return HGT_ERR_LAUNCH;
-    }
-    k_type_offsets<<<1, 256, 0, stream>>>(nkeys_out, NQ, T, off_q, hdr);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }
