@@ -170,8 +170,8 @@ __global__ __launch_bounds__(64 * NW, (KPAN == 64 && RT == 1 && CT == 1) ? 4 : 2
     for (int j = 0; j < NL; ++j) {
         rscale[j] = 1.0f;
         if constexpr (F16) {
-#pragma unroll
-            for (int o = 1; o < LPR; o <<= 1) mb[j] = max(mb[j], (unsigned)__shfl_xor((int)mb[j], o));
+            mb[j] = row16_max_bits(mb[j]);      // (a row's panel slice = LPR = 16 or 32 lanes: one or two DPP rows)
+            if constexpr (LPR == 32) mb[j] = max(mb[j], (unsigned)__shfl_xor((int)mb[j], 16));
             float inv;
             f16_row_scale(mb[j], rscale[j], inv);
             if ((lane % LPR) == 0) s_rinv[(j * NW + wave) * RPI + lrow] = inv;
@@ -496,8 +496,7 @@ __global__ __launch_bounds__(512, 2) void k_tile_linear_stream(const TileArgs a)
             v.w = (row_ok && kk_ + 3 < k) ? v.w : 0.f;                                                                  \
             float scale = 1.0f;                                                                                         \
             if constexpr (F16) {                                                                                        \
-                unsigned mb = abs_bits4(v);                                                                             \
-                _Pragma("unroll") for (int o = 1; o < LPR; o <<= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o));     \
+                const unsigned mb = row16_max_bits(abs_bits4(v));      /* (LPR = 16: the row's panel sits in one DPP row) */ \
                 float inv;                                                                                              \
                 f16_row_scale(mb, scale, inv);                                                                          \
                 if ((P) > 0) {                                                                                          \

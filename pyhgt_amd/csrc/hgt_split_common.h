@@ -130,6 +130,15 @@ __device__ __forceinline__ unsigned wave_max_bits(unsigned v) {
     const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
     return max(max(a, b), max(c, d));
 }
+// max over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15) of a NON-NEGATIVE float's bits: every lane of the row gets the result.
+// Four DPP moves -- a __shfl_xor is a ds_bpermute: an LDS round trip per step (the per-panel row maxima of hgt_gemm_tile.hip).
+__device__ __forceinline__ unsigned row16_max_bits(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
 __device__ __forceinline__ unsigned abs_bits4(const float4 v) {
     return __builtin_bit_cast(unsigned, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
 }
