@@ -260,7 +260,10 @@ int hgt_edge_logits(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t 
  * (frag_f16 = 0) or hgt_relation_frag_pack_f16(att_t) (frag_f16 = 1), 16 distinct targets of a work item at a time, 3-term split
  * products like the aggregation's.  The form for d_k >= 64 (the reference's own widths: n_hid 400 / 512 with 8 heads), where the
  * vector-ALU kernel needs a 4-way head-group split and is instruction-bound; layouts it does not cover fall through to
- * hgt_edge_logits (att_t is required for that). */
+ * hgt_edge_logits (att_t is required for that).
+ * frag_f16 bits (ABI 7, here and in hgt_edge_aggregate_items[_update]): bit 0 = the fp16 images; for d_k >= 64 and the 16-edge work
+ * items of a sampled batch the four wavefronts of a workgroup SHARE the relation transform (a quarter of the fragment image each, kept
+ * in registers while consecutive items share the relation; same result bit for bit): bit 1 = never, bit 2 = for larger items too. */
 int hgt_edge_logits_mfma(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                          int32_t n_heads, int32_t dk_pad, const float* Q, const float* K, const float* rte_k,
                          const float* att_t, const void* att_frag, int32_t frag_f16, float* logits, void* stream);
@@ -608,6 +611,11 @@ typedef struct hgt_conv_args {
                                       * kernel (HGT_LINEAR_NO_TILE): bit-identical results; tests / A/B timings */
 #define HGT_FLAG_NO_MERGE_UPDATE 8192 /* ABI 7: sampled batches: hgt_edge_aggregate_items + hgt_linear_update_* as two calls instead of
                                       * hgt_edge_aggregate_items_update (identical output; tests / A/B timings) */
+#define HGT_FLAG_NO_COOP_EDGE 16384  /* ABI 7: d_k >= 64: the one-wavefront-per-item forms of hgt_edge_logits_mfma / the runs kernel of
+                                      * hgt_edge_aggregate_items instead of the forms that share the relation transform across the workgroup
+                                      * (identical output bit for bit; tests / A/B timings).  The same switch is bit 1 of `frag_f16` of those calls */
+#define HGT_FLAG_COOP_EDGE_ALWAYS 32768 /* ... the shared-transform forms for work items of more than 16 edges too (default: the 16-edge items
+                                      * of sampled batches only; larger items measured slower in lock-step rounds).  Bit 2 of `frag_f16` */
 #define HGT_FLAG_RING_AGGREGATE 512 /* LAB builds only (hgt_build_features() & HGT_FEATURE_LAB_KERNELS; ignored otherwise): the LDS-ring form of the fused
                                      * aggregation kernel (round 5, csrc/lab/hgt_edge_agg_ring.h: rows by LDS-DMA, U tile in registers) where it exists
                                      * (d = 256 / 8 heads, no temporal rows, bf16 split): bit-identical, measured 9 % slower at c2 */

@@ -26,6 +26,8 @@ HGT_FLAG_XS_GEMM_ALWAYS = 1024
 HGT_FLAG_XS_GEMM_NEVER = 2048
 HGT_FLAG_NO_TILE_GEMM = 4096
 HGT_FLAG_NO_MERGE_UPDATE = 8192
+HGT_FLAG_NO_COOP_EDGE = 16384
+HGT_FLAG_COOP_EDGE_ALWAYS = 32768
 HGT_LINEAR_FORCE_XS = 0x100
 HGT_LINEAR_NO_XS = 0x200
 HGT_LINEAR_NO_TILE = 0x400

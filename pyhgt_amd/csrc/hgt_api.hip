@@ -207,6 +207,7 @@ extern "C" int hgt_conv_forward(const hgt_conv_args* a, void* stream_) {
     // precision 2 (fp16 hi/lo split, include/hgt_hip.h): whole-layer calls only -- the staged multi-GPU calls share one prepared
     // image between a sliced edge phase (whose state does not carry the fp16 row scales) and the rest, and stay on precision 1
     const bool f16 = (a->precision == 2);
+    const int fmode = (f16 ? 1 : 0) | ((a->flags & HGT_FLAG_NO_COOP_EDGE) ? 2 : 0) | ((a->flags & HGT_FLAG_COOP_EDGE_ALWAYS) ? 4 : 0);      // `frag_f16` of the item kernels
     if (f16 && a->stage != 0) return HGT_ERR_UNSUPPORTED;
     if (dense && (!a->mid_w || !a->mid_b || !a->out_w || !a->out_b || !a->out_ln_w || !a->out_ln_b)) return HGT_ERR_INVALID_ARG;
     hgt_layout lay;
@@ -448,7 +449,7 @@ edge_phase:
     // (4) edge phase: logits, then softmax fused into the aggregation (online, per target sub-tile)
     if (E > 0 && !agg_done) {
         rc = sliced ? hgt_edge_logits_slice(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, sl_lo, sl_hi, stream)
-             : mfma_logits ? hgt_edge_logits_mfma(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, att_f, f16 ? 1 : 0, logits, stream)
+             : mfma_logits ? hgt_edge_logits_mfma(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, att_f, fmode, logits, stream)
                            : hgt_edge_logits(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, logits, stream);
         if (rc != HGT_OK) return rc;
     }
@@ -493,7 +494,7 @@ edge_phase:
             rc = split_weights(a->w_a, (int64_t)dout * dp, T, dp, dout, ws_upd, stream);
             if (rc != HGT_OK) return rc;
         }
-        rc = hgt_edge_aggregate_items_update(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_f, f16 ? 1 : 0, NQ, wb + w.off_zitems,
+        rc = hgt_edge_aggregate_items_update(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_f, fmode, NQ, wb + w.off_zitems,
                                              w.zitems_bytes, pr.rows_q, pr.off_q, T, ws_upd, a->b_a, a->x, din, a->skip, a->ln_w, a->ln_b,
                                              a->use_norm, dout, a->out, stream);
         if (rc == HGT_OK) {
@@ -512,7 +513,7 @@ edge_phase:
         if (rc != HGT_ERR_UNSUPPORTED) return rc;
     }
     if (items_agg && !agg_done)
-        rc = hgt_edge_aggregate_items(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_f, f16 ? 1 : 0, agg, NQ, dense ? 0 : 1,
+        rc = hgt_edge_aggregate_items(a->plan, N, E, T, R, H, lay.dk_pad, logits, V, rte_v, msg_f, fmode, agg, NQ, dense ? 0 : 1,
                                       wb + w.off_zitems, w.zitems_bytes, stream);
     if (rc != HGT_ERR_UNSUPPORTED) {
         // (done, or a real error)

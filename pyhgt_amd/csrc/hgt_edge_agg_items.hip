@@ -21,6 +21,9 @@
 #ifndef HGT_LOGITS_XCD
 #define HGT_LOGITS_XCD 1
 #endif
+#ifndef HGT_COOP_PREFETCH
+#define HGT_COOP_PREFETCH 0      // measured: c5 runs 40.6 vs 38.8 us with the first relation's fragments requested up front
+#endif
 #ifndef HGT_AGI_GS
 #define HGT_AGI_GS 8      // column-tile steps whose fragments are requested together (16 loads in flight)
 #endif
@@ -233,6 +236,232 @@ __global__ __launch_bounds__(256, 2) void k_edge_runs_mfma(
             __builtin_amdgcn_wave_barrier();         // the tile / position table are rewritten by the next group
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+    }
+}
+
+// k_edge_runs_mfma with the TRANSFORM shared by the workgroup (see k_edge_logits_coop: same reason, same split).  Every wavefront
+// walks the runs of its own work item and parks them in its tile; then wavefront w is the column tiles [w NCT/4, (w + 1) NCT/4) of
+// z^T = fragments x u^T for the tiles of all four -- a quarter of the relation's image in registers, re-requested only when the
+// relation changes between consecutive items.  Rows, statistics and flags are the single-wavefront kernel's, bit for bit.
+__device__ __forceinline__ void coop_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int VEC, int LPH, bool RTE, bool F16>
+__global__ __launch_bounds__(256, 2) void k_edge_runs_coop(
+    const HgtItem* __restrict__ items, const HgtPlanHeader* __restrict__ hdr, const int32_t* __restrict__ esrc,
+    const int32_t* __restrict__ edst, const uint16_t* __restrict__ ertei, const float* __restrict__ logits,
+    const float* __restrict__ V, const float* __restrict__ rteV, const unsigned short* __restrict__ msgF, float* __restrict__ zrows,
+    float* __restrict__ zstat, unsigned char* __restrict__ zflag, int R, int HT, int raw, int items_cap) {
+    using G = AG<VEC, LPH>;
+    constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS;
+    constexpr int UN = RTE ? (unroll_for<VEC>() * 3) / 4 : unroll_for<VEC>(), HB = UN / 2;
+    constexpr int CTW = NCT / 4, SW = CTW * NKS;
+    static_assert(NCT % 4 == 0 && SW <= 8, "a wavefront's share of the fragment image stays in registers");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4][2 * G::PLANE];
+    __shared__ int s_pos[4][16];
+    __shared__ int s_rel[4], s_nrows[4];
+    __shared__ float s_rinv[F16 ? 4 : 1][16];
+
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if HGT_LOGITS_XCD
+    constexpr int XC = 16;
+    const int q8 = (int)(blockIdx.x >> 3), vblock = (q8 / XC) * (8 * XC) + (int)(blockIdx.x & 7u) * XC + (q8 % XC);
+#else
+    const int vblock = blockIdx.x;
+#endif
+    const int item = vblock * 4 + wib;
+    const HgtItem it = items[min(item, items_cap - 1)];
+    const int n_items = hdr->n_items;
+    const int beg = __builtin_amdgcn_readfirstlane(it.beg), end = __builtin_amdgcn_readfirstlane(it.end);
+    const int rel = __builtin_amdgcn_readfirstlane(it.rel);
+    bool more = item < n_items && rel < R && beg < end;      // (edges no meta relation claims carry no message: k_merge_runs counts them)
+    const int hg = blockIdx.y;
+    const int64_t ld = (int64_t)HT * DKP;
+    const int co = hg * DP, NY = HT / H;
+    const int h = lane / LPH, p = lane % LPH;
+
+    unsigned char* tile = smem[wib];
+    const int fi = lane & 15, fg = lane >> 4;
+    const int wb = lane * VEC * 2;
+    const int rrow = fi * ROWB;
+    float minv = 1.0f;
+    if constexpr (F16) minv = reinterpret_cast<const float*>(msgF + (int64_t)R * NY * NCT * NKS * 2 * 512)[0];
+
+    bf16x8 fh[SW], fm[SW];
+#pragma unroll
+    for (int j = 0; j < SW; ++j) fh[j] = fm[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    int have = -1;
+#if HGT_COOP_PREFETCH     // (see k_edge_logits_coop)
+    {
+        const int rel0 = __builtin_amdgcn_readfirstlane(items[min(item - wib, items_cap - 1)].rel);
+        if (rel0 >= 0 && rel0 < R) {
+            have = rel0;
+            const unsigned short* mf = msgF + ((((int64_t)have * NY + hg) * NCT + wib * CTW) * NKS) * 2 * 512 + lane * 8;
+#pragma unroll
+            for (int j = 0; j < SW; ++j) {
+                fh[j] = *reinterpret_cast<const bf16x8*>(mf + (int64_t)(j * 2) * 512);
+                fm[j] = *reinterpret_cast<const bf16x8*>(mf + (int64_t)(j * 2 + 1) * 512);
+            }
+        }
+    }
+#endif
+    int base = beg - 64, t0 = 0, nd = 0, nb = 0;
+    int my_src = 0, my_rte = 0, my_slot = 0;
+    bool lead = false;
+
+    for (;;) {
+        const bool active = more;
+        int nrows = 0;
+        if (active) {
+            if (t0 >= nd) {
+                base += 64;
+                nb = min(64, end - base);
+                const int li = base + min(lane, nb - 1);
+                my_src = esrc[li];
+                const int my_dst = edst[li];
+                my_rte = RTE ? (int)ertei[li] : 0;
+                const int prev_dst = __shfl_up(my_dst, 1);
+                lead = (lane == 0) || (my_dst != prev_dst);
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(lead);
+                my_slot = __builtin_popcountll(mask & (~0ull >> (63 - lane))) - 1;
+                nd = __builtin_popcountll(mask);
+                if (hg == 0 && lane < nb) zflag[base + lane] = lead ? 1 : 0;
+                t0 = 0;
+            }
+            const unsigned long long in_g = __builtin_amdgcn_ballot_w64(my_slot >= t0 && my_slot < t0 + 16 && lane < nb);
+            const int e_lo = __builtin_ctzll(in_g), e_end = e_lo + __builtin_popcountll(in_g);
+            nrows = min(16, nd - t0);
+            if (lead && my_slot >= t0 && my_slot < t0 + 16) s_pos[wib][my_slot - t0] = base + lane;
+
+            int cur_r = -1, cur_pos = 0;
+            float U[VEC], m_run = HGT_NEG, l_run = 0.0f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) U[i] = 0.0f;
+            auto flush = [&]() {
+                if (cur_r < 0) return;
+                float scale = 1.0f;
+                if constexpr (F16) {
+                    float inv;
+                    f16_row_scale(wave_max_bits(abs_bits_v<VEC>(U)), scale, inv);
+                    if (lane == 0) s_rinv[wib][cur_r] = inv;
+                }
+                unsigned char* w = tile + cur_r * ROWB + ((((wb >> 4) ^ (cur_r & (NS - 1)))) << 4) + (wb & 15);
+                if constexpr (VEC == 1) {
+                    unsigned short hi, mid;
+                    split1_t<F16>(U[0], scale, hi, mid);
+                    *reinterpret_cast<unsigned short*>(w) = hi;
+                    *reinterpret_cast<unsigned short*>(w + G::PLANE) = mid;
+                } else if constexpr (VEC == 2) {
+                    unsigned hi, mid;
+                    split2_t<F16>(U[0], U[1], scale, hi, mid);
+                    *reinterpret_cast<unsigned*>(w) = hi;
+                    *reinterpret_cast<unsigned*>(w + G::PLANE) = mid;
+                } else {
+                    uint2 hi, mid;
+                    split4_t<F16>(make_float4(U[0], U[1], U[2], U[3]), scale, hi, mid);
+                    *reinterpret_cast<uint2*>(w) = hi;
+                    *reinterpret_cast<uint2*>(w + G::PLANE) = mid;
+                }
+                if (p == 0) *reinterpret_cast<float2*>(zstat + ((int64_t)cur_pos * HT + hg * H + h) * 2) = make_float2(m_run, l_run);
+            };
+            float vrA[HB][VEC], trA[RTE ? HB : 1][VEC], slA[HB], vrB[HB][VEC], trB[RTE ? HB : 1][VEC], slB[HB];
+#define AGC_ISSUE(VR, TR, SL, I0)                                                                  \
+    _Pragma("unroll") for (int u = 0; u < HB; ++u) {                                               \
+        const int idx = min((I0) + u, e_end - 1);                                                  \
+        const int s_ = __builtin_amdgcn_readlane(my_src, idx);                                     \
+        load_vec<VEC>(V + (int64_t)s_ * ld + co + lane * VEC, VR[u]);                              \
+        SL[u] = logits[(int64_t)(base + idx) * HT + hg * H + h];                                   \
+        if constexpr (RTE) {                                                                       \
+            const int ri = __builtin_amdgcn_readlane(my_rte, idx);                                 \
+            load_vec<VEC>(rteV + (int64_t)ri * ld + co + lane * VEC, TR[u]);                       \
+        }                                                                                          \
+    }
+#define AGC_PROCESS(VR, TR, SL, I0)                                                                \
+    _Pragma("unroll") for (int u = 0; u < HB; ++u) {                                               \
+        if ((I0) + u < e_end) {                                                                    \
+            const int r_ = __builtin_amdgcn_readlane(my_slot, (I0) + u) - t0;                      \
+            if (r_ != cur_r) {                                                                     \
+                flush();                                                                           \
+                cur_r = r_;                                                                        \
+                cur_pos = base + (I0) + u;                                                         \
+                m_run = HGT_NEG;                                                                   \
+                l_run = 0.0f;                                                                      \
+                _Pragma("unroll") for (int i = 0; i < VEC; ++i) U[i] = 0.0f;                       \
+            }                                                                                      \
+            const float m_new = raw ? 0.0f : fmaxf(m_run, SL[u]);                                  \
+            const float sc = raw ? 1.0f : __expf(m_run - m_new), pe = raw ? SL[u] : __expf(SL[u] - m_new); \
+            _Pragma("unroll") for (int i = 0; i < VEC; ++i) {                                      \
+                float vv = VR[u][i];                                                               \
+                if constexpr (RTE) vv += TR[u][i];                                                 \
+                U[i] = fmaf(pe, vv, U[i] * sc);                                                    \
+            }                                                                                      \
+            l_run = fmaf(l_run, sc, pe);                                                           \
+            m_run = m_new;                                                                         \
+        }                                                                                          \
+    }
+            AGC_ISSUE(vrA, trA, slA, e_lo)
+            for (int i0 = e_lo; i0 < e_end; i0 += 2 * HB) {
+                AGC_ISSUE(vrB, trB, slB, i0 + HB)
+                AGC_PROCESS(vrA, trA, slA, i0)
+                AGC_ISSUE(vrA, trA, slA, i0 + 2 * HB)
+                AGC_PROCESS(vrB, trB, slB, i0 + HB)
+            }
+#undef AGC_ISSUE
+#undef AGC_PROCESS
+            flush();
+            t0 += 16;
+            more = (t0 < nd) || (base + 64 < end);
+        }
+        if (lane == 0) {
+            s_rel[wib] = active ? rel : -1;
+            s_nrows[wib] = nrows;
+        }
+        coop_barrier();
+        int rk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rk[k] = __builtin_amdgcn_readfirstlane(s_rel[k]);
+        if ((rk[0] & rk[1] & rk[2] & rk[3]) < 0) break;
+
+        // ---- this wavefront's column tiles of z^T = message fragments x u^T, for the tiles of all four wavefronts
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (rk[k] < 0) continue;
+            if (rk[k] != have) {
+                have = rk[k];
+                const unsigned short* mf = msgF + ((((int64_t)have * NY + hg) * NCT + wib * CTW) * NKS) * 2 * 512 + lane * 8;
+#pragma unroll
+                for (int j = 0; j < SW; ++j) {
+                    fh[j] = *reinterpret_cast<const bf16x8*>(mf + (int64_t)(j * 2) * 512);
+                    fm[j] = *reinterpret_cast<const bf16x8*>(mf + (int64_t)(j * 2 + 1) * 512);
+                }
+            }
+            f32x4 acc[CTW];
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const unsigned char* tk = smem[k] + rrow;
+#pragma unroll
+            for (int j = 0; j < SW; ++j) {
+                const int cc = j / NKS, ks = j % NKS;
+                const int c = wib * CTW + cc;
+                const int kbase = (16 * c / KW) * KW;
+                const int slot = (kbase + 32 * ks) / 8 + fg;
+                const unsigned char* up = tk + ((slot ^ (fi & (NS - 1))) << 4);
+                const bf16x8 uh = *reinterpret_cast<const bf16x8*>(up);
+                const bf16x8 um = *reinterpret_cast<const bf16x8*>(up + G::PLANE);
+                acc[cc] = mfma16_t<F16>(fm[j], uh, acc[cc]);
+                acc[cc] = mfma16_t<F16>(fh[j], um, acc[cc]);
+                acc[cc] = mfma16_t<F16>(fh[j], uh, acc[cc]);
+            }
+            if (fi < s_nrows[k]) {
+                float sc = 1.0f;
+                if constexpr (F16) sc = s_rinv[k][fi] * minv;
+                float* zr = zrows + (int64_t)s_pos[k][fi] * ld + co + 16 * (wib * CTW) + 4 * fg;
+#pragma unroll
+                for (int c = 0; c < CTW; ++c)
+                    store_wt16(zr + 16 * c, acc[c][0] * sc, acc[c][1] * sc, acc[c][2] * sc, acc[c][3] * sc);      // (read by the merge kernel only)
+            }
+        }
+        coop_barrier();               // tiles, positions and scales are rewritten by the next round
     }
 }
 
@@ -562,15 +791,27 @@ __global__ __launch_bounds__(64 * MU_NW, 4) void k_merge_update(const MergeUpdat
 }
 
 template <int VEC, int LPH>
-static int launch_runs(bool f16, const HgtPlanView& pv, const float* logits, const float* V, const float* rteV, const unsigned short* msgF,
+static int launch_runs(int mode, const HgtPlanView& pv, const float* logits, const float* V, const float* rteV, const unsigned short* msgF,
                        float* zrows, float* zstat, unsigned char* zflag, int R, int HT, hipStream_t stream, int raw = 0) {
+    const bool f16 = (mode & 1) != 0;
+    const int item_edges = mode >> 8;
     const unsigned blocks = ((unsigned)((pv.L.max_items + 3) / 4) + 127u) & ~127u;
     dim3 grid(blocks, (unsigned)(HT / (64 / LPH)));
-#define AGI_LAUNCH(RTE_, F16_)                                                                                                     \
-    k_edge_runs_mfma<VEC, LPH, RTE_, F16_><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF, \
-                                                                     zrows, zstat, zflag, R, HT, raw, (int)pv.L.max_items)
-    if (rteV) { if (f16) AGI_LAUNCH(true, true); else AGI_LAUNCH(true, false); }
-    else      { if (f16) AGI_LAUNCH(false, true); else AGI_LAUNCH(false, false); }
+#define AGI_LAUNCH(KERNEL, RTE_, F16_)                                                                                     \
+    KERNEL<VEC, LPH, RTE_, F16_><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF, \
+                                                           zrows, zstat, zflag, R, HT, raw, (int)pv.L.max_items)
+    using G = AG<VEC, LPH>;
+    // d_k >= 64 and 16-edge items: the transform shared by the workgroup (a wavefront's quarter of the fragment image fits its
+    // registers); larger items: a wavefront each (see launch_logits_mfma)
+    if constexpr (G::DKP >= 64 && G::NCT % 4 == 0 && (G::NCT / 4) * G::NKS <= 8) {
+        if (!(mode & 2) && ((mode & 4) || item_edges <= 16)) {
+            if (rteV) { if (f16) AGI_LAUNCH(k_edge_runs_coop, true, true); else AGI_LAUNCH(k_edge_runs_coop, true, false); }
+            else      { if (f16) AGI_LAUNCH(k_edge_runs_coop, false, true); else AGI_LAUNCH(k_edge_runs_coop, false, false); }
+            return HGT_OK;
+        }
+    }
+    if (rteV) { if (f16) AGI_LAUNCH(k_edge_runs_mfma, true, true); else AGI_LAUNCH(k_edge_runs_mfma, true, false); }
+    else      { if (f16) AGI_LAUNCH(k_edge_runs_mfma, false, true); else AGI_LAUNCH(k_edge_runs_mfma, false, false); }
 #undef AGI_LAUNCH
     return HGT_OK;
 }
@@ -634,13 +875,13 @@ static int aggregate_items_impl(const void* plan, int64_t N, int64_t E, int32_t 
     if (vec_full / sp > 4) return HGT_ERR_UNSUPPORTED;
     const int vec = vec_full / sp, lphs = lph * sp;
     if (E > 0 && spa) {
-        int rc = hgt_launch_single_pass_runs(vec, lphs, frag_f16 != 0, pv, spa->Q, spa->K, V, spa->rte_k, rte_v, (const unsigned short*)spa->att_frag,
+        int rc = hgt_launch_single_pass_runs(vec, lphs, (frag_f16 & 1) != 0, pv, spa->Q, spa->K, V, spa->rte_k, rte_v, (const unsigned short*)spa->att_frag,
                                              (const unsigned short*)msg_frag, zrows, zstat, zflag, (int)R, (int)H, stream);
         if (rc != HGT_OK) return rc;
     } else if (E > 0) {
         int rc = HGT_ERR_UNSUPPORTED;
 #define AGI_CASE(V_, L_) \
-        if (vec == V_ && lphs == L_) rc = launch_runs<V_, L_>(frag_f16 != 0, pv, logits, V, rte_v, (const unsigned short*)msg_frag, zrows, zstat, zflag, (int)R, (int)H, stream, apply_gelu == 2 ? 1 : 0);
+        if (vec == V_ && lphs == L_) rc = launch_runs<V_, L_>((frag_f16 & 7) | (hgt_item_edges(E) << 8), pv, logits, V, rte_v, (const unsigned short*)msg_frag, zrows, zstat, zflag, (int)R, (int)H, stream, apply_gelu == 2 ? 1 : 0);
 #ifdef HGT_DEV_LAYOUTS
         AGI_CASE(4, 8) AGI_CASE(4, 16) AGI_CASE(1, 16)
 #else
@@ -664,10 +905,10 @@ static int aggregate_items_impl(const void* plan, int64_t N, int64_t E, int32_t 
 #define AGI_MU(VF)                                                                                      \
         do {                                                                                            \
             if (tpw == 1) {                                                                             \
-                if (frag_f16) k_merge_update<VF, true, 1><<<ugrid, 64 * MU_NW, 0, stream>>>(m);         \
+                if (frag_f16 & 1) k_merge_update<VF, true, 1><<<ugrid, 64 * MU_NW, 0, stream>>>(m);         \
                 else k_merge_update<VF, false, 1><<<ugrid, 64 * MU_NW, 0, stream>>>(m);                 \
             } else {                                                                                    \
-                if (frag_f16) k_merge_update<VF, true, 2><<<ugrid, 64 * MU_NW, 0, stream>>>(m);         \
+                if (frag_f16 & 1) k_merge_update<VF, true, 2><<<ugrid, 64 * MU_NW, 0, stream>>>(m);         \
                 else k_merge_update<VF, false, 2><<<ugrid, 64 * MU_NW, 0, stream>>>(m);                 \
             }                                                                                           \
         } while (0)

@@ -250,7 +250,7 @@ extern "C" int hgt_relation_pack(const float* relation_att, const float* relatio
 }
 
 // hgt_edge_logits_mfma.hip
-int hgt_launch_logits_mfma(int vec, int lph, bool f16, const HgtPlanView& pv, const float* Q, const float* K, const float* rteK,
+int hgt_launch_logits_mfma(int vec, int lph, int mode, const HgtPlanView& pv, const float* Q, const float* K, const float* rteK,
                            const unsigned short* attF, float* logits, int R, int HT, int rel_lo, int rel_hi, int item_lo, int item_hi, hipStream_t stream);
 
 // head-group split of the matrix-core kernels (hgt_edge_agg_mfma.hip): the wave's slice must be <= 256 columns
@@ -272,7 +272,7 @@ static int edge_logits_impl(const void* plan, int64_t N, int64_t E, int32_t T, i
     if (att_frag) {      // target-side transforms on the matrix cores; layouts it does not cover take the vector-ALU kernel below
         const int spm = mfma_logits_split_for(dk_pad / lph, lph);
         if (spm != 0) {
-            int rc = hgt_launch_logits_mfma(dk_pad / lph / spm, lph * spm, frag_f16 != 0, pv, Q, K, rte_k, (const unsigned short*)att_frag,
+            int rc = hgt_launch_logits_mfma(dk_pad / lph / spm, lph * spm, (frag_f16 & 7) | (hgt_item_edges(E) << 8), pv, Q, K, rte_k, (const unsigned short*)att_frag,
                                             logits, (int)R, (int)H, rel_lo, rel_hi, item_lo, item_hi, (hipStream_t)stream);
             if (rc == HGT_OK) HGT_CHECK_LAUNCH();
             if (rc != HGT_ERR_UNSUPPORTED) return rc;

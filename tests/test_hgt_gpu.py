@@ -242,6 +242,48 @@ def test_merge_pass_fused_with_the_node_update_is_bit_identical(case, precision,
     assert err < PREC_TOL[precision]
 
 
+COOP_CASES = ITEM_AGG_CASES[1:3] + [
+    (2000, 20000, 64, 1, 2, 3, True, {}),                         # (1, 64): one column tile per wavefront
+    (3000, 40000, 128, 2, 3, 5, False, {}),                       # (2, 32)
+    (1100, 9000, 256, 2, 2, 7, True, {}),                         # (2, 64) x 2 head groups: d_k = 128, eight fragment steps per wavefront
+    (12000, 600000, 64, 1, 3, 4, True, dict(dst_skew=1.1)),       # 128-edge items: two chunks, several rounds of 16 slots, hub runs
+    (12000, 2200000, 64, 1, 2, 3, False, dict(dst_skew=0.6)),     # 512-edge items: every wavefront of a workgroup walks two chunks of ONE item
+    (15000, 560000, 128, 2, 3, 6, False, {}),                     # 128-edge items, no hubs: the wavefronts of a workgroup run out of slots at different rounds
+]
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("case", COOP_CASES, ids=[str(i) for i in range(len(COOP_CASES))])
+def test_relation_transform_shared_by_the_workgroup_is_bit_identical(case, precision):
+    """Round 6, d_k >= 64: k_edge_logits_coop / k_edge_runs_coop -- the four wavefronts of a workgroup keep their own work items but
+    split the relation transform (conv.py:98-99, 101-102) by columns, a quarter of the fragment image each, kept in registers while
+    consecutive items share the relation -- against the one-wavefront-per-item kernels (HGT_FLAG_NO_COOP_EDGE): the same MFMA
+    products in the same order, so the layer's output is the same bit for bit; also against the fp64 closed form.  16-edge items
+    (sampled batches: the default domain of the shared form) and 128 / 512-edge items (HGT_FLAG_COOP_EDGE_ALWAYS: several chunks and
+    lock-step rounds per workgroup), hub runs, unclaimed relations, unknown types."""
+    if HGTConv.EXTRA_KERNEL_FLAGS & _lib.HGT_FLAG_FUSED_ANY_SIZE:
+        pytest.skip("the forced-kernel pass puts the fused sub-tile kernel on every layer: the runs kernels under test do not run")
+    N, E, d, H, T, R, use_RTE, gk = case
+    sd = O.make_state_dict(d, d, T, R, H, True, use_RTE, seed=N + E + 9)
+    x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=E + 17, **gk)
+    nt, et = nt.clone(), et.clone()
+    nt[::131] = T + 2
+    et[::37] = R
+    layer = _layer_from(sd, d, T, R, H, True, use_RTE, keep_att=False, precision=precision)
+    layer.kernel_flags = _lib.HGT_FLAG_ITEM_AGGREGATE | _lib.HGT_FLAG_MFMA_LOGITS | _lib.HGT_FLAG_COOP_EDGE_ALWAYS
+    coop, _ = _run(layer, x, nt, ei, et, tm if use_RTE else None)
+    coop_b, _ = _run(layer, x, nt, ei, et, tm if use_RTE else None)
+    layer.kernel_flags = _lib.HGT_FLAG_ITEM_AGGREGATE | _lib.HGT_FLAG_MFMA_LOGITS | _lib.HGT_FLAG_NO_COOP_EDGE
+    single, _ = _run(layer, x, nt, ei, et, tm if use_RTE else None)
+    single_b, _ = _run(layer, x, nt, ei, et, tm if use_RTE else None)
+    assert torch.equal(single, single_b), "one wavefront per item: two forwards differ"
+    assert torch.equal(coop, coop_b), "shared transform: two forwards differ"
+    assert torch.equal(coop, single)
+    if E <= 100000:
+        ref = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm, use_norm=True, use_RTE=use_RTE, dtype=torch.float64)
+        assert (coop.double() - ref).abs().max().item() < PREC_TOL[precision]
+
+
 DENSE_CASES = [
     # N, E, d, H, T, R, use_norm, use_RTE
     (2500, 25000, 256, 8, 4, 8, True, False),      # c2 shape
