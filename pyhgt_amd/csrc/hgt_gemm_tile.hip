@@ -391,8 +391,20 @@ __global__ __launch_bounds__(64 * NW, (KPAN == 64 && RT == 1 && CT == 1) ? 4 : 2
 // the panel's own maximum needs it; accumulators of lowered rows are multiplied by the exact power-of-two ratio) -- no pass over x
 // for the row maxima.
 // ---------------------------------------------------------------------------------------------------------------------------------
+// 32-row tiles (RT = 1) with a two-slot fragment ring: 124 registers -> TWO workgroups per CU, so up to 512 tiles are resident at once.
+// The OAG adapter (4 096 x 1 169 -> 400: 262 tiles at RT = 1) took 49 us (f16x3) / 45 (bf16x3) as 134 tiles of 64 rows on 134 CUs;
+// 31 us this way.  128-row tiles (RT = 4, two slots as well: 244 registers) where nothing smaller fits one round (c5 Q|K|V,
+// 4 096 x 400 -> 1 536: 32 us against 38 on the slab kernel; RT = 3 at 270 tiles -- a second round of 14 -- 50 us).
+#ifndef HGT_TS_R1_SMALL
+#define HGT_TS_R1_SMALL 1
+#endif
+#ifndef HGT_TS_R1_TILES
+#define HGT_TS_R1_TILES 512
+#endif
+#define HGT_TS_OCC(RT) ((HGT_TS_R1_SMALL && (RT) == 1) ? 4 : 2)
+#define HGT_TS_WR(RT) (((RT) >= 4 || (HGT_TS_R1_SMALL && (RT) == 1)) ? 2 : 3)
 template <int RT, bool F16>
-__global__ __launch_bounds__(512, 2) void k_tile_linear_stream(const TileArgs a) {
+__global__ __launch_bounds__(512, HGT_TS_OCC(RT)) void k_tile_linear_stream(const TileArgs a) {
     constexpr int NW = 8, KPAN = 64, BMT = 32 * RT, KCP = 4, LPR = 16, RPI = 4, NL = RT;      // a lane: RT rows x 16 bytes per panel
     constexpr int ASTR = KPAN * 2 + 16, APLANE = BMT * ASTR;
     __shared__ __attribute__((aligned(16))) unsigned char sA[2][2 * APLANE];
@@ -458,7 +470,8 @@ __global__ __launch_bounds__(512, 2) void k_tile_linear_stream(const TileArgs a)
     // Rings: the B fragments of THREE panels in registers (a panel is requested two panels of MFMAs before its use), the x rows of
     // two panels in registers (requested two panels before they are split into the LDS panel that is free by then), two LDS panels.
     // One panel ahead (r6, first form) left every wavefront waiting ~1.5 us per panel for its own requests: 26 us for 6 us of MFMAs.
-    bf16x8 wh[3][KCP], wm[3][KCP];
+    constexpr int WR = HGT_TS_WR(RT);      // (128-row tiles: two ring slots -- the third would not fit the register file -- and twice the MFMAs per panel to cover a request)
+    bf16x8 wh[WR][KCP], wm[WR][KCP];
     float4 areg[2][NL];
 #define TS_LOAD_W(B, P)                                                                                    \
     _Pragma("unroll") for (int kc = 0; kc < KCP; ++kc) {                                                   \
@@ -522,7 +535,9 @@ __global__ __launch_bounds__(512, 2) void k_tile_linear_stream(const TileArgs a)
     TS_LOAD_W(0, 0)
     TS_LOAD_A(0, 0)
     if (n_pan > 1) { TS_LOAD_W(1, 1) TS_LOAD_A(1, 1) }
-    if (n_pan > 2) TS_LOAD_W(2, 2)
+    if constexpr (WR > 2) {
+        if (n_pan > 2) TS_LOAD_W(2, 2)
+    }
     TS_COMMIT_A(0, 0, sA[0])
     if (n_pan > 2) TS_LOAD_A(0, 2)
 
@@ -568,8 +583,8 @@ __global__ __launch_bounds__(512, 2) void k_tile_linear_stream(const TileArgs a)
     if (P0 + (I) < n_pan) {                                                                                             \
         const int P = P0 + (I);                                                                                         \
         TS_RESCALE(P)                                                                                                   \
-        TS_COMPUTE((I) % 3, (I) & 1)                                                                                    \
-        if (P + 3 < n_pan) TS_LOAD_W((I) % 3, P + 3)                                                                    \
+        TS_COMPUTE((I) % WR, (I) & 1)                                                                                   \
+        if (P + WR < n_pan) TS_LOAD_W((I) % WR, P + WR)                                                                 \
         if (P + 1 < n_pan) {                                                                                            \
             TS_COMMIT_A(((I) + 1) & 1, P + 1, sA[((I) + 1) & 1])                                                        \
             if (P + 3 < n_pan) TS_LOAD_A(((I) + 1) & 1, P + 3)                                                          \
@@ -615,6 +630,10 @@ __global__ __launch_bounds__(512, 2) void k_tile_linear_stream(const TileArgs a)
             }
     }
 }
+
+#ifndef HGT_TILE_MAX_TILES
+#define HGT_TILE_MAX_TILES 256
+#endif
 
 template <int RT>
 static void launch_stream(bool f16, const TileArgs& a, int64_t n_rows, hipStream_t stream) {
@@ -666,23 +685,28 @@ int hgt_typed_linear_tile_try(bool f16, const float* x, int64_t ldx, const int32
         // the slab kernels are as fast or faster (K = 512: 36 vs 31 us at 3 200 rows): not this kernel's domain
         const int64_t wgs = ((n_rows + 31) / 32 + n_groups) * ((n_out + 127) / 128);
         if (k > 256) {
-            // (32 RT) x 256 tiles, RT <= 3, when they fit the chip in ONE round; among those the RT with the shortest workgroup under a
-            // two-term model -- matrix-core time ~ 6 RT, bytes through its CU's L1 ~ (RT + 8): whichever is larger -- ties: the larger
-            // tile (fewer passes over W).  Measured (r6, warm): 3 200 x 512 -> 1 536: RT = 3 (216 tiles) 25.8 us, slab kernel 31.7;
-            // 4 096 x 1 169 -> 400: RT = 2, 41.0 vs 46.7; 4 096 x 400 -> 1 536 needs two rounds at every RT (33.6 vs 31.3): the slab kernel
+            // (32 RT) x 256 tiles, RT <= 4, when all of them are RESIDENT at once (RT = 1: two workgroups per CU, 512 tiles; otherwise one
+            // per CU, 256); among those the RT with the shortest workgroup under a two-term model -- matrix-core time ~ 6 RT, bytes
+            // through its CU's L1 ~ (RT + 8): whichever is larger -- ties: the larger tile (fewer passes over W).  Measured (r6, warm,
+            // f16x3): 3 200 x 512 -> 1 536: RT = 3 (216 tiles) 28 us, slab kernel 37; 4 096 x 1 169 -> 400: RT = 1 (262 tiles) 31, RT = 2
+            // 49, slab 52; 4 096 x 400 -> 1 536: RT = 4 (210 tiles) 32, slab 38, RT = 1 in 1.5 rounds 31 (not taken: slower at n_hid 512)
             const int64_t passes = (n_out + BNP - 1) / BNP;
             int best = 0;
             int64_t best_cost = 0;
-            for (int rt = 1; rt <= 3; ++rt) {
+            for (int rt = 1; rt <= 4; ++rt) {
+#ifdef HGT_TILE_FORCE_RT
+                if (rt != HGT_TILE_FORCE_RT) continue;
+#endif
                 const int64_t tiles = ((n_rows + 32 * rt - 1) / (32 * rt) + n_groups / 2) * passes;      // (about half the groups end in a partial tile)
-                if (tiles > 256) continue;
+                if (tiles > ((HGT_TS_R1_SMALL && rt == 1) ? HGT_TS_R1_TILES : HGT_TILE_MAX_TILES)) continue;
                 const int64_t cost = std::max<int64_t>(6 * rt, rt + 8);
                 if (best == 0 || cost <= best_cost) { best = rt; best_cost = cost; }
             }
             if (best == 0) return 0;
             if (best == 1) launch_stream<1>(f16, a, n_rows, stream);
             else if (best == 2) launch_stream<2>(f16, a, n_rows, stream);
-            else launch_stream<3>(f16, a, n_rows, stream);
+            else if (best == 3) launch_stream<3>(f16, a, n_rows, stream);
+            else launch_stream<4>(f16, a, n_rows, stream);
         } else {
             if (wgs > 1024) return 0;
             launch_tile<4, 1, 1, 64, 4, false>(f16, a, n_rows, stream);

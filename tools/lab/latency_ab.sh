@@ -7,6 +7,6 @@ for n in "$@"; do
     for wl in c3:1 c5:2 mag4:4; do
         w=${wl%%:*}; nl=${wl##*:}
         rm -rf /tmp/la; HGT_LIB_PATH=$ROOT/$L timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/la -o t -- python $ROOT/tools/trace_latency.py run $w $prec > /tmp/la.log 2>&1 || tail -3 /tmp/la.log
-        echo "== $n $w $prec"; python $ROOT/tools/trace_latency.py show /tmp/la $nl | cut -c1-90 | tail -7
+        echo "== $n $w $prec"; python $ROOT/tools/trace_latency.py show /tmp/la $nl | cut -c1-90 | tail -12
     done
 done
