@@ -633,7 +633,7 @@ extern "C" int hgt_plan_build(const int64_t* edge_index, int64_t stride_row, int
                                                    eid, esrc, edst, ertei, hdr);
     }
     k_segptr<<<nblk(L.n_bins + 1, BS), BS, 0, stream>>>(keys_out, E, L.n_bins, segptr);
-    if (L.n_pairs + 1 <= 65536) {      // sampled batches: counts + scan in one workgroup
+    if (L.n_pairs + 1 <= 8192) {      // sampled batches: counts + scan in one workgroup (c2's 35 k pairs: 189 us this way, ~25 as three launches)
         k_pair_scan_small<<<1, 1024, 0, stream>>>(segptr, L.n_pairs, hgt_item_edges(E), pair_off);
     } else {
         k_pair_counts<<<nblk(L.n_pairs + 1, BS), BS, 0, stream>>>(segptr, L.n_pairs, hgt_item_edges(E), pair_cnt);
