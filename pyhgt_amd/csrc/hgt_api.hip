@@ -405,7 +405,7 @@ edge_phase:
         if (!can_fuse) return HGT_ERR_UNSUPPORTED;
         if (a->q_begin == a->q_end) return HGT_OK;
         if (E > 0 && a->item_end > a->item_begin) {
-            rc = hgt_edge_logits_range(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, mfma_logits ? att_f : nullptr, 0, logits,
+            rc = hgt_edge_logits_range(a->plan, N, E, T, R, H, lay.dk_pad, Q, K, rte_k, att_t, mfma_logits ? att_f : nullptr, fmode, logits,
                                        a->item_begin, a->item_end, stream);
             if (rc != HGT_OK) return rc;
         }

@@ -1432,12 +1432,14 @@ def test_target_blocked_schedule_with_real_halos(compress, use_rte, tmp_path):
         assert torch.equal(out, out_p)
 
 
-@pytest.mark.parametrize("use_rte,zipf", [(False, False), (True, True)])
-def test_target_blocks_are_bit_identical_to_the_one_call_layer(use_rte, zipf):
+@pytest.mark.parametrize("use_rte,zipf,precision,H", [(False, False, "bf16x3", 8), (True, True, "bf16x3", 8), (True, False, "f16x3", 4)])
+def test_target_blocks_are_bit_identical_to_the_one_call_layer(use_rte, zipf, precision, H):
     """hgt_conv_forward stage 5 (ABI 6): the edge phase + fused update of a range of destination tiles.  Running the blocks of a
     graph one after the other (in any order) must reproduce the one-call layer BIT FOR BIT -- with source-only halo rows, hub
-    targets inside and outside a block (the hub kernels filter by range), unclaimed edges and unknown node types."""
-    T, R, H, d, N, NQ, E = 4, 8, 8, 256, 90_000, 70_000, 900_000
+    targets inside and outside a block (the hub kernels filter by range), unclaimed edges and unknown node types.  The third case:
+    heads of 64 columns in the fp16 split -- the block's logits run on the matrix cores and must read the fp16 fragment image
+    (round 6: the call passed the bf16 selector)."""
+    T, R, d, N, NQ, E = 4, 8, 256, 90_000, 70_000, 900_000
     sd = O.make_state_dict(d, d, T, R, H, True, use_rte, seed=51)
     x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=52, sorted_types=False)
     nt, ei, et = nt.clone(), ei.clone(), et.clone()
@@ -1447,7 +1449,7 @@ def test_target_blocks_are_bit_identical_to_the_one_call_layer(use_rte, zipf):
         ei[1, 4000:6500] = 40_000          # hub in a later block
     et[::11] = R + 2
     nt[::17] = T
-    layer = _layer_from(sd, d, T, R, H, True, use_rte, keep_att=False, precision="bf16x3")
+    layer = _layer_from(sd, d, T, R, H, True, use_rte, keep_att=False, precision=precision)
     layer.kernel_flags = _lib.HGT_FLAG_DETERMINISTIC_HUBS      # hub rows without atomics: bit-reproducible (the default path is not)
     xd, ntd, eid, etd, tmd = _to_dev(x, nt, ei, et, tm)
     GraphPlan.clear_cache()
