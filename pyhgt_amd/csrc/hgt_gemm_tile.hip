@@ -694,9 +694,6 @@ int hgt_typed_linear_tile_try(bool f16, const float* x, int64_t ldx, const int32
             int best = 0;
             int64_t best_cost = 0;
             for (int rt = 1; rt <= 4; ++rt) {
-#ifdef HGT_TILE_FORCE_RT
-                if (rt != HGT_TILE_FORCE_RT) continue;
-#endif
                 const int64_t tiles = ((n_rows + 32 * rt - 1) / (32 * rt) + n_groups / 2) * passes;      // (about half the groups end in a partial tile)
                 if (tiles > ((HGT_TS_R1_SMALL && rt == 1) ? HGT_TS_R1_TILES : HGT_TILE_MAX_TILES)) continue;
                 const int64_t cost = std::max<int64_t>(6 * rt, rt + 8);
