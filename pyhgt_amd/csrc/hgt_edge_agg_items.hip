@@ -773,6 +773,198 @@ __global__ __launch_bounds__(64 * MU_NW, 4) void k_merge_update(const MergeUpdat
     }
 }
 
+// k_merge_update with one target per wavefront and the update GEMM on 16 x 16 x 32 MFMAs: the 16 merged rows are the B operand (16
+// targets), W_a's fragments the A operand -- no wasted lower half of a 32-row tile (half the matrix-core time and half the LDS fragment
+// reads of phase 2: 5.2 of c5's 29 us, 4.7 of the 4-layer model's 24, were MFMAs + fragment reads), a lane ends up with 4 consecutive
+// output columns of ONE target (no quad transpose, one row scale per lane).  The SAME weight image: lane (m = l & 15, kg = l >> 4) of
+// column tile t and 32-k step ks reads the 16 bytes the 32 x 32 form's lane (16 t + m, kg & 1) reads for k-chunk 2 ks + (kg >> 1).
+// Products in the order  mid x hi, hi x mid, hi x hi  per 32-k step: the sums differ from the 32 x 32 form's in the last bits only.
+template <int VECF, bool F16>
+__global__ __launch_bounds__(64 * MU_NW, 4) void k_merge_update16(const MergeUpdateArgs a) {
+    constexpr int DP = 64 * VECF, ASTRK = DP * 2 + 16, NKC = (DP / 16 + 3) & ~3, NKS = NKC / 2, NB = VECF >= 8 ? 2 : 4;
+    constexpr int STG = NKS < 4 ? NKS : 4;                 // ring: 32-k steps whose fragments (2 column tiles x 2 planes) are in registers
+    __shared__ __attribute__((aligned(16))) unsigned char sA[2][MU_ROWS * ASTRK];      // [plane][row][k]
+    __shared__ int s_rid[MU_ROWS];
+    __shared__ float s_rinv[F16 ? MU_ROWS : 1];
+    __shared__ __attribute__((aligned(16))) float s_red[2][MU_ROWS * MU_NW];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int g = 0, row0 = 0, nrows = 0;
+    {
+        const int t = (int)blockIdx.x;
+        int before = 0;
+        bool found = false;
+        for (g = 0; g < a.n_groups; ++g) {
+            const int gb = a.group_off[g], ge = a.group_off[g + 1];
+            const int nt = (ge - gb + MU_ROWS - 1) / MU_ROWS;
+            if (t < before + nt) {
+                row0 = gb + (t - before) * MU_ROWS;
+                nrows = min(MU_ROWS, ge - row0);
+                found = true;
+                break;
+            }
+            before += nt;
+        }
+        if (!found) return;
+    }
+    const int n_out = a.n_out;
+    const int n_pass = (n_out + BNP - 1) / BNP;
+    const bool live = (wave >> 3) < n_pass;
+    const int m16 = lane & 15, kg = lane >> 4;
+    const unsigned short* wp = a.wsplit + (((int64_t)g * n_pass + (live ? (wave >> 3) : 0)) * NKC + (kg >> 1)) * 2 * W_PLANE_ELEMS +
+                               ((wave & 7) * 64 + (kg & 1) * 32 + m16) * 8;
+    float winv = 1.0f;
+    if constexpr (F16) winv = reinterpret_cast<const float*>(a.wsplit + (int64_t)a.n_groups * n_pass * NKC * 2 * W_PLANE_ELEMS)[g];
+    // fragments of 32-k step ks: column tile t at + 128 elements, hi / mid planes; requested while the merge runs
+    bf16x8 wh[STG][2], wm[STG][2];
+#define MU16_LOAD_W(S, KS)                                                                                        \
+    _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {                                                            \
+        const unsigned short* q_ = wp + (int64_t)(KS) * 4 * W_PLANE_ELEMS + t_ * 128;                             \
+        wh[S][t_] = *reinterpret_cast<const bf16x8*>(q_);                                                         \
+        wm[S][t_] = *reinterpret_cast<const bf16x8*>(q_ + W_PLANE_ELEMS);                                         \
+    }
+    if (live) {
+#pragma unroll
+        for (int s_ = 0; s_ < STG; ++s_) { MU16_LOAD_W(s_, s_) }
+    }
+    // this lane's outputs: target m16, columns col0 + 16 t + 0..3; their skip rows travel while the merge runs
+    const int col0 = wave * 32 + 4 * kg;
+    const bool t_ok = m16 < nrows;
+    bool c_ok[2];
+    float4 xv[2];
+#pragma unroll
+    for (int t_ = 0; t_ < 2; ++t_) {
+        c_ok[t_] = live && (col0 + 16 * t_) < n_out;
+        xv[t_] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c_ok[t_] && t_ok) xv[t_] = *reinterpret_cast<const float4*>(a.xs + (int64_t)a.rows[row0 + m16] * a.ldxs + col0 + 16 * t_);
+    }
+    // ---- phase 1: wavefront w merges target rows[row0 + w]  (k_merge_update's, TPW = 1)
+    {
+        const int r = wave;
+        const int rid = (r < nrows) ? a.rows[row0 + r] : -1;
+        if (lane == 0) s_rid[r] = rid;
+        float o[VECF];
+        if (rid >= 0) {
+            merge_target<VECF, NB>((int64_t)rid, lane, a.segptr, a.zrows, a.zstat, a.zflag, a.R, a.HT, a.DKP, a.apply_gelu, o);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VECF; ++k) o[k] = 0.0f;
+        }
+        float scale = 1.0f;
+        if constexpr (F16) {
+            float inv;
+            f16_row_scale(wave_max_bits(abs_bits_v<VECF>(o)), scale, inv);
+            if (lane == 0) s_rinv[r] = inv;
+        }
+        unsigned char* w_ = sA[0] + r * ASTRK + lane * VECF * 2;
+        if constexpr (VECF == 1) {
+            unsigned short hi, mid;
+            split1_t<F16>(o[0], scale, hi, mid);
+            *reinterpret_cast<unsigned short*>(w_) = hi;
+            *reinterpret_cast<unsigned short*>(w_ + MU_ROWS * ASTRK) = mid;
+        } else if constexpr (VECF == 2) {
+            unsigned hi, mid;
+            split2_t<F16>(o[0], o[1], scale, hi, mid);
+            *reinterpret_cast<unsigned*>(w_) = hi;
+            *reinterpret_cast<unsigned*>(w_ + MU_ROWS * ASTRK) = mid;
+        } else {
+#pragma unroll
+            for (int q = 0; q < VECF / 4; ++q) {
+                uint2 hi, mid;
+                split4_t<F16>(make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]), scale, hi, mid);
+                *reinterpret_cast<uint2*>(w_ + 8 * q) = hi;
+                *reinterpret_cast<uint2*>(w_ + 8 * q + MU_ROWS * ASTRK) = mid;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: out^T[32 columns x 16 targets] = W_a fragments x slab^T
+    float y[2][4];
+    if (live) {
+        f32x4 acc[2];
+        acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* sl_ = sA[0] + m16 * ASTRK + kg * 16;
+#pragma unroll
+        for (int ks0 = 0; ks0 < NKS; ks0 += STG) {
+#pragma unroll
+            for (int s_ = 0; s_ < STG; ++s_) {
+                const int ks = ks0 + s_;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(sl_ + ks * 64);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(sl_ + ks * 64 + MU_ROWS * ASTRK);
+#pragma unroll
+                for (int t_ = 0; t_ < 2; ++t_) {
+                    acc[t_] = mfma16_t<F16>(wm[s_][t_], bh, acc[t_]);
+                    acc[t_] = mfma16_t<F16>(wh[s_][t_], bm, acc[t_]);
+                    acc[t_] = mfma16_t<F16>(wh[s_][t_], bh, acc[t_]);
+                }
+                if (ks + STG < NKS) { MU16_LOAD_W(s_, ks + STG) }
+            }
+        }
+        const float alpha = 1.0f / (1.0f + expf(-a.skip[g]));
+        const float sc = F16 ? s_rinv[F16 ? m16 : 0] * winv : 1.0f;
+#pragma unroll
+        for (int t_ = 0; t_ < 2; ++t_) {
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c_ok[t_] && a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + (int64_t)g * n_out + col0 + 16 * t_);
+            y[t_][0] = c_ok[t_] ? (acc[t_][0] * sc + b4.x) * alpha + xv[t_].x * (1.0f - alpha) : 0.0f;
+            y[t_][1] = c_ok[t_] ? (acc[t_][1] * sc + b4.y) * alpha + xv[t_].y * (1.0f - alpha) : 0.0f;
+            y[t_][2] = c_ok[t_] ? (acc[t_][2] * sc + b4.z) * alpha + xv[t_].z * (1.0f - alpha) : 0.0f;
+            y[t_][3] = c_ok[t_] ? (acc[t_][3] * sc + b4.w) * alpha + xv[t_].w * (1.0f - alpha) : 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int t_ = 0; t_ < 2; ++t_) y[t_][0] = y[t_][1] = y[t_][2] = y[t_][3] = 0.0f;
+    }
+#undef MU16_LOAD_W
+    // ---- LayerNorm over the row of target m16: this lane's 8 columns, the 4 lanes of the target, the 16 wavefronts
+    const float inv_n = 1.0f / (float)n_out;
+    float rstd = 1.0f;
+    if (a.use_norm) {
+        float ps = (y[0][0] + y[0][1] + y[0][2] + y[0][3]) + (y[1][0] + y[1][1] + y[1][2] + y[1][3]);
+        ps += __shfl_xor(ps, 16);
+        ps += __shfl_xor(ps, 32);
+        if (kg == 0) s_red[0][m16 * MU_NW + wave] = ps;
+        __syncthreads();
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < MU_NW; ++w) s += s_red[0][m16 * MU_NW + w];
+        const float mean = s * inv_n;
+        ps = 0.0f;
+#pragma unroll
+        for (int t_ = 0; t_ < 2; ++t_)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                y[t_][i] -= mean;
+                const float d = c_ok[t_] ? y[t_][i] : 0.0f;
+                ps = fmaf(d, d, ps);
+            }
+        ps += __shfl_xor(ps, 16);
+        ps += __shfl_xor(ps, 32);
+        if (kg == 0) s_red[1][m16 * MU_NW + wave] = ps;
+        __syncthreads();
+        s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < MU_NW; ++w) s += s_red[1][m16 * MU_NW + w];
+        rstd = rsqrtf(s * inv_n + 1e-5f);
+    }
+    if (t_ok) {
+        const int64_t orow = (int64_t)s_rid[m16] * n_out;
+#pragma unroll
+        for (int t_ = 0; t_ < 2; ++t_) {
+            if (!c_ok[t_]) continue;
+            float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f), c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.use_norm) {
+                w4 = *reinterpret_cast<const float4*>(a.lnw + (int64_t)g * n_out + col0 + 16 * t_);
+                c4 = *reinterpret_cast<const float4*>(a.lnb + (int64_t)g * n_out + col0 + 16 * t_);
+            }
+            // (the layer's output: read by the next layer's projections -- another kernel)
+            store_wt16(a.out + orow + col0 + 16 * t_, y[t_][0] * rstd * w4.x + c4.x, y[t_][1] * rstd * w4.y + c4.y,
+                       y[t_][2] * rstd * w4.z + c4.z, y[t_][3] * rstd * w4.w + c4.w);
+        }
+    }
+}
+
 template <int VEC, int LPH>
 static int launch_runs(int mode, const HgtPlanView& pv, const float* logits, const float* V, const float* rteV, const unsigned short* msgF,
                        float* zrows, float* zstat, unsigned char* zflag, int R, int HT, hipStream_t stream, int raw = 0) {
@@ -888,8 +1080,8 @@ static int aggregate_items_impl(const void* plan, int64_t N, int64_t E, int32_t 
 #define AGI_MU(VF)                                                                                      \
         do {                                                                                            \
             if (tpw == 1) {                                                                             \
-                if (frag_f16 & 1) k_merge_update<VF, true, 1><<<ugrid, 64 * MU_NW, 0, stream>>>(m);         \
-                else k_merge_update<VF, false, 1><<<ugrid, 64 * MU_NW, 0, stream>>>(m);                 \
+                if (frag_f16 & 1) k_merge_update16<VF, true><<<ugrid, 64 * MU_NW, 0, stream>>>(m);          \
+                else k_merge_update16<VF, false><<<ugrid, 64 * MU_NW, 0, stream>>>(m);                  \
             } else {                                                                                    \
                 if (frag_f16 & 1) k_merge_update<VF, true, 2><<<ugrid, 64 * MU_NW, 0, stream>>>(m);         \
                 else k_merge_update<VF, false, 2><<<ugrid, 64 * MU_NW, 0, stream>>>(m);                 \

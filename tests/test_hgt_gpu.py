@@ -215,9 +215,9 @@ def test_item_parallel_aggregation(case, precision):
 def test_merge_pass_fused_with_the_node_update_is_bit_identical(case, precision, use_norm):
     """Round 6 (sampled batches): k_merge_update -- the merge pass of the item-parallel aggregation IS the node update (a_linear +
     gated skip + LayerNorm, conv.py:119-133), the merged rows are never written -- against hgt_edge_aggregate_items +
-    hgt_linear_update_* as two calls (HGT_FLAG_NO_MERGE_UPDATE): the same merged row bit for bit, the same products in the same
-    order; the epilogue's fused multiply-adds are contracted differently by the two kernels and the LayerNorm sums meet in a different
-    wavefront order (16 wavefronts x 32 columns instead of 8): last-bit differences only.  Unclaimed relations, unknown node types, one / sixteen heads, 64 .. 512 columns; also against the fp64 closed form."""
+    hgt_linear_update_* as two calls (HGT_FLAG_NO_MERGE_UPDATE): the same merged row bit for bit and the same split products; the
+    16 x 16 x 32 MFMAs of the one-target-per-wavefront form sum 32 k per instruction where the tile kernels sum 16, the epilogue's fused
+    multiply-adds are contracted differently and the LayerNorm sums meet in a different wavefront order: last-bit differences only.  Unclaimed relations, unknown node types, one / sixteen heads, 64 .. 512 columns; also against the fp64 closed form."""
     if HGTConv.EXTRA_KERNEL_FLAGS & _lib.HGT_FLAG_FUSED_ANY_SIZE:
         pytest.skip("the forced-kernel pass (tools/gpu.sh final) puts the fused sub-tile kernel on every layer: neither form under test runs")
     N, E, d, H, T, R, use_RTE, gk = case
