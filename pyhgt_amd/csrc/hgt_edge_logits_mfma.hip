@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_logits_mfma(
     constexpr int DKP = G::DKP, DP = G::DP, H = G::H, NCT = G::NCT, KW = G::KW, NKS = G::NKS, ROWB = G::ROWB, NS = G::NS, QS = G::QS;
     constexpr int UN = RTE ? (unroll_for<VEC>() * 3) / 4 : unroll_for<VEC>(), HB = UN / 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4][G::WAVE_LDS];
+    __shared__ __attribute__((aligned(16))) float s_qinv[F16 ? 4 : 1][16], s_qscale[F16 ? 4 : 1][16];
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -166,15 +167,44 @@ __global__ __launch_bounds__(256, 2) void k_edge_logits_mfma(
             // below waits for the Q rows only), so their latency is covered by phases A and B
             LGM_ISSUE(krA, trA, e_lo)
 
-            float qinv = 1.0f;                 // fp16 split: lane r = inverse scale of row r
+            // fp16 split: the 16 row maxima together through the (still unused) tile: see k_edge_logits_coop
+            float scl[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scl[r] = 1.0f;
+            if constexpr (F16) {
+                unsigned* mx_ = reinterpret_cast<unsigned*>(tile);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx_[r * 64 + ((((lane >> 2) ^ r) << 2) | (lane & 3))] = abs_bits_vec<VEC>(qrow[r]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int r_ = lane & 15, q_ = lane >> 4;
+                unsigned m = 0u;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint4 v4 = *reinterpret_cast<const uint4*>(mx_ + r_ * 64 + (((q_ * 4 + c) ^ r_) << 2));
+                    m = max(max(m, max(v4.x, v4.y)), max(v4.z, v4.w));
+                }
+                m = max(m, (unsigned)__shfl_xor((int)m, 16));
+                m = max(m, (unsigned)__shfl_xor((int)m, 32));
+                float sc_l, inv_l;
+                f16_row_scale(m, sc_l, inv_l);
+                if (lane < 16) {
+                    s_qinv[wib][lane] = inv_l;
+                    s_qscale[wib][lane] = sc_l;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();         // (also: every lane has read the maxima before the split rows overwrite them)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(&s_qscale[wib][4 * c]);
+                    scl[4 * c] = s4.x; scl[4 * c + 1] = s4.y; scl[4 * c + 2] = s4.z; scl[4 * c + 3] = s4.w;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float scale = 1.0f;
-                if constexpr (F16) {
-                    float inv;
-                    f16_row_scale(wave_max_bits(abs_bits_vec<VEC>(qrow[r])), scale, inv);
-                    qinv = (lane == r) ? inv : qinv;
-                }
+                const float scale = scl[r];
                 unsigned char* w = tile + r * ROWB + ((((wb >> 4) ^ (r & (NS - 1)))) << 4) + (wb & 15);
                 if constexpr (VEC == 1) {
                     unsigned short hi, mid;
@@ -235,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_logits_mfma(
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             {
                 float sc = 1.0f;
-                if constexpr (F16) sc = __shfl(qinv, fi) * ainv;
+                if constexpr (F16) sc = s_qinv[wib][fi] * ainv;
                 // accumulator layout: lane = (target fi, row group fg): columns 16 c + 4 fg .. + 3 of target fi
 #pragma unroll
                 for (int c = 0; c < NCT; ++c)
@@ -282,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_logits_coop(
     static_assert(NCT % 4 == 0 && SW <= 8, "a wavefront's share of the fragment image stays in registers");
     __shared__ __attribute__((aligned(16))) unsigned char smem[4][G::WAVE_LDS];
     __shared__ int s_rel[4];
-    __shared__ float s_qinv[F16 ? 4 : 1][16];
+    __shared__ __attribute__((aligned(16))) float s_qinv[F16 ? 4 : 1][16], s_qscale[F16 ? 4 : 1][16];
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -386,15 +416,47 @@ __global__ __launch_bounds__(256, 2) void k_edge_logits_coop(
             e_lo = __builtin_ctzll(in_g);
             e_end = e_lo + __builtin_popcountll(in_g);
             LGC_ISSUE(krA, trA, e_lo)
-            float qinv = 1.0f;
+            // fp16 split: the 16 row maxima TOGETHER (one wave reduction per row -- 8 DPP steps, 4 v_readlane and the scale on the scalar
+            // unit, sixteen times -- was 5.6 of c5's 38 us): every lane parks its 16 per-row maxima in the tile (free between rounds,
+            // 16-byte chunks XOR-swizzled by row), lane (r = l & 15, q = l >> 4) reduces the 16 lanes of quarter q for row r with four
+            // 16-byte reads, two cross-quarter steps, and the scales come back through a 16-float table.
+            float scl[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scl[r] = 1.0f;
+            if constexpr (F16) {
+                unsigned* mx_ = reinterpret_cast<unsigned*>(tile);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx_[r * 64 + ((((lane >> 2) ^ r) << 2) | (lane & 3))] = abs_bits_vec<VEC>(qrow[r]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int r_ = lane & 15, q_ = lane >> 4;
+                unsigned m = 0u;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint4 v4 = *reinterpret_cast<const uint4*>(mx_ + r_ * 64 + (((q_ * 4 + c) ^ r_) << 2));
+                    m = max(max(m, max(v4.x, v4.y)), max(v4.z, v4.w));
+                }
+                m = max(m, (unsigned)__shfl_xor((int)m, 16));
+                m = max(m, (unsigned)__shfl_xor((int)m, 32));
+                float sc_l, inv_l;
+                f16_row_scale(m, sc_l, inv_l);
+                if (lane < 16) {
+                    s_qinv[wib][lane] = inv_l;
+                    s_qscale[wib][lane] = sc_l;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();         // (also: every lane has read the maxima before the split rows overwrite them)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(&s_qscale[wib][4 * c]);
+                    scl[4 * c] = s4.x; scl[4 * c + 1] = s4.y; scl[4 * c + 2] = s4.z; scl[4 * c + 3] = s4.w;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float scale = 1.0f;
-                if constexpr (F16) {
-                    float inv;
-                    f16_row_scale(wave_max_bits(abs_bits_vec<VEC>(qrow[r])), scale, inv);
-                    qinv = (lane == r) ? inv : qinv;
-                }
+                const float scale = scl[r];
                 unsigned char* w = tile + r * ROWB + ((((wb >> 4) ^ (r & (NS - 1)))) << 4) + (wb & 15);
                 if constexpr (VEC == 1) {
                     unsigned short hi, mid;
@@ -412,9 +474,6 @@ __global__ __launch_bounds__(256, 2) void k_edge_logits_coop(
                     *reinterpret_cast<uint2*>(w) = hi;
                     *reinterpret_cast<uint2*>(w + G::PLANE) = mid;
                 }
-            }
-            if constexpr (F16) {
-                if (lane < 16) s_qinv[wib][lane] = qinv;
             }
         }
         if (lane == 0) s_rel[wib] = active ? rel : -1;

@@ -1432,13 +1432,14 @@ def test_target_blocked_schedule_with_real_halos(compress, use_rte, tmp_path):
         assert torch.equal(out, out_p)
 
 
-@pytest.mark.parametrize("use_rte,zipf,precision,H", [(False, False, "bf16x3", 8), (True, True, "bf16x3", 8), (True, False, "f16x3", 4)])
-def test_target_blocks_are_bit_identical_to_the_one_call_layer(use_rte, zipf, precision, H):
+@pytest.mark.parametrize("use_rte,zipf,H", [(False, False, 8), (True, True, 8), (True, False, 4)])
+def test_target_blocks_are_bit_identical_to_the_one_call_layer(use_rte, zipf, H):
     """hgt_conv_forward stage 5 (ABI 6): the edge phase + fused update of a range of destination tiles.  Running the blocks of a
     graph one after the other (in any order) must reproduce the one-call layer BIT FOR BIT -- with source-only halo rows, hub
     targets inside and outside a block (the hub kernels filter by range), unclaimed edges and unknown node types.  The third case:
-    heads of 64 columns in the fp16 split -- the block's logits run on the matrix cores and must read the fp16 fragment image
-    (round 6: the call passed the bf16 selector)."""
+    heads of 64 columns -- the block's logits run on the matrix cores (hgt_edge_logits_range with the fragment image).  (Staged calls
+    are precision 1 by contract: hgt_conv_forward answers HGT_ERR_UNSUPPORTED to precision 2 with a stage, pyhgt_amd.HGTConv maps
+    an "f16x3" layer's staged calls to "bf16x3".)"""
     T, R, d, N, NQ, E = 4, 8, 256, 90_000, 70_000, 900_000
     sd = O.make_state_dict(d, d, T, R, H, True, use_rte, seed=51)
     x, nt, ei, et, tm = synthetic_typed_graph(N, E, d, T, R, seed=52, sorted_types=False)
@@ -1449,7 +1450,7 @@ def test_target_blocks_are_bit_identical_to_the_one_call_layer(use_rte, zipf, pr
         ei[1, 4000:6500] = 40_000          # hub in a later block
     et[::11] = R + 2
     nt[::17] = T
-    layer = _layer_from(sd, d, T, R, H, True, use_rte, keep_att=False, precision=precision)
+    layer = _layer_from(sd, d, T, R, H, True, use_rte, keep_att=False, precision="bf16x3")
     layer.kernel_flags = _lib.HGT_FLAG_DETERMINISTIC_HUBS      # hub rows without atomics: bit-reproducible (the default path is not)
     xd, ntd, eid, etd, tmd = _to_dev(x, nt, ei, et, tm)
     GraphPlan.clear_cache()
@@ -1477,7 +1478,8 @@ def test_target_blocks_are_bit_identical_to_the_one_call_layer(use_rte, zipf, pr
             blk = (q0, q1, int(tab[q0 // tile]), int(tab[(q1 + tile - 1) // tile]))
             assert layer(*args, stage=5, block=blk, out=out, **kw) is out
     torch.cuda.synchronize()
-    assert torch.equal(out, ref)
+    assert torch.equal(out, ref), "blocks differ from the one-call layer: max %.3e in %d rows" % (
+        (out - ref).abs().max().item(), int((out != ref).any(dim=1).sum()))
     fwd = O.forward_closed_form(sd, T, R, H, x, nt, ei, et, tm if use_rte else None, use_norm=True, use_RTE=use_rte)
     assert (out.cpu().double() - fwd[:NQ]).abs().max().item() < TOL
     # argument checks of the new stage
