@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_runs_mfma(
     constexpr int UN = RTE ? (unroll_for<VEC>() * 3) / 4 : unroll_for<VEC>(), HB = UN / 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4][2 * G::PLANE];
     __shared__ int s_pos[4][16];
-    __shared__ float s_rinv[F16 ? 4 : 1][16];
+    __shared__ __attribute__((aligned(16))) float s_rinv[F16 ? 4 : 1][16][4];      // [wavefront][run][quarter of the row (16 lanes)]
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -117,9 +117,18 @@ __global__ __launch_bounds__(256, 2) void k_edge_runs_mfma(
                 if (cur_r < 0) return;
                 float scale = 1.0f;
                 if constexpr (F16) {
+                    // one power-of-two scale per QUARTER of the row where a head does not span quarters (LPH <= 16: the transform is
+                    // block-diagonal by head, any scale uniform over a head's columns factors out of its products): four DPP steps
+                    // and the rule in the vector ALU instead of a wave reduction through v_readlane and the scalar unit on the
+                    // chain every run of a one-edge segment goes through
                     float inv;
-                    f16_row_scale(wave_max_bits(abs_bits_v<VEC>(U)), scale, inv);
-                    if (lane == 0) s_rinv[wib][cur_r] = inv;
+                    if constexpr (LPH <= 16) {
+                        f16_row_scale(row16_max_bits(abs_bits_v<VEC>(U)), scale, inv);
+                        if ((lane & 15) == 0) s_rinv[wib][cur_r][lane >> 4] = inv;
+                    } else {
+                        f16_row_scale(wave_max_bits(abs_bits_v<VEC>(U)), scale, inv);
+                        if (lane < 4) s_rinv[wib][cur_r][lane] = inv;
+                    }
                 }
                 unsigned char* w = tile + cur_r * ROWB + ((((wb >> 4) ^ (cur_r & (NS - 1)))) << 4) + (wb & 15);
                 if constexpr (VEC == 1) {
@@ -222,12 +231,17 @@ __global__ __launch_bounds__(256, 2) void k_edge_runs_mfma(
             }
             // ---- transformed rows -> scratch, at the position of the run's first edge
             if (fi < nrows) {
-                float sc = 1.0f;
-                if constexpr (F16) sc = s_rinv[wib][fi] * minv;
+                float sc4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+                if constexpr (F16) {
+                    const float4 q4 = *reinterpret_cast<const float4*>(s_rinv[wib][fi]);
+                    sc4[0] = q4.x * minv; sc4[1] = q4.y * minv; sc4[2] = q4.z * minv; sc4[3] = q4.w * minv;
+                }
                 float* zr = zrows + (int64_t)s_pos[wib][fi] * ld + co + 4 * fg;
 #pragma unroll
-                for (int c = 0; c < NCT; ++c)
+                for (int c = 0; c < NCT; ++c) {
+                    const float sc = sc4[c / (NCT / 4)];      // (column tile c lies in quarter c / VEC of the row)
                     store_wt16(zr + 16 * c, acc[c][0] * sc, acc[c][1] * sc, acc[c][2] * sc, acc[c][3] * sc);      // (read by the merge kernel only)
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();         // the tile / position table are rewritten by the next group
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_runs_coop(
     __shared__ __attribute__((aligned(16))) unsigned char smem[4][2 * G::PLANE];
     __shared__ int s_pos[4][16];
     __shared__ int s_rel[4], s_nrows[4];
-    __shared__ float s_rinv[F16 ? 4 : 1][16];
+    __shared__ __attribute__((aligned(16))) float s_rinv[F16 ? 4 : 1][16][4];      // [wavefront][run][quarter of the row (16 lanes)]
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -324,9 +338,18 @@ __global__ __launch_bounds__(256, 2) void k_edge_runs_coop(
                 if (cur_r < 0) return;
                 float scale = 1.0f;
                 if constexpr (F16) {
+                    // one power-of-two scale per QUARTER of the row where a head does not span quarters (LPH <= 16: the transform is
+                    // block-diagonal by head, any scale uniform over a head's columns factors out of its products): four DPP steps
+                    // and the rule in the vector ALU instead of a wave reduction through v_readlane and the scalar unit on the
+                    // chain every run of a one-edge segment goes through
                     float inv;
-                    f16_row_scale(wave_max_bits(abs_bits_v<VEC>(U)), scale, inv);
-                    if (lane == 0) s_rinv[wib][cur_r] = inv;
+                    if constexpr (LPH <= 16) {
+                        f16_row_scale(row16_max_bits(abs_bits_v<VEC>(U)), scale, inv);
+                        if ((lane & 15) == 0) s_rinv[wib][cur_r][lane >> 4] = inv;
+                    } else {
+                        f16_row_scale(wave_max_bits(abs_bits_v<VEC>(U)), scale, inv);
+                        if (lane < 4) s_rinv[wib][cur_r][lane] = inv;
+                    }
                 }
                 unsigned char* w = tile + cur_r * ROWB + ((((wb >> 4) ^ (cur_r & (NS - 1)))) << 4) + (wb & 15);
                 if constexpr (VEC == 1) {
@@ -437,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_runs_coop(
             }
             if (fi < s_nrows[k]) {
                 float sc = 1.0f;
-                if constexpr (F16) sc = s_rinv[k][fi] * minv;
+                if constexpr (F16) sc = s_rinv[k][fi][wib] * minv;      // (this wavefront's column tiles are quarter wib of the row)
                 float* zr = zrows + (int64_t)s_pos[k][fi] * ld + co + 16 * (wib * CTW) + 4 * fg;
 #pragma unroll
                 for (int c = 0; c < CTW; ++c)
