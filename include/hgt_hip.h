@@ -261,8 +261,8 @@ int hgt_edge_logits(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t 
  * products like the aggregation's.  The form for d_k >= 64 (the reference's own widths: n_hid 400 / 512 with 8 heads), where the
  * vector-ALU kernel needs a 4-way head-group split and is instruction-bound; layouts it does not cover fall through to
  * hgt_edge_logits (att_t is required for that).
- * frag_f16 bits (ABI 7, here and in hgt_edge_aggregate_items[_update]): bit 0 = the fp16 images; for d_k >= 64 and the 16-edge work
- * items of a sampled batch the four wavefronts of a workgroup SHARE the relation transform (a quarter of the fragment image each, kept
+ * frag_f16 bits (ABI 7, here and in hgt_edge_aggregate_items[_update]): bit 0 = the fp16 images; for d_k >= 64 (the runs kernel of the
+ * item-parallel aggregation: >= 32) and the 16-edge work items of a sampled batch the four wavefronts of a workgroup SHARE the relation transform (a quarter of the fragment image each, kept
  * in registers while consecutive items share the relation; same result bit for bit): bit 1 = never, bit 2 = for larger items too. */
 int hgt_edge_logits_mfma(const void* plan, int64_t n_nodes, int64_t n_edges, int32_t n_types, int32_t n_relations,
                          int32_t n_heads, int32_t dk_pad, const float* Q, const float* K, const float* rte_k,
@@ -611,7 +611,7 @@ typedef struct hgt_conv_args {
                                       * kernel (HGT_LINEAR_NO_TILE): bit-identical results; tests / A/B timings */
 #define HGT_FLAG_NO_MERGE_UPDATE 8192 /* ABI 7: sampled batches: hgt_edge_aggregate_items + hgt_linear_update_* as two calls instead of
                                       * hgt_edge_aggregate_items_update (identical output; tests / A/B timings) */
-#define HGT_FLAG_NO_COOP_EDGE 16384  /* ABI 7: d_k >= 64: the one-wavefront-per-item forms of hgt_edge_logits_mfma / the runs kernel of
+#define HGT_FLAG_NO_COOP_EDGE 16384  /* ABI 7: d_k >= 64 (logits) / >= 32 (runs): the one-wavefront-per-item forms of hgt_edge_logits_mfma / the runs kernel of
                                       * hgt_edge_aggregate_items instead of the forms that share the relation transform across the workgroup
                                       * (identical output bit for bit; tests / A/B timings).  The same switch is bit 1 of `frag_f16` of those calls */
 #define HGT_FLAG_COOP_EDGE_ALWAYS 32768 /* ... the shared-transform forms for work items of more than 16 edges too (default: the 16-edge items

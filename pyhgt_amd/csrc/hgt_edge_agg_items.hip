@@ -999,9 +999,9 @@ static int launch_runs(int mode, const HgtPlanView& pv, const float* logits, con
     KERNEL<VEC, LPH, RTE_, F16_><<<grid, 256, 0, stream>>>(pv.items, pv.hdr, pv.esrc, pv.edst, pv.ertei, logits, V, rteV, msgF, \
                                                            zrows, zstat, zflag, R, HT, raw, (int)pv.L.max_items)
     using G = AG<VEC, LPH>;
-    // d_k >= 64 and 16-edge items: the transform shared by the workgroup (a wavefront's quarter of the fragment image fits its
-    // registers); larger items: a wavefront each (see launch_logits_mfma)
-    if constexpr (G::DKP >= 64 && G::NCT % 4 == 0 && (G::NCT / 4) * G::NKS <= 8) {
+    // d_k >= 32 and 16-edge items: the transform shared by the workgroup (a wavefront's quarter of the fragment image fits its
+    // registers); larger items: a wavefront each (see launch_logits_mfma).  d_k = 32 (c3): 14.25 -> 13.9 us (f16x3), 13.6 -> 12.7 (bf16x3)
+    if constexpr (G::DKP >= 32 && G::NCT % 4 == 0 && (G::NCT / 4) * G::NKS <= 8) {
         if (!(mode & 2) && ((mode & 4) || item_edges <= 16)) {
             if (rteV) { if (f16) AGI_LAUNCH(k_edge_runs_coop, true, true); else AGI_LAUNCH(k_edge_runs_coop, true, false); }
             else      { if (f16) AGI_LAUNCH(k_edge_runs_coop, false, true); else AGI_LAUNCH(k_edge_runs_coop, false, false); }

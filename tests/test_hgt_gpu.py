@@ -242,7 +242,7 @@ def test_merge_pass_fused_with_the_node_update_is_bit_identical(case, precision,
     assert err < PREC_TOL[precision]
 
 
-COOP_CASES = ITEM_AGG_CASES[1:3] + [
+COOP_CASES = ITEM_AGG_CASES[0:3] + [
     (2000, 20000, 64, 1, 2, 3, True, {}),                         # (1, 64): one column tile per wavefront
     (3000, 40000, 128, 2, 3, 5, False, {}),                       # (2, 32)
     (1100, 9000, 256, 2, 2, 7, True, {}),                         # (2, 64) x 2 head groups: d_k = 128, eight fragment steps per wavefront
@@ -255,7 +255,7 @@ COOP_CASES = ITEM_AGG_CASES[1:3] + [
 @pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
 @pytest.mark.parametrize("case", COOP_CASES, ids=[str(i) for i in range(len(COOP_CASES))])
 def test_relation_transform_shared_by_the_workgroup_is_bit_identical(case, precision):
-    """Round 6, d_k >= 64: k_edge_logits_coop / k_edge_runs_coop -- the four wavefronts of a workgroup keep their own work items but
+    """Round 6, d_k >= 64 (logits) / >= 32 (runs): k_edge_logits_coop / k_edge_runs_coop -- the four wavefronts of a workgroup keep their own work items but
     split the relation transform (conv.py:98-99, 101-102) by columns, a quarter of the fragment image each, kept in registers while
     consecutive items share the relation -- against the one-wavefront-per-item kernels (HGT_FLAG_NO_COOP_EDGE): the same MFMA
     products in the same order, so the layer's output is the same bit for bit; also against the fp64 closed form.  16-edge items

@@ -103,6 +103,9 @@ def show(d, n_layers=1):
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
+        if os.environ.get("HGT_TRACE_FLAGS"):      # A/B runs: HGT_FLAG_* bits OR-ed into every layer
+            from pyhgt_amd import HGTConv
+            HGTConv.EXTRA_KERNEL_FLAGS = int(os.environ["HGT_TRACE_FLAGS"])
         run(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "bf16x3")
     else:
         show(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 1)
