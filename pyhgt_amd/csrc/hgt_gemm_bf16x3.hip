@@ -177,7 +177,7 @@ __device__ __forceinline__ void store_pass(f32x16 (&acc)[2], int pass, int wave,
                 const int64_t orow = by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
                 const float sc = s_inv ? s_inv[rt] * winv : 1.0f;
                 float4 o4 = make_float4(v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w);
-                if (act_tanh) o4 = make_float4(tanhf(o4.x), tanhf(o4.y), tanhf(o4.z), tanhf(o4.w));
+                if (act_tanh) o4 = make_float4(hgt_tanh(o4.x), hgt_tanh(o4.y), hgt_tanh(o4.z), hgt_tanh(o4.w));
                 *reinterpret_cast<float4*>(ob + orow * block_cols + cc) = o4;
             }
         }

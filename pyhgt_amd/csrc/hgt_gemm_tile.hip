@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64 * NW, (KPAN == 64 && RT == 1 && CT == 1) ? 4 : 2
                         const float sc = F16 ? s_rinv[F16 ? rt : 0] * winv : 1.0f;
                         const int64_t orow = a.by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
                         float4 o4 = make_float4(v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w);
-                        if (a.prologue) o4 = make_float4(tanhf(o4.x), tanhf(o4.y), tanhf(o4.z), tanhf(o4.w));
+                        if (a.prologue) o4 = make_float4(hgt_tanh(o4.x), hgt_tanh(o4.y), hgt_tanh(o4.z), hgt_tanh(o4.w));
                         store_wt16(ob + orow * a.block_cols + cc, o4.x, o4.y, o4.z, o4.w);      // (read by the next kernel only)
                     }
                 }
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(512, HGT_TS_OCC(RT)) void k_tile_linear_stream(cons
                     const float sc = F16 ? s_rinv[F16 ? rt : 0] * winv : 1.0f;
                     const int64_t orow = a.by_pos ? (int64_t)(row0 + rt) : (int64_t)s_rid[rt];
                     float4 o4 = make_float4(v0 * sc + b4.x, v1 * sc + b4.y, v2 * sc + b4.z, v3 * sc + b4.w);
-                    if (a.prologue) o4 = make_float4(tanhf(o4.x), tanhf(o4.y), tanhf(o4.z), tanhf(o4.w));
+                    if (a.prologue) o4 = make_float4(hgt_tanh(o4.x), hgt_tanh(o4.y), hgt_tanh(o4.z), hgt_tanh(o4.w));
                     store_wt16(ob + orow * a.block_cols + cc, o4.x, o4.y, o4.z, o4.w);
                 }
             }

@@ -143,6 +143,14 @@ __device__ __forceinline__ unsigned abs_bits4(const float4 v) {
     return __builtin_bit_cast(unsigned, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
 }
 
+// tanh of the typed input adapter (model.py:74) as  1 - 2 / (e^(2x) + 1)  on the hardware exp2 / rcp (each ~1 ulp: |error| <= ~1.5e-7,
+// saturates to +-1 without a branch; libm's tanhf is ~40 instructions with two of them) -- one definition for the fused epilogues and
+// hgt_tanh_inplace, so that both forms of the adapter publish the same values
+__device__ __forceinline__ float hgt_tanh(float x) {
+    const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // e^(2x) = 2^(2x log2 e)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));

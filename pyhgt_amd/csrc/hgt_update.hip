@@ -4,6 +4,7 @@
 // followed by the per-type LayerNorm (eps 1e-5, affine).  Rows whose type is outside [0,T) are
 // written as zeros (the reference's zero-initialised `res`, conv.py:120).
 #include "hgt_common.h"
+#include "hgt_split_common.h"
 
 namespace {
 
@@ -154,10 +155,10 @@ __global__ void k_tanh_inplace(float* __restrict__ x, int64_t n) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {
         float4 v = *reinterpret_cast<float4*>(x + i);
-        v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+        v.x = hgt_tanh(v.x); v.y = hgt_tanh(v.y); v.z = hgt_tanh(v.z); v.w = hgt_tanh(v.w);
         *reinterpret_cast<float4*>(x + i) = v;
     } else {
-        for (int64_t j = i; j < n; ++j) x[j] = tanhf(x[j]);
+        for (int64_t j = i; j < n; ++j) x[j] = hgt_tanh(x[j]);
     }
 }
 
