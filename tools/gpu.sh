@@ -123,7 +123,7 @@ judged)
     summ gpurun_out/${TAG}_bench.json
     ;;
 suite)
-    HGT_TEST_KERNEL_FLAGS=${3:-0} timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 | tee gpurun_out/suite_${TAG}_flags${3:-0}.txt
+    HGT_TEST_KERNEL_FLAGS=${3:-0} timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 | tee gpurun_out/suite_${TAG}_flags${3:-0}.txt
     ;;
 sanity)
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
