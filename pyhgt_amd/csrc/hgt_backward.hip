@@ -38,12 +38,12 @@ __global__ __launch_bounds__(256) void k_node_update_bwd(
     const float* __restrict__ gout, const float* __restrict__ trans, const float* __restrict__ x, int64_t ldx,
     const int64_t* __restrict__ node_type, const float* __restrict__ skip, const float* __restrict__ lnw, int use_norm,
     const float* __restrict__ drop_mask, int64_t NQ, int d, int T, float* __restrict__ d_trans, float* __restrict__ dx, int64_t ld_dx,
-    float* __restrict__ d_alpha, float* __restrict__ d_lnw, float* __restrict__ d_lnb, int shared_norm) {
+    float* __restrict__ d_alpha, float* __restrict__ d_lnw, float* __restrict__ d_lnb, int shared_norm, int rows_per_wave) {
     // skip == NULL: plain residual y = o + x (DenseHGTConv.update, conv.py:259,271), no gate gradient;
     // shared_norm: ONE LayerNorm for every type (out_norm, conv.py:272): its parameters / gradients are row 0 of lnw / d_lnw / d_lnb
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t r0 = wave * NUB_ROWS;
+    const int64_t r0 = wave * rows_per_wave;
     if (r0 >= NQ) return;
     const int nc = (d + 63) / 64;
     float gw[NUB_MAXC], gb[NUB_MAXC], ga = 0.0f;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_node_update_bwd(
             ga = 0.0f;
         }
     };
-    for (int64_t r = r0; r < min(r0 + NUB_ROWS, NQ); ++r) {
+    for (int64_t r = r0; r < min(r0 + (int64_t)rows_per_wave, NQ); ++r) {
         const int64_t t64 = node_type[r];
         const int t = (t64 >= 0 && t64 < T) ? (int)t64 : -1;
         if (t != cur_t) { flush(); cur_t = t; }
@@ -690,10 +690,13 @@ static int node_update_bwd_impl(const float* grad_out, const float* trans, const
         return HGT_ERR_INVALID_ARG;
     if (use_norm && (!ln_w || !d_ln_w || !d_ln_b)) return HGT_ERR_INVALID_ARG;
     if (n_rows == 0) return HGT_OK;
-    const int64_t waves = (n_rows + NUB_ROWS - 1) / NUB_ROWS;
+    // rows per wavefront: 32 amortise the parameter-gradient atomics on a large graph; a sampled batch of a few thousand rows would be
+    // ~100 wavefronts walking 32 rows one after the other (c3: 119 us) -- 2 rows there, 8 in between
+    const int rpw = n_rows >= 65536 ? NUB_ROWS : (n_rows >= 16384 ? 8 : 2);
+    const int64_t waves = (n_rows + rpw - 1) / rpw;
     k_node_update_bwd<<<nblk(waves, 4), 256, 0, (hipStream_t)stream>>>(grad_out, trans, x, ldx, node_type, skip, ln_w, use_norm, drop_mask,
                                                                        n_rows, d, n_types, d_trans, dx, ld_dx, d_alpha, d_ln_w, d_ln_b,
-                                                                       shared_norm);
+                                                                       shared_norm, rpw);
     HGT_CHECK_LAUNCH();
     return HGT_OK;
 }
